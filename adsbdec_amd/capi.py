@@ -1,0 +1,277 @@
+"""ctypes binding of include/adsbdec_amd.h.
+
+This is plumbing for tests/ and bench.py: the product's host side is C
+(csrc/cli/adsbdec_amd_cli.c) and everything of substance lives behind the C-ABI.
+There is no Python or CPU fallback: if the shared library is missing or no
+gfx950 device is present, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libadsbdec_amd.so")
+CLI_PATH = os.path.join(PKG, "lib", "adsbdec_amd_cli")
+
+
+class AdsbError(RuntimeError):
+    pass
+
+
+class Frame(C.Structure):
+    _fields_ = [("g", C.c_uint64), ("ts", C.c_uint64), ("pw", C.c_uint32), ("len", C.c_uint8),
+                ("frame", C.c_uint8 * 14), ("reserved", C.c_uint8)]
+
+
+class Candidate(C.Structure):
+    _fields_ = [("g", C.c_uint64), ("pw", C.c_uint32), ("len", C.c_uint8),
+                ("frame", C.c_uint8 * 14), ("reserved", C.c_uint8)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("try_", C.c_uint64 * 3), ("ok", C.c_uint64 * 3)]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("df18", C.c_int32), ("device", C.c_int32),
+                ("collect_stats", C.c_int32), ("profile", C.c_int32), ("reserved0", C.c_int32),
+                ("stage_samples", C.c_uint64), ("stream", C.c_void_p)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("relaunches", C.c_uint64), ("offsets", C.c_uint64),
+                ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double), ("last_offsets", C.c_uint64),
+                ("candidates", C.c_uint64), ("tries", C.c_uint64)]
+
+
+# every symbol include/adsbdec_amd.h declares: (restype, argtypes)
+SYMBOLS = {
+    "adsb_abi_version": (C.c_int, []),
+    "adsb_config_default": (None, [C.POINTER(Config)]),
+    "adsb_create": (C.c_void_p, [C.POINTER(Config)]),
+    "adsb_destroy": (None, [C.c_void_p]),
+    "adsb_reset": (C.c_int, [C.c_void_p]),
+    "adsb_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "adsb_push_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "adsb_finish": (C.c_int, [C.c_void_p]),
+    "adsb_drain": (C.c_long, [C.c_void_p, C.POINTER(Frame), C.c_size_t]),
+    "adsb_pending": (C.c_size_t, [C.c_void_p]),
+    "adsb_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "adsb_get_profile": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
+    "adsb_last_error": (C.c_char_p, [C.c_void_p]),
+    "adsb_format_frame": (C.c_int, [C.POINTER(Frame), C.c_int, C.c_char_p]),
+    "adsb_resolver_create": (C.c_void_p, []),
+    "adsb_resolver_destroy": (None, [C.c_void_p]),
+    "adsb_resolver_feed": (C.c_int, [C.c_void_p, C.POINTER(Candidate), C.c_size_t,
+                                     C.POINTER(C.c_uint64), C.c_size_t]),
+    "adsb_resolver_advance": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "adsb_resolver_drain": (C.c_long, [C.c_void_p, C.POINTER(Frame), C.c_size_t]),
+    "adsb_resolver_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "adsb_plan_shards": (C.c_int, [C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "adsb_scan_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64,
+                                  C.c_uint64, C.POINTER(Candidate), C.c_size_t,
+                                  C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_size_t,
+                                  C.POINTER(C.c_size_t)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and bind every declared symbol. Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AdsbError(f"{LIB_PATH} is missing: run `python -m adsbdec_amd._build` "
+                            "(there is no fallback implementation)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _frames_to_dicts(arr, n):
+    return [dict(g=int(f.g), ts=int(f.ts), pw=int(f.pw), frame=bytes(f.frame[: f.len])) for f in arr[:n]]
+
+
+def _stats_to_dict(st: Stats):
+    return {"try": {11: int(st.try_[0]), 17: int(st.try_[1]), 18: int(st.try_[2])},
+            "ok": {11: int(st.ok[0]), 17: int(st.ok[1]), 18: int(st.ok[2])}}
+
+
+def format_frame(fr: dict, outformat: int) -> bytes:
+    f = Frame()
+    f.g, f.ts, f.pw, f.len = fr.get("g", 0), fr["ts"], fr["pw"], len(fr["frame"])
+    for i, b in enumerate(fr["frame"]):
+        f.frame[i] = b
+    buf = C.create_string_buffer(256)
+    n = load().adsb_format_frame(C.byref(f), outformat, buf)
+    return buf.raw[:n]
+
+
+class Decoder:
+    """One stream (== the statics of air.c / demod.c / valid.c)."""
+
+    def __init__(self, df18: bool = False, device: int = -1, collect_stats: bool = False,
+                 profile: bool = False, stage_samples: int = 0, stream: int | None = None):
+        L = load()
+        cfg = Config()
+        L.adsb_config_default(C.byref(cfg))
+        cfg.df18 = int(df18)
+        cfg.device = device
+        cfg.collect_stats = int(collect_stats)
+        cfg.profile = int(profile)
+        cfg.stage_samples = stage_samples
+        cfg.stream = stream
+        self._L = L
+        self._h = L.adsb_create(C.byref(cfg))
+        if not self._h:
+            raise AdsbError("adsb_create failed: " + (L.adsb_last_error(None) or b"").decode())
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise AdsbError(f"{what} failed: " + (self._L.adsb_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h:
+            self._L.adsb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self._check(self._L.adsb_reset(self._h), "adsb_reset")
+
+    def push(self, x: np.ndarray):
+        x = np.ascontiguousarray(x)
+        assert x.dtype == np.uint16
+        self._check(self._L.adsb_push(self._h, x.ctypes.data, x.size), "adsb_push")
+
+    def push_device(self, ptr: int, n: int):
+        self._check(self._L.adsb_push_device(self._h, ptr, n), "adsb_push_device")
+
+    def finish(self):
+        self._check(self._L.adsb_finish(self._h), "adsb_finish")
+
+    def pending(self) -> int:
+        return int(self._L.adsb_pending(self._h))
+
+    def drain(self):
+        out = []
+        buf = (Frame * 4096)()
+        while True:
+            n = self._L.adsb_drain(self._h, buf, 4096)
+            if n < 0:
+                raise AdsbError("adsb_drain failed")
+            if n == 0:
+                return out
+            out.extend(_frames_to_dicts(buf, n))
+
+    def stats(self):
+        st = Stats()
+        self._check(self._L.adsb_get_stats(self._h, C.byref(st)), "adsb_get_stats")
+        return _stats_to_dict(st)
+
+    def profile(self):
+        p = Profile()
+        self._check(self._L.adsb_get_profile(self._h, C.byref(p)), "adsb_get_profile")
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    def scan_shard(self, ptr: int, first_sample: int, n: int, g_begin: int, g_end: int,
+                   cand_cap: int = 1 << 16, try_cap: int = 1 << 20):
+        """Stateless per-shard scan -> (Candidate array, count, tries ndarray)."""
+        while True:
+            cands = (Candidate * cand_cap)()
+            tries = np.empty(try_cap, dtype=np.uint64)
+            nc, nt = C.c_size_t(0), C.c_size_t(0)
+            rc = self._L.adsb_scan_shard(self._h, ptr, first_sample, n, g_begin, g_end, cands, cand_cap,
+                                         C.byref(nc), tries.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                         try_cap, C.byref(nt))
+            if rc == -2:
+                cand_cap, try_cap = max(cand_cap, nc.value), max(try_cap, nt.value)
+                continue
+            self._check(rc, "adsb_scan_shard")
+            return cands, nc.value, tries[: nt.value].copy()
+
+    def decode(self, x: np.ndarray, chunk: int | None = None):
+        """Whole-buffer convenience: push (optionally in chunks), finish, drain."""
+        self.reset()
+        if chunk is None:
+            self.push(x)
+        else:
+            for i in range(0, x.size, chunk):
+                self.push(x[i:i + chunk])
+        self.finish()
+        return self.drain()
+
+
+class Resolver:
+    """Host-side greedy resolver handle (usable without a GPU)."""
+
+    def __init__(self):
+        self._L = load()
+        self._h = self._L.adsb_resolver_create()
+
+    def close(self):
+        if self._h:
+            self._L.adsb_resolver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feed(self, cands, tries=None):
+        """cands: ctypes Candidate array slice or list of (g, pw, frame-bytes)."""
+        if isinstance(cands, list):
+            arr = (Candidate * max(1, len(cands)))()
+            for i, (g, pw, fr) in enumerate(cands):
+                arr[i].g, arr[i].pw, arr[i].len = g, pw, len(fr)
+                for k, b in enumerate(fr):
+                    arr[i].frame[k] = b
+            n = len(cands)
+        else:
+            arr, n = cands
+        t = np.ascontiguousarray(tries if tries is not None else np.empty(0, np.uint64), dtype=np.uint64)
+        rc = self._L.adsb_resolver_feed(self._h, arr, n, t.ctypes.data_as(C.POINTER(C.c_uint64)), t.size)
+        if rc != 0:
+            raise AdsbError("adsb_resolver_feed failed")
+
+    def advance(self, power_samples: int, g_complete: int):
+        if self._L.adsb_resolver_advance(self._h, power_samples, g_complete) != 0:
+            raise AdsbError("adsb_resolver_advance failed")
+
+    def drain(self):
+        out = []
+        buf = (Frame * 4096)()
+        while True:
+            n = self._L.adsb_resolver_drain(self._h, buf, 4096)
+            if n <= 0:
+                return out
+            out.extend(_frames_to_dicts(buf, n))
+
+    def stats(self):
+        st = Stats()
+        self._L.adsb_resolver_stats(self._h, C.byref(st))
+        return _stats_to_dict(st)
+
+
+def plan_shards(total_samples: int, n_shards: int):
+    arrs = [(C.c_uint64 * n_shards)() for _ in range(4)]
+    if load().adsb_plan_shards(total_samples, n_shards, *arrs) != 0:
+        raise AdsbError("adsb_plan_shards failed")
+    return [dict(g_begin=int(arrs[0][i]), g_end=int(arrs[1][i]), first_sample=int(arrs[2][i]),
+                 n_samples=int(arrs[3][i])) for i in range(n_shards)]

@@ -1,0 +1,662 @@
+// decoder.hip -- host side of libadsbdec_amd.so: stream state, device staging,
+// kernel launches, record gather and the C-ABI of include/adsbdec_amd.h.
+//
+// Data layout in HBM
+//   stage[2]   uint16 samples, ping-pong; holds stream samples
+//              [stage_first, stage_first+stage_fill): the unscanned tail plus the
+//              newest push.  stage_first is a multiple of 8 samples so that pair
+//              index/4 alignment and 16-byte loads line up with the stream.
+//   cands      kCandWords dwords per CRC-valid candidate, appended with one atomic
+//   tries      one dword per DF-gate pass (only with collect_stats)
+//   counters   2 dwords
+// A buffer pushed with adsb_push_device() at a stream position that is a multiple
+// of 8 samples and a 16-byte aligned address is scanned IN PLACE: only the ~4 KiB
+// seam with the previous push and the ~5 KiB tail go through the staging buffer.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/adsbdec_amd.h"
+#include "resolver.hpp"
+#include "scan_kernel.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr uint64_t kDefaultStageSamples = 32ull << 20; // 64 MiB per staging buffer
+constexpr uint64_t kStageSlack = 4096;                 // samples kept free for alignment padding
+constexpr size_t kInPlaceMinSamples = 1u << 16;
+constexpr size_t kSeamSamples = 4096; // > 2*(28+8+1196): enough for the first in-place tile's pre-halo
+
+inline uint64_t round_down(uint64_t v, uint64_t q) { return v - v % q; }
+
+} // namespace
+
+struct adsb_decoder {
+    adsb_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // stream position
+    uint64_t n_samples = 0; // samples accepted
+    uint64_t g_scanned = 0; // every offset below has been evaluated on the device
+    bool finished = false;
+
+    // staging
+    uint16_t *stage[2] = {nullptr, nullptr};
+    int cur = 0;
+    uint64_t stage_cap = 0;   // samples per staging buffer
+    uint64_t stage_first = 0; // stream index of stage[cur][0]
+    uint64_t stage_fill = 0;  // samples held
+
+    // device record buffers + pinned mirrors
+    uint32_t *d_counters = nullptr;
+    uint32_t *d_cands = nullptr;
+    uint32_t *d_tries = nullptr;
+    uint32_t *h_counters = nullptr;
+    uint32_t *h_cands = nullptr;
+    uint32_t *h_tries = nullptr;
+    size_t cand_cap = 0, try_cap = 0;
+    size_t h_cand_cap = 0, h_try_cap = 0;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    adsb_profile prof{};
+    adsb::Resolver res;
+    std::vector<adsb_candidate> cand_buf;
+    std::vector<uint64_t> try_buf;
+
+    int fail(const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return -1;
+    }
+};
+
+#define HIP_TRY(d, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return (d)->fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                             __LINE__);                                                       \
+    } while (0)
+
+namespace {
+
+int ensure_record_capacity(adsb_decoder *d, size_t want_cands, size_t want_tries)
+{
+    if (want_cands > d->cand_cap) {
+        if (d->d_cands)
+            HIP_TRY(d, hipFree(d->d_cands));
+        d->d_cands = nullptr;
+        HIP_TRY(d, hipMalloc(&d->d_cands, want_cands * adsb::kCandWords * sizeof(uint32_t)));
+        d->cand_cap = want_cands;
+    }
+    if (want_tries > d->try_cap) {
+        if (d->d_tries)
+            HIP_TRY(d, hipFree(d->d_tries));
+        d->d_tries = nullptr;
+        HIP_TRY(d, hipMalloc(&d->d_tries, want_tries * sizeof(uint32_t)));
+        d->try_cap = want_tries;
+    }
+    return 0;
+}
+
+int ensure_host_mirrors(adsb_decoder *d, size_t n_cands, size_t n_tries)
+{
+    if (n_cands > d->h_cand_cap) {
+        if (d->h_cands)
+            HIP_TRY(d, hipHostFree(d->h_cands));
+        d->h_cands = nullptr;
+        size_t cap = std::max<size_t>(n_cands, 2 * d->h_cand_cap);
+        HIP_TRY(d, hipHostMalloc(&d->h_cands, cap * adsb::kCandWords * sizeof(uint32_t)));
+        d->h_cand_cap = cap;
+    }
+    if (n_tries > d->h_try_cap) {
+        if (d->h_tries)
+            HIP_TRY(d, hipHostFree(d->h_tries));
+        d->h_tries = nullptr;
+        size_t cap = std::max<size_t>(n_tries, 2 * d->h_try_cap);
+        HIP_TRY(d, hipHostMalloc(&d->h_tries, cap * sizeof(uint32_t)));
+        d->h_try_cap = cap;
+    }
+    return 0;
+}
+
+// Evaluate offsets [g_begin, g_end) on a device buffer holding stream samples
+// [buf_first, buf_first + buf_n) (buf_first % 8 == 0, buf 16-byte aligned) and
+// append the sorted records to cands/tries with absolute g.
+int scan_range(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64_t buf_n,
+               uint64_t g_begin, uint64_t g_end, std::vector<adsb_candidate> &cands,
+               std::vector<uint64_t> &tries)
+{
+    const bool stats = d->cfg.collect_stats != 0;
+    while (g_begin < g_end) {
+        const uint64_t g_stop = std::min(g_end, g_begin + round_down(adsb::kMaxLaunchOffsets, 28));
+        const uint64_t n_off = g_stop - g_begin;
+
+        // Sparse output: size the buffers for far more than noise produces and grow
+        // on overflow (counters keep counting past the capacity).
+        size_t want_c = std::max<size_t>(d->cand_cap, (size_t)(n_off / 256 + 16384));
+        size_t want_t = stats ? std::max<size_t>(d->try_cap, (size_t)(n_off / 32 + 65536)) : d->try_cap;
+        for (int attempt = 0;; attempt++) {
+            if (ensure_record_capacity(d, want_c, want_t))
+                return -1;
+            adsb::ScanArgs a{};
+            a.x = reinterpret_cast<const uint32_t *>(buf);
+            a.pbuf0 = (int64_t)(buf_first / 2);
+            a.p_lo = a.pbuf0; // stream start: pairs below 0 read as silence (air.c:33)
+            a.p_hi = a.pbuf0 + (int64_t)(buf_n / 2);
+            a.g_begin = g_begin;
+            a.g_end = g_stop;
+            a.df18 = d->cfg.df18 ? 1 : 0;
+            a.counters = d->d_counters;
+            a.cands = d->d_cands;
+            a.cand_cap = (uint32_t)std::min<size_t>(d->cand_cap, 0xFFFFFFFFu);
+            a.tries = d->d_tries;
+            a.try_cap = (uint32_t)std::min<size_t>(d->try_cap, 0xFFFFFFFFu);
+
+            HIP_TRY(d, hipMemsetAsync(d->d_counters, 0, 2 * sizeof(uint32_t), d->stream));
+            if (d->cfg.profile)
+                HIP_TRY(d, hipEventRecord(d->ev0, d->stream));
+            HIP_TRY(d, adsb::launch_scan(a, stats, d->stream));
+            if (d->cfg.profile)
+                HIP_TRY(d, hipEventRecord(d->ev1, d->stream));
+            HIP_TRY(d, hipMemcpyAsync(d->h_counters, d->d_counters, 2 * sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, d->stream));
+            HIP_TRY(d, hipStreamSynchronize(d->stream));
+            d->prof.launches++;
+            d->prof.offsets += n_off;
+            d->prof.last_offsets = n_off;
+            if (d->cfg.profile) {
+                float ms = 0;
+                HIP_TRY(d, hipEventElapsedTime(&ms, d->ev0, d->ev1));
+                d->prof.kernel_ms += ms;
+                d->prof.last_kernel_ms = ms;
+            }
+            const size_t nc = d->h_counters[0], nt = d->h_counters[1];
+            if (nc <= d->cand_cap && nt <= d->try_cap) {
+                if (ensure_host_mirrors(d, nc, nt))
+                    return -1;
+                if (nc)
+                    HIP_TRY(d, hipMemcpyAsync(d->h_cands, d->d_cands,
+                                              nc * adsb::kCandWords * sizeof(uint32_t),
+                                              hipMemcpyDeviceToHost, d->stream));
+                if (nt)
+                    HIP_TRY(d, hipMemcpyAsync(d->h_tries, d->d_tries, nt * sizeof(uint32_t),
+                                              hipMemcpyDeviceToHost, d->stream));
+                if (nc || nt)
+                    HIP_TRY(d, hipStreamSynchronize(d->stream));
+
+                // The device appends in arrival order; the reference's order is ascending g.
+                std::vector<uint32_t> order(nc);
+                for (size_t i = 0; i < nc; i++)
+                    order[i] = (uint32_t)i;
+                const uint32_t *hc = d->h_cands;
+                std::sort(order.begin(), order.end(), [hc](uint32_t x, uint32_t y) {
+                    return hc[(size_t)x * adsb::kCandWords] < hc[(size_t)y * adsb::kCandWords];
+                });
+                for (size_t i = 0; i < nc; i++) {
+                    const uint32_t *r = hc + (size_t)order[i] * adsb::kCandWords;
+                    adsb_candidate c;
+                    std::memset(&c, 0, sizeof c);
+                    c.g = g_begin + r[0];
+                    c.pw = r[1];
+                    std::memcpy(c.frame, &r[2], 14);
+                    c.len = (uint8_t)((r[5] >> 16) & 0xFF);
+                    cands.push_back(c);
+                }
+                if (nt) {
+                    std::sort(d->h_tries, d->h_tries + nt);
+                    for (size_t i = 0; i < nt; i++)
+                        tries.push_back((((uint64_t)(d->h_tries[i] >> 2) + g_begin) << 2) |
+                                        (d->h_tries[i] & 3u));
+                }
+                d->prof.candidates += nc;
+                d->prof.tries += nt;
+                break;
+            }
+            if (attempt >= 2)
+                return d->fail("record buffers overflowed repeatedly (%zu candidates, %zu tries)", nc, nt);
+            d->prof.relaunches++;
+            want_c = std::max(want_c, nc + nc / 8);
+            want_t = std::max(want_t, nt + nt / 8);
+        }
+        g_begin = g_stop;
+    }
+    return 0;
+}
+
+inline uint64_t power_samples_produced(uint64_t n_samples)
+{
+    return 2 * (n_samples / 4); // air.c:59-92: two power samples per four input samples
+}
+
+// Scan what the staged samples allow, resolve, and keep only the unscanned tail.
+int process_stage(adsb_decoder *d, bool final)
+{
+    const uint64_t m_real = power_samples_produced(d->n_samples);
+    uint64_t g_end = m_real >= ADSB_WINDOW ? m_real - ADSB_WINDOW + 1 : 0;
+    if (!final)
+        g_end = round_down(g_end, 28);
+    if (g_end > d->g_scanned) {
+        d->cand_buf.clear();
+        d->try_buf.clear();
+        if (scan_range(d, d->stage[d->cur], d->stage_first, d->stage_fill, d->g_scanned, g_end,
+                       d->cand_buf, d->try_buf))
+            return -1;
+        d->res.feed(d->cand_buf.data(), d->cand_buf.size(), d->try_buf.data(), d->try_buf.size());
+        d->g_scanned = g_end;
+    }
+    // At EOF a trailing partial quad still makes the reference produce two (garbage)
+    // power samples (air.c:59 loop bound); they can never be read by a visited
+    // offset but they count for the `aidx >= APBUFFSZ` test.
+    const uint64_t m_ref = final ? 2 * ((d->n_samples + 3) / 4) : m_real;
+    d->res.advance(m_ref, d->g_scanned);
+    if (final)
+        return 0;
+
+    // keep samples from pair (g_scanned - 8) on; that index is a multiple of 8 samples
+    const uint64_t keep_first = d->g_scanned >= 8 ? 2 * (d->g_scanned - 8) : 0;
+    if (keep_first > d->stage_first) {
+        const uint64_t skip = keep_first - d->stage_first;
+        const uint64_t left = d->stage_fill > skip ? d->stage_fill - skip : 0;
+        if (left)
+            HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur ^ 1], d->stage[d->cur] + skip,
+                                      left * sizeof(uint16_t), hipMemcpyDeviceToDevice, d->stream));
+        d->cur ^= 1;
+        d->stage_first = keep_first;
+        d->stage_fill = left;
+    }
+    return 0;
+}
+
+int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind)
+{
+    const uint16_t *p = static_cast<const uint16_t *>(src);
+    while (n) {
+        const uint64_t room = d->stage_cap - kStageSlack - d->stage_fill;
+        if (room == 0)
+            return d->fail("staging buffer exhausted (stage_samples too small)");
+        const size_t take = (size_t)std::min<uint64_t>(room, n);
+        HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind,
+                                  d->stream));
+        if (kind == hipMemcpyHostToDevice)
+            HIP_TRY(d, hipStreamSynchronize(d->stream)); // `samples` is only borrowed for the call
+        d->stage_fill += take;
+        d->n_samples += take;
+        p += take;
+        n -= take;
+        if (process_stage(d, false))
+            return -1;
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int adsb_abi_version(void) { return ADSB_ABI_VERSION; }
+
+void adsb_config_default(adsb_config *cfg)
+{
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
+    cfg->device = -1;
+}
+
+adsb_decoder *adsb_create(const adsb_config *cfg_in)
+{
+    adsb_config cfg;
+    adsb_config_default(&cfg);
+    if (cfg_in) {
+        if (cfg_in->struct_size == 0 || cfg_in->struct_size > sizeof cfg) {
+            g_create_error = "adsb_config.struct_size is not one this library knows";
+            return nullptr;
+        }
+        std::memcpy(&cfg, cfg_in, cfg_in->struct_size);
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("no HIP device available: ") +
+                         (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                         " (libadsbdec_amd has no CPU fallback)";
+        return nullptr;
+    }
+    int dev = cfg.device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess)
+        dev = 0;
+    if (dev >= ndev) {
+        g_create_error = "adsb_config.device is out of range";
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        g_create_error = "hipGetDeviceProperties failed";
+        return nullptr;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName +
+                         "; this library carries gfx950 (MI355X) code objects only";
+        return nullptr;
+    }
+    adsb_decoder *d = new (std::nothrow) adsb_decoder();
+    if (!d) {
+        g_create_error = "out of memory";
+        return nullptr;
+    }
+    d->cfg = cfg;
+    d->device = dev;
+    d->stage_cap = cfg.stage_samples ? round_down(cfg.stage_samples + 7, 8) : kDefaultStageSamples;
+    if (d->stage_cap < (1u << 16))
+        d->stage_cap = 1u << 16;
+
+    auto bail = [&](const char *what, hipError_t err) -> adsb_decoder * {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        adsb_destroy(d);
+        return nullptr;
+    };
+    if ((e = hipSetDevice(dev)) != hipSuccess)
+        return bail("hipSetDevice", e);
+    if (cfg.stream) {
+        d->stream = static_cast<hipStream_t>(cfg.stream);
+    } else {
+        if ((e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)) != hipSuccess)
+            return bail("hipStreamCreate", e);
+        d->own_stream = true;
+    }
+    for (int i = 0; i < 2; i++)
+        if ((e = hipMalloc(&d->stage[i], d->stage_cap * sizeof(uint16_t))) != hipSuccess)
+            return bail("hipMalloc(stage)", e);
+    if ((e = hipMalloc(&d->d_counters, 2 * sizeof(uint32_t))) != hipSuccess)
+        return bail("hipMalloc(counters)", e);
+    if ((e = hipHostMalloc(&d->h_counters, 2 * sizeof(uint32_t))) != hipSuccess)
+        return bail("hipHostMalloc(counters)", e);
+    if ((e = hipEventCreate(&d->ev0)) != hipSuccess || (e = hipEventCreate(&d->ev1)) != hipSuccess)
+        return bail("hipEventCreate", e);
+    d->res.reset();
+    return d;
+}
+
+void adsb_destroy(adsb_decoder *d)
+{
+    if (!d)
+        return;
+    (void)hipSetDevice(d->device);
+    if (d->stream)
+        (void)hipStreamSynchronize(d->stream);
+    for (int i = 0; i < 2; i++)
+        if (d->stage[i])
+            (void)hipFree(d->stage[i]);
+    if (d->d_counters) (void)hipFree(d->d_counters);
+    if (d->d_cands) (void)hipFree(d->d_cands);
+    if (d->d_tries) (void)hipFree(d->d_tries);
+    if (d->h_counters) (void)hipHostFree(d->h_counters);
+    if (d->h_cands) (void)hipHostFree(d->h_cands);
+    if (d->h_tries) (void)hipHostFree(d->h_tries);
+    if (d->ev0) (void)hipEventDestroy(d->ev0);
+    if (d->ev1) (void)hipEventDestroy(d->ev1);
+    if (d->own_stream && d->stream)
+        (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+int adsb_reset(adsb_decoder *d)
+{
+    if (!d)
+        return -1;
+    d->n_samples = 0;
+    d->g_scanned = 0;
+    d->finished = false;
+    d->stage_first = 0;
+    d->stage_fill = 0;
+    d->cur = 0;
+    d->res.reset();
+    std::memset(&d->prof, 0, sizeof d->prof);
+    d->err.clear();
+    return 0;
+}
+
+int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n)
+{
+    if (!d)
+        return -1;
+    if (d->finished)
+        return d->fail("adsb_push after adsb_finish");
+    if (n == 0)
+        return 0;
+    if (!samples)
+        return d->fail("adsb_push: NULL samples");
+    HIP_TRY(d, hipSetDevice(d->device));
+    return push_copy(d, samples, n, hipMemcpyHostToDevice);
+}
+
+int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n)
+{
+    if (!d)
+        return -1;
+    if (d->finished)
+        return d->fail("adsb_push_device after adsb_finish");
+    if (n == 0)
+        return 0;
+    if (!device_samples)
+        return d->fail("adsb_push_device: NULL samples");
+    HIP_TRY(d, hipSetDevice(d->device));
+    const uint16_t *p = static_cast<const uint16_t *>(device_samples);
+    const bool aligned = (d->n_samples % 8 == 0) && ((uintptr_t)p % 16 == 0);
+    if (!aligned || n < kInPlaceMinSamples)
+        return push_copy(d, p, n, hipMemcpyDeviceToDevice);
+
+    // In-place scan.  First the seam: offsets whose window starts in earlier data.
+    const uint64_t first = d->n_samples; // stream index of p[0]
+    if (first != 0) {
+        if (push_copy(d, p, kSeamSamples, hipMemcpyDeviceToDevice))
+            return -1;
+    }
+    // Bulk: every offset whose whole window lies inside this buffer.
+    const uint64_t total = first + n;
+    const uint64_t m_real = power_samples_produced(total);
+    const uint64_t g_end = round_down(m_real >= ADSB_WINDOW ? m_real - ADSB_WINDOW + 1 : 0, 28);
+    d->n_samples = total;
+    if (g_end > d->g_scanned) {
+        d->cand_buf.clear();
+        d->try_buf.clear();
+        if (scan_range(d, p, first, n, d->g_scanned, g_end, d->cand_buf, d->try_buf))
+            return -1;
+        d->res.feed(d->cand_buf.data(), d->cand_buf.size(), d->try_buf.data(), d->try_buf.size());
+        d->g_scanned = g_end;
+    }
+    d->res.advance(m_real, d->g_scanned);
+    // Tail: what the next push (or adsb_finish) still needs goes to the staging buffer.
+    const uint64_t keep_first = std::max<uint64_t>(d->g_scanned >= 8 ? 2 * (d->g_scanned - 8) : 0, first);
+    const uint64_t left = total - keep_first;
+    if (left > d->stage_cap - kStageSlack)
+        return d->fail("in-place tail (%llu samples) exceeds the staging buffer", (unsigned long long)left);
+    HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur], p + (keep_first - first), left * sizeof(uint16_t),
+                              hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(d, hipStreamSynchronize(d->stream)); // the caller may free the buffer after return
+    d->stage_first = keep_first;
+    d->stage_fill = left;
+    return 0;
+}
+
+int adsb_finish(adsb_decoder *d)
+{
+    if (!d)
+        return -1;
+    if (d->finished)
+        return 0;
+    HIP_TRY(d, hipSetDevice(d->device));
+    if (process_stage(d, true))
+        return -1;
+    d->finished = true;
+    return 0;
+}
+
+long adsb_drain(adsb_decoder *d, adsb_frame *out, size_t cap)
+{
+    if (!d || (!out && cap))
+        return -1;
+    auto &q = d->res.out();
+    size_t n = 0;
+    while (n < cap && !q.empty()) {
+        out[n++] = q.front();
+        q.pop_front();
+    }
+    return (long)n;
+}
+
+size_t adsb_pending(const adsb_decoder *d)
+{
+    return d ? const_cast<adsb_decoder *>(d)->res.out().size() : 0;
+}
+
+int adsb_get_stats(const adsb_decoder *d, adsb_stats *out)
+{
+    if (!d || !out)
+        return -1;
+    *out = d->res.stats();
+    return 0;
+}
+
+int adsb_get_profile(const adsb_decoder *d, adsb_profile *out)
+{
+    if (!d || !out)
+        return -1;
+    *out = d->prof;
+    return 0;
+}
+
+const char *adsb_last_error(const adsb_decoder *d)
+{
+    return d ? d->err.c_str() : g_create_error.c_str();
+}
+
+// ---- stateless per-shard scan (multi-GPU path) -----------------
+int adsb_scan_shard(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n,
+                    uint64_t g_begin, uint64_t g_end, adsb_candidate *cands, size_t cand_cap,
+                    size_t *n_cands, uint64_t *tries, size_t try_cap, size_t *n_tries)
+{
+    if (!d || !device_samples || !n_cands || !n_tries)
+        return -1;
+    if (first_sample % 8 || (uintptr_t)device_samples % 16)
+        return d->fail("adsb_scan_shard: buffer must start at a multiple of 8 samples, 16-byte aligned");
+    if (g_begin % 28)
+        return d->fail("adsb_scan_shard: g_begin must be a multiple of 28");
+    if (g_end > g_begin) {
+        const uint64_t need_lo = g_begin >= 6 ? 2 * (g_begin - 6) : 0;
+        const uint64_t need_hi = 2 * (g_end - 1 + ADSB_WINDOW);
+        if (first_sample > need_lo || first_sample + n < need_hi)
+            return d->fail("adsb_scan_shard: buffer does not cover the window of the owned offsets");
+    }
+    HIP_TRY(d, hipSetDevice(d->device));
+    std::vector<adsb_candidate> cv;
+    std::vector<uint64_t> tv;
+    if (scan_range(d, static_cast<const uint16_t *>(device_samples), first_sample, n, g_begin, g_end, cv, tv))
+        return -1;
+    *n_cands = cv.size();
+    *n_tries = tv.size();
+    if (cv.size() > cand_cap || tv.size() > try_cap)
+        return -2;
+    if (!cv.empty())
+        std::memcpy(cands, cv.data(), cv.size() * sizeof(adsb_candidate));
+    if (!tv.empty())
+        std::memcpy(tries, tv.data(), tv.size() * sizeof(uint64_t));
+    return 0;
+}
+
+int adsb_plan_shards(uint64_t total_samples, int n_shards, uint64_t *g_begin, uint64_t *g_end,
+                     uint64_t *first_sample, uint64_t *n_samples)
+{
+    if (n_shards <= 0 || !g_begin || !g_end || !first_sample || !n_samples)
+        return -1;
+    const uint64_t m = 2 * (total_samples / 4);
+    const uint64_t n_off = m >= ADSB_WINDOW ? m - ADSB_WINDOW + 1 : 0;
+    for (int i = 0; i < n_shards; i++) {
+        const uint64_t lo = round_down((uint64_t)((__uint128_t)n_off * (unsigned)i / (unsigned)n_shards), 28);
+        const uint64_t hi = (i == n_shards - 1)
+                                ? n_off
+                                : round_down((uint64_t)((__uint128_t)n_off * (unsigned)(i + 1) / (unsigned)n_shards), 28);
+        g_begin[i] = lo;
+        g_end[i] = hi;
+        // pre-halo: 8 pairs (6 needed; 8 keeps 16-byte alignment); post-halo: one window
+        const uint64_t s0 = lo >= 8 ? 2 * (lo - 8) : 0;
+        uint64_t s1 = hi > lo ? 2 * (hi - 1 + ADSB_WINDOW) : s0;
+        if (s1 > total_samples)
+            s1 = total_samples;
+        first_sample[i] = s0;
+        n_samples[i] = s1 > s0 ? s1 - s0 : 0;
+    }
+    return 0;
+}
+
+// ---- resolver handle ----------------------------------------------------------
+struct adsb_resolver {
+    adsb::Resolver r;
+};
+
+adsb_resolver *adsb_resolver_create(void)
+{
+    adsb_resolver *r = new (std::nothrow) adsb_resolver();
+    if (r)
+        r->r.reset();
+    return r;
+}
+
+void adsb_resolver_destroy(adsb_resolver *r) { delete r; }
+
+int adsb_resolver_feed(adsb_resolver *r, const adsb_candidate *cands, size_t n_cands,
+                       const uint64_t *tries, size_t n_tries)
+{
+    if (!r || (n_cands && !cands) || (n_tries && !tries))
+        return -1;
+    r->r.feed(cands, n_cands, tries, n_tries);
+    return 0;
+}
+
+int adsb_resolver_advance(adsb_resolver *r, uint64_t power_samples, uint64_t g_complete)
+{
+    if (!r)
+        return -1;
+    r->r.advance(power_samples, g_complete);
+    return 0;
+}
+
+long adsb_resolver_drain(adsb_resolver *r, adsb_frame *out, size_t cap)
+{
+    if (!r || (!out && cap))
+        return -1;
+    auto &q = r->r.out();
+    size_t n = 0;
+    while (n < cap && !q.empty()) {
+        out[n++] = q.front();
+        q.pop_front();
+    }
+    return (long)n;
+}
+
+int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out)
+{
+    if (!r || !out)
+        return -1;
+    *out = r->r.stats();
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,170 @@
+/*
+ * adsbdec_amd.h -- C-ABI of libadsbdec_amd.so: the MI355X (gfx950) drop-in for the
+ * offline "-f" demodulation path of TLeconte/adsbdec.
+ *
+ * The reference has no plugin/FFI interface; its seams are plain extern C
+ * functions with file-scope state.  Each entry point below names
+ * the reference interface it stands behind (file:line under /root/reference).
+ * INTEGRATION.md shows the three-line change a maintainer makes in air.c /
+ * output.c to bind them.
+ *
+ * Conventions follow the reference: int 0 / -1 with a message retrievable through
+ * adsb_last_error() (the reference prints to stderr, air.c:113-118); one producer
+ * thread per handle (decodeiq is not re-entrant, air.c:33-34,49-50; demod.c:86).
+ * Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * The HIP path is the only implementation behind these symbols: there is no CPU
+ * fallback, and adsb_create() fails loudly when no gfx950 device is usable.
+ */
+#ifndef ADSBDEC_AMD_H
+#define ADSBDEC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADSB_ABI_VERSION 1
+
+/* Constants of the path (adsbdec.h:1-3, air.c:32,47). */
+#define ADSB_PULSEW 5
+#define ADSB_DECOFFSET 1200
+#define ADSB_APBUFFSZ 40980
+#define ADSB_WINDOW 1196 /* power samples one long-frame evaluation touches: a[g .. g+1195] */
+
+typedef struct adsb_decoder adsb_decoder; /* one stream == the statics of air.c/demod.c/valid.c */
+
+/* Record leaving the path == the arguments of netout() (valid.c:26, output.c:159)
+ * == blk_t (output.c:45-52), plus the global power-sample index of the preamble. */
+typedef struct adsb_frame {
+    uint64_t g;        /* global 10 MS/s power-sample index of the preamble start */
+    uint64_t ts;       /* demod.c:86,99: loop-iteration counter at acceptance      */
+    uint32_t pw;       /* demod.c:127,133: (p1+p2)/4                               */
+    uint8_t len;       /* 7 (DF11) or 14 (DF17/18)                                 */
+    uint8_t frame[14]; /* demod.c:110-123                                          */
+    uint8_t reserved;
+} adsb_frame;
+
+/* A CRC-valid candidate before greedy resolution (what one GPU emits for the
+ * offsets it owns; the unit the host gathers across shards). */
+typedef struct adsb_candidate {
+    uint64_t g;
+    uint32_t pw;
+    uint8_t len;
+    uint8_t frame[14];
+    uint8_t reserved;
+} adsb_candidate;
+
+/* valid.c:30-31,84-100: Try/Ok per DF, in the order 11, 17, 18. */
+typedef struct adsb_stats {
+    uint64_t try_[3];
+    uint64_t ok[3];
+} adsb_stats;
+
+typedef struct adsb_config {
+    uint32_t struct_size;      /* sizeof(adsb_config), for forward compatibility */
+    int32_t df18;              /* demod.c:26 `df`, set by -a (main.c:76-78)        */
+    int32_t device;            /* HIP device ordinal; -1 = the current device     */
+    int32_t collect_stats;     /* reproduce valid.c's Try counters (costs a try list) */
+    int32_t profile;           /* time the scan kernel with HIP events on its stream */
+    int32_t reserved0;
+    uint64_t stage_samples;    /* device staging capacity for adsb_push(); 0 = default (32 Mi) */
+    void *stream;              /* hipStream_t to launch on; NULL = a stream owned by the handle */
+} adsb_config;
+
+typedef struct adsb_profile {
+    uint64_t launches;         /* scan-kernel launches since create/reset           */
+    uint64_t relaunches;       /* launches repeated after a record-buffer overflow  */
+    uint64_t offsets;          /* preamble offsets those launches covered           */
+    double kernel_ms;          /* sum of their HIP-event durations (profile=1 only)  */
+    double last_kernel_ms;
+    uint64_t last_offsets;
+    uint64_t candidates;       /* CRC-valid candidates received from the device     */
+    uint64_t tries;            /* DF-gate passes received (collect_stats=1 only)    */
+} adsb_profile;
+
+void adsb_config_default(adsb_config *cfg);
+
+/* Allocates the stream state that air.c:33-34,49-50 / demod.c:86 / valid.c:30-31
+ * keep in statics. NULL on failure (adsb_last_error(NULL) has the reason). */
+adsb_decoder *adsb_create(const adsb_config *cfg);
+void adsb_destroy(adsb_decoder *d);
+
+/* Restart the stream on the same handle (fresh ring, ts, stats), keeping device buffers. */
+int adsb_reset(adsb_decoder *d);
+
+/* Sample ingress; replaces `decodeiq(const unsigned short *r, const int len)`
+ * (air.c:54), called from fileInput (air.c:239) / rx_callback (air.c:175).
+ * `samples` is borrowed for the call. Any n is accepted; the stream is the
+ * concatenation of all pushes (the reference requires n % 4 == 0). */
+int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n);
+
+/* Same, for samples already resident in HBM (device pointer valid on cfg.device).
+ * A 16-byte aligned pointer at a stream position that is a multiple of 8 samples
+ * is scanned in place; anything else goes through the staging buffer. */
+int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n);
+
+/* End of input (fileInput's EOF, air.c:241-244): runs the remaining offsets and
+ * applies the reference's end-of-file horizon. */
+int adsb_finish(adsb_decoder *d);
+
+/* Frame egress; the records the reference hands to netout() (output.c:159), in
+ * the same order. Returns the number copied (<= cap), or -1. */
+long adsb_drain(adsb_decoder *d, adsb_frame *out, size_t cap);
+/* Number of frames currently waiting in the handle. */
+size_t adsb_pending(const adsb_decoder *d);
+
+/* print_stats() counters (valid.c:84-100); needs collect_stats=1 for try_. */
+int adsb_get_stats(const adsb_decoder *d, adsb_stats *out);
+int adsb_get_profile(const adsb_decoder *d, adsb_profile *out);
+
+/* Last error text of a handle, or of the last failed adsb_create() when d==NULL. */
+const char *adsb_last_error(const adsb_decoder *d);
+
+/* formatpkt() (output.c:204-262, WITH_AIR). outformat 0 = AVR "*hex;\n",
+ * 1 = AVR-MLAT "@ts48hex;\n", 2 = Beast binary. pkt must hold 256 bytes.
+ * Returns the packet length. */
+int adsb_format_frame(const adsb_frame *f, int outformat, char *pkt);
+
+/* ---- host-side greedy resolver (demod.c:89,99,125-141 + air.c:94-99) --------
+ * Exposed so that a host that gathers candidates from several GPUs/ranks can
+ * replay the reference's sequential rules once, and so that the
+ * host logic is testable without a GPU. */
+typedef struct adsb_resolver adsb_resolver;
+adsb_resolver *adsb_resolver_create(void);
+void adsb_resolver_destroy(adsb_resolver *r);
+/* Candidates (ascending g) and tries (ascending; (g<<2)|code, code 0/1/2 = DF11/17/18),
+ * all with g >= the previous g_complete. */
+int adsb_resolver_feed(adsb_resolver *r, const adsb_candidate *cands, size_t n_cands,
+                       const uint64_t *tries, size_t n_tries);
+/* Everything with g < g_complete has been fed; the stream has produced
+ * power_samples 10 MS/s samples so far. Appends accepted frames internally. */
+int adsb_resolver_advance(adsb_resolver *r, uint64_t power_samples, uint64_t g_complete);
+long adsb_resolver_drain(adsb_resolver *r, adsb_frame *out, size_t cap);
+int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out);
+
+/* ---- shard planning -------------------------------------------
+ * Splits the offsets [0, power_samples-ADSB_WINDOW] of one stream over n_shards
+ * owners. Shard i owns offsets [g_begin[i], g_end[i]) (g_begin multiple of 28) and
+ * must be given input samples [first_sample[i], first_sample[i]+n_samples[i]). */
+int adsb_plan_shards(uint64_t total_samples, int n_shards, uint64_t *g_begin, uint64_t *g_end,
+                     uint64_t *first_sample, uint64_t *n_samples);
+
+/* Scan a stand-alone device buffer that holds stream samples
+ * [first_sample, first_sample+n) for the owned offsets [g_begin, g_end) and
+ * return its CRC-valid candidates / tries (sorted). No stream state is touched:
+ * this is the per-shard call of the multi-GPU path. Returns counts through
+ * n_cands/n_tries; -1 on error, -2 if a capacity was too small (counts are set
+ * to what is needed). */
+int adsb_scan_shard(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n,
+                    uint64_t g_begin, uint64_t g_end, adsb_candidate *cands, size_t cand_cap,
+                    size_t *n_cands, uint64_t *tries, size_t try_cap, size_t *n_tries);
+
+int adsb_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -296,6 +296,64 @@ int orc_eval_offset(const float *a, int df18, uint8_t frame[14], int *len, uint3
     return orc_crc_residual(frame, nbytes) == 0 ? 3 : 2;
 }
 
+/* demod/valid stages only, on a caller-supplied power array: replays air.c:94-99's
+ * accumulate/carry around orc_deqframe exactly as oracle/ref_harness.c does
+ * around the real deqframe. */
+size_t orc_demod_power(const float *a, size_t m, int df18, orc_frame_t *out, size_t cap,
+                       uint32_t *stats6)
+{
+    orc_state_t *o = (orc_state_t *)malloc(sizeof *o);
+    collect_t c = {out, cap, 0};
+    orc_init(o, df18, collect_sink, &c);
+    for (size_t i = 0; i + 1 < m; i += 2) {
+        o->ampbuff[o->aidx++] = a[i];
+        o->ampbuff[o->aidx++] = a[i + 1];
+        carry_if_full(o);
+    }
+    if (stats6) {
+        stats6[0] = o->stat_try[11];
+        stats6[1] = o->stat_try[17];
+        stats6[2] = o->stat_try[18];
+        stats6[3] = o->stat_ok[11];
+        stats6[4] = o->stat_ok[17];
+        stats6[5] = o->stat_ok[18];
+    }
+    free(o);
+    return c.n;
+}
+
+/* Exhaustive, order-free evaluation of every offset g in [g0, g1) of a power
+ * array (what a data-parallel device computes); used to test the candidate
+ * resolver and the shard planner without a GPU. */
+size_t orc_scan_all(const float *a, uint64_t g0, uint64_t g1, int df18, orc_frame_t *cands,
+                    size_t cand_cap, size_t *n_cands, uint64_t *tries, size_t try_cap)
+{
+    size_t nc = 0, nt = 0;
+    for (uint64_t g = g0; g < g1; g++) {
+        uint8_t fr[14];
+        int len = 0;
+        uint32_t pw = 0;
+        int k = orc_eval_offset(a + g, df18, fr, &len, &pw);
+        if (k < 2)
+            continue;
+        if (nt < try_cap)
+            tries[nt] = (g << 2) | (uint64_t)((fr[0] >> 3) == 11 ? 0 : (fr[0] >> 3) == 17 ? 1 : 2);
+        nt++;
+        if (k == 3) {
+            if (nc < cand_cap) {
+                memset(&cands[nc], 0, sizeof cands[nc]);
+                cands[nc].g = g;
+                cands[nc].pw = pw;
+                cands[nc].len = (uint8_t)len;
+                memcpy(cands[nc].frame, fr, (size_t)len);
+            }
+            nc++;
+        }
+    }
+    *n_cands = nc;
+    return nt;
+}
+
 /* ---- output.c:204-262 (WITH_AIR) ---------------------------------------- */
 int orc_formatpkt(const uint8_t *frame, int len, uint64_t ts, uint32_t pw, int outformat,
                   char *pkt)

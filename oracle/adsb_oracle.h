@@ -80,6 +80,10 @@ void orc_decode_buffer(orc_state_t *o, const uint16_t *x, size_t n);
 size_t orc_decode(const uint16_t *x, size_t n, int df18, orc_frame_t *out, size_t cap,
                   uint32_t *stats6);
 
+/* demod.c/valid.c stages only, driven on power samples (see ref_harness.c). */
+size_t orc_demod_power(const float *a, size_t m, int df18, orc_frame_t *out, size_t cap,
+                       uint32_t *stats6);
+
 /* Front end only: power samples a[m], m < 2*ceil(n/4), ring zero-initialised. */
 size_t orc_power(const uint16_t *x, size_t n, float *a);
 
@@ -92,6 +96,11 @@ uint32_t orc_crc_table(int i);
  * returns 0 if the preamble test fails, 1 if it passes but the DF gate rejects,
  * 2 if DF gate passes but CRC fails, 3 if CRC-valid. frame/len/pw filled for >=2. */
 int orc_eval_offset(const float *a, int df18, uint8_t frame[14], int *len, uint32_t *pw);
+
+/* Every offset in [g0,g1) evaluated independently: CRC-valid ones go to cands
+ * (ts unused), DF-gate passes to tries as (g<<2)|code. Returns the try count. */
+size_t orc_scan_all(const float *a, uint64_t g0, uint64_t g1, int df18, orc_frame_t *cands,
+                    size_t cand_cap, size_t *n_cands, uint64_t *tries, size_t try_cap);
 
 /* output.c:204-262 with WITH_AIR. outformat 0 AVR, 1 AVR-MLAT, 2 Beast. */
 int orc_formatpkt(const uint8_t *frame, int len, uint64_t ts, uint32_t pw, int outformat,

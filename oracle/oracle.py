@@ -49,6 +49,9 @@ def lib():
         L.orc_decode.restype = C.c_size_t
         L.orc_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(OrcFrame), C.c_size_t,
                                  C.POINTER(C.c_uint32)]
+        L.orc_demod_power.restype = C.c_size_t
+        L.orc_demod_power.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(OrcFrame), C.c_size_t,
+                                      C.POINTER(C.c_uint32)]
         L.orc_power.restype = C.c_size_t
         L.orc_power.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_crc_residual.restype = C.c_uint32
@@ -58,6 +61,9 @@ def lib():
         L.orc_eval_offset.restype = C.c_int
         L.orc_eval_offset.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int),
                                       C.POINTER(C.c_uint32)]
+        L.orc_scan_all.restype = C.c_size_t
+        L.orc_scan_all.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(OrcFrame),
+                                   C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]
         L.orc_formatpkt.restype = C.c_int
         L.orc_formatpkt.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p]
         _lib = L
@@ -89,6 +95,19 @@ def decode(x, df18: bool = False, cap: int | None = None):
     return frames, stats
 
 
+def demod_power(a: np.ndarray, df18: bool = False, cap: int = 1 << 16):
+    """demod.c/valid.c stages of the restatement on a float32 power array."""
+    assert a.dtype == np.float32
+    out = (OrcFrame * cap)()
+    st = (C.c_uint32 * 6)()
+    n = lib().orc_demod_power(a.ctypes.data, a.size, int(df18), out, cap, st)
+    assert n <= cap
+    frames = [dict(g=int(f.g), ts=int(f.ts), pw=int(f.pw), frame=bytes(f.frame[: f.len]))
+              for f in out[:n]]
+    stats = {"try": {11: st[0], 17: st[1], 18: st[2]}, "ok": {11: st[3], 17: st[4], 18: st[5]}}
+    return frames, stats
+
+
 def power(x) -> np.ndarray:
     x = _as_u16(x)
     m = 2 * ((x.size + 3) // 4)
@@ -110,6 +129,23 @@ def eval_offset(a: np.ndarray, g: int, df18: bool):
     pw = C.c_uint32(0)
     k = lib().orc_eval_offset(a.ctypes.data + 4 * g, int(df18), fr, C.byref(ln), C.byref(pw))
     return k, bytes(fr[: ln.value]) if k >= 2 else b"", int(pw.value)
+
+
+def scan_all(a: np.ndarray, g0: int, g1: int, df18: bool):
+    """Exhaustive per-offset evaluation -> (cands [(g, pw, frame)], tries ndarray u64)."""
+    assert a.dtype == np.float32 and (g1 <= g0 or g1 - 1 + 1196 <= a.size)
+    cc, tc = 4096, 1 << 16
+    while True:
+        cands = (OrcFrame * cc)()
+        tries = np.empty(tc, dtype=np.uint64)
+        nc = C.c_size_t(0)
+        nt = lib().orc_scan_all(a.ctypes.data, g0, g1, int(df18), cands, cc, C.byref(nc),
+                                tries.ctypes.data, tc)
+        if nc.value <= cc and nt <= tc:
+            break
+        cc, tc = max(cc, nc.value), max(tc, nt)
+    return ([(int(c.g), int(c.pw), bytes(c.frame[: c.len])) for c in cands[: nc.value]],
+            tries[:nt].copy())
 
 
 def formatpkt(frame: bytes, ts: int, pw: int, outformat: int) -> bytes:

@@ -1,0 +1,136 @@
+"""CPU tests of the product's host logic, through the C-ABI (no GPU compute calls):
+library loads and exports every declared symbol, the greedy resolver replays the
+reference's sequential rules, formatter bytes, shard planner, and that creating a
+decoder without a GPU fails loudly instead of falling back to anything."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_cases, golden_records, load_golden, records, shard_power
+
+
+def test_library_exports_every_declared_symbol(capi):
+    header = open(os.path.join(ROOT, "include", "adsbdec_amd.h")).read()
+    declared = set(re.findall(r"\b(adsb_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    L = capi.load()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/adsbdec_amd.h but not exported"
+    assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
+    assert L.adsb_abi_version() == 1
+
+
+def test_struct_layouts_match_header(capi):
+    import ctypes as C
+    assert C.sizeof(capi.Frame) == 40 and C.sizeof(capi.Candidate) == 32
+    assert C.sizeof(capi.Stats) == 48
+    assert capi.Frame.frame.offset == 21 and capi.Candidate.frame.offset == 13
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped path must never route through oracle/ (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "adsbdec_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hpp", ".hip", ".cpp")):
+                src = open(os.path.join(base, f), errors="ignore").read()
+                assert not re.search(r"(^|\n)\s*(from|import)\s+oracle\b", src), f
+                assert "liboracle" not in src and "adsb_oracle.h" not in src, f
+
+
+def test_create_without_gpu_fails_loudly(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.AdsbError, match="no HIP device|no CPU fallback|failed"):
+        capi.Decoder()
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_resolver_replays_reference_order_on_golden(capi, oracle, name):
+    x, rec = load_golden(name)
+    a = oracle.power(x)
+    m_real = 2 * (x.size // 4)
+    g_end = max(0, m_real - 1196 + 1)
+    cands, tries = oracle.scan_all(a, 0, g_end, rec["df18"])
+    r = capi.Resolver()
+    r.feed(cands, tries)
+    r.advance(2 * ((x.size + 3) // 4), g_end)
+    assert records(r.drain()) == golden_records(rec)
+    assert r.stats() == rec["stats"]
+
+
+def test_resolver_streaming_equals_one_shot(capi, oracle):
+    """Feeding candidates piecewise as the stream grows gives the same frames."""
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture(1 << 19, seed=21, sigma=60.0, n_frames=200)
+    a = oracle.power(x)
+    g_end = a.size - 1195
+    cands, tries = oracle.scan_all(a, 0, g_end, True)
+    want, wstats = oracle.decode(x, df18=True)
+    r = capi.Resolver()
+    step, done = 28 * 500, 0
+    while done < g_end:
+        nxt = min(g_end, done + step)
+        r.feed([c for c in cands if done <= c[0] < nxt], tries[(tries >> 2 >= done) & (tries >> 2 < nxt)])
+        r.advance(min(a.size, nxt + 1195), nxt)
+        done = nxt
+    r.advance(a.size, g_end)
+    assert records(r.drain()) == records(want)
+    assert r.stats() == wstats
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_format_frame_bytes(capi, name):
+    _, rec = load_golden(name)
+    for g in rec["frames"]:
+        fr = dict(g=g["g"], ts=g["ts"], pw=g["pw"], frame=bytes.fromhex(g["frame"]))
+        assert capi.format_frame(fr, 0) == g["avr"].encode()
+        assert capi.format_frame(fr, 1) == g["mlat"].encode()
+        assert capi.format_frame(fr, 2) == bytes.fromhex(g["beast"])
+
+
+def test_format_frame_escapes_and_large_ts(capi, oracle):
+    fr = dict(g=0, ts=(0x1A1A1A1A1A1A * 10) // 12 + 1, pw=123456, frame=bytes([0x8D, 0x1A, 0x1A] + [0x1A] * 11))
+    for fmt in (0, 1, 2):
+        assert capi.format_frame(fr, fmt) == oracle.formatpkt(fr["frame"], fr["ts"], fr["pw"], fmt)
+    short = dict(g=0, ts=2**50 + 7, pw=0, frame=bytes([0x5D, 1, 2, 3, 4, 5, 0x1A]))
+    for fmt in (0, 1, 2):
+        assert capi.format_frame(short, fmt) == oracle.formatpkt(short["frame"], short["ts"], 0, fmt)
+
+
+@pytest.mark.parametrize("total,n", [(1 << 20, 1), (1 << 20, 2), (1 << 20, 8), ((1 << 22) + 6, 3), (5000, 4), (100, 2)])
+def test_plan_shards_partition(capi, total, n):
+    plan = capi.plan_shards(total, n)
+    m = 2 * (total // 4)
+    n_off = max(0, m - 1195)
+    assert plan[0]["g_begin"] == 0 and plan[-1]["g_end"] == n_off
+    for i, s in enumerate(plan):
+        assert s["g_begin"] % 28 == 0 and s["first_sample"] % 8 == 0
+        if i:
+            assert s["g_begin"] == plan[i - 1]["g_end"]
+        if s["g_end"] > s["g_begin"]:
+            # the buffer covers the pre-halo (6 pairs) and one full window after the last offset
+            assert s["first_sample"] <= max(0, 2 * (s["g_begin"] - 6))
+            assert s["first_sample"] + s["n_samples"] >= 2 * (s["g_end"] - 1 + 1196)
+            assert s["first_sample"] + s["n_samples"] <= total
+
+
+def test_sharded_candidates_resolve_like_one_stream(capi, oracle):
+    """SURVEY 8e on CPU: per-shard exhaustive scans (oracle standing in for the device,
+    tests only) over the planner's halo'd sample ranges + one host resolver == the
+    sequential reference."""
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture(1 << 20, seed=33, sigma=45.0, n_frames=300)
+    want, wstats = oracle.decode(x, df18=True)
+    for n_shards in (2, 5):
+        r = capi.Resolver()
+        for s in capi.plan_shards(x.size, n_shards):
+            a, off = shard_power(oracle, x, s)
+            cands, tries = oracle.scan_all(a, s["g_begin"] - off, s["g_end"] - off, True)
+            r.feed([(g + off, pw, fr) for g, pw, fr in cands], tries + np.uint64(off << 2))
+        r.advance(2 * (x.size // 4), 2 * (x.size // 4) - 1195)
+        assert records(r.drain()) == records(want)
+        assert r.stats() == wstats
