@@ -167,16 +167,18 @@ class Decoder:
     def pending(self) -> int:
         return int(self._L.adsb_pending(self._h))
 
+    def drain_raw(self):
+        """All pending frames as one ctypes Frame array (no per-frame Python work)."""
+        n = self.pending()
+        buf = (Frame * max(1, n))()
+        got = self._L.adsb_drain(self._h, buf, n) if n else 0
+        if got < 0:
+            raise AdsbError("adsb_drain failed")
+        return buf, int(got)
+
     def drain(self):
-        out = []
-        buf = (Frame * 4096)()
-        while True:
-            n = self._L.adsb_drain(self._h, buf, 4096)
-            if n < 0:
-                raise AdsbError("adsb_drain failed")
-            if n == 0:
-                return out
-            out.extend(_frames_to_dicts(buf, n))
+        buf, n = self.drain_raw()
+        return _frames_to_dicts(buf, n)
 
     def stats(self):
         st = Stats()

@@ -1,0 +1,18 @@
+import sys, time, os
+sys.path.insert(0, os.getcwd())
+import torch, numpy as np
+from adsbdec_amd import capi
+from bench import make_workload
+torch.cuda.set_device(0)
+n = (256<<20); n -= n % 28
+x, truth = make_workload(torch, n, seed=1)
+torch.cuda.synchronize()
+dec = capi.Decoder(profile=True)
+for it in range(6):
+    t0=time.perf_counter(); dec.reset()
+    t1=time.perf_counter(); dec.push_device(x.data_ptr(), x.numel())
+    t2=time.perf_counter(); dec.finish()
+    t3=time.perf_counter(); raw = dec.drain_raw()
+    t4=time.perf_counter()
+    p = dec.profile()
+    print(f"reset {1e3*(t1-t0):.3f} push {1e3*(t2-t1):.3f} finish {1e3*(t3-t2):.3f} drain {1e3*(t4-t3):.3f} ms | kernel {p['kernel_ms']:.3f} ms launches {p['launches']} cands {p['candidates']}")
