@@ -60,6 +60,8 @@ struct adsb_decoder {
     uint64_t stage_fill = 0;  // samples held
 
     // device record buffers + pinned mirrors
+    uint32_t *d_synd = nullptr; // 14 x 256 CRC-24 syndrome table (scan_kernel.h)
+    int n_cus = 256;
     uint32_t *d_counters = nullptr;
     uint32_t *d_cands = nullptr;
     uint32_t *d_tries = nullptr;
@@ -164,6 +166,8 @@ int scan_range(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64_
             a.g_begin = g_begin;
             a.g_end = g_stop;
             a.df18 = d->cfg.df18 ? 1 : 0;
+            a.passes = adsb::choose_passes(n_off, d->n_cus);
+            a.synd = d->d_synd;
             a.counters = d->d_counters;
             a.cands = d->d_cands;
             a.cand_cap = (uint32_t)std::min<size_t>(d->cand_cap, 0xFFFFFFFFu);
@@ -386,6 +390,15 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipMalloc(stage)", e);
     if ((e = hipMalloc(&d->d_counters, 2 * sizeof(uint32_t))) != hipSuccess)
         return bail("hipMalloc(counters)", e);
+    {
+        std::vector<uint32_t> synd(adsb::kSyndWords);
+        adsb::make_syndrome_table(synd.data());
+        if ((e = hipMalloc(&d->d_synd, synd.size() * sizeof(uint32_t))) != hipSuccess)
+            return bail("hipMalloc(synd)", e);
+        if ((e = hipMemcpy(d->d_synd, synd.data(), synd.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
+            return bail("hipMemcpy(synd)", e);
+    }
+    d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((e = hipHostMalloc(&d->h_counters, 2 * sizeof(uint32_t))) != hipSuccess)
         return bail("hipHostMalloc(counters)", e);
     if ((e = hipEventCreate(&d->ev0)) != hipSuccess || (e = hipEventCreate(&d->ev1)) != hipSuccess)
@@ -405,6 +418,7 @@ void adsb_destroy(adsb_decoder *d)
         if (d->stage[i])
             (void)hipFree(d->stage[i]);
     if (d->d_counters) (void)hipFree(d->d_counters);
+    if (d->d_synd) (void)hipFree(d->d_synd);
     if (d->d_cands) (void)hipFree(d->d_cands);
     if (d->d_tries) (void)hipFree(d->d_tries);
     if (d->h_counters) (void)hipHostFree(d->h_counters);

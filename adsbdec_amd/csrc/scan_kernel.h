@@ -6,17 +6,32 @@
 
 namespace adsb {
 
-constexpr int kRun = 28;       // power samples per thread run (4 x 7: see scan_kernel.hip)
-constexpr int kThreads = 256;  // 4 wavefronts
-constexpr int kPasses = 2;     // runs per thread
-constexpr int kTileA = kRun * kThreads * kPasses; // 14336 power samples staged in LDS
-constexpr int kHalo = 1204;    // >= ADSB_WINDOW (1196), multiple of 28
-constexpr int kTileG = kTileA - kHalo; // 13132 offsets owned by one workgroup
-constexpr int kCandWords = 6;  // {g_rel, pw, frame[0..13] | len<<16 in the last word}
-constexpr uint64_t kMaxLaunchOffsets = (1ull << 30) - kTileG; // g_rel must fit 30 bits
+// Tuning knobs; the defaults are what ships. tools/kbench.hip overrides them with -D.
+#ifndef ADSB_ABLATE
+#define ADSB_ABLATE 0 // kbench only: 1 = loads only, 2 = front end + bit planes only
+#endif
+#ifndef ADSB_MIN_WAVES
+#define ADSB_MIN_WAVES 4 // __launch_bounds__ second argument (waves per SIMD)
+#endif
 
-static_assert(kTileG % 28 == 0, "tiles must start on a multiple of 28 power samples");
-static_assert(kHalo >= 1196, "halo must cover one long-frame evaluation");
+constexpr int kRun = 28;        // power samples per thread run (4 x 7: see scan_kernel.hip)
+constexpr int kThreads = 256;   // 4 wavefronts
+constexpr int kWaveRuns = 63;   // distinct runs per wave and pass (lane 63 re-computes the next wave's first run)
+constexpr int kPassRuns = 4 * kWaveRuns;        // 252
+constexpr int kReachRuns = 44;  // runs of bit planes one long-frame evaluation reaches ahead: ceil((27+1195)/28)
+constexpr int kMaxPasses = 32;
+constexpr int kQueueCap = 1024; // survivors compacted per round
+constexpr int kPlanePad = 8;
+constexpr int kCandWords = 6;   // {g_rel, pw, frame[0..13] | len<<16 in the last word}
+constexpr int kSyndWords = 14 * 256;
+
+constexpr int owned_runs(int passes) { return kPassRuns * passes - kReachRuns; }
+constexpr int tile_offsets(int passes) { return kRun * owned_runs(passes); }
+constexpr size_t lds_bytes(int passes)
+{
+    return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 8);
+}
+constexpr uint64_t kMaxLaunchOffsets = (1ull << 30) - tile_offsets(kMaxPasses); // g_rel must fit 30 bits
 
 struct ScanArgs {
     const uint32_t *x;   // (I,Q) pairs; x[0] is stream pair index pbuf0 (16-byte aligned, pbuf0 % 4 == 0)
@@ -25,6 +40,8 @@ struct ScanArgs {
     uint64_t g_begin;    // first offset to evaluate, multiple of 28
     uint64_t g_end;      // one past the last offset
     int df18;            // demod.c:26
+    int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
+    const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
     uint32_t *counters;  // [0] candidates, [1] tries (may exceed the capacities)
     uint32_t *cands;     // kCandWords dwords per record
     uint32_t cand_cap;
@@ -32,6 +49,11 @@ struct ScanArgs {
     uint32_t try_cap;
 };
 
+// Host: fill the 14 x 256 syndrome table (crc.h generator 0xFFF409).
+void make_syndrome_table(uint32_t *out /* kSyndWords */);
+// Host: choose the passes-per-tile for a launch of n_offsets on a device with
+// `slots` resident workgroups (balances halo overhead against tail quantisation).
+int choose_passes(uint64_t n_offsets, int cus);
 hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream);
 
 } // namespace adsb

@@ -4,7 +4,7 @@
 // real uint16 20 MS/s samples and appends a record for each offset at which the
 // reference would have found a CRC-valid frame had it visited that offset:
 //
-//   air.c:54-92    u16 -> f32, fs/4 sign, 14-tap FIR (7 I + 7 Q), |.|^2, /2 decimation
+//   air.c:54-92     u16 -> f32, fs/4 sign, 14-tap FIR (7 I + 7 Q), |.|^2, /2 decimation
 //   demod.c:102-107 preamble test   p1 > 2*s1 && p2 > 2*s2  (f32 add -> int)
 //   demod.c:46-81   DF gate on byte 0 (DF11 / DF17 / DF18 with -a)
 //   demod.c:31-44   PPM slicer, 8 strict '>' compares per byte
@@ -13,22 +13,44 @@
 // The greedy skip, ts and the end-of-file horizon are sequential and are replayed
 // on the host over these sparse records (resolver.hpp).
 //
-// Layout / mapping (HBM-bound integer+f32 scan; no MFMA -- there is no contraction):
-//   * input is read once as (I,Q) uint16 PAIRS, one dword each, 16 B per lane-load;
-//   * a workgroup owns kTileG consecutive offsets and computes kTileA = kTileG + halo
-//     power samples into LDS (f32); the halo (1204 >= 1196) is the reach of one
-//     long-frame evaluation, so tiles are independent and no power sample ever
-//     goes to HBM;
-//   * a thread computes a RUN of 28 consecutive power samples. 28 = 4 x 7 keeps the
-//     FIR's summation order -- which in the reference depends on (sample index mod
-//     14), i.e. on m mod 7 -- a compile-time property of each output,
-//     so the 7 rounding orders are straight-line code, and 28 dwords = 112 B keeps
-//     every LDS access a conflict-free 16-byte one (28*t mod 64 hits 16 distinct
-//     4-bank slots for any 16 lanes with distinct t mod 16);
-//   * arithmetic is strict binary32: multiply, then add (file is built with
-//     -ffp-contract=off; the ISA is checked for the absence of v_fma/v_mac).
+// Structure (HBM-bound integer+f32 scan; no MFMA -- there is no contraction):
+//
+//  Stage A (all the arithmetic; no barriers, no divergence).  A thread computes a
+//  RUN of 28 consecutive power samples in registers.  28 = 4 x 7 keeps the FIR's
+//  summation order -- which in the reference depends on (sample index mod 14), i.e.
+//  on m mod 7 -- a compile-time property of each output, so the seven
+//  rounding orders are straight-line code with immediate taps.  Every comparison
+//  the reference will ever make on those samples is then reduced to ONE BIT per
+//  power sample, packed 28 to a word ("bit planes"):
+//      D [m] = a[m]   > a[m+5]                (every slicer / DF-gate decision)
+//      E1[m] = c[m]   > 2*c[m+5]              (p1 > 2*s1 for the offset g = m)
+//      E2[m] = c[m+5] > 2*c[m]                (p2 > 2*s2 for the offset g = m-30)
+//  with c[m] = (int)(a[m] + a[m+10]) -- all four preamble sums of demod.c:102-105
+//  have that form.  The 16 samples a thread needs from the following run come from
+//  the next lane by DPP (wave_shl:1); lane 63 of a wave re-computes the first run
+//  of the next wave (1/64 redundancy) so waves never exchange data and Stage A has
+//  no barrier.  Power samples never leave registers; LDS receives 12 bytes per 28
+//  samples.
+//
+//  Stage B (bit logic).  For the 28 offsets of a run the preamble test and the DF
+//  gate are ~30 word-wide bit operations on funnel-shifted plane words (SIMD within
+//  a register: no per-offset branch).  Survivors (~0.5 % of offsets on noise) are
+//  compacted through an LDS queue, so the slicer runs with dense lanes.  The slicer
+//  gathers the 112 frame bits as 14 columns of 8 bits (bit k = 14b + c sits in word
+//  +5b at a fixed bit position, because 140 = 5 x 28) and checks the CRC as the XOR
+//  of 14 syndrome-table lookups; only CRC-valid offsets (~1e-4) take the slow path
+//  that rebuilds the bytes in order and recomputes pw from the input samples.
+//
+//  A workgroup owns owned_runs(K) = 252 K - 44 runs and computes 252 K (+1): the halo
+//  (the 1196-sample reach of a long frame) costs 44 runs of planes per tile (2 % at
+//  K = 8) instead of 1204 float samples of LDS.
+//
+// Arithmetic is strict binary32: multiply, then add (built with -ffp-contract=off;
+// tests/test_build_flags.py checks the ISA for the absence of v_fma/v_mac).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "scan_kernel.h"
 
@@ -87,53 +109,107 @@ __device__ __forceinline__ float power_sample(const float (&vi)[34], const float
     return si * si + sq * sq; // air.c:76,91
 }
 
-template <int J0>
-__device__ __forceinline__ float4 power_quad(const float (&vi)[34], const float (&vq)[34])
+template <int J0, int N>
+__device__ __forceinline__ void power_block(const float (&vi)[34], const float (&vq)[34], float *a)
 {
-    return make_float4(power_sample<J0>(vi, vq), power_sample<J0 + 1>(vi, vq),
-                       power_sample<J0 + 2>(vi, vq), power_sample<J0 + 3>(vi, vq));
+    if constexpr (N > 0) {
+        a[J0] = power_sample<J0>(vi, vq);
+        power_block<J0 + 1, N - 1>(vi, vq, a);
+    }
 }
 
-// demod.c:31-44: bit i of a byte starting at power index l is a[l+10i] > a[l+10i+5].
-__device__ __forceinline__ uint32_t slice_byte(const float *a)
+// Same arithmetic for ONE power sample at a run-time index (slow path: pw of a
+// CRC-valid candidate).  Rounds exactly like power_sample<>: same products, same
+// order, first product not added to zero.
+__device__ __noinline__ float power_at(const uint32_t *__restrict__ x, int64_t pbuf0, int64_t p_lo, int64_t p_hi,
+                                         int64_t m)
 {
-    uint32_t b = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        b |= (a[10 * i] > a[10 * i + 5]) ? (0x80u >> i) : 0u;
-    return b;
+    static constexpr float tabI[7] = {tap<12>(), tap<10>(), tap<8>(), tap<6>(), tap<4>(), tap<2>(), tap<0>()};
+    static constexpr float tabQ[7] = {tap<13>(), tap<11>(), tap<9>(), tap<7>(), tap<5>(), tap<3>(), tap<1>()};
+    const int p = (int)(m % 7);
+    float si = 0.0f, sq = 0.0f;
+#pragma unroll 1
+    for (int step = 0; step < 7; step++) {
+        const int age = (step <= p) ? (p - step) : (6 - (step - p - 1));
+        const int64_t pr = m - age;
+        const uint32_t d = (pr >= p_lo && pr < p_hi) ? x[pr - pbuf0] : 0x08000800u;
+        const float fi = (float)(d & 0xFFFFu), fq = (float)(d >> 16);
+        const float vi = (pr & 1) ? 2048.0f - fi : fi - 2048.0f;
+        const float vq = (pr & 1) ? 2048.0f - fq : fq - 2048.0f;
+        const float pi = tabI[age] * vi, pq = tabQ[age] * vq;
+        si = (step == 0) ? pi : si + pi;
+        sq = (step == 0) ? pq : sq + pq;
+    }
+    return si * si + sq * sq;
+}
+
+// acc = (acc << 1) | sign(v): one v_alignbit_b32
+__device__ __forceinline__ uint32_t push_sign(uint32_t acc, uint32_t v)
+{
+    return __builtin_amdgcn_alignbit(acc, v, 31);
+}
+
+// value held by lane+1 (DPP wave_shl:1); lane 63 receives 0
+__device__ __forceinline__ float from_next_lane(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+
+// 28 bits starting at bit `POS` of the stream w[0] | w[1]<<28 | w[2]<<56 | ... (28 valid bits per word)
+template <int POS>
+__device__ __forceinline__ uint32_t take28(const uint32_t *w)
+{
+    constexpr int k = POS / 28, s = POS % 28;
+    uint32_t r = w[k] >> s;
+    if constexpr (s != 0)
+        r |= w[k + 1] << (28 - s);
+    return r & 0x0FFFFFFFu;
 }
 
 } // namespace
 
 template <bool kStats>
-__global__ __launch_bounds__(kThreads) void scan_kernel(const ScanArgs args)
+__global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const ScanArgs args)
 {
-    __shared__ __attribute__((aligned(16))) float a_lds[kTileA];
-    __shared__ uint32_t crc_lds[256];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int K = args.passes;
+    const int nplane = kPassRuns * K + kPlanePad;
+    uint32_t *pl_d = smem;
+    uint32_t *pl_e1 = smem + nplane;
+    uint32_t *pl_e2 = smem + 2 * nplane;
+    uint32_t *queue = smem + 3 * nplane;
+    uint32_t *qcount = queue + kQueueCap;
+
+    // kernel arguments are only ever used by value (taking their address would
+    // demote the sample pointer to a flat/scratch access)
+    const uint32_t *__restrict__ xin = args.x;
+    const int64_t pbuf0 = args.pbuf0, p_lo = args.p_lo, p_hi = args.p_hi;
 
     const int tid = threadIdx.x;
-    const int64_t t0 = (int64_t)args.g_begin + (int64_t)blockIdx.x * kTileG; // first owned offset
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int own = kPassRuns * K - kReachRuns;
+    const int64_t t0 = (int64_t)args.g_begin + (int64_t)blockIdx.x * kRun * own; // first owned offset
 
-    // crc.h:1-34: MSB-first byte table of generator 0xFFF409, built in place.
-    {
-        uint32_t c = (uint32_t)tid << 16;
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            c = (c & 0x800000u) ? ((c << 1) ^ 0xFFF409u) : (c << 1);
-        crc_lds[tid] = c & 0xFFFFFFu;
+    // plane words past the last computed run are read (never used) by Stage B
+    if (tid < kPlanePad) {
+        pl_d[kPassRuns * K + tid] = 0;
+        pl_e1[kPassRuns * K + tid] = 0;
+        pl_e2[kPassRuns * K + tid] = 0;
     }
 
-    // ---------------- phase 1: front end, kTileA power samples into LDS ----------------
-    // A tile is "interior" when every pair it loads lies inside the buffer.
-    const bool interior = (t0 - 8 >= args.p_lo) && (t0 + kTileA <= args.p_hi);
+    // ------------------------------ Stage A ------------------------------
 #pragma unroll 1
-    for (int pass = 0; pass < kPasses; pass++) {
-        const int run = pass * kThreads + tid;
-        const int64_t pr0 = t0 + (int64_t)kRun * run - 8; // first pair loaded; multiple of 4
+    for (int pass = 0; pass < K; pass++) {
+        const int v0 = kWaveRuns * (4 * pass + wave); // first run of this wave in this pass
+        const int v = v0 + lane;
+        const int64_t pr0 = t0 + (int64_t)kRun * v - 8; // first pair loaded; multiple of 4
+        // wave-uniform: every pair this wave loads lies inside the buffer
+        const int64_t wlo = t0 + (int64_t)kRun * v0 - 8;
+        const bool interior = (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
         uint32_t w[36];
         if (interior) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(args.x + (pr0 - args.pbuf0));
+            const uint4 *src = reinterpret_cast<const uint4 *>(xin + (pr0 - pbuf0));
 #pragma unroll
             for (int k = 0; k < 9; k++) {
                 const uint4 q = src[k];
@@ -148,10 +224,20 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanArgs args)
 #pragma unroll
             for (int k = 0; k < 36; k++) {
                 const int64_t pr = pr0 + k;
-                w[k] = (pr >= args.p_lo && pr < args.p_hi) ? args.x[pr - args.pbuf0] : 0x08000800u;
+                w[k] = (pr >= p_lo && pr < p_hi) ? xin[pr - pbuf0] : 0x08000800u;
             }
         }
-
+#if ADSB_ABLATE == 1
+        {   // kbench: price the loads alone
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 36; k++)
+                acc ^= w[k];
+            if (lane < kWaveRuns)
+                pl_d[v] = acc;
+            continue;
+        }
+#endif
         // air.c:64-67,79-82: v = (float)x - 2048; pairs with odd index are negated
         // (samples n mod 4 in {2,3}).  The run starts at an even pair index, so the
         // sign is a compile-time property of the slot.  -(x-2048) == 2048-x exactly.
@@ -170,122 +256,207 @@ __global__ __launch_bounds__(kThreads) void scan_kernel(const ScanArgs args)
             }
         }
 
-        float4 *dst = reinterpret_cast<float4 *>(a_lds + kRun * run);
-        dst[0] = power_quad<0>(vi, vq);
-        dst[1] = power_quad<4>(vi, vq);
-        dst[2] = power_quad<8>(vi, vq);
-        dst[3] = power_quad<12>(vi, vq);
-        dst[4] = power_quad<16>(vi, vq);
-        dst[5] = power_quad<20>(vi, vq);
-        dst[6] = power_quad<24>(vi, vq);
+        // a[0..27]: this run; a[28..43]: the first 16 samples of the next run (next lane)
+        float a[44];
+        power_block<0, 28>(vi, vq, a);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            a[28 + k] = from_next_lane(a[k]);
+
+        // demod.c:102-105: every preamble sum is c[k] = (int)(a[k] + a[k+10])
+        int c[33];
+#pragma unroll
+        for (int k = 0; k < 33; k++)
+            c[k] = __float2int_rz(a[k] + a[k + 10]);
+
+        uint32_t d = 0, e1 = 0, e2 = 0;
+#pragma unroll
+        for (int m = 27; m >= 0; m--) { // bit m of each word <-> sample m of the run
+            d = push_sign(d, __float_as_uint(a[m + 5] - a[m]));  // a[m] > a[m+5]   (demod.c:34)
+            e1 = push_sign(e1, (uint32_t)(2 * c[m + 5] - c[m])); // c[m] > 2 c[m+5] (SN = 2, demod.c:83)
+            e2 = push_sign(e2, (uint32_t)(2 * c[m] - c[m + 5])); // c[m+5] > 2 c[m]
+        }
+        if (lane < kWaveRuns) { // lane 63 only feeds lane 62
+            pl_d[v] = d;
+            pl_e1[v] = e1;
+            pl_e2[v] = e2;
+        }
     }
     __syncthreads();
+#if ADSB_ABLATE != 0
+    if (pl_d[(tid * 29) % (kPassRuns * K)] == 0x12345678u) // kbench: keep Stage A alive, skip the rest
+        atomicAdd(&args.counters[0], 1u);
+    return;
+#endif
 
-    // ---------------- phase 2: preamble test for 28 offsets per thread ----------------
-    const int64_t owned_end = (int64_t)args.g_end - t0; // offsets of this tile below g_end
+    // ------------------------------ Stage B ------------------------------
+    int64_t off_end = (int64_t)args.g_end - t0; // offsets of this tile that exist
+    if (off_end > (int64_t)kRun * own)
+        off_end = (int64_t)kRun * own;
+
 #pragma unroll 1
-    for (int pass = 0; pass < kPasses; pass++) {
-        const int run = pass * kThreads + tid;
-        const int gl0 = kRun * run;
-        int64_t nvalid = kTileG - gl0;
-        if (owned_end - gl0 < nvalid)
-            nvalid = owned_end - gl0;
-        if (nvalid <= 0)
-            continue;
-
-        float f[76];
-        {
-            const float4 *src = reinterpret_cast<const float4 *>(a_lds + gl0);
-#pragma unroll
-            for (int k = 0; k < 19; k++) {
-                const float4 q = src[k];
-                f[4 * k + 0] = q.x;
-                f[4 * k + 1] = q.y;
-                f[4 * k + 2] = q.z;
-                f[4 * k + 3] = q.w;
-            }
+    for (int base = 0; base < own; base += kThreads) {
+        const int v = base + tid;
+        uint32_t gate = 0, m11 = 0, m17 = 0;
+        if (v < own && (int64_t)kRun * v < off_end) {
+            const uint32_t e2w[2] = {pl_e2[v + 1], pl_e2[v + 2]};
+            const uint32_t dw[4] = {pl_d[v + 2], pl_d[v + 3], pl_d[v + 4], pl_d[v + 5]};
+            // preamble: p1 > 2 s1 at g, p2 > 2 s2 <=> E2 at g + 30
+            const uint32_t pre = pl_e1[v] & take28<30 - 28>(e2w);
+            // byte 0, bits 0..4 sit 80, 90, .., 120 samples after g (demod.c:109,46-81)
+            const uint32_t b0 = take28<80 - 56>(dw), b1 = take28<90 - 56>(dw), b2 = take28<100 - 56>(dw),
+                           b3 = take28<110 - 56>(dw), b4 = take28<120 - 56>(dw);
+            m17 = b0 & ~b1 & ~b2 & ~b3 & b4;                                   // 10001 (demod.c:64-67)
+            m11 = ~b0 & b1 & ~b2 & b3 & b4;                                    // 01011 (demod.c:70-77)
+            const uint32_t m18 = args.df18 ? (b0 & ~b1 & ~b2 & b3 & ~b4) : 0u; // 10010 (demod.c:57-62)
+            gate = pre & (m17 | m11 | m18);
+            const int64_t nvalid = off_end - (int64_t)kRun * v;
+            if (nvalid < kRun)
+                gate &= (1u << (int)nvalid) - 1u;
         }
-        // demod.c:102-105: p1 = a[g]+a[g+10], s1 = a[g+5]+a[g+15], p2 = a[g+35]+a[g+45],
-        // s2 = a[g+30]+a[g+40]; every one of them is c[k] = (int)(a[k] + a[k+10]).
-        int c[63];
+
+        // compaction rounds: normally exactly one
+        while (__syncthreads_or(gate != 0)) {
+            for (int q = tid; q < kQueueCap; q += kThreads)
+                queue[q] = 0xFFFFFFFFu;
+            if (tid == 0)
+                *qcount = 0;
+            __syncthreads();
+            const int n = __popc(gate);
+            if (n) {
+                const uint32_t slot = atomicAdd(qcount, (uint32_t)n);
+                if (slot + n <= kQueueCap) {
+                    uint32_t s = slot;
+                    while (gate) {
+                        const int j = __ffs(gate) - 1;
+                        gate &= gate - 1;
+                        const uint32_t code = ((m11 >> j) & 1u) ? 0u : ((m17 >> j) & 1u) ? 1u : 2u;
+                        queue[s++] = ((uint32_t)v << 7) | ((uint32_t)j << 2) | code;
+                    }
+                }
+            }
+            __syncthreads();
+            const int qn = min((int)*qcount, kQueueCap);
+            for (int q = tid; q < qn; q += kThreads) {
+                const uint32_t ent = queue[q];
+                if (ent == 0xFFFFFFFFu)
+                    continue; // hole left by a reservation that did not fit
+                const int sv = (int)(ent >> 7), sj = (int)((ent >> 2) & 31u);
+                const uint32_t code = ent & 3u;
+                const uint32_t g_rel = (uint32_t)(t0 - (int64_t)args.g_begin) + (uint32_t)(kRun * sv + sj);
+                if (kStats) { // valid.c:46,68: every DF-gate pass that is visited is a Try
+                    const uint32_t ts = atomicAdd(&args.counters[1], 1u);
+                    if (ts < args.try_cap)
+                        args.tries[ts] = (g_rel << 2) | code;
+                }
+                // Frame bit k = 14 b + c lies 80 + 10 k samples after g: column c is
+                // at stream position sj + 80 + 10 c (+ 140 b = 5 words per b).
+                const uint32_t *dcol = pl_d + sv;
+                uint32_t syn = 0;
 #pragma unroll
-        for (int k = 0; k < 63; k++)
-            c[k] = __float2int_rz(f[k] + f[k + 10]);
-        uint32_t mask = 0;
+                for (int cc = 0; cc < 14; cc++) {
+                    const int pos = sj + 80 + 10 * cc;
+                    const int wi = (pos * 2341) >> 16; // pos / 28 for pos < 5000
+                    const int bp = pos - 28 * wi;
+                    uint32_t col = 0;
 #pragma unroll
-        for (int j = 0; j < kRun; j++) {
-            const bool hit = (c[j] > 2 * c[j + 5]) && (c[j + 35] > 2 * c[j + 30]); // SN = 2
-            mask |= hit ? (1u << j) : 0u;
-        }
-        if (nvalid < kRun)
-            mask &= (1u << (int)nvalid) - 1u;
+                    for (int b = 0; b < 8; b++)
+                        col |= ((dcol[wi + 5 * b] >> bp) & 1u) << b;
+                    // short frames are bits 0..55 = rows b < 4; their syndromes are the
+                    // long frame's 56 bits (4 rows) further on
+                    const uint32_t idx = (code == 0) ? ((col & 15u) << 4) : col;
+                    syn ^= args.synd[cc * 256 + idx];
+                }
+                if (syn != 0)
+                    continue; // valid.c:51,73
 
-        // ------------- phase 3: DF gate, slicer, CRC for the offsets that passed -------------
-        while (mask) {
-            const int j = __ffs(mask) - 1;
-            mask &= mask - 1;
-            const int gl = gl0 + j;
-            const float *a = a_lds + gl;
-
-            const uint32_t b0 = slice_byte(a + 80); // demod.c:109-112
-            const uint32_t dfv = b0 >> 3;
-            int nbytes;
-            uint32_t code;
-            if (dfv == 11) { // demod.c:72-77
-                nbytes = 7;
-                code = 0;
-            } else if (dfv == 17) { // demod.c:64-67
-                nbytes = 14;
-                code = 1;
-            } else if (dfv == 18 && args.df18) { // demod.c:57-62
-                nbytes = 14;
-                code = 2;
-            } else {
-                continue; // demod.c:113-116
-            }
-            const uint32_t g_rel = (uint32_t)(t0 - (int64_t)args.g_begin) + (uint32_t)gl;
-            if (kStats) { // valid.c:46,68 count every DF-gate pass that is visited
-                const uint32_t slot = atomicAdd(&args.counters[1], 1u);
-                if (slot < args.try_cap)
-                    args.tries[slot] = (g_rel << 2) | code;
-            }
-
-            // valid.c:49-51 / 71-73: table CRC over the first n-3 bytes, xor last three
-            uint32_t crc = crc_lds[b0]; // CrcStep(b0, 0) == table[b0]
-            uint32_t tail = 0;
-            for (int k = 1; k < nbytes; k++) {
-                const uint32_t b = slice_byte(a + 80 + 80 * k);
-                if (k < nbytes - 3)
-                    crc = (crc << 8) ^ crc_lds[(b ^ (crc >> 16)) & 0xFFu];
-                else
-                    tail = (tail << 8) | b;
-            }
-            if (((crc & 0xFFFFFFu) ^ tail) != 0)
-                continue;
-
-            // CRC-valid: emit {g_rel, pw, frame[14], len}
-            const int p1 = __float2int_rz(a[0] + a[10]);
-            const int p2 = __float2int_rz(a[35] + a[45]);
-            const uint32_t pw = (uint32_t)((p1 + p2) / 4); // demod.c:127,133
-            const uint32_t slot = atomicAdd(&args.counters[0], 1u);
-            if (slot < args.cand_cap) {
-                uint32_t *rec = args.cands + (size_t)slot * kCandWords;
+                // CRC-valid (rare): rebuild the bytes in order and recompute pw
+                const int nbytes = (code == 0) ? 7 : 14;
                 uint32_t wds[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int k = 0; k < 14; k++) {
-                    const uint32_t b = (k < nbytes) ? slice_byte(a + 80 + 80 * k) : 0u;
-                    wds[k >> 2] |= b << (8 * (k & 3));
+                    uint32_t byte = 0;
+                    if (k < nbytes) {
+#pragma unroll 1
+                        for (int i = 0; i < 8; i++) {
+                            const int pos = sj + 80 + 80 * k + 10 * i;
+                            const int wi = (pos * 2341) >> 16;
+                            byte |= ((dcol[wi] >> (pos - 28 * wi)) & 1u) ? (0x80u >> i) : 0u;
+                        }
+                    }
+                    wds[k >> 2] |= byte << (8 * (k & 3));
                 }
                 wds[3] |= (uint32_t)nbytes << 16;
-                rec[0] = g_rel;
-                rec[1] = pw;
-                rec[2] = wds[0];
-                rec[3] = wds[1];
-                rec[4] = wds[2];
-                rec[5] = wds[3];
+                const int64_t g = t0 + (int64_t)kRun * sv + sj;
+                const int p1 = __float2int_rz(power_at(xin, pbuf0, p_lo, p_hi, g) + power_at(xin, pbuf0, p_lo, p_hi, g + 10));
+                const int p2 = __float2int_rz(power_at(xin, pbuf0, p_lo, p_hi, g + 35) + power_at(xin, pbuf0, p_lo, p_hi, g + 45));
+                const uint32_t pw = (uint32_t)((p1 + p2) / 4); // demod.c:127,133
+                const uint32_t slot = atomicAdd(&args.counters[0], 1u);
+                if (slot < args.cand_cap) {
+                    uint32_t *rec = args.cands + (size_t)slot * kCandWords;
+                    rec[0] = g_rel;
+                    rec[1] = pw;
+                    rec[2] = wds[0];
+                    rec[3] = wds[1];
+                    rec[4] = wds[2];
+                    rec[5] = wds[3];
+                }
             }
+            // the __syncthreads_or at the loop head orders the reuse of the queue
         }
     }
+}
+
+void make_syndrome_table(uint32_t *out)
+{
+    // S[k] = x^(111-k) mod G, G = x^24 + 0xFFF409 (crc.h): the residual of
+    // valid.c:49-51,71-73 is the XOR of S[k] over the set frame bits k.
+    uint32_t s[112];
+    uint32_t r = 1;
+    for (int e = 0; e < 112; e++) {
+        s[111 - e] = r;
+        r <<= 1;
+        if (r & 0x1000000u)
+            r ^= 0x1FFF409u;
+    }
+    for (int c = 0; c < 14; c++)
+        for (int v = 0; v < 256; v++) {
+            uint32_t acc = 0;
+            for (int b = 0; b < 8; b++)
+                if (v & (1 << b))
+                    acc ^= s[14 * b + c];
+            out[c * 256 + v] = acc;
+        }
+}
+
+int choose_passes(uint64_t n_offsets, int cus)
+{
+    // Estimated time = rounds x passes, rounds = ceil(tiles / resident workgroups);
+    // long tiles amortise the 44-run halo, short ones fill the last round better.
+    if (cus <= 0)
+        cus = 256;
+    int best = 2;
+    double best_cost = 1e300;
+    for (int k = 2; k <= 16; k++) {
+        const uint64_t per = (uint64_t)tile_offsets(k);
+        const uint64_t tiles = (n_offsets + per - 1) / per;
+        int per_cu = (int)(160 * 1024 / lds_bytes(k));
+        if (per_cu > ADSB_MIN_WAVES)
+            per_cu = ADSB_MIN_WAVES; // register-limited: __launch_bounds__(256, ADSB_MIN_WAVES)
+        if (per_cu < 1)
+            continue;
+        const uint64_t slots = (uint64_t)cus * per_cu;
+        const uint64_t rounds = (tiles + slots - 1) / slots;
+        // a partially filled last round runs faster per workgroup; weight it by its fill
+        const double last = (double)(tiles - (rounds - 1) * slots) / (double)slots;
+        const double eff_rounds = (double)(rounds - 1) + (0.35 + 0.65 * last);
+        const double cost = eff_rounds * (k + 0.25) / per_cu;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = k;
+        }
+    }
+    return best;
 }
 
 hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream)
@@ -293,11 +464,17 @@ hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream)
     if (args.g_end <= args.g_begin)
         return hipSuccess;
     const uint64_t n = args.g_end - args.g_begin;
-    const uint64_t blocks = (n + kTileG - 1) / kTileG;
+    const uint64_t per = (uint64_t)tile_offsets(args.passes);
+    const uint64_t blocks = (n + per - 1) / per;
+    const size_t lds = lds_bytes(args.passes);
+    if (getenv("ADSB_DEBUG_LAUNCH"))
+        fprintf(stderr, "launch_scan: n=%llu passes=%d per=%llu blocks=%llu lds=%zu prior_err=%d\n",
+                (unsigned long long)n, args.passes, (unsigned long long)per, (unsigned long long)blocks, lds,
+                (int)hipPeekAtLastError());
     if (stats)
-        hipLaunchKernelGGL(scan_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, args);
+        hipLaunchKernelGGL(scan_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args);
     else
-        hipLaunchKernelGGL(scan_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, args);
+        hipLaunchKernelGGL(scan_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args);
     return hipGetLastError();
 }
 

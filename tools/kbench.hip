@@ -1,0 +1,61 @@
+// kbench.hip -- stand-alone timing of adsb::scan_kernel variants (tile shape via
+// -DADSB_THREADS / -DADSB_PASSES, ablations via -DADSB_ABLATE). Not part of the library.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I adsbdec_amd/csrc tools/kbench.hip -o kbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include "scan_kernel.hip"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+__global__ void fill_noise(uint16_t *x, size_t n, uint32_t seed)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        // sum of 4 uniform nibbles-ish -> roughly bell shaped, sigma ~ 8 around 2048
+        int v = 2048 + (int)(h & 15) + (int)((h >> 4) & 15) + (int)((h >> 8) & 15) + (int)((h >> 12) & 15) - 30;
+        x[i] = (uint16_t)v;
+    }
+}
+
+int main(int argc, char **argv)
+{
+    size_t n = (size_t)(argc > 1 ? atoll(argv[1]) : 256) << 20;
+    int iters = argc > 2 ? atoi(argv[2]) : 20;
+    n -= n % 28;
+    uint16_t *x; uint32_t *counters, *cands;
+    CK(hipMalloc(&x, n * 2));
+    CK(hipMalloc(&counters, 8));
+    CK(hipMalloc(&cands, (1u << 20) * 24));
+    fill_noise<<<4096, 256>>>(x, n, 12345);
+    CK(hipDeviceSynchronize());
+    adsb::ScanArgs a{};
+    a.x = (const uint32_t *)x; a.pbuf0 = 0; a.p_lo = 0; a.p_hi = n / 2;
+    a.g_begin = 0; a.g_end = (n / 2 - 1195) / 28 * 28; a.df18 = 0;
+    a.counters = counters; a.cands = cands; a.cand_cap = 1u << 20; a.tries = nullptr; a.try_cap = 0;
+    std::vector<uint32_t> synd(adsb::kSyndWords); adsb::make_syndrome_table(synd.data());
+    uint32_t *dsynd; CK(hipMalloc(&dsynd, synd.size() * 4)); CK(hipMemcpy(dsynd, synd.data(), synd.size() * 4, hipMemcpyHostToDevice));
+    a.synd = dsynd;
+    a.passes = argc > 3 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) { CK(hipMemset(counters, 0, 8)); CK(adsb::launch_scan(a, false, 0)); }
+    CK(hipDeviceSynchronize());
+    std::vector<float> t;
+    for (int i = 0; i < iters; i++) {
+        CK(hipMemsetAsync(counters, 0, 8, 0));
+        CK(hipEventRecord(e0, 0)); CK(adsb::launch_scan(a, false, 0)); CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms);
+    }
+    std::sort(t.begin(), t.end());
+    uint32_t hc[2]; CK(hipMemcpy(hc, counters, 8, hipMemcpyDeviceToHost));
+    double med = t[t.size() / 2];
+    printf("passes=%d ablate=%d minwaves=%d tile=%d lds=%zu | median %.4f ms min %.4f | %.1f GB/s alg | %.1f Gsamples/s | cands=%u\n",
+           a.passes, ADSB_ABLATE, ADSB_MIN_WAVES, adsb::tile_offsets(a.passes), adsb::lds_bytes(a.passes), med, t[0],
+           2.0 * n / med / 1e6, n / med / 1e6, hc[0]);
+    return 0;
+}
