@@ -37,7 +37,7 @@ class Stats(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("df18", C.c_int32), ("device", C.c_int32),
-                ("collect_stats", C.c_int32), ("profile", C.c_int32), ("reserved0", C.c_int32),
+                ("collect_stats", C.c_int32), ("profile", C.c_int32), ("debug_queue_cap", C.c_int32),
                 ("stage_samples", C.c_uint64), ("stream", C.c_void_p)]
 
 
@@ -120,7 +120,8 @@ class Decoder:
     """One stream (== the statics of air.c / demod.c / valid.c)."""
 
     def __init__(self, df18: bool = False, device: int = -1, collect_stats: bool = False,
-                 profile: bool = False, stage_samples: int = 0, stream: int | None = None):
+                 profile: bool = False, stage_samples: int = 0, stream: int | None = None,
+                 debug_queue_cap: int = 0):
         L = load()
         cfg = Config()
         L.adsb_config_default(C.byref(cfg))
@@ -130,6 +131,7 @@ class Decoder:
         cfg.profile = int(profile)
         cfg.stage_samples = stage_samples
         cfg.stream = stream
+        cfg.debug_queue_cap = debug_queue_cap
         self._L = L
         self._h = L.adsb_create(C.byref(cfg))
         if not self._h:

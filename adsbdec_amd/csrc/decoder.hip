@@ -168,6 +168,8 @@ int scan_range(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64_
             a.df18 = d->cfg.df18 ? 1 : 0;
             a.passes = adsb::choose_passes(n_off, d->n_cus);
             a.synd = d->d_synd;
+            a.queue_cap = (d->cfg.debug_queue_cap >= 256 && d->cfg.debug_queue_cap <= adsb::kQueueCap)
+                              ? d->cfg.debug_queue_cap : adsb::kQueueCap;
             a.counters = d->d_counters;
             a.cands = d->d_cands;
             a.cand_cap = (uint32_t)std::min<size_t>(d->cand_cap, 0xFFFFFFFFu);

@@ -41,6 +41,7 @@ struct ScanArgs {
     uint64_t g_end;      // one past the last offset
     int df18;            // demod.c:26
     int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
+    int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
     const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
     uint32_t *counters;  // [0] candidates, [1] tries (may exceed the capacities)
     uint32_t *cands;     // kCandWords dwords per record

@@ -76,45 +76,49 @@ __device__ __forceinline__ constexpr float tap()
 // reference adds in physical ring order k = 0,2,..,12: the pair whose index is a
 // multiple of 7 first, then forward in time to the newest, then the wrapped older
 // ones: ages p, p-1, .., 0, 6, 5, .., p+1 with p = m mod 7.
-// vi/vq hold the run's pairs with the fs/4 sign already applied: slot s = rel+6.
+// vv holds the run's pairs as (I, Q) with the fs/4 sign already applied: slot s = rel+6.
+//
+// The I and Q sums are the two halves of ONE packed-f32 register pair: on gfx950
+// a wave64 VALU instruction occupies the SIMD for 4 cycles whether it is scalar or
+// packed (measured: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles), so
+// v_pk_mul_f32 / v_pk_add_f32 double the arithmetic rate.  Each half is still an
+// IEEE binary32 multiply followed by a binary32 add.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int J, int STEP>
-__device__ __forceinline__ void fir_step(const float (&vi)[34], const float (&vq)[34], float &si,
-                                         float &sq)
+__device__ __forceinline__ void fir_step(const f32x2 (&vv)[34], f32x2 &s)
 {
     constexpr int p = J % 7;
     constexpr int age = (STEP <= p) ? (p - STEP) : (6 - (STEP - p - 1));
     constexpr int slot = J - age + 6;
-    constexpr float ti = tap<12 - 2 * age>();
-    constexpr float tq = tap<13 - 2 * age>();
-    if constexpr (STEP == 0) {
-        si = ti * vi[slot]; // 0.0f + x == x up to the sign of zero, which the square erases
-        sq = tq * vq[slot];
-    } else {
-        si = si + ti * vi[slot];
-        sq = sq + tq * vq[slot];
-    }
+    constexpr f32x2 t = {tap<12 - 2 * age>(), tap<13 - 2 * age>()};
+    if constexpr (STEP == 0)
+        s = t * vv[slot]; // 0.0f + x == x up to the sign of zero, which the square erases
+    else
+        s = s + t * vv[slot];
 }
 
 template <int J>
-__device__ __forceinline__ float power_sample(const float (&vi)[34], const float (&vq)[34])
+__device__ __forceinline__ float power_sample(const f32x2 (&vv)[34])
 {
-    float si, sq;
-    fir_step<J, 0>(vi, vq, si, sq);
-    fir_step<J, 1>(vi, vq, si, sq);
-    fir_step<J, 2>(vi, vq, si, sq);
-    fir_step<J, 3>(vi, vq, si, sq);
-    fir_step<J, 4>(vi, vq, si, sq);
-    fir_step<J, 5>(vi, vq, si, sq);
-    fir_step<J, 6>(vi, vq, si, sq);
-    return si * si + sq * sq; // air.c:76,91
+    f32x2 s;
+    fir_step<J, 0>(vv, s);
+    fir_step<J, 1>(vv, s);
+    fir_step<J, 2>(vv, s);
+    fir_step<J, 3>(vv, s);
+    fir_step<J, 4>(vv, s);
+    fir_step<J, 5>(vv, s);
+    fir_step<J, 6>(vv, s);
+    const f32x2 sq = s * s;
+    return sq.x + sq.y; // air.c:76,91
 }
 
 template <int J0, int N>
-__device__ __forceinline__ void power_block(const float (&vi)[34], const float (&vq)[34], float *a)
+__device__ __forceinline__ void power_block(const f32x2 (&vv)[34], float *a)
 {
     if constexpr (N > 0) {
-        a[J0] = power_sample<J0>(vi, vq);
-        power_block<J0 + 1, N - 1>(vi, vq, a);
+        a[J0] = power_sample<J0>(vv);
+        power_block<J0 + 1, N - 1>(vv, a);
     }
 }
 
@@ -152,7 +156,7 @@ __device__ __forceinline__ uint32_t push_sign(uint32_t acc, uint32_t v)
 // value held by lane+1 (DPP wave_shl:1); lane 63 receives 0
 __device__ __forceinline__ float from_next_lane(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
 }
 
 // 28 bits starting at bit `POS` of the stream w[0] | w[1]<<28 | w[2]<<56 | ... (28 valid bits per word)
@@ -241,24 +245,18 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         // air.c:64-67,79-82: v = (float)x - 2048; pairs with odd index are negated
         // (samples n mod 4 in {2,3}).  The run starts at an even pair index, so the
         // sign is a compile-time property of the slot.  -(x-2048) == 2048-x exactly.
-        float vi[34], vq[34];
+        f32x2 vv[34];
 #pragma unroll
         for (int s = 0; s < 34; s++) {
             const uint32_t d = w[s + 2];
-            const float fi = (float)(d & 0xFFFFu);
-            const float fq = (float)(d >> 16);
-            if ((s & 1) == 0) { // slot s <-> rel pair s-6: same parity
-                vi[s] = fi - 2048.0f;
-                vq[s] = fq - 2048.0f;
-            } else {
-                vi[s] = 2048.0f - fi;
-                vq[s] = 2048.0f - fq;
-            }
+            const f32x2 f = {(float)(d & 0xFFFFu), (float)(d >> 16)};
+            const f32x2 mid = {2048.0f, 2048.0f};
+            vv[s] = ((s & 1) == 0) ? (f - mid) : (mid - f); // slot s <-> rel pair s-6: same parity
         }
 
         // a[0..27]: this run; a[28..43]: the first 16 samples of the next run (next lane)
         float a[44];
-        power_block<0, 28>(vi, vq, a);
+        power_block<0, 28>(vv, a);
 #pragma unroll
         for (int k = 0; k < 16; k++)
             a[28 + k] = from_next_lane(a[k]);
@@ -293,12 +291,27 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     int64_t off_end = (int64_t)args.g_end - t0; // offsets of this tile that exist
     if (off_end > (int64_t)kRun * own)
         off_end = (int64_t)kRun * own;
+    const int nchunks = (own + kThreads - 1) / kThreads;
+    uint32_t *qover = qcount + 1;
+    const uint32_t qcap = (uint32_t)args.queue_cap;
+
+    // Normally ONE round: the survivors of the whole tile (~0.5 % of its offsets)
+    // fit the queue and all four waves slice with dense lanes.  If they do not fit,
+    // the tile is redone chunk by chunk, one bit position (offset within the run)
+    // per round: <= 256 entries, which cannot overflow (queue_cap >= 256).
+    int ch_lo = 0, ch_hi = nchunks, grp = -1;
+    for (;;) {
+        if (tid == 0) {
+            *qcount = 0;
+            *qover = 0;
+        }
+        __syncthreads();
 
 #pragma unroll 1
-    for (int base = 0; base < own; base += kThreads) {
-        const int v = base + tid;
-        uint32_t gate = 0, m11 = 0, m17 = 0;
-        if (v < own && (int64_t)kRun * v < off_end) {
+        for (int ch = ch_lo; ch < ch_hi; ch++) {
+            const int v = ch * kThreads + tid;
+            if (v >= own || (int64_t)kRun * v >= off_end)
+                continue;
             const uint32_t e2w[2] = {pl_e2[v + 1], pl_e2[v + 2]};
             const uint32_t dw[4] = {pl_d[v + 2], pl_d[v + 3], pl_d[v + 4], pl_d[v + 5]};
             // preamble: p1 > 2 s1 at g, p2 > 2 s2 <=> E2 at g + 30
@@ -306,104 +319,113 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             // byte 0, bits 0..4 sit 80, 90, .., 120 samples after g (demod.c:109,46-81)
             const uint32_t b0 = take28<80 - 56>(dw), b1 = take28<90 - 56>(dw), b2 = take28<100 - 56>(dw),
                            b3 = take28<110 - 56>(dw), b4 = take28<120 - 56>(dw);
-            m17 = b0 & ~b1 & ~b2 & ~b3 & b4;                                   // 10001 (demod.c:64-67)
-            m11 = ~b0 & b1 & ~b2 & b3 & b4;                                    // 01011 (demod.c:70-77)
+            const uint32_t m17 = b0 & ~b1 & ~b2 & ~b3 & b4;                    // 10001 (demod.c:64-67)
+            const uint32_t m11 = ~b0 & b1 & ~b2 & b3 & b4;                     // 01011 (demod.c:70-77)
             const uint32_t m18 = args.df18 ? (b0 & ~b1 & ~b2 & b3 & ~b4) : 0u; // 10010 (demod.c:57-62)
-            gate = pre & (m17 | m11 | m18);
+            uint32_t gate = pre & (m17 | m11 | m18);
             const int64_t nvalid = off_end - (int64_t)kRun * v;
             if (nvalid < kRun)
                 gate &= (1u << (int)nvalid) - 1u;
-        }
-
-        // compaction rounds: normally exactly one
-        while (__syncthreads_or(gate != 0)) {
-            for (int q = tid; q < kQueueCap; q += kThreads)
-                queue[q] = 0xFFFFFFFFu;
-            if (tid == 0)
-                *qcount = 0;
-            __syncthreads();
+            if (grp >= 0)
+                gate &= 1u << grp;
             const int n = __popc(gate);
             if (n) {
-                const uint32_t slot = atomicAdd(qcount, (uint32_t)n);
-                if (slot + n <= kQueueCap) {
-                    uint32_t s = slot;
+                uint32_t slot = atomicAdd(qcount, (uint32_t)n);
+                if (slot + n <= qcap) {
                     while (gate) {
                         const int j = __ffs(gate) - 1;
                         gate &= gate - 1;
                         const uint32_t code = ((m11 >> j) & 1u) ? 0u : ((m17 >> j) & 1u) ? 1u : 2u;
-                        queue[s++] = ((uint32_t)v << 7) | ((uint32_t)j << 2) | code;
+                        queue[slot++] = ((uint32_t)v << 7) | ((uint32_t)j << 2) | code;
                     }
+                } else {
+                    *qover = 1;
                 }
             }
-            __syncthreads();
-            const int qn = min((int)*qcount, kQueueCap);
-            for (int q = tid; q < qn; q += kThreads) {
-                const uint32_t ent = queue[q];
-                if (ent == 0xFFFFFFFFu)
-                    continue; // hole left by a reservation that did not fit
-                const int sv = (int)(ent >> 7), sj = (int)((ent >> 2) & 31u);
-                const uint32_t code = ent & 3u;
-                const uint32_t g_rel = (uint32_t)(t0 - (int64_t)args.g_begin) + (uint32_t)(kRun * sv + sj);
-                if (kStats) { // valid.c:46,68: every DF-gate pass that is visited is a Try
-                    const uint32_t ts = atomicAdd(&args.counters[1], 1u);
-                    if (ts < args.try_cap)
-                        args.tries[ts] = (g_rel << 2) | code;
-                }
-                // Frame bit k = 14 b + c lies 80 + 10 k samples after g: column c is
-                // at stream position sj + 80 + 10 c (+ 140 b = 5 words per b).
-                const uint32_t *dcol = pl_d + sv;
-                uint32_t syn = 0;
-#pragma unroll
-                for (int cc = 0; cc < 14; cc++) {
-                    const int pos = sj + 80 + 10 * cc;
-                    const int wi = (pos * 2341) >> 16; // pos / 28 for pos < 5000
-                    const int bp = pos - 28 * wi;
-                    uint32_t col = 0;
-#pragma unroll
-                    for (int b = 0; b < 8; b++)
-                        col |= ((dcol[wi + 5 * b] >> bp) & 1u) << b;
-                    // short frames are bits 0..55 = rows b < 4; their syndromes are the
-                    // long frame's 56 bits (4 rows) further on
-                    const uint32_t idx = (code == 0) ? ((col & 15u) << 4) : col;
-                    syn ^= args.synd[cc * 256 + idx];
-                }
-                if (syn != 0)
-                    continue; // valid.c:51,73
-
-                // CRC-valid (rare): rebuild the bytes in order and recompute pw
-                const int nbytes = (code == 0) ? 7 : 14;
-                uint32_t wds[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int k = 0; k < 14; k++) {
-                    uint32_t byte = 0;
-                    if (k < nbytes) {
-#pragma unroll 1
-                        for (int i = 0; i < 8; i++) {
-                            const int pos = sj + 80 + 80 * k + 10 * i;
-                            const int wi = (pos * 2341) >> 16;
-                            byte |= ((dcol[wi] >> (pos - 28 * wi)) & 1u) ? (0x80u >> i) : 0u;
-                        }
-                    }
-                    wds[k >> 2] |= byte << (8 * (k & 3));
-                }
-                wds[3] |= (uint32_t)nbytes << 16;
-                const int64_t g = t0 + (int64_t)kRun * sv + sj;
-                const int p1 = __float2int_rz(power_at(xin, pbuf0, p_lo, p_hi, g) + power_at(xin, pbuf0, p_lo, p_hi, g + 10));
-                const int p2 = __float2int_rz(power_at(xin, pbuf0, p_lo, p_hi, g + 35) + power_at(xin, pbuf0, p_lo, p_hi, g + 45));
-                const uint32_t pw = (uint32_t)((p1 + p2) / 4); // demod.c:127,133
-                const uint32_t slot = atomicAdd(&args.counters[0], 1u);
-                if (slot < args.cand_cap) {
-                    uint32_t *rec = args.cands + (size_t)slot * kCandWords;
-                    rec[0] = g_rel;
-                    rec[1] = pw;
-                    rec[2] = wds[0];
-                    rec[3] = wds[1];
-                    rec[4] = wds[2];
-                    rec[5] = wds[3];
-                }
-            }
-            // the __syncthreads_or at the loop head orders the reuse of the queue
         }
+        __syncthreads();
+        const bool over = *qover != 0;
+        const int qn = over ? 0 : (int)*qcount;
+#pragma unroll 1
+        for (int q = tid; q < qn; q += kThreads) {
+            const uint32_t ent = queue[q];
+            const int sv = (int)(ent >> 7), sj = (int)((ent >> 2) & 31u);
+            const uint32_t code = ent & 3u;
+            const uint32_t g_rel = (uint32_t)(t0 - (int64_t)args.g_begin) + (uint32_t)(kRun * sv + sj);
+            if (kStats) { // valid.c:46,68: every DF-gate pass that is visited is a Try
+                const uint32_t ts = atomicAdd(&args.counters[1], 1u);
+                if (ts < args.try_cap)
+                    args.tries[ts] = (g_rel << 2) | code;
+            }
+            // Frame bit k = 14 b + c lies 80 + 10 k samples after g: column c is
+            // at stream position sj + 80 + 10 c (+ 140 b = 5 words per b).
+            const uint32_t *dcol = pl_d + sv;
+            uint32_t syn = 0;
+#pragma unroll
+            for (int cc = 0; cc < 14; cc++) {
+                const int pos = sj + 80 + 10 * cc;
+                const int wi = (pos * 2341) >> 16; // pos / 28 for pos < 5000
+                const int bp = pos - 28 * wi;
+                uint32_t col = 0;
+#pragma unroll
+                for (int b = 0; b < 8; b++)
+                    col |= ((dcol[wi + 5 * b] >> bp) & 1u) << b;
+                // short frames are bits 0..55 = rows b < 4; their syndromes are the
+                // long frame's 56 bits (4 rows) further on
+                const uint32_t idx = (code == 0) ? ((col & 15u) << 4) : col;
+                syn ^= args.synd[cc * 256 + idx];
+            }
+            if (syn != 0)
+                continue; // valid.c:51,73
+
+            // CRC-valid (rare): rebuild the bytes in order and recompute pw
+            const int nbytes = (code == 0) ? 7 : 14;
+            uint32_t wds[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 14; k++) {
+                uint32_t byte = 0;
+                if (k < nbytes) {
+#pragma unroll 1
+                    for (int i = 0; i < 8; i++) {
+                        const int pos = sj + 80 + 80 * k + 10 * i;
+                        const int wi = (pos * 2341) >> 16;
+                        byte |= ((dcol[wi] >> (pos - 28 * wi)) & 1u) ? (0x80u >> i) : 0u;
+                    }
+                }
+                wds[k >> 2] |= byte << (8 * (k & 3));
+            }
+            wds[3] |= (uint32_t)nbytes << 16;
+            const int64_t g = t0 + (int64_t)kRun * sv + sj;
+            const int p1 = __float2int_rz(power_at(xin, pbuf0, p_lo, p_hi, g) + power_at(xin, pbuf0, p_lo, p_hi, g + 10));
+            const int p2 = __float2int_rz(power_at(xin, pbuf0, p_lo, p_hi, g + 35) + power_at(xin, pbuf0, p_lo, p_hi, g + 45));
+            const uint32_t pw = (uint32_t)((p1 + p2) / 4); // demod.c:127,133
+            const uint32_t slot = atomicAdd(&args.counters[0], 1u);
+            if (slot < args.cand_cap) {
+                uint32_t *rec = args.cands + (size_t)slot * kCandWords;
+                rec[0] = g_rel;
+                rec[1] = pw;
+                rec[2] = wds[0];
+                rec[3] = wds[1];
+                rec[4] = wds[2];
+                rec[5] = wds[3];
+            }
+        }
+
+        // next round (all of this is workgroup-uniform)
+        if (grp < 0) {
+            if (!over)
+                break;
+            ch_lo = 0;
+            ch_hi = 1;
+            grp = 0;
+        } else if (++grp == kRun) {
+            grp = 0;
+            ch_lo++;
+            ch_hi++;
+            if (ch_lo >= nchunks)
+                break;
+        }
+        __syncthreads(); // queue is rewritten
     }
 }
 

@@ -69,7 +69,7 @@ typedef struct adsb_config {
     int32_t device;            /* HIP device ordinal; -1 = the current device     */
     int32_t collect_stats;     /* reproduce valid.c's Try counters (costs a try list) */
     int32_t profile;           /* time the scan kernel with HIP events on its stream */
-    int32_t reserved0;
+    int32_t debug_queue_cap;   /* test knob: survivor-queue entries per workgroup round (256..1024); 0 = default */
     uint64_t stage_samples;    /* device staging capacity for adsb_push(); 0 = default (32 Mi) */
     void *stream;              /* hipStream_t to launch on; NULL = a stream owned by the handle */
 } adsb_config;

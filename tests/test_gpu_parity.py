@@ -192,6 +192,19 @@ def test_record_buffer_overflow_is_regrown(oracle, dec_factory):
     assert d.stats() == wstats
 
 
+def test_survivor_queue_overflow_fallback(oracle, dec_factory):
+    """With the per-workgroup survivor queue shrunk to 256 entries about half the
+    tiles of a noise capture overflow it and take the bit-position-by-bit-position
+    fallback; results must not change."""
+    rng = np.random.default_rng(31)
+    x = rng.integers(0, 4096, 1 << 21, dtype=np.uint16)
+    want, wstats = oracle.decode(x, df18=True)
+    d = dec_factory(df18=True, collect_stats=True, debug_queue_cap=256)
+    assert records(d.decode(x)) == records(want)
+    assert d.stats() == wstats
+    assert sum(wstats["try"].values()) > 5000
+
+
 # ------------------------------------------------------------------ sharding on one device
 def test_shard_scan_and_host_gather(capi, oracle, dec_factory, torch_cuda):
     """SURVEY 8e with every shard on this one GPU: per-shard stateless scans over the
