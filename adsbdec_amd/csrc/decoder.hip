@@ -40,6 +40,30 @@ inline uint64_t round_down(uint64_t v, uint64_t q) { return v - v % q; }
 
 } // namespace
 
+// One scan in flight: the kernel of a chunk of offsets appends its records straight
+// into this slot's PINNED HOST buffers (the records are tens of bytes per frame;
+// PCIe posted writes are free next to the sample traffic), so collecting a chunk is
+// one event wait -- no device-to-host copy and no second synchronisation.
+struct ScanSlot {
+    uint32_t *d_counters = nullptr; // device: [0] candidates, [1] tries
+    uint32_t *h_counters = nullptr; // pinned
+    uint32_t *cands = nullptr;      // pinned, written by the kernel
+    uint32_t *tries = nullptr;      // pinned, written by the kernel
+    size_t cand_cap = 0, try_cap = 0;
+    hipEvent_t ev_start = nullptr, ev_done = nullptr; // kernel timing (cfg.profile)
+    hipEvent_t ev_ready = nullptr;                    // counters have landed in h_counters
+    adsb::ScanArgs args{};
+    bool busy = false;
+};
+
+constexpr int kSlots = 3;
+constexpr uint64_t kChunkOffsets = 28ull * ((32ull << 20) / 28); // offsets per pipelined launch
+
+struct ScanSink { // where collected records go: a caller's vectors, or (null) the stream's resolver
+    std::vector<adsb_candidate> *cands = nullptr;
+    std::vector<uint64_t> *tries = nullptr;
+};
+
 struct adsb_decoder {
     adsb_config cfg{};
     int device = 0;
@@ -49,7 +73,7 @@ struct adsb_decoder {
 
     // stream position
     uint64_t n_samples = 0; // samples accepted
-    uint64_t g_scanned = 0; // every offset below has been evaluated on the device
+    uint64_t g_scanned = 0; // every offset below has been submitted to the device
     bool finished = false;
 
     // staging
@@ -59,23 +83,15 @@ struct adsb_decoder {
     uint64_t stage_first = 0; // stream index of stage[cur][0]
     uint64_t stage_fill = 0;  // samples held
 
-    // device record buffers + pinned mirrors
     uint32_t *d_synd = nullptr; // 14 x 256 CRC-24 syndrome table (scan_kernel.h)
     int n_cus = 256;
-    uint32_t *d_counters = nullptr;
-    uint32_t *d_cands = nullptr;
-    uint32_t *d_tries = nullptr;
-    uint32_t *h_counters = nullptr;
-    uint32_t *h_cands = nullptr;
-    uint32_t *h_tries = nullptr;
-    size_t cand_cap = 0, try_cap = 0;
-    size_t h_cand_cap = 0, h_try_cap = 0;
+    ScanSlot slots[kSlots];
+    int slot_head = 0, slot_count = 0; // FIFO of busy slots
+    ScanSink sink;                     // sink of the scans in flight
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     adsb_profile prof{};
     adsb::Resolver res;
-    std::vector<adsb_candidate> cand_buf;
-    std::vector<uint64_t> try_buf;
+    std::vector<uint32_t> order, scratch_a, scratch_b;
 
     int fail(const char *fmt, ...)
     {
@@ -99,157 +115,208 @@ struct adsb_decoder {
 
 namespace {
 
-int ensure_record_capacity(adsb_decoder *d, size_t want_cands, size_t want_tries)
-{
-    if (want_cands > d->cand_cap) {
-        if (d->d_cands)
-            HIP_TRY(d, hipFree(d->d_cands));
-        d->d_cands = nullptr;
-        HIP_TRY(d, hipMalloc(&d->d_cands, want_cands * adsb::kCandWords * sizeof(uint32_t)));
-        d->cand_cap = want_cands;
-    }
-    if (want_tries > d->try_cap) {
-        if (d->d_tries)
-            HIP_TRY(d, hipFree(d->d_tries));
-        d->d_tries = nullptr;
-        HIP_TRY(d, hipMalloc(&d->d_tries, want_tries * sizeof(uint32_t)));
-        d->try_cap = want_tries;
-    }
-    return 0;
-}
-
-int ensure_host_mirrors(adsb_decoder *d, size_t n_cands, size_t n_tries)
-{
-    if (n_cands > d->h_cand_cap) {
-        if (d->h_cands)
-            HIP_TRY(d, hipHostFree(d->h_cands));
-        d->h_cands = nullptr;
-        size_t cap = std::max<size_t>(n_cands, 2 * d->h_cand_cap);
-        HIP_TRY(d, hipHostMalloc(&d->h_cands, cap * adsb::kCandWords * sizeof(uint32_t)));
-        d->h_cand_cap = cap;
-    }
-    if (n_tries > d->h_try_cap) {
-        if (d->h_tries)
-            HIP_TRY(d, hipHostFree(d->h_tries));
-        d->h_tries = nullptr;
-        size_t cap = std::max<size_t>(n_tries, 2 * d->h_try_cap);
-        HIP_TRY(d, hipHostMalloc(&d->h_tries, cap * sizeof(uint32_t)));
-        d->h_try_cap = cap;
-    }
-    return 0;
-}
-
-// Evaluate offsets [g_begin, g_end) on a device buffer holding stream samples
-// [buf_first, buf_first + buf_n) (buf_first % 8 == 0, buf 16-byte aligned) and
-// append the sorted records to cands/tries with absolute g.
-int scan_range(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64_t buf_n,
-               uint64_t g_begin, uint64_t g_end, std::vector<adsb_candidate> &cands,
-               std::vector<uint64_t> &tries)
-{
-    const bool stats = d->cfg.collect_stats != 0;
-    while (g_begin < g_end) {
-        const uint64_t g_stop = std::min(g_end, g_begin + round_down(adsb::kMaxLaunchOffsets, 28));
-        const uint64_t n_off = g_stop - g_begin;
-
-        // Sparse output: size the buffers for far more than noise produces and grow
-        // on overflow (counters keep counting past the capacity).
-        size_t want_c = std::max<size_t>(d->cand_cap, (size_t)(n_off / 256 + 16384));
-        size_t want_t = stats ? std::max<size_t>(d->try_cap, (size_t)(n_off / 32 + 65536)) : d->try_cap;
-        for (int attempt = 0;; attempt++) {
-            if (ensure_record_capacity(d, want_c, want_t))
-                return -1;
-            adsb::ScanArgs a{};
-            a.x = reinterpret_cast<const uint32_t *>(buf);
-            a.pbuf0 = (int64_t)(buf_first / 2);
-            a.p_lo = a.pbuf0; // stream start: pairs below 0 read as silence (air.c:33)
-            a.p_hi = a.pbuf0 + (int64_t)(buf_n / 2);
-            a.g_begin = g_begin;
-            a.g_end = g_stop;
-            a.df18 = d->cfg.df18 ? 1 : 0;
-            a.passes = adsb::choose_passes(n_off, d->n_cus);
-            a.synd = d->d_synd;
-            a.queue_cap = (d->cfg.debug_queue_cap >= 256 && d->cfg.debug_queue_cap <= adsb::kQueueCap)
-                              ? d->cfg.debug_queue_cap : adsb::kQueueCap;
-            a.counters = d->d_counters;
-            a.cands = d->d_cands;
-            a.cand_cap = (uint32_t)std::min<size_t>(d->cand_cap, 0xFFFFFFFFu);
-            a.tries = d->d_tries;
-            a.try_cap = (uint32_t)std::min<size_t>(d->try_cap, 0xFFFFFFFFu);
-
-            HIP_TRY(d, hipMemsetAsync(d->d_counters, 0, 2 * sizeof(uint32_t), d->stream));
-            if (d->cfg.profile)
-                HIP_TRY(d, hipEventRecord(d->ev0, d->stream));
-            HIP_TRY(d, adsb::launch_scan(a, stats, d->stream));
-            if (d->cfg.profile)
-                HIP_TRY(d, hipEventRecord(d->ev1, d->stream));
-            HIP_TRY(d, hipMemcpyAsync(d->h_counters, d->d_counters, 2 * sizeof(uint32_t),
-                                      hipMemcpyDeviceToHost, d->stream));
-            HIP_TRY(d, hipStreamSynchronize(d->stream));
-            d->prof.launches++;
-            d->prof.offsets += n_off;
-            d->prof.last_offsets = n_off;
-            if (d->cfg.profile) {
-                float ms = 0;
-                HIP_TRY(d, hipEventElapsedTime(&ms, d->ev0, d->ev1));
-                d->prof.kernel_ms += ms;
-                d->prof.last_kernel_ms = ms;
-            }
-            const size_t nc = d->h_counters[0], nt = d->h_counters[1];
-            if (nc <= d->cand_cap && nt <= d->try_cap) {
-                if (ensure_host_mirrors(d, nc, nt))
-                    return -1;
-                if (nc)
-                    HIP_TRY(d, hipMemcpyAsync(d->h_cands, d->d_cands,
-                                              nc * adsb::kCandWords * sizeof(uint32_t),
-                                              hipMemcpyDeviceToHost, d->stream));
-                if (nt)
-                    HIP_TRY(d, hipMemcpyAsync(d->h_tries, d->d_tries, nt * sizeof(uint32_t),
-                                              hipMemcpyDeviceToHost, d->stream));
-                if (nc || nt)
-                    HIP_TRY(d, hipStreamSynchronize(d->stream));
-
-                // The device appends in arrival order; the reference's order is ascending g.
-                std::vector<uint32_t> order(nc);
-                for (size_t i = 0; i < nc; i++)
-                    order[i] = (uint32_t)i;
-                const uint32_t *hc = d->h_cands;
-                std::sort(order.begin(), order.end(), [hc](uint32_t x, uint32_t y) {
-                    return hc[(size_t)x * adsb::kCandWords] < hc[(size_t)y * adsb::kCandWords];
-                });
-                for (size_t i = 0; i < nc; i++) {
-                    const uint32_t *r = hc + (size_t)order[i] * adsb::kCandWords;
-                    adsb_candidate c;
-                    std::memset(&c, 0, sizeof c);
-                    c.g = g_begin + r[0];
-                    c.pw = r[1];
-                    std::memcpy(c.frame, &r[2], 14);
-                    c.len = (uint8_t)((r[5] >> 16) & 0xFF);
-                    cands.push_back(c);
-                }
-                if (nt) {
-                    std::sort(d->h_tries, d->h_tries + nt);
-                    for (size_t i = 0; i < nt; i++)
-                        tries.push_back((((uint64_t)(d->h_tries[i] >> 2) + g_begin) << 2) |
-                                        (d->h_tries[i] & 3u));
-                }
-                d->prof.candidates += nc;
-                d->prof.tries += nt;
-                break;
-            }
-            if (attempt >= 2)
-                return d->fail("record buffers overflowed repeatedly (%zu candidates, %zu tries)", nc, nt);
-            d->prof.relaunches++;
-            want_c = std::max(want_c, nc + nc / 8);
-            want_t = std::max(want_t, nt + nt / 8);
-        }
-        g_begin = g_stop;
-    }
-    return 0;
-}
-
 inline uint64_t power_samples_produced(uint64_t n_samples)
 {
     return 2 * (n_samples / 4); // air.c:59-92: two power samples per four input samples
+}
+
+int slot_reserve(adsb_decoder *d, ScanSlot &s, size_t want_cands, size_t want_tries)
+{
+    if (want_cands > s.cand_cap) {
+        if (s.cands)
+            HIP_TRY(d, hipHostFree(s.cands));
+        s.cands = nullptr;
+        s.cand_cap = 0;
+        HIP_TRY(d, hipHostMalloc(&s.cands, want_cands * adsb::kCandWords * sizeof(uint32_t), hipHostMallocDefault));
+        s.cand_cap = want_cands;
+    }
+    if (want_tries > s.try_cap) {
+        if (s.tries)
+            HIP_TRY(d, hipHostFree(s.tries));
+        s.tries = nullptr;
+        s.try_cap = 0;
+        HIP_TRY(d, hipHostMalloc(&s.tries, want_tries * sizeof(uint32_t), hipHostMallocDefault));
+        s.try_cap = want_tries;
+    }
+    return 0;
+}
+
+int slot_launch(adsb_decoder *d, ScanSlot &s)
+{
+    const bool stats = d->cfg.collect_stats != 0;
+    s.args.counters = s.d_counters;
+    s.args.cands = s.cands;
+    s.args.cand_cap = (uint32_t)std::min<size_t>(s.cand_cap, 0xFFFFFFFFu);
+    s.args.tries = s.tries;
+    s.args.try_cap = (uint32_t)std::min<size_t>(s.try_cap, 0xFFFFFFFFu);
+    HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, 2 * sizeof(uint32_t), d->stream));
+    if (d->cfg.profile)
+        HIP_TRY(d, hipEventRecord(s.ev_start, d->stream));
+    HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
+    if (d->cfg.profile)
+        HIP_TRY(d, hipEventRecord(s.ev_done, d->stream));
+    HIP_TRY(d, hipMemcpyAsync(s.h_counters, s.d_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(d, hipEventRecord(s.ev_ready, d->stream));
+    s.busy = true;
+    return 0;
+}
+
+// LSD radix sort of the record indices by their 30-bit g_rel (3 x 10 bits).
+void sort_order(adsb_decoder *d, const uint32_t *recs, size_t n)
+{
+    d->order.resize(n);
+    d->scratch_a.resize(n);
+    d->scratch_b.resize(n);
+    uint32_t *idx = d->order.data(), *tmp = d->scratch_a.data(), *key = d->scratch_b.data();
+    bool sorted = true;
+    for (size_t i = 0; i < n; i++) {
+        idx[i] = (uint32_t)i;
+        key[i] = recs[i * adsb::kCandWords];
+        if (i && key[i] < key[i - 1])
+            sorted = false;
+    }
+    if (sorted)
+        return;
+    for (int shift = 0; shift < 30; shift += 10) {
+        uint32_t hist[1025] = {0};
+        for (size_t i = 0; i < n; i++)
+            hist[((key[idx[i]] >> shift) & 1023u) + 1]++;
+        for (int b = 0; b < 1024; b++)
+            hist[b + 1] += hist[b];
+        for (size_t i = 0; i < n; i++)
+            tmp[hist[(key[idx[i]] >> shift) & 1023u]++] = idx[i];
+        std::swap(idx, tmp);
+    }
+    if (idx != d->order.data())
+        std::memcpy(d->order.data(), idx, n * sizeof(uint32_t)); // odd number of passes
+}
+
+void sort_tries(adsb_decoder *d, uint32_t *t, size_t n)
+{
+    bool sorted = true;
+    for (size_t i = 1; i < n && sorted; i++)
+        sorted = t[i] >= t[i - 1];
+    if (sorted)
+        return;
+    d->scratch_a.resize(n);
+    uint32_t *src = t, *dst = d->scratch_a.data();
+    for (int shift = 0; shift < 32; shift += 11) {
+        uint32_t hist[2049] = {0};
+        for (size_t i = 0; i < n; i++)
+            hist[((src[i] >> shift) & 2047u) + 1]++;
+        for (int b = 0; b < 2048; b++)
+            hist[b + 1] += hist[b];
+        for (size_t i = 0; i < n; i++)
+            dst[hist[(src[i] >> shift) & 2047u]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != t)
+        std::memcpy(t, src, n * sizeof(uint32_t));
+}
+
+// Wait for the oldest scan in flight and hand its records on, in ascending g.
+int slot_collect(adsb_decoder *d)
+{
+    ScanSlot &s = d->slots[d->slot_head];
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(d, hipEventSynchronize(s.ev_ready));
+        if (d->cfg.profile) {
+            float ms = 0;
+            HIP_TRY(d, hipEventElapsedTime(&ms, s.ev_start, s.ev_done));
+            d->prof.kernel_ms += ms;
+            d->prof.last_kernel_ms = ms;
+        }
+        d->prof.launches++;
+        d->prof.offsets += s.args.g_end - s.args.g_begin;
+        d->prof.last_offsets = s.args.g_end - s.args.g_begin;
+        const size_t nc = s.h_counters[0], nt = s.h_counters[1];
+        if (nc <= s.cand_cap && nt <= s.try_cap)
+            break;
+        // Sparse output sized for far more than noise produces; the counters keep
+        // counting past the capacity, so one repeat with exact sizes suffices.
+        if (attempt >= 2)
+            return d->fail("record buffers overflowed repeatedly (%zu candidates, %zu tries)", nc, nt);
+        d->prof.relaunches++;
+        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        if (slot_reserve(d, s, std::max(s.cand_cap, nc + nc / 8 + 64), std::max(s.try_cap, nt + nt / 8 + 64)))
+            return -1;
+        if (slot_launch(d, s))
+            return -1;
+    }
+    const size_t nc = s.h_counters[0], nt = s.h_counters[1];
+    sort_order(d, s.cands, nc);
+    if (nt)
+        sort_tries(d, s.tries, nt);
+    d->prof.candidates += nc;
+    d->prof.tries += nt;
+    if (d->sink.cands) {
+        for (size_t i = 0; i < nc; i++) {
+            const uint32_t *r = s.cands + (size_t)d->order[i] * adsb::kCandWords;
+            adsb_candidate c;
+            std::memset(&c, 0, sizeof c);
+            c.g = s.args.g_begin + r[0];
+            c.pw = r[1];
+            std::memcpy(c.frame, &r[2], 14);
+            c.len = (uint8_t)((r[5] >> 16) & 0xFF);
+            d->sink.cands->push_back(c);
+        }
+        for (size_t i = 0; i < nt; i++)
+            d->sink.tries->push_back((((uint64_t)(s.tries[i] >> 2) + s.args.g_begin) << 2) | (s.tries[i] & 3u));
+    } else {
+        d->res.feed_device(s.cands, d->order.data(), nc, adsb::kCandWords, s.args.g_begin, s.tries, nt);
+        d->res.advance(power_samples_produced(d->n_samples), s.args.g_end);
+    }
+    s.busy = false;
+    d->slot_head = (d->slot_head + 1) % kSlots;
+    d->slot_count--;
+    return 0;
+}
+
+int scan_drain(adsb_decoder *d)
+{
+    while (d->slot_count)
+        if (slot_collect(d))
+            return -1;
+    return 0;
+}
+
+// Submit offsets [g_begin, g_end) of a device buffer holding stream samples
+// [buf_first, buf_first + buf_n) (buf_first % 8 == 0, buf 16-byte aligned) as a
+// pipeline of chunked launches: while the device scans chunk k+1 the host sorts
+// and resolves chunk k.  Records reach the sink in ascending g.
+int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64_t buf_n, uint64_t g_begin,
+                uint64_t g_end)
+{
+    const bool stats = d->cfg.collect_stats != 0;
+    while (g_begin < g_end) {
+        const uint64_t g_stop = std::min(g_end, g_begin + kChunkOffsets);
+        const uint64_t n_off = g_stop - g_begin;
+        if (d->slot_count == kSlots && slot_collect(d))
+            return -1;
+        ScanSlot &s = d->slots[(d->slot_head + d->slot_count) % kSlots];
+        if (slot_reserve(d, s, std::max<size_t>(s.cand_cap, (size_t)(n_off / 128 + 32768)),
+                         stats ? std::max<size_t>(s.try_cap, (size_t)(n_off / 32 + 65536)) : s.try_cap))
+            return -1;
+        adsb::ScanArgs &a = s.args;
+        a = adsb::ScanArgs{};
+        a.x = reinterpret_cast<const uint32_t *>(buf);
+        a.pbuf0 = (int64_t)(buf_first / 2);
+        a.p_lo = a.pbuf0; // stream start: pairs below 0 read as silence (air.c:33)
+        a.p_hi = a.pbuf0 + (int64_t)(buf_n / 2);
+        a.g_begin = g_begin;
+        a.g_end = g_stop;
+        a.df18 = d->cfg.df18 ? 1 : 0;
+        a.passes = adsb::choose_passes(n_off, d->n_cus);
+        a.synd = d->d_synd;
+        a.queue_cap = (d->cfg.debug_queue_cap >= 256 && d->cfg.debug_queue_cap <= adsb::kQueueCap)
+                          ? d->cfg.debug_queue_cap
+                          : adsb::kQueueCap;
+        if (slot_launch(d, s))
+            return -1;
+        d->slot_count++;
+        g_begin = g_stop;
+    }
+    return 0;
 }
 
 // Scan what the staged samples allow, resolve, and keep only the unscanned tail.
@@ -260,14 +327,12 @@ int process_stage(adsb_decoder *d, bool final)
     if (!final)
         g_end = round_down(g_end, 28);
     if (g_end > d->g_scanned) {
-        d->cand_buf.clear();
-        d->try_buf.clear();
-        if (scan_range(d, d->stage[d->cur], d->stage_first, d->stage_fill, d->g_scanned, g_end,
-                       d->cand_buf, d->try_buf))
+        if (scan_submit(d, d->stage[d->cur], d->stage_first, d->stage_fill, d->g_scanned, g_end))
             return -1;
-        d->res.feed(d->cand_buf.data(), d->cand_buf.size(), d->try_buf.data(), d->try_buf.size());
         d->g_scanned = g_end;
     }
+    if (scan_drain(d)) // frames become drainable within the call that supplied their samples
+        return -1;
     // At EOF a trailing partial quad still makes the reference produce two (garbage)
     // power samples (air.c:59 loop bound); they can never be read by a visited
     // offset but they count for the `aidx >= APBUFFSZ` test.
@@ -390,8 +455,15 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
     for (int i = 0; i < 2; i++)
         if ((e = hipMalloc(&d->stage[i], d->stage_cap * sizeof(uint16_t))) != hipSuccess)
             return bail("hipMalloc(stage)", e);
-    if ((e = hipMalloc(&d->d_counters, 2 * sizeof(uint32_t))) != hipSuccess)
-        return bail("hipMalloc(counters)", e);
+    for (ScanSlot &sl : d->slots) {
+        if ((e = hipMalloc(&sl.d_counters, 2 * sizeof(uint32_t))) != hipSuccess)
+            return bail("hipMalloc(counters)", e);
+        if ((e = hipHostMalloc(&sl.h_counters, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+            return bail("hipHostMalloc(counters)", e);
+        if ((e = hipEventCreate(&sl.ev_start)) != hipSuccess || (e = hipEventCreate(&sl.ev_done)) != hipSuccess ||
+            (e = hipEventCreate(&sl.ev_ready)) != hipSuccess)
+            return bail("hipEventCreate", e);
+    }
     {
         std::vector<uint32_t> synd(adsb::kSyndWords);
         adsb::make_syndrome_table(synd.data());
@@ -401,10 +473,6 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipMemcpy(synd)", e);
     }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if ((e = hipHostMalloc(&d->h_counters, 2 * sizeof(uint32_t))) != hipSuccess)
-        return bail("hipHostMalloc(counters)", e);
-    if ((e = hipEventCreate(&d->ev0)) != hipSuccess || (e = hipEventCreate(&d->ev1)) != hipSuccess)
-        return bail("hipEventCreate", e);
     d->res.reset();
     return d;
 }
@@ -419,15 +487,16 @@ void adsb_destroy(adsb_decoder *d)
     for (int i = 0; i < 2; i++)
         if (d->stage[i])
             (void)hipFree(d->stage[i]);
-    if (d->d_counters) (void)hipFree(d->d_counters);
     if (d->d_synd) (void)hipFree(d->d_synd);
-    if (d->d_cands) (void)hipFree(d->d_cands);
-    if (d->d_tries) (void)hipFree(d->d_tries);
-    if (d->h_counters) (void)hipHostFree(d->h_counters);
-    if (d->h_cands) (void)hipHostFree(d->h_cands);
-    if (d->h_tries) (void)hipHostFree(d->h_tries);
-    if (d->ev0) (void)hipEventDestroy(d->ev0);
-    if (d->ev1) (void)hipEventDestroy(d->ev1);
+    for (ScanSlot &sl : d->slots) {
+        if (sl.d_counters) (void)hipFree(sl.d_counters);
+        if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+        if (sl.cands) (void)hipHostFree(sl.cands);
+        if (sl.tries) (void)hipHostFree(sl.tries);
+        if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        if (sl.ev_ready) (void)hipEventDestroy(sl.ev_ready);
+    }
     if (d->own_stream && d->stream)
         (void)hipStreamDestroy(d->stream);
     delete d;
@@ -444,6 +513,8 @@ int adsb_reset(adsb_decoder *d)
     d->stage_fill = 0;
     d->cur = 0;
     d->res.reset();
+    d->slot_head = 0;
+    d->slot_count = 0;
     std::memset(&d->prof, 0, sizeof d->prof);
     d->err.clear();
     return 0;
@@ -491,13 +562,12 @@ int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n)
     const uint64_t g_end = round_down(m_real >= ADSB_WINDOW ? m_real - ADSB_WINDOW + 1 : 0, 28);
     d->n_samples = total;
     if (g_end > d->g_scanned) {
-        d->cand_buf.clear();
-        d->try_buf.clear();
-        if (scan_range(d, p, first, n, d->g_scanned, g_end, d->cand_buf, d->try_buf))
+        if (scan_submit(d, p, first, n, d->g_scanned, g_end))
             return -1;
-        d->res.feed(d->cand_buf.data(), d->cand_buf.size(), d->try_buf.data(), d->try_buf.size());
         d->g_scanned = g_end;
     }
+    if (scan_drain(d))
+        return -1;
     d->res.advance(m_real, d->g_scanned);
     // Tail: what the next push (or adsb_finish) still needs goes to the staging buffer.
     const uint64_t keep_first = std::max<uint64_t>(d->g_scanned >= 8 ? 2 * (d->g_scanned - 8) : 0, first);
@@ -529,18 +599,12 @@ long adsb_drain(adsb_decoder *d, adsb_frame *out, size_t cap)
 {
     if (!d || (!out && cap))
         return -1;
-    auto &q = d->res.out();
-    size_t n = 0;
-    while (n < cap && !q.empty()) {
-        out[n++] = q.front();
-        q.pop_front();
-    }
-    return (long)n;
+    return (long)d->res.drain(out, cap);
 }
 
 size_t adsb_pending(const adsb_decoder *d)
 {
-    return d ? const_cast<adsb_decoder *>(d)->res.out().size() : 0;
+    return d ? d->res.pending() : 0;
 }
 
 int adsb_get_stats(const adsb_decoder *d, adsb_stats *out)
@@ -584,7 +648,15 @@ int adsb_scan_shard(adsb_decoder *d, const void *device_samples, uint64_t first_
     HIP_TRY(d, hipSetDevice(d->device));
     std::vector<adsb_candidate> cv;
     std::vector<uint64_t> tv;
-    if (scan_range(d, static_cast<const uint16_t *>(device_samples), first_sample, n, g_begin, g_end, cv, tv))
+    if (scan_drain(d))
+        return -1;
+    d->sink.cands = &cv;
+    d->sink.tries = &tv;
+    int rc = scan_submit(d, static_cast<const uint16_t *>(device_samples), first_sample, n, g_begin, g_end);
+    if (rc == 0)
+        rc = scan_drain(d);
+    d->sink = ScanSink{};
+    if (rc)
         return -1;
     *n_cands = cv.size();
     *n_tries = tv.size();
@@ -658,13 +730,7 @@ long adsb_resolver_drain(adsb_resolver *r, adsb_frame *out, size_t cap)
 {
     if (!r || (!out && cap))
         return -1;
-    auto &q = r->r.out();
-    size_t n = 0;
-    while (n < cap && !q.empty()) {
-        out[n++] = q.front();
-        q.pop_front();
-    }
-    return (long)n;
+    return (long)r->r.drain(out, cap);
 }
 
 int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out)

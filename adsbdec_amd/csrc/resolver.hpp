@@ -10,11 +10,13 @@
 //      samples are buffered, scans [G, T-1200) and carries the rest, so the last
 //      ~41k power samples of a stream are never scanned.
 // Also valid.c:30-31's Try/Ok counters, which only count VISITED offsets.
+//
+// Cost matters: at device speed the host sees ~2e8 candidates per second, so the
+// queues are flat vectors with a head index, and records are consumed in place.
 #pragma once
 
 #include <cstdint>
 #include <cstring>
-#include <deque>
 #include <vector>
 
 #include "../../include/adsbdec_amd.h"
@@ -28,16 +30,45 @@ public:
         base_ = 0;
         skipped_ = 0;
         cands_.clear();
+        chead_ = 0;
         tries_.clear();
+        thead_ = 0;
         out_.clear();
+        ohead_ = 0;
         std::memset(&stats_, 0, sizeof stats_);
     }
 
     // Records must arrive in ascending g over the life of the stream.
     void feed(const adsb_candidate *c, size_t n, const uint64_t *tries, size_t nt)
     {
-        cands_.insert(cands_.end(), c, c + n);
-        tries_.insert(tries_.end(), tries, tries + nt);
+        compact();
+        if (n)
+            cands_.insert(cands_.end(), c, c + n);
+        if (nt)
+            tries_.insert(tries_.end(), tries, tries + nt);
+    }
+
+    // Device records: kWords dwords each {g_rel, pw, frame bytes 0..13, len in byte 14},
+    // visited through `order` (ascending g_rel); tries ascending ((g_rel << 2) | code).
+    void feed_device(const uint32_t *recs, const uint32_t *order, size_t n, int words, uint64_t g_base,
+                     const uint32_t *tries, size_t nt)
+    {
+        compact();
+        const size_t at = cands_.size();
+        cands_.resize(at + n);
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t *r = recs + (size_t)order[i] * words;
+            adsb_candidate &c = cands_[at + i];
+            c.g = g_base + r[0];
+            c.pw = r[1];
+            std::memcpy(c.frame, &r[2], 14);
+            c.len = (uint8_t)((r[5] >> 16) & 0xFF);
+            c.reserved = 0;
+        }
+        const size_t tat = tries_.size();
+        tries_.resize(tat + nt);
+        for (size_t i = 0; i < nt; i++)
+            tries_[tat + i] = (((uint64_t)(tries[i] >> 2) + g_base) << 2) | (tries[i] & 3u);
     }
 
     // power_samples: samples the front end has produced so far (air.c `aidx` grows
@@ -55,11 +86,27 @@ public:
             const uint64_t limit = fire - ADSB_DECOFFSET; // demod.c:89 `idx < len-DECOFFSET`
             if (limit > g_complete)
                 break; // the device has not scanned that far yet
+            // Nothing pending before the limit: the call only moves the base, and so
+            // does every following call up to the next record (skip them in one step).
             run_call(limit);
         }
     }
 
-    std::deque<adsb_frame> &out() { return out_; }
+    size_t pending() const { return out_.size() - ohead_; }
+    size_t drain(adsb_frame *dst, size_t cap)
+    {
+        size_t n = out_.size() - ohead_;
+        if (n > cap)
+            n = cap;
+        if (n)
+            std::memcpy(dst, out_.data() + ohead_, n * sizeof(adsb_frame));
+        ohead_ += n;
+        if (ohead_ == out_.size()) {
+            out_.clear();
+            ohead_ = 0;
+        }
+        return n;
+    }
     const adsb_stats &stats() const { return stats_; }
     uint64_t base() const { return base_; }
 
@@ -73,53 +120,74 @@ private:
         }
     }
 
+    void compact()
+    {
+        if (chead_ && chead_ == cands_.size()) {
+            cands_.clear();
+            chead_ = 0;
+        } else if (chead_ > (1u << 16)) {
+            cands_.erase(cands_.begin(), cands_.begin() + (ptrdiff_t)chead_);
+            chead_ = 0;
+        }
+        if (thead_ && thead_ == tries_.size()) {
+            tries_.clear();
+            thead_ = 0;
+        } else if (thead_ > (1u << 18)) {
+            tries_.erase(tries_.begin(), tries_.begin() + (ptrdiff_t)thead_);
+            thead_ = 0;
+        }
+    }
+
     // valid.c:46,68: one Try per visited offset that passed the DF gate.
     void count_tries(uint64_t from, uint64_t to_inclusive)
     {
-        while (!tries_.empty() && (tries_.front() >> 2) < from)
-            tries_.pop_front(); // shadowed by an accepted frame: never visited
-        while (!tries_.empty() && (tries_.front() >> 2) <= to_inclusive) {
-            stats_.try_[tries_.front() & 3]++;
-            tries_.pop_front();
-        }
+        const size_t n = tries_.size();
+        while (thead_ < n && (tries_[thead_] >> 2) < from)
+            thead_++; // shadowed by an accepted frame: never visited
+        while (thead_ < n && (tries_[thead_] >> 2) <= to_inclusive)
+            stats_.try_[tries_[thead_++] & 3]++;
     }
 
     // One deqframe(ampbuff, len) call: visits offsets from base_ while < limit.
     void run_call(uint64_t limit)
     {
         uint64_t idx = base_;
+        const size_t n = cands_.size();
         while (idx < limit) {
-            while (!cands_.empty() && cands_.front().g < idx)
-                cands_.pop_front(); // inside an accepted frame: never evaluated
-            if (cands_.empty() || cands_.front().g >= limit) {
+            while (chead_ < n && cands_[chead_].g < idx)
+                chead_++; // inside an accepted frame: never evaluated
+            if (chead_ == n || cands_[chead_].g >= limit) {
                 count_tries(idx, limit - 1);
                 idx = limit; // all remaining offsets advance by one (demod.c:141)
                 break;
             }
-            const adsb_candidate &c = cands_.front();
+            const adsb_candidate &c = cands_[chead_];
             count_tries(idx, c.g);
             const uint64_t span = 80 + 80 * (uint64_t)c.len; // demod.c:109,120,123: lidx
-            adsb_frame f;
-            std::memset(&f, 0, sizeof f);
+            out_.emplace_back();
+            adsb_frame &f = out_.back();
             f.g = c.g;
             f.ts = c.g + 1 - skipped_; // demod.c:99: one ts++ per visited offset
             f.pw = c.pw;
             f.len = c.len;
-            std::memcpy(f.frame, c.frame, c.len);
-            out_.push_back(f);
+            std::memcpy(f.frame, c.frame, 14);
+            f.reserved = 0;
             stats_.ok[df_slot(c.frame[0])]++;
             skipped_ += span - 1;
             idx = c.g + span; // demod.c:128,134
-            cands_.pop_front();
+            chead_++;
         }
         base_ = idx; // deqframe's return value; air.c:96-98 carries the rest
     }
 
     uint64_t base_ = 0;    // global index of ampbuff[0] at the next deqframe call
     uint64_t skipped_ = 0; // offsets jumped over by accepted frames
-    std::deque<adsb_candidate> cands_;
-    std::deque<uint64_t> tries_;
-    std::deque<adsb_frame> out_;
+    std::vector<adsb_candidate> cands_;
+    size_t chead_ = 0;
+    std::vector<uint64_t> tries_;
+    size_t thead_ = 0;
+    std::vector<adsb_frame> out_;
+    size_t ohead_ = 0;
     adsb_stats stats_{};
 };
 
