@@ -38,13 +38,14 @@ class Stats(C.Structure):
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("df18", C.c_int32), ("device", C.c_int32),
                 ("collect_stats", C.c_int32), ("profile", C.c_int32), ("debug_queue_cap", C.c_int32),
-                ("stage_samples", C.c_uint64), ("stream", C.c_void_p)]
+                ("stage_samples", C.c_uint64), ("stream", C.c_void_p), ("all_candidates", C.c_int32),
+                ("reserved1", C.c_int32)]
 
 
 class Profile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("relaunches", C.c_uint64), ("offsets", C.c_uint64),
                 ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double), ("last_offsets", C.c_uint64),
-                ("candidates", C.c_uint64), ("tries", C.c_uint64)]
+                ("candidates", C.c_uint64), ("tries", C.c_uint64), ("host_ms", C.c_double), ("wait_ms", C.c_double)]
 
 
 # every symbol include/adsbdec_amd.h declares: (restype, argtypes)
@@ -121,7 +122,7 @@ class Decoder:
 
     def __init__(self, df18: bool = False, device: int = -1, collect_stats: bool = False,
                  profile: bool = False, stage_samples: int = 0, stream: int | None = None,
-                 debug_queue_cap: int = 0):
+                 debug_queue_cap: int = 0, all_candidates: bool = False):
         L = load()
         cfg = Config()
         L.adsb_config_default(C.byref(cfg))
@@ -132,6 +133,7 @@ class Decoder:
         cfg.stage_samples = stage_samples
         cfg.stream = stream
         cfg.debug_queue_cap = debug_queue_cap
+        cfg.all_candidates = int(all_candidates)
         self._L = L
         self._h = L.adsb_create(C.byref(cfg))
         if not self._h:

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -218,6 +219,8 @@ void sort_tries(adsb_decoder *d, uint32_t *t, size_t n)
 int slot_collect(adsb_decoder *d)
 {
     ScanSlot &s = d->slots[d->slot_head];
+    using clk = std::chrono::steady_clock;
+    const auto t_wait = clk::now();
     for (int attempt = 0;; attempt++) {
         HIP_TRY(d, hipEventSynchronize(s.ev_ready));
         if (d->cfg.profile) {
@@ -243,6 +246,8 @@ int slot_collect(adsb_decoder *d)
         if (slot_launch(d, s))
             return -1;
     }
+    const auto t_host = clk::now();
+    d->prof.wait_ms += std::chrono::duration<double, std::milli>(t_host - t_wait).count();
     const size_t nc = s.h_counters[0], nt = s.h_counters[1];
     sort_order(d, s.cands, nc);
     if (nt)
@@ -266,6 +271,7 @@ int slot_collect(adsb_decoder *d)
         d->res.feed_device(s.cands, d->order.data(), nc, adsb::kCandWords, s.args.g_begin, s.tries, nt);
         d->res.advance(power_samples_produced(d->n_samples), s.args.g_end);
     }
+    d->prof.host_ms += std::chrono::duration<double, std::milli>(clk::now() - t_host).count();
     s.busy = false;
     d->slot_head = (d->slot_head + 1) % kSlots;
     d->slot_count--;
@@ -311,6 +317,7 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
         a.queue_cap = (d->cfg.debug_queue_cap >= 256 && d->cfg.debug_queue_cap <= adsb::kQueueCap)
                           ? d->cfg.debug_queue_cap
                           : adsb::kQueueCap;
+        a.all_candidates = d->cfg.all_candidates ? 1 : 0;
         if (slot_launch(d, s))
             return -1;
         d->slot_count++;

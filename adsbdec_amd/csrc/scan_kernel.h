@@ -22,6 +22,8 @@ constexpr int kReachRuns = 44;  // runs of bit planes one long-frame evaluation 
 constexpr int kMaxPasses = 32;
 constexpr int kQueueCap = 1024; // survivors compacted per round
 constexpr int kPlanePad = 8;
+constexpr int kClistCap = 192;  // CRC-valid candidates staged per tile for the never-visited filter
+constexpr int ADSB_DECOFFSET_K = 1200; // longest span an accepted frame jumps (adsbdec.h:3)
 constexpr int kCandWords = 6;   // {g_rel, pw, frame[0..13] | len<<16 in the last word}
 constexpr int kSyndWords = 14 * 256;
 
@@ -29,7 +31,7 @@ constexpr int owned_runs(int passes) { return kPassRuns * passes - kReachRuns; }
 constexpr int tile_offsets(int passes) { return kRun * owned_runs(passes); }
 constexpr size_t lds_bytes(int passes)
 {
-    return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 8);
+    return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 8 + kClistCap * 6);
 }
 constexpr uint64_t kMaxLaunchOffsets = (1ull << 30) - tile_offsets(kMaxPasses); // g_rel must fit 30 bits
 
@@ -42,6 +44,7 @@ struct ScanArgs {
     int df18;            // demod.c:26
     int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
     int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
+    int all_candidates;  // 1: emit every CRC-valid offset (no never-visited filter)
     const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
     uint32_t *counters;  // [0] candidates, [1] tries (may exceed the capacities)
     uint32_t *cands;     // kCandWords dwords per record

@@ -122,29 +122,70 @@ __device__ __forceinline__ void power_block(const f32x2 (&vv)[34], float *a)
     }
 }
 
-// Same arithmetic for ONE power sample at a run-time index (slow path: pw of a
-// CRC-valid candidate).  Rounds exactly like power_sample<>: same products, same
-// order, first product not added to zero.
-__device__ __noinline__ float power_at(const uint32_t *__restrict__ x, int64_t pbuf0, int64_t p_lo, int64_t p_hi,
-                                         int64_t m)
+// Same arithmetic for power samples at RUN-TIME indices (rare path: pw of a
+// CRC-valid candidate needs a[g], a[g+10], a[g+35], a[g+45]).  Rounds exactly like
+// power_sample<>: same products, same order (one static order per phase p = m mod
+// 7), first product not added to zero.  All loads are issued before any use: the
+// whole workgroup waits for this path at the next barrier.
+template <int P>
+__device__ __forceinline__ float power_ordered(const f32x2 (&pr)[7])
 {
-    static constexpr float tabI[7] = {tap<12>(), tap<10>(), tap<8>(), tap<6>(), tap<4>(), tap<2>(), tap<0>()};
-    static constexpr float tabQ[7] = {tap<13>(), tap<11>(), tap<9>(), tap<7>(), tap<5>(), tap<3>(), tap<1>()};
-    const int p = (int)(m % 7);
-    float si = 0.0f, sq = 0.0f;
-#pragma unroll 1
-    for (int step = 0; step < 7; step++) {
-        const int age = (step <= p) ? (p - step) : (6 - (step - p - 1));
-        const int64_t pr = m - age;
-        const uint32_t d = (pr >= p_lo && pr < p_hi) ? x[pr - pbuf0] : 0x08000800u;
-        const float fi = (float)(d & 0xFFFFu), fq = (float)(d >> 16);
-        const float vi = (pr & 1) ? 2048.0f - fi : fi - 2048.0f;
-        const float vq = (pr & 1) ? 2048.0f - fq : fq - 2048.0f;
-        const float pi = tabI[age] * vi, pq = tabQ[age] * vq;
-        si = (step == 0) ? pi : si + pi;
-        sq = (step == 0) ? pq : sq + pq;
+    // pr[a] = (T[12-2a], T[13-2a]) * (I, Q) of the pair of age a; order p, p-1, .., 0, 6, .., p+1
+    f32x2 s = pr[P];
+#pragma unroll
+    for (int a = P - 1; a >= 0; a--)
+        s = s + pr[a];
+#pragma unroll
+    for (int a = 6; a > P; a--)
+        s = s + pr[a];
+    const f32x2 sq = s * s;
+    return sq.x + sq.y;
+}
+
+__device__ __noinline__ uint32_t pw_at(const uint32_t *__restrict__ x, int64_t pbuf0, int64_t p_lo, int64_t p_hi,
+                                       int64_t g)
+{
+    const int off[4] = {0, 10, 35, 45}; // demod.c:102-105
+    uint32_t raw[4][7];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int a = 0; a < 7; a++) {
+            const int64_t pi = g + off[k] - a;
+            raw[k][a] = (pi >= p_lo && pi < p_hi) ? x[pi - pbuf0] : 0x08000800u;
+        }
+    float pw_s[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t m = g + off[k];
+        const int p = (int)(m % 7);
+        const f32x2 taps[7] = {{tap<12>(), tap<13>()}, {tap<10>(), tap<11>()}, {tap<8>(), tap<9>()},
+                               {tap<6>(), tap<7>()},   {tap<4>(), tap<5>()},   {tap<2>(), tap<3>()},
+                               {tap<0>(), tap<1>()}};
+        f32x2 pr[7];
+#pragma unroll
+        for (int a = 0; a < 7; a++) {
+            const uint32_t d = raw[k][a];
+            const f32x2 f = {(float)(d & 0xFFFFu), (float)(d >> 16)};
+            const f32x2 mid = {2048.0f, 2048.0f};
+            const f32x2 v = (((m - a) & 1) == 0) ? (f - mid) : (mid - f); // fs/4 sign of the pair
+            pr[a] = taps[a] * v;
+        }
+        float r;
+        switch (p) {
+        case 0: r = power_ordered<0>(pr); break;
+        case 1: r = power_ordered<1>(pr); break;
+        case 2: r = power_ordered<2>(pr); break;
+        case 3: r = power_ordered<3>(pr); break;
+        case 4: r = power_ordered<4>(pr); break;
+        case 5: r = power_ordered<5>(pr); break;
+        default: r = power_ordered<6>(pr); break;
+        }
+        pw_s[k] = r;
     }
-    return si * si + sq * sq;
+    const int p1 = __float2int_rz(pw_s[0] + pw_s[1]);
+    const int p2 = __float2int_rz(pw_s[2] + pw_s[3]);
+    return (uint32_t)((p1 + p2) / 4); // demod.c:127,133
 }
 
 // acc = (acc << 1) | sign(v): one v_alignbit_b32
@@ -293,7 +334,11 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         off_end = (int64_t)kRun * own;
     const int nchunks = (own + kThreads - 1) / kThreads;
     uint32_t *qover = qcount + 1;
+    uint32_t *cl_n = qcount + 2;    // CRC-valid candidates staged in LDS this round
+    uint32_t *cl_over = qcount + 3; // some were emitted directly: the staged list is incomplete
+    uint32_t *cl_rec = qcount + 8;  // kClistCap records of kCandWords
     const uint32_t qcap = (uint32_t)args.queue_cap;
+    const uint32_t tile_rel = (uint32_t)(t0 - (int64_t)args.g_begin);
 
     // Normally ONE round: the survivors of the whole tile (~0.5 % of its offsets)
     // fit the queue and all four waves slice with dense lanes.  If they do not fit,
@@ -304,8 +349,13 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         if (tid == 0) {
             *qcount = 0;
             *qover = 0;
+            *cl_n = 0;
+            *cl_over = 0;
         }
         __syncthreads();
+        // Whole-tile rounds see every CRC-valid candidate of the tile, which is what
+        // the never-visited filter below needs; fallback rounds emit directly.
+        const bool stage_cands = (grp < 0) && !args.all_candidates;
 
 #pragma unroll 1
         for (int ch = ch_lo; ch < ch_hi; ch++) {
@@ -396,18 +446,75 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             }
             wds[3] |= (uint32_t)nbytes << 16;
             const int64_t g = t0 + (int64_t)kRun * sv + sj;
-            const int p1 = __float2int_rz(power_at(xin, pbuf0, p_lo, p_hi, g) + power_at(xin, pbuf0, p_lo, p_hi, g + 10));
-            const int p2 = __float2int_rz(power_at(xin, pbuf0, p_lo, p_hi, g + 35) + power_at(xin, pbuf0, p_lo, p_hi, g + 45));
-            const uint32_t pw = (uint32_t)((p1 + p2) / 4); // demod.c:127,133
-            const uint32_t slot = atomicAdd(&args.counters[0], 1u);
-            if (slot < args.cand_cap) {
-                uint32_t *rec = args.cands + (size_t)slot * kCandWords;
+            const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, g);
+            uint32_t *rec = nullptr;
+            if (stage_cands) {
+                const uint32_t ci = atomicAdd(cl_n, 1u);
+                if (ci < (uint32_t)kClistCap)
+                    rec = cl_rec + ci * kCandWords;
+                else
+                    *cl_over = 1;
+            }
+            if (!rec) {
+                const uint32_t slot = atomicAdd(&args.counters[0], 1u);
+                if (slot < args.cand_cap)
+                    rec = args.cands + (size_t)slot * kCandWords;
+            }
+            if (rec) {
                 rec[0] = g_rel;
                 rec[1] = pw;
                 rec[2] = wds[0];
                 rec[3] = wds[1];
                 rec[4] = wds[2];
                 rec[5] = wds[3];
+            }
+        }
+
+        if (stage_cands) {
+            // Drop candidates the greedy scan (demod.c:89,128,134,141) can never visit.
+            // Let c' be the closest candidate before c, with c inside c' (c.g < c'.g +
+            // span').  The scan reaches c only by landing in (c'.g, c.g]: it cannot
+            // walk there (it would visit c' first and jump past c), so some candidate
+            // frame must END in (c'.g, c.g].  If the tile knows every candidate that
+            // could (they start at >= c'.g - 1199, i.e. inside this tile, and the staged
+            // list is complete), and none does, c is unreachable.  These are the +-1/2
+            // sample shifted copies of every real frame: 3 of 4 records.
+            __syncthreads();
+            const int ncl = min((int)*cl_n, kClistCap);
+            const bool complete = *cl_over == 0;
+#pragma unroll 1
+            for (int i = tid; i < ncl; i += kThreads) {
+                const uint32_t *ri = cl_rec + i * kCandWords;
+                const int gi = (int)(ri[0] - tile_rel); // tile-local offset
+                bool drop = false;
+                if (complete) {
+                    int pg = -1, pspan = 0;
+                    for (int j = 0; j < ncl; j++) {
+                        const int gj = (int)(cl_rec[j * kCandWords] - tile_rel);
+                        if (gj < gi && gj > pg) {
+                            pg = gj;
+                            pspan = 80 + 80 * (int)((cl_rec[j * kCandWords + 5] >> 16) & 0xFFu);
+                        }
+                    }
+                    if (pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan) {
+                        bool lands = false;
+                        for (int j = 0; j < ncl; j++) {
+                            const int ej = (int)(cl_rec[j * kCandWords] - tile_rel) + 80 +
+                                           80 * (int)((cl_rec[j * kCandWords + 5] >> 16) & 0xFFu);
+                            lands |= (ej > pg && ej <= gi);
+                        }
+                        drop = !lands;
+                    }
+                }
+                if (!drop) {
+                    const uint32_t slot = atomicAdd(&args.counters[0], 1u);
+                    if (slot < args.cand_cap) {
+                        uint32_t *rec = args.cands + (size_t)slot * kCandWords;
+#pragma unroll
+                        for (int k = 0; k < kCandWords; k++)
+                            rec[k] = ri[k];
+                    }
+                }
             }
         }
 

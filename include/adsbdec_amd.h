@@ -72,6 +72,9 @@ typedef struct adsb_config {
     int32_t debug_queue_cap;   /* test knob: survivor-queue entries per workgroup round (256..1024); 0 = default */
     uint64_t stage_samples;    /* device staging capacity for adsb_push(); 0 = default (32 Mi) */
     void *stream;              /* hipStream_t to launch on; NULL = a stream owned by the handle */
+    int32_t all_candidates;    /* 1: the device reports EVERY CRC-valid offset; 0 (default): it drops the
+                                  ones the greedy scan can provably never visit (same frames, ~4x fewer records) */
+    int32_t reserved1;
 } adsb_config;
 
 typedef struct adsb_profile {
@@ -83,6 +86,8 @@ typedef struct adsb_profile {
     uint64_t last_offsets;
     uint64_t candidates;       /* CRC-valid candidates received from the device     */
     uint64_t tries;            /* DF-gate passes received (collect_stats=1 only)    */
+    double host_ms;            /* host time spent sorting + resolving records       */
+    double wait_ms;            /* host time blocked waiting for the device          */
 } adsb_profile;
 
 void adsb_config_default(adsb_config *cfg);

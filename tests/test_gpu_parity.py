@@ -235,11 +235,24 @@ def test_shard_candidates_equal_oracle_exhaustive(capi, oracle, dec_factory, tor
     g_end = a.size - 1195
     wc, wt = oracle.scan_all(a, 0, g_end, True)
     t = _dev(torch_cuda, x)
-    d = dec_factory(df18=True, collect_stats=True)
+    d = dec_factory(df18=True, collect_stats=True, all_candidates=True)
     cands, nc, tries = d.scan_shard(t.data_ptr(), 0, x.size, 0, g_end)
     got = [(int(c.g), int(c.pw), bytes(c.frame[: c.len])) for c in cands[:nc]]
     assert got == wc
     assert np.array_equal(tries, wt)
+    # default mode: candidates the greedy scan can never visit are dropped on the
+    # device; what is left is a subset that resolves to exactly the same frames
+    d2 = dec_factory(df18=True, collect_stats=True)
+    cands2, nc2, tries2 = d2.scan_shard(t.data_ptr(), 0, x.size, 0, g_end)
+    got2 = [(int(c.g), int(c.pw), bytes(c.frame[: c.len])) for c in cands2[:nc2]]
+    assert set(got2) <= set(wc) and len(got2) < len(wc)
+    assert np.array_equal(tries2, wt)
+    want, wstats = oracle.decode(x, df18=True)
+    r = capi.Resolver()
+    r.feed(got2, tries2)
+    r.advance(a.size, g_end)
+    assert records(r.drain()) == records(want)
+    assert r.stats() == wstats
 
 
 # ------------------------------------------------------------------ size-independent properties

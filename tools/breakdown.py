@@ -15,4 +15,4 @@ for it in range(6):
     t3=time.perf_counter(); raw = dec.drain_raw()
     t4=time.perf_counter()
     p = dec.profile()
-    print(f"reset {1e3*(t1-t0):.3f} push {1e3*(t2-t1):.3f} finish {1e3*(t3-t2):.3f} drain {1e3*(t4-t3):.3f} ms | kernel {p['kernel_ms']:.3f} ms launches {p['launches']} cands {p['candidates']}")
+    print(f"reset {1e3*(t1-t0):.3f} push {1e3*(t2-t1):.3f} finish {1e3*(t3-t2):.3f} drain {1e3*(t4-t3):.3f} ms | kernel {p['kernel_ms']:.3f} ms launches {p['launches']} cands {p['candidates']} host {p['host_ms']:.3f} wait {p['wait_ms']:.3f}")
