@@ -188,6 +188,28 @@ __device__ __noinline__ uint32_t pw_at(const uint32_t *__restrict__ x, int64_t p
     return (uint32_t)((p1 + p2) / 4); // demod.c:127,133
 }
 
+// The slicer gathers the frame as 14 column bytes (frame bit k = 14 b + c is bit b
+// of column c; four columns per word).  Rebuild the 14 frame bytes in order (bit k
+// is bit 7 - k%8 of byte k/8), packed little-endian into wds[0..3], with the
+// length in byte 14.  A static 112-bit transpose: 2 operations per bit.
+__device__ __forceinline__ void columns_to_bytes(const uint32_t (&cw)[4], bool is_short, uint32_t (&wds)[4])
+{
+    wds[0] = wds[1] = wds[2] = wds[3] = 0;
+#pragma unroll
+    for (int k = 0; k < 112; k++) {
+        const int b = k / 14, c = k % 14;
+        const uint32_t bit = (cw[c >> 2] >> (8 * (c & 3) + b)) & 1u;
+        const int n = k >> 3;
+        wds[n >> 2] |= bit << (8 * (n & 3) + 7 - (k & 7));
+    }
+    if (is_short) { // DF11: 56 bits = 7 bytes
+        wds[1] &= 0x00FFFFFFu;
+        wds[2] = 0;
+        wds[3] = 0;
+    }
+    wds[3] |= (is_short ? 7u : 14u) << 16;
+}
+
 // acc = (acc << 1) | sign(v): one v_alignbit_b32
 __device__ __forceinline__ uint32_t push_sign(uint32_t acc, uint32_t v)
 {
@@ -411,6 +433,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             // at stream position sj + 80 + 10 c (+ 140 b = 5 words per b).
             const uint32_t *dcol = pl_d + sv;
             uint32_t syn = 0;
+            uint32_t cw[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int cc = 0; cc < 14; cc++) {
                 const int pos = sj + 80 + 10 * cc;
@@ -424,43 +447,33 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 // long frame's 56 bits (4 rows) further on
                 const uint32_t idx = (code == 0) ? ((col & 15u) << 4) : col;
                 syn ^= args.synd[cc * 256 + idx];
+                cw[cc >> 2] |= col << (8 * (cc & 3));
             }
             if (syn != 0)
                 continue; // valid.c:51,73
 
-            // CRC-valid (rare): rebuild the bytes in order and recompute pw
-            const int nbytes = (code == 0) ? 7 : 14;
-            uint32_t wds[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 14; k++) {
-                uint32_t byte = 0;
-                if (k < nbytes) {
-#pragma unroll 1
-                    for (int i = 0; i < 8; i++) {
-                        const int pos = sj + 80 + 80 * k + 10 * i;
-                        const int wi = (pos * 2341) >> 16;
-                        byte |= ((dcol[wi] >> (pos - 28 * wi)) & 1u) ? (0x80u >> i) : 0u;
-                    }
-                }
-                wds[k >> 2] |= byte << (8 * (k & 3));
-            }
-            wds[3] |= (uint32_t)nbytes << 16;
-            const int64_t g = t0 + (int64_t)kRun * sv + sj;
-            const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, g);
-            uint32_t *rec = nullptr;
+            // CRC-valid (about 1e-4 of the offsets).  Normally only staged here --
+            // {g_rel, code, columns} -- and finished below with dense lanes.
             if (stage_cands) {
                 const uint32_t ci = atomicAdd(cl_n, 1u);
-                if (ci < (uint32_t)kClistCap)
-                    rec = cl_rec + ci * kCandWords;
-                else
-                    *cl_over = 1;
+                if (ci < (uint32_t)kClistCap) {
+                    uint32_t *rec = cl_rec + ci * kCandWords;
+                    rec[0] = g_rel;
+                    rec[1] = code;
+                    rec[2] = cw[0];
+                    rec[3] = cw[1];
+                    rec[4] = cw[2];
+                    rec[5] = cw[3];
+                    continue;
+                }
+                *cl_over = 1; // list full: this one is finished and emitted right here
             }
-            if (!rec) {
-                const uint32_t slot = atomicAdd(&args.counters[0], 1u);
-                if (slot < args.cand_cap)
-                    rec = args.cands + (size_t)slot * kCandWords;
-            }
-            if (rec) {
+            uint32_t wds[4];
+            columns_to_bytes(cw, code == 0, wds);
+            const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, t0 + (int64_t)kRun * sv + sj);
+            const uint32_t slot = atomicAdd(&args.counters[0], 1u);
+            if (slot < args.cand_cap) {
+                uint32_t *rec = args.cands + (size_t)slot * kCandWords;
                 rec[0] = g_rel;
                 rec[1] = pw;
                 rec[2] = wds[0];
@@ -482,6 +495,20 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             __syncthreads();
             const int ncl = min((int)*cl_n, kClistCap);
             const bool complete = *cl_over == 0;
+            // finish the staged records: bytes in order, pw (demod.c:127,133)
+#pragma unroll 1
+            for (int i = tid; i < ncl; i += kThreads) {
+                uint32_t *rec = cl_rec + i * kCandWords;
+                const uint32_t cw[4] = {rec[2], rec[3], rec[4], rec[5]};
+                uint32_t wds[4];
+                columns_to_bytes(cw, rec[1] == 0, wds);
+                rec[1] = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + rec[0]);
+                rec[2] = wds[0];
+                rec[3] = wds[1];
+                rec[4] = wds[2];
+                rec[5] = wds[3];
+            }
+            __syncthreads();
 #pragma unroll 1
             for (int i = tid; i < ncl; i += kThreads) {
                 const uint32_t *ri = cl_rec + i * kCandWords;

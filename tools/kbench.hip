@@ -10,15 +10,23 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
-__global__ void fill_noise(uint16_t *x, size_t n, uint32_t seed)
+__device__ inline uint32_t mix(uint32_t h)
+{
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    return h;
+}
+
+// Gaussian noise of standard deviation sigma around 2048 (Box-Muller on hashed uniforms)
+__global__ void fill_noise(uint16_t *x, size_t n, uint32_t seed, float sigma)
 {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
-        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
-        // sum of 4 uniform nibbles-ish -> roughly bell shaped, sigma ~ 8 around 2048
-        int v = 2048 + (int)(h & 15) + (int)((h >> 4) & 15) + (int)((h >> 8) & 15) + (int)((h >> 12) & 15) - 30;
+        uint32_t h1 = mix((uint32_t)i * 2654435761u ^ seed), h2 = mix(h1 ^ 0x9E3779B9u);
+        float u1 = ((h1 >> 8) + 1) * (1.0f / 16777217.0f), u2 = (h2 >> 8) * (1.0f / 16777216.0f);
+        float g = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+        int v = (int)rintf(2048.0f + sigma * g);
+        v = v < 0 ? 0 : (v > 4095 ? 4095 : v);
         x[i] = (uint16_t)v;
     }
 }
@@ -32,7 +40,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&x, n * 2));
     CK(hipMalloc(&counters, 8));
     CK(hipMalloc(&cands, (1u << 20) * 24));
-    fill_noise<<<4096, 256>>>(x, n, 12345);
+    fill_noise<<<4096, 256>>>(x, n, 12345, argc > 4 ? (float)atof(argv[4]) : 8.0f);
     CK(hipDeviceSynchronize());
     adsb::ScanArgs a{};
     a.x = (const uint32_t *)x; a.pbuf0 = 0; a.p_lo = 0; a.p_hi = n / 2;
