@@ -57,7 +57,7 @@ struct ScanSlot {
     bool busy = false;
 };
 
-constexpr int kSlots = 3;
+constexpr int kSlots = 4;
 constexpr uint64_t kChunkOffsets = 28ull * ((32ull << 20) / 28); // offsets per pipelined launch
 
 struct ScanSink { // where collected records go: a caller's vectors, or (null) the stream's resolver
@@ -568,24 +568,29 @@ int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n)
     const uint64_t m_real = power_samples_produced(total);
     const uint64_t g_end = round_down(m_real >= ADSB_WINDOW ? m_real - ADSB_WINDOW + 1 : 0, 28);
     d->n_samples = total;
+    // Tail first: what the next push (or adsb_finish) still needs goes to the staging
+    // buffer.  Issued ahead of the scans so that it is finished, in stream order, by
+    // the time the last scan is collected (the caller may free the buffer on return).
+    const uint64_t g_after = std::max(g_end, d->g_scanned);
+    const uint64_t keep_first = std::max<uint64_t>(g_after >= 8 ? 2 * (g_after - 8) : 0, first);
+    const uint64_t left = total - keep_first;
+    if (left > d->stage_cap - kStageSlack)
+        return d->fail("in-place tail (%llu samples) exceeds the staging buffer", (unsigned long long)left);
+    d->cur ^= 1; // the seam scan above may still be reading the other buffer
+    HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur], p + (keep_first - first), left * sizeof(uint16_t),
+                              hipMemcpyDeviceToDevice, d->stream));
+    d->stage_first = keep_first;
+    d->stage_fill = left;
     if (g_end > d->g_scanned) {
         if (scan_submit(d, p, first, n, d->g_scanned, g_end))
             return -1;
         d->g_scanned = g_end;
+    } else {
+        HIP_TRY(d, hipStreamSynchronize(d->stream));
     }
     if (scan_drain(d))
         return -1;
     d->res.advance(m_real, d->g_scanned);
-    // Tail: what the next push (or adsb_finish) still needs goes to the staging buffer.
-    const uint64_t keep_first = std::max<uint64_t>(d->g_scanned >= 8 ? 2 * (d->g_scanned - 8) : 0, first);
-    const uint64_t left = total - keep_first;
-    if (left > d->stage_cap - kStageSlack)
-        return d->fail("in-place tail (%llu samples) exceeds the staging buffer", (unsigned long long)left);
-    HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur], p + (keep_first - first), left * sizeof(uint16_t),
-                              hipMemcpyDeviceToDevice, d->stream));
-    HIP_TRY(d, hipStreamSynchronize(d->stream)); // the caller may free the buffer after return
-    d->stage_first = keep_first;
-    d->stage_fill = left;
     return 0;
 }
 

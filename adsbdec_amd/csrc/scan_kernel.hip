@@ -324,18 +324,28 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         for (int k = 0; k < 16; k++)
             a[28 + k] = from_next_lane(a[k]);
 
-        // demod.c:102-105: every preamble sum is c[k] = (int)(a[k] + a[k+10])
-        int c[33];
+        // demod.c:102-105: every preamble sum is c[k] = (int)(a[k] + a[k+10]).  The
+        // truncated value is kept as a float (v_trunc_f32 == the C conversion for the
+        // magnitudes in the input domain); the integer comparisons `c > 2 c'` are
+        // decided by the SIGN of 2 c' - c, which one fused multiply-add gives exactly
+        // (a single rounding cannot change the sign of a non-zero difference and an
+        // exact zero stays zero).  These are the only FMAs in the kernel; the signal
+        // arithmetic above is mul-then-add.
+        float c[34];
 #pragma unroll
-        for (int k = 0; k < 33; k++)
-            c[k] = __float2int_rz(a[k] + a[k + 10]);
+        for (int k = 0; k < 34; k += 2) {
+            const f32x2 lo = {a[k], a[k + 1]}, hi = {a[k + 10], a[k + 11]};
+            const f32x2 sum = lo + hi;
+            c[k] = __builtin_truncf(sum.x);
+            c[k + 1] = __builtin_truncf(sum.y);
+        }
 
         uint32_t d = 0, e1 = 0, e2 = 0;
 #pragma unroll
         for (int m = 27; m >= 0; m--) { // bit m of each word <-> sample m of the run
-            d = push_sign(d, __float_as_uint(a[m + 5] - a[m]));  // a[m] > a[m+5]   (demod.c:34)
-            e1 = push_sign(e1, (uint32_t)(2 * c[m + 5] - c[m])); // c[m] > 2 c[m+5] (SN = 2, demod.c:83)
-            e2 = push_sign(e2, (uint32_t)(2 * c[m] - c[m + 5])); // c[m+5] > 2 c[m]
+            d = push_sign(d, __float_as_uint(a[m + 5] - a[m]));                           // a[m] > a[m+5]   (demod.c:34)
+            e1 = push_sign(e1, __float_as_uint(__builtin_fmaf(c[m + 5], 2.0f, -c[m])));  // c[m] > 2 c[m+5] (SN = 2, demod.c:83)
+            e2 = push_sign(e2, __float_as_uint(__builtin_fmaf(c[m], 2.0f, -c[m + 5])));  // c[m+5] > 2 c[m]
         }
         if (lane < kWaveRuns) { // lane 63 only feeds lane 62
             pl_d[v] = d;

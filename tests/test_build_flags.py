@@ -19,10 +19,20 @@ def isa():
 
 
 def test_no_fused_multiply_add_in_scan_kernel(isa):
+    """The signal arithmetic (FIR, power, pair sums) must be mul-THEN-add.  The only
+    fused operations allowed are the 56 per kernel instantiation that decide the SIGN
+    of 2*c' - c on already-truncated integers (exact by construction, see
+    scan_kernel.hip); anything else fused is a contraction bug."""
     fused = re.findall(r"^\s*(v_(?:pk_)?(?:fma|mac|mad|fmac|dot)\w*f(?:32|16)\w*)", isa, flags=re.M)
-    assert not fused, f"contracted arithmetic in the ISA: {sorted(set(fused))}"
+    kernels = len(re.findall(r"^\s*\.amdhsa_kernel\s", isa, flags=re.M))
+    assert kernels == 2
+    assert sorted(set(fused)) in ([], ["v_fma_f32"]), f"contracted arithmetic in the ISA: {sorted(set(fused))}"
+    assert len(fused) == 56 * kernels, f"{len(fused)} fused ops, expected {56 * kernels} (E1/E2 sign tests only)"
+    # each of them multiplies by the literal 2.0 (the SN factor of demod.c:83)
+    for line in re.findall(r"^\s*v_fma_f32.*$", isa, flags=re.M):
+        assert re.search(r"\b2\.0\b", line), line
     assert "-ffp-contract=off" in __import__("adsbdec_amd._build", fromlist=["HIP_FLAGS"]).HIP_FLAGS
-    assert re.search(r"v_(pk_)?mul_f32", isa) and re.search(r"v_(pk_)?add_f32", isa)
+    assert re.search(r"v_pk_mul_f32", isa) and re.search(r"v_pk_add_f32", isa)
 
 
 def test_no_scratch_and_gfx950_only(isa):
