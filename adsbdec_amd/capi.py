@@ -45,7 +45,8 @@ class Config(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("relaunches", C.c_uint64), ("offsets", C.c_uint64),
                 ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double), ("last_offsets", C.c_uint64),
-                ("candidates", C.c_uint64), ("tries", C.c_uint64), ("host_ms", C.c_double), ("wait_ms", C.c_double)]
+                ("candidates", C.c_uint64), ("tries", C.c_uint64), ("host_ms", C.c_double), ("wait_ms", C.c_double), ("big_offsets", C.c_uint64),
+                ("big_launches", C.c_uint64), ("big_ms", C.c_double)]
 
 
 # every symbol include/adsbdec_amd.h declares: (restype, argtypes)

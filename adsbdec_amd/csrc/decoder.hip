@@ -58,7 +58,18 @@ struct ScanSlot {
 };
 
 constexpr int kSlots = 4;
-constexpr uint64_t kChunkOffsets = 28ull * ((32ull << 20) / 28); // offsets per pipelined launch
+// offsets per pipelined launch (ADSB_CHUNK_MI overrides, for tuning runs)
+static uint64_t chunk_offsets()
+{
+    static const uint64_t v = [] {
+        const char *e = getenv("ADSB_CHUNK_MI");
+        uint64_t mi = e ? strtoull(e, nullptr, 10) : 0;
+        if (mi < 1 || mi > 512)
+            mi = 64;
+        return 28ull * ((mi << 20) / 28);
+    }();
+    return v;
+}
 
 struct ScanSink { // where collected records go: a caller's vectors, or (null) the stream's resolver
     std::vector<adsb_candidate> *cands = nullptr;
@@ -228,6 +239,16 @@ int slot_collect(adsb_decoder *d)
             HIP_TRY(d, hipEventElapsedTime(&ms, s.ev_start, s.ev_done));
             d->prof.kernel_ms += ms;
             d->prof.last_kernel_ms = ms;
+            const uint64_t no = s.args.g_end - s.args.g_begin;
+            if (no > d->prof.big_offsets) {
+                d->prof.big_offsets = no;
+                d->prof.big_launches = 0;
+                d->prof.big_ms = 0;
+            }
+            if (no == d->prof.big_offsets) {
+                d->prof.big_launches++;
+                d->prof.big_ms += ms;
+            }
         }
         d->prof.launches++;
         d->prof.offsets += s.args.g_end - s.args.g_begin;
@@ -295,7 +316,7 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
 {
     const bool stats = d->cfg.collect_stats != 0;
     while (g_begin < g_end) {
-        const uint64_t g_stop = std::min(g_end, g_begin + kChunkOffsets);
+        const uint64_t g_stop = std::min(g_end, g_begin + chunk_offsets());
         const uint64_t n_off = g_stop - g_begin;
         if (d->slot_count == kSlots && slot_collect(d))
             return -1;

@@ -505,23 +505,9 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             __syncthreads();
             const int ncl = min((int)*cl_n, kClistCap);
             const bool complete = *cl_over == 0;
-            // finish the staged records: bytes in order, pw (demod.c:127,133)
 #pragma unroll 1
             for (int i = tid; i < ncl; i += kThreads) {
-                uint32_t *rec = cl_rec + i * kCandWords;
-                const uint32_t cw[4] = {rec[2], rec[3], rec[4], rec[5]};
-                uint32_t wds[4];
-                columns_to_bytes(cw, rec[1] == 0, wds);
-                rec[1] = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + rec[0]);
-                rec[2] = wds[0];
-                rec[3] = wds[1];
-                rec[4] = wds[2];
-                rec[5] = wds[3];
-            }
-            __syncthreads();
-#pragma unroll 1
-            for (int i = tid; i < ncl; i += kThreads) {
-                const uint32_t *ri = cl_rec + i * kCandWords;
+                uint32_t *ri = cl_rec + i * kCandWords;
                 const int gi = (int)(ri[0] - tile_rel); // tile-local offset
                 bool drop = false;
                 if (complete) {
@@ -530,27 +516,35 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                         const int gj = (int)(cl_rec[j * kCandWords] - tile_rel);
                         if (gj < gi && gj > pg) {
                             pg = gj;
-                            pspan = 80 + 80 * (int)((cl_rec[j * kCandWords + 5] >> 16) & 0xFFu);
+                            pspan = cl_rec[j * kCandWords + 1] == 0 ? 640 : 1200; // staged word 1 = code
                         }
                     }
                     if (pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan) {
                         bool lands = false;
                         for (int j = 0; j < ncl; j++) {
-                            const int ej = (int)(cl_rec[j * kCandWords] - tile_rel) + 80 +
-                                           80 * (int)((cl_rec[j * kCandWords + 5] >> 16) & 0xFFu);
+                            const int ej = (int)(cl_rec[j * kCandWords] - tile_rel) +
+                                           (cl_rec[j * kCandWords + 1] == 0 ? 640 : 1200);
                             lands |= (ej > pg && ej <= gi);
                         }
                         drop = !lands;
                     }
                 }
-                if (!drop) {
-                    const uint32_t slot = atomicAdd(&args.counters[0], 1u);
-                    if (slot < args.cand_cap) {
-                        uint32_t *rec = args.cands + (size_t)slot * kCandWords;
-#pragma unroll
-                        for (int k = 0; k < kCandWords; k++)
-                            rec[k] = ri[k];
-                    }
+                if (drop)
+                    continue;
+                // finish the record: bytes in order, pw (demod.c:127,133), and emit
+                const uint32_t cw[4] = {ri[2], ri[3], ri[4], ri[5]};
+                uint32_t wds[4];
+                columns_to_bytes(cw, ri[1] == 0, wds);
+                const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + ri[0]);
+                const uint32_t slot = atomicAdd(&args.counters[0], 1u);
+                if (slot < args.cand_cap) {
+                    uint32_t *rec = args.cands + (size_t)slot * kCandWords;
+                    rec[0] = ri[0];
+                    rec[1] = pw;
+                    rec[2] = wds[0];
+                    rec[3] = wds[1];
+                    rec[4] = wds[2];
+                    rec[5] = wds[3];
                 }
             }
         }

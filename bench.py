@@ -150,6 +150,7 @@ def main():
 
     kernel_ms = 0.0
     kernel_offsets = 0
+    big = {}  # offsets-per-launch of the dominant launches -> [count, sum of ms]
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -157,6 +158,9 @@ def main():
         p = dec.profile()  # reset() clears it, so read per step
         kernel_ms += p["kernel_ms"]
         kernel_offsets += p["offsets"]
+        b = big.setdefault(p["big_offsets"], [0, 0.0])
+        b[0] += p["big_launches"]
+        b[1] += p["big_ms"]
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -168,11 +172,28 @@ def main():
     frames = capi._frames_to_dicts(raw[0], raw[1])
 
     # ---- roofline of the scan kernel (rank 0's launches) ----
-    alg_bytes = 4.0 * kernel_offsets             # 2 B/sample, 2 samples per preamble offset
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # Dominant kernel = adsb::scan_kernel at its largest launch size (the pipelined
+    # chunks).  achieved = algorithmic bytes of ONE such launch (4 B per preamble offset
+    # = 2 B per input sample) / its average duration from HIP events recorded inside
+    # the library on the launching stream.  traffic = HBM bytes of one such launch
+    # from the committed rocprofv3 PMC passes over this same command (FETCH_SIZE x 2 on
+    # gfx950 + WRITE_SIZE), when the launch size matches.
+    big_off = max(big) if big else 0
+    n_big, ms_big = big.get(big_off, (0, 0.0))
+    avg_ms = ms_big / n_big if n_big else 0.0
+    achieved = 4.0 * big_off / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r1_v4_pmc.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        if pmc.get("launch_offsets") == big_off:
+            traffic = int(pmc["hbm_bytes_per_launch"])
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "adsb::scan_kernel", "kernel_ms_per_step": round(kernel_ms / args.steps, 4)}
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel": "adsb::scan_kernel", "launch_offsets": big_off, "launch_bytes": 4 * big_off,
+                "launch_ms": round(avg_ms, 5), "launches_per_step": round(n_big / args.steps, 2),
+                "kernel_ms_per_step": round(kernel_ms / args.steps, 4)}
 
     # ---- CPU baseline + correctness gate (rank 0 only, N == 1 only) ----
     cpu = None

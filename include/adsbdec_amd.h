@@ -88,6 +88,9 @@ typedef struct adsb_profile {
     uint64_t tries;            /* DF-gate passes received (collect_stats=1 only)    */
     double host_ms;            /* host time spent sorting + resolving records       */
     double wait_ms;            /* host time blocked waiting for the device          */
+    uint64_t big_offsets;      /* offsets per launch of the largest launch size seen */
+    uint64_t big_launches;     /* launches of that size                             */
+    double big_ms;             /* sum of their HIP-event durations (profile=1)       */
 } adsb_profile;
 
 void adsb_config_default(adsb_config *cfg);
