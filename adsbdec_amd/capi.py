@@ -59,6 +59,8 @@ SYMBOLS = {
     "adsb_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_push_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_finish": (C.c_int, [C.c_void_p]),
+    "adsb_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "adsb_host_free": (None, [C.c_void_p]),
     "adsb_drain": (C.c_long, [C.c_void_p, C.POINTER(Frame), C.c_size_t]),
     "adsb_pending": (C.c_size_t, [C.c_void_p]),
     "adsb_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),

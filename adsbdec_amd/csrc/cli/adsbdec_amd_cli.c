@@ -96,7 +96,13 @@ int main(int argc, char **argv)
     int rc = 0;
     int fd = open(filename, O_RDONLY);
     if (fd >= 0) { /* an unopenable file ends the run silently (air.c:225-228) */
-        uint16_t *buf = (uint16_t *)malloc((size_t)READ_SAMPLES * sizeof(uint16_t));
+        /* page-locked, so that adsb_push() is one DMA (air.c:230 uses malloc) */
+        uint16_t *buf = (uint16_t *)adsb_host_alloc((size_t)READ_SAMPLES * sizeof(uint16_t));
+        if (!buf) {
+            fprintf(stderr, "adsb_host_alloc() failed\n");
+            adsb_destroy(dec);
+            return 255;
+        }
         size_t have = 0; /* bytes carried when read() returns an odd count */
         for (;;) {
             ssize_t n = read(fd, (char *)buf + have, (size_t)READ_SAMPLES * 2 - have);
@@ -114,7 +120,7 @@ int main(int argc, char **argv)
             if (flush_frames(dec, outformat) != 0)
                 break;
         }
-        free(buf);
+        adsb_host_free(buf);
         close(fd);
         if (rc == 0 && adsb_finish(dec) != 0) {
             fprintf(stderr, "adsb_finish() failed: %s\n", adsb_last_error(dec));

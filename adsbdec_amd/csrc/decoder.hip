@@ -394,8 +394,6 @@ int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind)
         const size_t take = (size_t)std::min<uint64_t>(room, n);
         HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind,
                                   d->stream));
-        if (kind == hipMemcpyHostToDevice)
-            HIP_TRY(d, hipStreamSynchronize(d->stream)); // `samples` is only borrowed for the call
         d->stage_fill += take;
         d->n_samples += take;
         p += take;
@@ -559,7 +557,24 @@ int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n)
     if (!samples)
         return d->fail("adsb_push: NULL samples");
     HIP_TRY(d, hipSetDevice(d->device));
-    return push_copy(d, samples, n, hipMemcpyHostToDevice);
+    if (push_copy(d, samples, n, hipMemcpyHostToDevice))
+        return -1;
+    HIP_TRY(d, hipStreamSynchronize(d->stream)); // `samples` is only borrowed for the call
+    return 0;
+}
+
+void *adsb_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+        return nullptr;
+    return p;
+}
+
+void adsb_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
 }
 
 int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n)

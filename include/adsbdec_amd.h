@@ -114,6 +114,12 @@ int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n);
  * is scanned in place; anything else goes through the staging buffer. */
 int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n);
 
+/* Page-locked host buffers for adsb_push(): the counterpart of fileInput's
+ * malloc'd iqbuff (air.c:230).  read() straight into one and the push is a single
+ * DMA; ordinary malloc'd memory works too, through the driver's bounce buffers. */
+void *adsb_host_alloc(size_t bytes);
+void adsb_host_free(void *p);
+
 /* End of input (fileInput's EOF, air.c:241-244): runs the remaining offsets and
  * applies the reference's end-of-file horizon. */
 int adsb_finish(adsb_decoder *d);
