@@ -58,6 +58,7 @@ SYMBOLS = {
     "adsb_reset": (C.c_int, [C.c_void_p]),
     "adsb_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_push_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "adsb_push_device_final": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_finish": (C.c_int, [C.c_void_p]),
     "adsb_host_alloc": (C.c_void_p, [C.c_size_t]),
     "adsb_host_free": (None, [C.c_void_p]),
@@ -167,6 +168,9 @@ class Decoder:
 
     def push_device(self, ptr: int, n: int):
         self._check(self._L.adsb_push_device(self._h, ptr, n), "adsb_push_device")
+
+    def push_device_final(self, ptr: int, n: int):
+        self._check(self._L.adsb_push_device_final(self._h, ptr, n), "adsb_push_device_final")
 
     def finish(self):
         self._check(self._L.adsb_finish(self._h), "adsb_finish")

@@ -577,21 +577,29 @@ void adsb_host_free(void *p)
         (void)hipHostFree(p);
 }
 
-int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n)
+} // extern "C"
+
+namespace {
+
+// adsb_push_device, optionally followed by adsb_finish in the same pass (`final`):
+// the last in-place scan then runs to the exact end of the stream and no tail has to
+// be staged.
+int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool final)
 {
     if (!d)
         return -1;
     if (d->finished)
         return d->fail("adsb_push_device after adsb_finish");
-    if (n == 0)
-        return 0;
-    if (!device_samples)
+    if (n && !device_samples)
         return d->fail("adsb_push_device: NULL samples");
     HIP_TRY(d, hipSetDevice(d->device));
     const uint16_t *p = static_cast<const uint16_t *>(device_samples);
     const bool aligned = (d->n_samples % 8 == 0) && ((uintptr_t)p % 16 == 0);
-    if (!aligned || n < kInPlaceMinSamples)
-        return push_copy(d, p, n, hipMemcpyDeviceToDevice);
+    if (!aligned || n < kInPlaceMinSamples) {
+        if (n && push_copy(d, p, n, hipMemcpyDeviceToDevice))
+            return -1;
+        return final ? adsb_finish(d) : 0;
+    }
 
     // In-place scan.  First the seam: offsets whose window starts in earlier data.
     const uint64_t first = d->n_samples; // stream index of p[0]
@@ -602,8 +610,23 @@ int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n)
     // Bulk: every offset whose whole window lies inside this buffer.
     const uint64_t total = first + n;
     const uint64_t m_real = power_samples_produced(total);
-    const uint64_t g_end = round_down(m_real >= ADSB_WINDOW ? m_real - ADSB_WINDOW + 1 : 0, 28);
+    uint64_t g_end = m_real >= ADSB_WINDOW ? m_real - ADSB_WINDOW + 1 : 0;
+    if (!final)
+        g_end = round_down(g_end, 28);
     d->n_samples = total;
+    if (final) {
+        if (g_end > d->g_scanned) {
+            if (scan_submit(d, p, first, n, d->g_scanned, g_end))
+                return -1;
+            d->g_scanned = g_end;
+        }
+        if (scan_drain(d))
+            return -1;
+        d->res.advance(2 * ((total + 3) / 4), d->g_scanned); // EOF rule: see process_stage()
+        d->stage_fill = 0;
+        d->finished = true;
+        return 0;
+    }
     // Tail first: what the next push (or adsb_finish) still needs goes to the staging
     // buffer.  Issued ahead of the scans so that it is finished, in stream order, by
     // the time the last scan is collected (the caller may free the buffer on return).
@@ -628,6 +651,22 @@ int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n)
         return -1;
     d->res.advance(m_real, d->g_scanned);
     return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n)
+{
+    if (n == 0 && d && !d->finished)
+        return 0;
+    return push_device_impl(d, device_samples, n, false);
+}
+
+int adsb_push_device_final(adsb_decoder *d, const void *device_samples, size_t n)
+{
+    return push_device_impl(d, device_samples, n, true);
 }
 
 int adsb_finish(adsb_decoder *d)

@@ -98,27 +98,38 @@ __device__ __forceinline__ void fir_step(const f32x2 (&vv)[34], f32x2 &s)
         s = s + t * vv[slot];
 }
 
-template <int J>
-__device__ __forceinline__ float power_sample(const f32x2 (&vv)[34])
+// G consecutive outputs advanced together, one FIR step at a time: G independent
+// accumulation chains are interleaved in program order, so a dependent add never
+// issues right behind the multiply it consumes (the compiler otherwise emits each
+// output's seven steps back to back and pads every mul->add pair with s_nop).
+template <int J0, int G, int STEP>
+__device__ __forceinline__ void fir_group_step(const f32x2 (&vv)[34], f32x2 (&s)[G])
 {
-    f32x2 s;
-    fir_step<J, 0>(vv, s);
-    fir_step<J, 1>(vv, s);
-    fir_step<J, 2>(vv, s);
-    fir_step<J, 3>(vv, s);
-    fir_step<J, 4>(vv, s);
-    fir_step<J, 5>(vv, s);
-    fir_step<J, 6>(vv, s);
-    const f32x2 sq = s * s;
-    return sq.x + sq.y; // air.c:76,91
+    if constexpr (STEP < 7) {
+        fir_step<J0 + 0, STEP>(vv, s[0]);
+        if constexpr (G > 1) fir_step<J0 + 1, STEP>(vv, s[1]);
+        if constexpr (G > 2) fir_step<J0 + 2, STEP>(vv, s[2]);
+        if constexpr (G > 3) fir_step<J0 + 3, STEP>(vv, s[3]);
+        if constexpr (G > 4) fir_step<J0 + 4, STEP>(vv, s[4]);
+        if constexpr (G > 5) fir_step<J0 + 5, STEP>(vv, s[5]);
+        if constexpr (G > 6) fir_step<J0 + 6, STEP>(vv, s[6]);
+        fir_group_step<J0, G, STEP + 1>(vv, s);
+    }
 }
 
-template <int J0, int N>
+template <int J0, int N, int G>
 __device__ __forceinline__ void power_block(const f32x2 (&vv)[34], float *a)
 {
     if constexpr (N > 0) {
-        a[J0] = power_sample<J0>(vv);
-        power_block<J0 + 1, N - 1>(vv, a);
+        constexpr int g = (N < G) ? N : G;
+        f32x2 s[g];
+        fir_group_step<J0, g, 0>(vv, s);
+#pragma unroll
+        for (int k = 0; k < g; k++) {
+            const f32x2 sq = s[k] * s[k];
+            a[J0 + k] = sq.x + sq.y; // air.c:76,91
+        }
+        power_block<J0 + g, N - g, G>(vv, a);
     }
 }
 
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
 
         // a[0..27]: this run; a[28..43]: the first 16 samples of the next run (next lane)
         float a[44];
-        power_block<0, 28>(vv, a);
+        power_block<0, 28, ADSB_FIR_GROUP>(vv, a);
 #pragma unroll
         for (int k = 0; k < 16; k++)
             a[28 + k] = from_next_lane(a[k]);

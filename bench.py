@@ -6,8 +6,8 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one full pass of the hot path over one synthetic capture that is
-already resident in HBM: adsb_reset -> adsb_push_device (fused scan kernel over
-every preamble offset + record gather) -> adsb_finish (tail + end-of-file rule)
+already resident in HBM: adsb_reset -> adsb_push_device_final (fused scan kernel
+over every preamble offset, record gather, greedy resolution, end-of-file rule)
 -> adsb_drain (frames in reference order).  Workload = BASELINE.json configs[1]:
 256 Mi uint16 samples @ 20 MS/s, sparse frames (~1 k frames/s, DF17 with some
 DF11), sigma = 8 noise.  With N > 1 every rank decodes its own independent stream
@@ -135,8 +135,7 @@ def main():
 
     def step():
         dec.reset()
-        dec.push_device(xptr, xn)
-        dec.finish()
+        dec.push_device_final(xptr, xn)  # == push_device + finish, in one pass
         return dec.drain_raw()  # frames stay in a C array; converted once, after timing
 
     for _ in range(args.warmup):

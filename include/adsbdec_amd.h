@@ -114,6 +114,12 @@ int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n);
  * is scanned in place; anything else goes through the staging buffer. */
 int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n);
 
+/* adsb_push_device() of the LAST piece of a stream followed by adsb_finish(), in one
+ * pass: the in-place scan runs to the exact end of the stream (one launch less, no
+ * tail staging).  This is the whole of `adsbdec -f` for a capture that is already
+ * resident in HBM. */
+int adsb_push_device_final(adsb_decoder *d, const void *device_samples, size_t n);
+
 /* Page-locked host buffers for adsb_push(): the counterpart of fileInput's
  * malloc'd iqbuff (air.c:230).  read() straight into one and the push is a single
  * DMA; ordinary malloc'd memory works too, through the driver's bounce buffers. */

@@ -65,6 +65,34 @@ def test_golden_device_resident(capi, dec_factory, torch_cuda, name):
     assert d.stats() == rec["stats"]
 
 
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_device_final_one_pass(capi, dec_factory, torch_cuda, name):
+    """adsb_push_device_final == adsb_push_device + adsb_finish."""
+    x, rec = load_golden(name)
+    t = _dev(torch_cuda, x)
+    d = dec_factory(df18=rec["df18"], collect_stats=True)
+    d.reset()
+    d.push_device_final(t.data_ptr(), t.numel())
+    assert records(d.drain()) == golden_records(rec)
+    assert d.stats() == rec["stats"]
+    with pytest.raises(capi.AdsbError):
+        d.push_device(t.data_ptr(), 8)   # the stream is finished
+
+
+def test_device_final_after_earlier_pushes(oracle, dec_factory, torch_cuda):
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture((1 << 20) + 6, seed=19, sigma=45.0, n_frames=250)
+    want, wstats = oracle.decode(x, df18=True)
+    t = _dev(torch_cuda, x)
+    d = dec_factory(df18=True, collect_stats=True)
+    split = 8 * 40_000
+    d.reset()
+    d.push_device(t.data_ptr(), split)
+    d.push_device_final(t.data_ptr() + 2 * split, t.numel() - split)
+    assert records(d.drain()) == records(want)
+    assert d.stats() == wstats
+
+
 # ------------------------------------------------------------------ seeded vs oracle
 @pytest.mark.parametrize("seed,sigma,nfr,df18", [(101, 8.0, 80, False), (102, 40.0, 300, True),
                                                  (103, 300.0, 60, True), (104, 120.0, 500, False)])
