@@ -273,6 +273,7 @@ int slot_collect(adsb_decoder *d)
     sort_order(d, s.cands, nc);
     if (nt)
         sort_tries(d, s.tries, nt);
+    const auto t_sorted = clk::now();
     d->prof.candidates += nc;
     d->prof.tries += nt;
     if (d->sink.cands) {
@@ -293,6 +294,10 @@ int slot_collect(adsb_decoder *d)
         d->res.advance(power_samples_produced(d->n_samples), s.args.g_end);
     }
     d->prof.host_ms += std::chrono::duration<double, std::milli>(clk::now() - t_host).count();
+    if (getenv("ADSB_DEBUG_HOST"))
+        fprintf(stderr, "collect: nc=%zu nt=%zu sort %.1f us, feed+resolve %.1f us\n", nc, nt,
+                std::chrono::duration<double, std::micro>(t_sorted - t_host).count(),
+                std::chrono::duration<double, std::micro>(clk::now() - t_sorted).count());
     s.busy = false;
     d->slot_head = (d->slot_head + 1) % kSlots;
     d->slot_count--;

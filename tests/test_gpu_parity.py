@@ -163,6 +163,25 @@ def test_device_pushes_in_place_and_staged(oracle, dec_factory, torch_cuda, spli
     assert d.stats() == wstats
 
 
+def test_small_staging_buffer_many_pieces(oracle, dec_factory, torch_cuda):
+    """A 64 Ki-sample staging buffer forces every push through many stage/scan/carry
+    cycles (host pushes and unaligned device pushes alike)."""
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture(700_001, seed=23, sigma=40.0, n_frames=150)
+    want, wstats = oracle.decode(x, df18=True)
+    d = dec_factory(df18=True, collect_stats=True, stage_samples=1 << 16)
+    assert records(d.decode(x)) == records(want)
+    assert d.stats() == wstats
+    t = _dev(torch_cuda, x)
+    d.reset()
+    d.push_device(t.data_ptr() + 2, 3)            # unaligned start: staged copies
+    d.push_device(t.data_ptr() + 8, x.size - 4)
+    d.finish()
+    want2, wstats2 = oracle.decode(x[1:], df18=True)
+    assert records(d.drain()) == records(want2)
+    assert d.stats() == wstats2
+
+
 # ------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("n", [0, 1, 3, 4, 2390, 2392, 81_956, 81_960, 81_964])
 def test_tiny_and_threshold_lengths(oracle, dec_factory, n):
