@@ -10,6 +10,9 @@ namespace adsb {
 #ifndef ADSB_ABLATE
 #define ADSB_ABLATE 0 // kbench only: 1 = loads only, 2 = front end + bit planes only
 #endif
+#ifndef ADSB_PREFETCH
+#define ADSB_PREFETCH 0 // 1: software-prefetch the next pass's loads (needs ~36 more VGPRs)
+#endif
 #ifndef ADSB_FIR_GROUP
 #define ADSB_FIR_GROUP 4 // FIR outputs advanced together (independent chains interleaved)
 #endif

@@ -277,15 +277,13 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     }
 
     // ------------------------------ Stage A ------------------------------
-#pragma unroll 1
-    for (int pass = 0; pass < K; pass++) {
-        const int v0 = kWaveRuns * (4 * pass + wave); // first run of this wave in this pass
-        const int v = v0 + lane;
-        const int64_t pr0 = t0 + (int64_t)kRun * v - 8; // first pair loaded; multiple of 4
+    // the 36 pairs (8 of pre-halo + 28) of this lane's run in pass `ps`
+    auto load_pass = [&](int ps, uint32_t (&w)[36]) {
+        const int lv0 = kWaveRuns * (4 * ps + wave);
+        const int64_t pr0 = t0 + (int64_t)kRun * (lv0 + lane) - 8; // first pair loaded; multiple of 4
         // wave-uniform: every pair this wave loads lies inside the buffer
-        const int64_t wlo = t0 + (int64_t)kRun * v0 - 8;
+        const int64_t wlo = t0 + (int64_t)kRun * lv0 - 8;
         const bool interior = (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
-        uint32_t w[36];
         if (interior) {
             const uint4 *src = reinterpret_cast<const uint4 *>(xin + (pr0 - pbuf0));
 #pragma unroll
@@ -305,6 +303,23 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 w[k] = (pr >= p_lo && pr < p_hi) ? xin[pr - pbuf0] : 0x08000800u;
             }
         }
+    };
+#if ADSB_PREFETCH
+    uint32_t w[36];
+    load_pass(0, w);
+#endif
+#pragma unroll 1
+    for (int pass = 0; pass < K; pass++) {
+        const int v0 = kWaveRuns * (4 * pass + wave); // first run of this wave in this pass
+        const int v = v0 + lane;
+#if ADSB_PREFETCH
+        uint32_t wn[36]; // next pass's samples, in flight while this pass computes
+        if (pass + 1 < K)
+            load_pass(pass + 1, wn);
+#else
+        uint32_t w[36];
+        load_pass(pass, w);
+#endif
 #if ADSB_ABLATE == 1
         {   // kbench: price the loads alone
             uint32_t acc = 0;
@@ -363,6 +378,11 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             pl_e1[v] = e1;
             pl_e2[v] = e2;
         }
+#if ADSB_PREFETCH
+#pragma unroll
+        for (int k = 0; k < 36; k++)
+            w[k] = wn[k];
+#endif
     }
     __syncthreads();
 #if ADSB_ABLATE != 0

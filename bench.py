@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--dense", action="store_true", help="configs[2]: wide-band noise, ~7%% preamble hits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=0, help="oracle sample size (default: the whole capture)")
+    ap.add_argument("--one-device-test", action="store_true",
+                    help="plumbing test only: every rank uses GPU 0 and gloo (numbers are meaningless)")
     args = ap.parse_args()
 
     import torch
@@ -105,10 +107,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    if args.one_device_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.one_device_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not os.path.exists(capi.LIB_PATH):
         if rank == 0:
             _build.build()
@@ -163,7 +170,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.one_device_test else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
