@@ -118,6 +118,31 @@ def test_full_range_12bit_noise_vs_oracle(oracle, dec_factory):
     assert sum(wstats["try"].values()) > 1000
 
 
+@pytest.mark.parametrize("hi", [20000, 24000])
+def test_beyond_12_bit_codes_vs_oracle(oracle, dec_factory, hi):
+    """uint16 codes far outside the ADC's 12 bits (|x-2048| up to ~22 k): power sums
+    exceed 2^24 (so float truncation is the identity and pair sums round), yet stay
+    below 2^31 where the reference's float->int conversion is defined."""
+    from oracle import gen_signal as G
+    rng = np.random.default_rng(hi)
+    x = rng.integers(0, hi, 1 << 20, dtype=np.uint16)
+    fr = [G.make_frame(17, rng) for _ in range(40)]
+    sig = np.zeros(x.size, np.float32)
+    for i, f in enumerate(fr):
+        s0 = 20_000 + 25_000 * i
+        env = G.frame_envelope(f)
+        sig[s0:s0 + env.size] += 9000.0 * env * np.cos(np.pi * np.arange(s0, s0 + env.size) / 2 + i)
+    x = np.clip(x.astype(np.float32) * 0.05 + 2048 - hi * 0.025 + sig, 0, hi).astype(np.uint16)
+    y = rng.integers(0, hi, 1 << 19, dtype=np.uint16)          # second half: raw wide noise
+    x = np.concatenate([x, y])
+    want, wstats = oracle.decode(x, df18=True)
+    d = dec_factory(df18=True, collect_stats=True)
+    assert records(d.decode(x)) == records(want)
+    assert d.stats() == wstats
+    a = oracle.power(x)
+    assert len(want) >= 30 and float((a[:-10] + a[10:]).max()) > 2.0 ** 24   # pair sums beyond 2^24
+
+
 @pytest.mark.parametrize("chunk", [4, 1000, 4096, 65536 + 12, 1 << 18])
 def test_chunked_pushes_equal_one_shot(oracle, dec_factory, chunk):
     """The stream is the concatenation of pushes (decodeiq's statics, air.c:33-34,49-50)."""
