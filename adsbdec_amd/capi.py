@@ -32,14 +32,14 @@ class Candidate(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("try_", C.c_uint64 * 3), ("ok", C.c_uint64 * 3)]
+    _fields_ = [("try_", C.c_uint64 * 3), ("ok", C.c_uint64 * 3), ("fixed", C.c_uint64)]
 
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("df18", C.c_int32), ("device", C.c_int32),
                 ("collect_stats", C.c_int32), ("profile", C.c_int32), ("debug_queue_cap", C.c_int32),
                 ("stage_samples", C.c_uint64), ("stream", C.c_void_p), ("all_candidates", C.c_int32),
-                ("reserved1", C.c_int32)]
+                ("fix_1bit", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -106,9 +106,12 @@ def _frames_to_dicts(arr, n):
     return [dict(g=int(f.g), ts=int(f.ts), pw=int(f.pw), frame=bytes(f.frame[: f.len])) for f in arr[:n]]
 
 
-def _stats_to_dict(st: Stats):
-    return {"try": {11: int(st.try_[0]), 17: int(st.try_[1]), 18: int(st.try_[2])},
-            "ok": {11: int(st.ok[0]), 17: int(st.ok[1]), 18: int(st.ok[2])}}
+def _stats_to_dict(st: Stats, with_fixed: bool = False):
+    d = {"try": {11: int(st.try_[0]), 17: int(st.try_[1]), 18: int(st.try_[2])},
+         "ok": {11: int(st.ok[0]), 17: int(st.ok[1]), 18: int(st.ok[2])}}
+    if with_fixed:
+        d["fixed"] = int(st.fixed)
+    return d
 
 
 def format_frame(fr: dict, outformat: int) -> bytes:
@@ -126,7 +129,7 @@ class Decoder:
 
     def __init__(self, df18: bool = False, device: int = -1, collect_stats: bool = False,
                  profile: bool = False, stage_samples: int = 0, stream: int | None = None,
-                 debug_queue_cap: int = 0, all_candidates: bool = False):
+                 debug_queue_cap: int = 0, all_candidates: bool = False, fix_1bit: bool = False):
         L = load()
         cfg = Config()
         L.adsb_config_default(C.byref(cfg))
@@ -138,7 +141,9 @@ class Decoder:
         cfg.stream = stream
         cfg.debug_queue_cap = debug_queue_cap
         cfg.all_candidates = int(all_candidates)
+        cfg.fix_1bit = int(fix_1bit)
         self._L = L
+        self._fix = bool(fix_1bit)
         self._h = L.adsb_create(C.byref(cfg))
         if not self._h:
             raise AdsbError("adsb_create failed: " + (L.adsb_last_error(None) or b"").decode())
@@ -194,7 +199,7 @@ class Decoder:
     def stats(self):
         st = Stats()
         self._check(self._L.adsb_get_stats(self._h, C.byref(st)), "adsb_get_stats")
-        return _stats_to_dict(st)
+        return _stats_to_dict(st, self._fix)
 
     def profile(self):
         p = Profile()

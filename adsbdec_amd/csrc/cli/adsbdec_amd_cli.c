@@ -8,6 +8,9 @@
  *     -m            AVR-MLAT output (outformat 1, main.c:79-81)
  *     -b            Beast binary output (outformat 2, main.c:82-84)
  *     -g n          accepted and ignored (gain only matters for the live radio)
+ *     -x            EXTENSION, not in the reference: repair single-bit errors in DF17/18
+ *                   frames (the reference's -e flag is parsed but does nothing and exits
+ *                   with the usage text, main.c:40,60,85-87; that behaviour is kept for -e)
  * -s / -l (TCP sinks), the live Airspy input and anything else print the usage
  * text and exit 1, like the reference's default: branch (main.c:85-87).
  *
@@ -34,6 +37,7 @@ static void usage(void)
     printf("\t-a : decode DF18 too\n");
     printf("\t-m : output avrmlat format (ie : with 12Mhz timestamp)\n");
     printf("\t-b : output binary beast format\n");
+    printf("\t-x : (extension) repair 1-bit CRC errors in DF17/18 frames\n");
     printf("\t-f : input from filename (raw 16 bits real, 12-bit ADC code centred on 2048)\n");
 }
 
@@ -55,9 +59,9 @@ static int flush_frames(adsb_decoder *dec, int outformat)
 int main(int argc, char **argv)
 {
     const char *filename = NULL;
-    int outformat = 0, df18 = 0, c;
+    int outformat = 0, df18 = 0, fix1 = 0, c;
 
-    while ((c = getopt(argc, argv, "f:g:amb")) != EOF) {
+    while ((c = getopt(argc, argv, "f:g:ambx")) != EOF) {
         switch (c) {
         case 'f':
             filename = optarg;
@@ -73,6 +77,9 @@ int main(int argc, char **argv)
         case 'b':
             outformat = 2;
             break;
+        case 'x':
+            fix1 = 1;
+            break;
         default:
             usage();
             return 1;
@@ -86,6 +93,7 @@ int main(int argc, char **argv)
     adsb_config cfg;
     adsb_config_default(&cfg);
     cfg.df18 = df18;
+    cfg.fix_1bit = fix1;
     cfg.collect_stats = 1; /* the reference always prints Try/Ok */
     adsb_decoder *dec = adsb_create(&cfg);
     if (!dec) {

@@ -96,6 +96,8 @@ struct adsb_decoder {
     uint64_t stage_fill = 0;  // samples held
 
     uint32_t *d_synd = nullptr; // 14 x 256 CRC-24 syndrome table (scan_kernel.h)
+    uint32_t *d_fix = nullptr;  // single-bit syndrome hash (extension, cfg.fix_1bit)
+    uint32_t fix_mul = 0;
     int n_cus = 256;
     ScanSlot slots[kSlots];
     int slot_head = 0, slot_count = 0; // FIFO of busy slots
@@ -285,6 +287,7 @@ int slot_collect(adsb_decoder *d)
             c.pw = r[1];
             std::memcpy(c.frame, &r[2], 14);
             c.len = (uint8_t)((r[5] >> 16) & 0xFF);
+            c.reserved = (uint8_t)((r[5] >> 24) & 1u);
             d->sink.cands->push_back(c);
         }
         for (size_t i = 0; i < nt; i++)
@@ -344,6 +347,8 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
                           ? d->cfg.debug_queue_cap
                           : adsb::kQueueCap;
         a.all_candidates = d->cfg.all_candidates ? 1 : 0;
+        a.fix_tab = d->cfg.fix_1bit ? d->d_fix : nullptr;
+        a.fix_mul = d->fix_mul;
         if (slot_launch(d, s))
             return -1;
         d->slot_count++;
@@ -503,6 +508,14 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         if ((e = hipMemcpy(d->d_synd, synd.data(), synd.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
             return bail("hipMemcpy(synd)", e);
     }
+    if (cfg.fix_1bit) {
+        std::vector<uint32_t> fix(adsb::kFixSlots);
+        d->fix_mul = adsb::make_fix_table(fix.data());
+        if ((e = hipMalloc(&d->d_fix, fix.size() * sizeof(uint32_t))) != hipSuccess)
+            return bail("hipMalloc(fix)", e);
+        if ((e = hipMemcpy(d->d_fix, fix.data(), fix.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
+            return bail("hipMemcpy(fix)", e);
+    }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     d->res.reset();
     return d;
@@ -519,6 +532,7 @@ void adsb_destroy(adsb_decoder *d)
         if (d->stage[i])
             (void)hipFree(d->stage[i]);
     if (d->d_synd) (void)hipFree(d->d_synd);
+    if (d->d_fix) (void)hipFree(d->d_fix);
     for (ScanSlot &sl : d->slots) {
         if (sl.d_counters) (void)hipFree(sl.d_counters);
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);

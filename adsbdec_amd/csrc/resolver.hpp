@@ -63,7 +63,7 @@ public:
             c.pw = r[1];
             std::memcpy(c.frame, &r[2], 14);
             c.len = (uint8_t)((r[5] >> 16) & 0xFF);
-            c.reserved = 0;
+            c.reserved = (uint8_t)((r[5] >> 24) & 1u); // bit 0: repaired by the 1-bit extension
         }
         const size_t tat = tries_.size();
         tries_.resize(tat + nt);
@@ -171,8 +171,9 @@ private:
             f.pw = c.pw;
             f.len = c.len;
             std::memcpy(f.frame, c.frame, 14);
-            f.reserved = 0;
+            f.reserved = c.reserved;
             stats_.ok[df_slot(c.frame[0])]++;
+            stats_.fixed += c.reserved & 1u;
             skipped_ += span - 1;
             idx = c.g + span; // demod.c:128,134
             chead_++;

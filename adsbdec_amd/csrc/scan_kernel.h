@@ -32,6 +32,7 @@ constexpr int kClistCap = 192;  // CRC-valid candidates staged per tile for the 
 constexpr int ADSB_DECOFFSET_K = 1200; // longest span an accepted frame jumps (adsbdec.h:3)
 constexpr int kCandWords = 6;   // {g_rel, pw, frame[0..13] | len<<16 in the last word}
 constexpr int kSyndWords = 14 * 256;
+constexpr int kFixSlots = 512;
 
 constexpr int owned_runs(int passes) { return kPassRuns * passes - kReachRuns; }
 constexpr int tile_offsets(int passes) { return kRun * owned_runs(passes); }
@@ -51,6 +52,8 @@ struct ScanArgs {
     int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
     int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
     int all_candidates;  // 1: emit every CRC-valid offset (no never-visited filter)
+    const uint32_t *fix_tab; // EXTENSION (not in the reference): 512-entry perfect hash syndrome -> bit, or null
+    uint32_t fix_mul;
     const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
     uint32_t *counters;  // [0] candidates, [1] tries (may exceed the capacities)
     uint32_t *cands;     // kCandWords dwords per record
@@ -61,6 +64,9 @@ struct ScanArgs {
 
 // Host: fill the 14 x 256 syndrome table (crc.h generator 0xFFF409).
 void make_syndrome_table(uint32_t *out /* kSyndWords */);
+// Host: perfect hash of the single-bit syndromes of bits 5..111 of a long frame:
+// tab[(syn * mul) >> 23] = (syn << 8) | bit. Returns the multiplier.
+uint32_t make_fix_table(uint32_t *tab /* kFixSlots */);
 // Host: choose the passes-per-tile for a launch of n_offsets on a device with
 // `slots` resident workgroups (balances halo overhead against tail quantisation).
 int choose_passes(uint64_t n_offsets, int cus);

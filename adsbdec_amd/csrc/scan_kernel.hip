@@ -490,8 +490,22 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 syn ^= args.synd[cc * 256 + idx];
                 cw[cc >> 2] |= col << (8 * (cc & 3));
             }
-            if (syn != 0)
-                continue; // valid.c:51,73
+            uint32_t fixed = 0;
+            if (syn != 0) {
+                // valid.c:51,73: the reference rejects.  EXTENSION (off unless
+                // cfg.fix_1bit): a long frame whose residual is the syndrome of ONE bit
+                // k in [5,112) is repaired by flipping that bit in its column byte.
+                if (!args.fix_tab || code == 0)
+                    continue;
+                const uint32_t e = args.fix_tab[(syn * args.fix_mul) >> 23];
+                if ((e >> 8) != syn)
+                    continue;
+                const uint32_t k = e & 0xFFu, kc = k % 14u, kb = k / 14u;
+#pragma unroll
+                for (int wq = 0; wq < 4; wq++)
+                    cw[wq] ^= ((kc >> 2) == (uint32_t)wq) ? (1u << (8 * (kc & 3u) + kb)) : 0u;
+                fixed = 1;
+            }
 
             // CRC-valid (about 1e-4 of the offsets).  Normally only staged here --
             // {g_rel, code, columns} -- and finished below with dense lanes.
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 if (ci < (uint32_t)kClistCap) {
                     uint32_t *rec = cl_rec + ci * kCandWords;
                     rec[0] = g_rel;
-                    rec[1] = code;
+                    rec[1] = code | (fixed << 8);
                     rec[2] = cw[0];
                     rec[3] = cw[1];
                     rec[4] = cw[2];
@@ -511,6 +525,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             }
             uint32_t wds[4];
             columns_to_bytes(cw, code == 0, wds);
+            wds[3] |= fixed << 24;
             const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, t0 + (int64_t)kRun * sv + sj);
             const uint32_t slot = atomicAdd(&args.counters[0], 1u);
             if (slot < args.cand_cap) {
@@ -547,14 +562,14 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                         const int gj = (int)(cl_rec[j * kCandWords] - tile_rel);
                         if (gj < gi && gj > pg) {
                             pg = gj;
-                            pspan = cl_rec[j * kCandWords + 1] == 0 ? 640 : 1200; // staged word 1 = code
+                            pspan = (cl_rec[j * kCandWords + 1] & 0xFFu) == 0 ? 640 : 1200; // staged word 1 = code
                         }
                     }
                     if (pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan) {
                         bool lands = false;
                         for (int j = 0; j < ncl; j++) {
                             const int ej = (int)(cl_rec[j * kCandWords] - tile_rel) +
-                                           (cl_rec[j * kCandWords + 1] == 0 ? 640 : 1200);
+                                           ((cl_rec[j * kCandWords + 1] & 0xFFu) == 0 ? 640 : 1200);
                             lands |= (ej > pg && ej <= gi);
                         }
                         drop = !lands;
@@ -565,7 +580,8 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 // finish the record: bytes in order, pw (demod.c:127,133), and emit
                 const uint32_t cw[4] = {ri[2], ri[3], ri[4], ri[5]};
                 uint32_t wds[4];
-                columns_to_bytes(cw, ri[1] == 0, wds);
+                columns_to_bytes(cw, (ri[1] & 0xFFu) == 0, wds);
+                wds[3] |= (ri[1] >> 8) << 24; // repaired-by-extension flag
                 const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + ri[0]);
                 const uint32_t slot = atomicAdd(&args.counters[0], 1u);
                 if (slot < args.cand_cap) {
@@ -618,6 +634,30 @@ void make_syndrome_table(uint32_t *out)
                     acc ^= s[14 * b + c];
             out[c * 256 + v] = acc;
         }
+}
+
+uint32_t make_fix_table(uint32_t *tab)
+{
+    uint32_t syn[112];
+    uint32_t r = 1;
+    for (int e = 0; e < 112; e++) {
+        syn[111 - e] = r;
+        r <<= 1;
+        if (r & 0x1000000u)
+            r ^= 0x1FFF409u;
+    }
+    for (uint32_t mul = 0x9E3779B1u;; mul += 2) {
+        for (int i = 0; i < kFixSlots; i++)
+            tab[i] = 0;
+        bool ok = true;
+        for (int k = 5; k < 112 && ok; k++) {
+            uint32_t &slot = tab[(uint32_t)(syn[k] * mul) >> 23];
+            ok = slot == 0;
+            slot = (syn[k] << 8) | (uint32_t)k;
+        }
+        if (ok)
+            return mul;
+    }
 }
 
 int choose_passes(uint64_t n_offsets, int cus)

@@ -44,7 +44,7 @@ typedef struct adsb_frame {
     uint32_t pw;       /* demod.c:127,133: (p1+p2)/4                               */
     uint8_t len;       /* 7 (DF11) or 14 (DF17/18)                                 */
     uint8_t frame[14]; /* demod.c:110-123                                          */
-    uint8_t reserved;
+    uint8_t reserved;  /* bit 0: frame was repaired by the 1-bit extension (cfg.fix_1bit) */
 } adsb_frame;
 
 /* A CRC-valid candidate before greedy resolution (what one GPU emits for the
@@ -61,6 +61,7 @@ typedef struct adsb_candidate {
 typedef struct adsb_stats {
     uint64_t try_[3];
     uint64_t ok[3];
+    uint64_t fixed;   /* frames accepted after a 1-bit repair (extension; always 0 by default) */
 } adsb_stats;
 
 typedef struct adsb_config {
@@ -74,7 +75,9 @@ typedef struct adsb_config {
     void *stream;              /* hipStream_t to launch on; NULL = a stream owned by the handle */
     int32_t all_candidates;    /* 1: the device reports EVERY CRC-valid offset; 0 (default): it drops the
                                   ones the greedy scan can provably never visit (same frames, ~4x fewer records) */
-    int32_t reserved1;
+    int32_t fix_1bit;          /* EXTENSION, not in the reference (its -e flag does nothing):
+                                  repair DF17/18 frames whose CRC residual is the syndrome of one bit
+                                  in [5,112). Off by default; no reference parity exists for it. */
 } adsb_config;
 
 typedef struct adsb_profile {

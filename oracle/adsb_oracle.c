@@ -111,13 +111,35 @@ static uint8_t slice_df(const float *a, int idx, int df, int *len)
     }
 }
 
-static int valid_frame(orc_state_t *o, const uint8_t *frame, int n, uint64_t ts, uint32_t pw,
+/* EXTENSION (not in the reference): single-bit repair of long frames.  The residual
+ * of a frame with one flipped bit k is x^(111-k) mod G; bits 0..4 (the DF field
+ * that selected the frame) are never touched. */
+static int try_fix1(uint8_t *frame, uint32_t residual)
+{
+    uint32_t r = 1;
+    for (int k = 111; k >= 5; k--) {
+        if (r == residual) {
+            frame[k >> 3] ^= (uint8_t)(0x80 >> (k & 7));
+            return 1;
+        }
+        r <<= 1;
+        if (r & 0x1000000u)
+            r ^= 0x1FFF409u;
+    }
+    return 0;
+}
+
+static int valid_frame(orc_state_t *o, uint8_t *frame, int n, uint64_t ts, uint32_t pw,
                        uint64_t g)
 {
     int type = frame[0] >> 3;
     o->stat_try[type]++; /* valid.c:46,68 */
-    if (orc_crc_residual(frame, n) != 0)
-        return 0;
+    uint32_t residual = orc_crc_residual(frame, n);
+    if (residual != 0) {
+        if (!(o->fix1 && n == 14 && try_fix1(frame, residual)))
+            return 0;
+        o->stat_fixed++;
+    }
     o->stat_ok[type]++; /* valid.c:53,75 */
     if (o->sink) {
         orc_frame_t f;
@@ -235,10 +257,19 @@ static void collect_sink(void *user, const orc_frame_t *f)
 size_t orc_decode(const uint16_t *x, size_t n, int df18, orc_frame_t *out, size_t cap,
                   uint32_t *stats6)
 {
+    return orc_decode_fix1(x, n, df18 | 0x100, out, cap, stats6, NULL);
+}
+
+size_t orc_decode_fix1(const uint16_t *x, size_t n, int df18, orc_frame_t *out, size_t cap,
+                       uint32_t *stats6, uint32_t *n_fixed)
+{
     orc_state_t *o = (orc_state_t *)malloc(sizeof *o);
     collect_t c = {out, cap, 0};
-    orc_init(o, df18, collect_sink, &c);
+    orc_init(o, df18 & 0xFF, collect_sink, &c);
+    o->fix1 = (df18 & 0x100) ? 0 : 1; /* 0x100 = plain reference behaviour (called from orc_decode) */
     orc_decode_buffer(o, x, n);
+    if (n_fixed)
+        *n_fixed = o->stat_fixed;
     if (stats6) {
         stats6[0] = o->stat_try[11];
         stats6[1] = o->stat_try[17];

@@ -51,6 +51,11 @@ typedef struct {
     uint32_t aidx;
     /* demod.c:26,86 */
     int df;
+    /* EXTENSION, not in the reference: accept DF17/18 frames whose CRC
+     * residual is the syndrome of exactly one bit k in [5,112) after flipping it.
+     * No reference parity exists for this mode. */
+    int fix1;
+    uint32_t stat_fixed;
     uint64_t ts;
     /* valid.c:30-31 */
     uint32_t stat_try[32];
@@ -79,6 +84,9 @@ void orc_decode_buffer(orc_state_t *o, const uint16_t *x, size_t n);
  * (may exceed cap; only cap are stored). stats may be NULL: else try[3],ok[3] for DF11/17/18. */
 size_t orc_decode(const uint16_t *x, size_t n, int df18, orc_frame_t *out, size_t cap,
                   uint32_t *stats6);
+/* Same with the 1-bit correction EXTENSION enabled (parity unpinned vs the reference). */
+size_t orc_decode_fix1(const uint16_t *x, size_t n, int df18, orc_frame_t *out, size_t cap,
+                       uint32_t *stats6, uint32_t *n_fixed);
 
 /* demod.c/valid.c stages only, driven on power samples (see ref_harness.c). */
 size_t orc_demod_power(const float *a, size_t m, int df18, orc_frame_t *out, size_t cap,

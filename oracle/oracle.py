@@ -52,6 +52,9 @@ def lib():
         L.orc_demod_power.restype = C.c_size_t
         L.orc_demod_power.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(OrcFrame), C.c_size_t,
                                       C.POINTER(C.c_uint32)]
+        L.orc_decode_fix1.restype = C.c_size_t
+        L.orc_decode_fix1.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(OrcFrame), C.c_size_t,
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_power.restype = C.c_size_t
         L.orc_power.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_crc_residual.restype = C.c_uint32
@@ -76,22 +79,30 @@ def _as_u16(x) -> np.ndarray:
     return x
 
 
-def decode(x, df18: bool = False, cap: int | None = None):
+def decode(x, df18: bool = False, cap: int | None = None, fix1: bool = False):
     """Whole-buffer decode. Returns (frames, stats) with frames a list of dicts
-    {g, ts, pw, frame(bytes)} and stats {'try': {11,17,18}, 'ok': {...}}."""
+    {g, ts, pw, frame(bytes)} and stats {'try': {11,17,18}, 'ok': {...}}.
+    fix1=True enables the 1-bit correction EXTENSION (no reference parity); stats then
+    also carries 'fixed'."""
     x = _as_u16(x)
     if cap is None:
         cap = max(1024, x.size // 1000)
+    nfix = C.c_uint32(0)
     while True:
         out = (OrcFrame * cap)()
         st = (C.c_uint32 * 6)()
-        n = lib().orc_decode(x.ctypes.data, x.size, int(df18), out, cap, st)
+        if fix1:
+            n = lib().orc_decode_fix1(x.ctypes.data, x.size, int(df18), out, cap, st, C.byref(nfix))
+        else:
+            n = lib().orc_decode(x.ctypes.data, x.size, int(df18), out, cap, st)
         if n <= cap:
             break
         cap = n
     frames = [dict(g=int(f.g), ts=int(f.ts), pw=int(f.pw), frame=bytes(f.frame[: f.len]))
               for f in out[:n]]
     stats = {"try": {11: st[0], 17: st[1], 18: st[2]}, "ok": {11: st[3], 17: st[4], 18: st[5]}}
+    if fix1:
+        stats["fixed"] = int(nfix.value)
     return frames, stats
 
 

@@ -277,6 +277,32 @@ def test_survivor_queue_overflow_fallback(oracle, dec_factory):
     assert sum(wstats["try"].values()) > 5000
 
 
+def test_one_bit_repair_extension_vs_oracle(oracle, dec_factory):
+    """cfg.fix_1bit (EXTENSION: the reference has no error correction; no
+    reference parity exists) against the oracle's restatement of the same rule; with
+    the flag off the very same capture decodes exactly like the reference."""
+    from oracle import gen_signal as G
+    rng = np.random.default_rng(3)
+    placed = []
+    for i in range(120):
+        f = bytearray(G.make_frame([17, 18, 11][i % 3], rng))
+        if i % 2:
+            k = int(rng.integers(0, 8 * len(f)))      # any bit, also the DF field / short frames
+            f[k >> 3] ^= 0x80 >> (k & 7)
+        placed.append((20_000 + 6_000 * i, bytes(f), float(rng.uniform(300, 1500)), float(i)))
+    x = G.synth(1 << 20, placed, 25.0, 3)
+    plain, pstats = oracle.decode(x, df18=True)
+    want, wstats = oracle.decode(x, df18=True, fix1=True)
+    assert wstats["fixed"] >= 25 and len(want) > len(plain)
+    d = dec_factory(df18=True, collect_stats=True, fix_1bit=True)
+    got = d.decode(x)
+    assert records(got) == records(want)
+    assert d.stats() == wstats
+    d0 = dec_factory(df18=True, collect_stats=True)
+    assert records(d0.decode(x)) == records(plain)
+    assert d0.stats() == pstats
+
+
 # ------------------------------------------------------------------ sharding on one device
 def test_shard_scan_and_host_gather(capi, oracle, dec_factory, torch_cuda):
     """SURVEY 8e with every shard on this one GPU: per-shard stateless scans over the

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(capi):
 def test_struct_layouts_match_header(capi):
     import ctypes as C
     assert C.sizeof(capi.Frame) == 40 and C.sizeof(capi.Candidate) == 32
-    assert C.sizeof(capi.Stats) == 48
+    assert C.sizeof(capi.Stats) == 56
     assert capi.Frame.frame.offset == 21 and capi.Candidate.frame.offset == 13
 
 
