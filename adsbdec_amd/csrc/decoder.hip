@@ -53,6 +53,13 @@ struct ScanSlot {
     size_t cand_cap = 0, try_cap = 0;
     hipEvent_t ev_start = nullptr, ev_done = nullptr; // kernel timing (cfg.profile)
     hipEvent_t ev_ready = nullptr;                    // counters have landed in h_counters
+    // streaming hand-off (scan_kernel.h): per-tile directory + dense record array, pinned
+    unsigned long long *tile_dir = nullptr;
+    uint32_t *hand = nullptr;
+    size_t tile_alloc = 0; // tiles tile_dir can hold
+    size_t hand_cap = 0;   // records hand can hold
+    uint32_t ntiles = 0;   // tiles of the launch in flight
+    bool streaming = false;
     adsb::ScanArgs args{};
     bool busy = false;
 };
@@ -105,7 +112,9 @@ struct adsb_decoder {
 
     adsb_profile prof{};
     adsb::Resolver res;
-    std::vector<uint32_t> order, scratch_a, scratch_b;
+    std::vector<uint32_t> order, scratch_a, scratch_b, gather;
+    bool no_streaming = false; // ADSB_NO_STREAMING=1: always collect after completion
+    uint32_t launch_gen = 0;   // makes every launch's hand-off tags distinct
 
     int fail(const char *fmt, ...)
     {
@@ -155,21 +164,68 @@ int slot_reserve(adsb_decoder *d, ScanSlot &s, size_t want_cands, size_t want_tr
     return 0;
 }
 
+int slot_reserve_tiles(adsb_decoder *d, ScanSlot &s, size_t ntiles, size_t want_hand)
+{
+    // fine-grained (coherent) so that the host sees the device's stores while the
+    // kernel is still running
+    static const unsigned mem_flags = [] {
+        const char *e = getenv("ADSB_TILE_MEM");
+        const int v = e ? atoi(e) : 0;
+        return v == 1 ? hipHostMallocDefault : v == 2 ? hipHostMallocNonCoherent : hipHostMallocCoherent;
+    }();
+    if (ntiles > s.tile_alloc) {
+        if (s.tile_dir)
+            HIP_TRY(d, hipHostFree(s.tile_dir));
+        s.tile_dir = nullptr;
+        s.tile_alloc = 0;
+        const size_t cap = ntiles + ntiles / 4 + 64;
+        HIP_TRY(d, hipHostMalloc(&s.tile_dir, cap * sizeof(unsigned long long), mem_flags));
+        s.tile_alloc = cap;
+    }
+    if (want_hand > s.hand_cap) {
+        if (s.hand)
+            HIP_TRY(d, hipHostFree(s.hand));
+        s.hand = nullptr;
+        s.hand_cap = 0;
+        HIP_TRY(d, hipHostMalloc(&s.hand, want_hand * adsb::kTileRecWords * sizeof(uint32_t), mem_flags));
+        s.hand_cap = want_hand;
+    }
+    return 0;
+}
+
 int slot_launch(adsb_decoder *d, ScanSlot &s)
 {
     const bool stats = d->cfg.collect_stats != 0;
+    const uint64_t per = (uint64_t)adsb::tile_offsets(s.args.passes);
+    s.ntiles = (uint32_t)((s.args.g_end - s.args.g_begin + per - 1) / per);
+    // The try list (collect_stats) is only complete when the kernel has finished, so
+    // statistics runs take the collect-after-completion path.
+    s.streaming = !stats && !d->no_streaming;
+    if (s.streaming) {
+        if (slot_reserve_tiles(d, s, s.ntiles, std::max<size_t>(s.hand_cap, s.cand_cap)))
+            return -1;
+        std::memset(s.tile_dir, 0, (size_t)s.ntiles * sizeof(unsigned long long));
+        s.args.tile_dir = s.tile_dir;
+        s.args.hand = s.hand;
+        s.args.hand_cap = (uint32_t)std::min<size_t>(s.hand_cap, 0xFFFFFFFFu);
+        s.args.gen = ++d->launch_gen * 0x9E3779B9u + 0x7F4A7C15u;
+    } else {
+        s.args.tile_dir = nullptr;
+        s.args.hand = nullptr;
+        s.args.hand_cap = 0;
+    }
     s.args.counters = s.d_counters;
     s.args.cands = s.cands;
     s.args.cand_cap = (uint32_t)std::min<size_t>(s.cand_cap, 0xFFFFFFFFu);
     s.args.tries = s.tries;
     s.args.try_cap = (uint32_t)std::min<size_t>(s.try_cap, 0xFFFFFFFFu);
-    HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, 2 * sizeof(uint32_t), d->stream));
+    HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d->stream));
     if (d->cfg.profile)
         HIP_TRY(d, hipEventRecord(s.ev_start, d->stream));
     HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
     if (d->cfg.profile)
         HIP_TRY(d, hipEventRecord(s.ev_done, d->stream));
-    HIP_TRY(d, hipMemcpyAsync(s.h_counters, s.d_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(d, hipMemcpyAsync(s.h_counters, s.d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(d, hipEventRecord(s.ev_ready, d->stream));
     s.busy = true;
     return 0;
@@ -228,11 +284,193 @@ void sort_tries(adsb_decoder *d, uint32_t *t, size_t n)
         std::memcpy(t, src, n * sizeof(uint32_t));
 }
 
+// Hand sorted records to the sink (a caller's vectors or the stream's resolver).
+void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uint32_t *order, size_t nc,
+             const uint32_t *tries, size_t nt, uint64_t g_complete)
+{
+    d->prof.candidates += nc;
+    d->prof.tries += nt;
+    if (d->sink.cands) {
+        for (size_t i = 0; i < nc; i++) {
+            const uint32_t *r = recs + (size_t)order[i] * adsb::kCandWords;
+            adsb_candidate c;
+            std::memset(&c, 0, sizeof c);
+            c.g = s.args.g_begin + r[0];
+            c.pw = r[1];
+            std::memcpy(c.frame, &r[2], 14);
+            c.len = (uint8_t)((r[5] >> 16) & 0xFF);
+            c.reserved = (uint8_t)((r[5] >> 24) & 1u);
+            d->sink.cands->push_back(c);
+        }
+        for (size_t i = 0; i < nt; i++)
+            d->sink.tries->push_back((((uint64_t)(tries[i] >> 2) + s.args.g_begin) << 2) | (tries[i] & 3u));
+    } else {
+        d->res.feed_device(recs, order, nc, adsb::kCandWords, s.args.g_begin, tries, nt);
+        d->res.advance(power_samples_produced(d->n_samples), g_complete);
+    }
+}
+
+// Streaming collect: consume the oldest scan WHILE its kernel is still running, so
+// that sorting and resolving overlap the scan.
+//   * tile_dir says which tiles are complete and where their records are;
+//   * tiles reserve their ranges of `hand` in COMPLETION order, so `hand` is read
+//     strictly sequentially (one prefetchable stream; records validate themselves),
+//     and each record is dropped into its place in TILE order by a counting sort whose
+//     counts come from the directory; a record of a tile beyond the current group waits
+//     in `early`;
+//   * tiles are taken in groups: polling a directory line the device is still writing
+//     costs a coherence miss per poll.
+// Returns 1 if a tile reported records on the loose list: the caller then finishes
+// the launch through the collect-after-completion path, from tile *resume_tile on.
+int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
+{
+    using clk = std::chrono::steady_clock;
+    const uint64_t per = (uint64_t)adsb::tile_offsets(s.args.passes);
+    const uint32_t gen = s.args.gen;
+    double wait_ms = 0;
+    const auto t_begin = clk::now();
+    // spin until `ready()`; gives up (with an error) once the kernel has long finished
+    auto wait_for = [&](auto &&ready) -> bool {
+        if (ready())
+            return true;
+        const auto t_w = clk::now();
+        bool ok = false;
+        uint64_t after_done = 0;
+        for (uint64_t spins = 1;; spins++) {
+            if (ready()) {
+                ok = true;
+                break;
+            }
+            __builtin_ia32_pause();
+            if ((spins & 0x3FF) == 0 && hipEventQuery(s.ev_ready) == hipSuccess && ++after_done > 2000)
+                break; // kernel and counter copy completed long ago: the bytes will not come
+        }
+        wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t_w).count();
+        return ok;
+    };
+
+    static const uint32_t kGroup = [] {
+        const char *e = getenv("ADSB_GROUP");
+        const int v = e ? atoi(e) : 0;
+        return (uint32_t)(v > 0 ? v : 512); // measured best of 128..1024 (ADSB_GROUP overrides)
+    }();
+    std::vector<uint32_t> &recs = d->gather;   // every record read so far, compact, in `hand` order
+    std::vector<uint32_t> &early = d->scratch_a; // indices (into recs) of records whose tile is not in a group yet
+    std::vector<uint32_t> &order = d->order;     // the group's records in ascending g
+    std::vector<uint32_t> &start = d->scratch_b; // per tile of the group: next free position in `order`
+    recs.clear();
+    early.clear();
+    uint32_t read_pos = 0; // records of `hand` consumed
+    uint32_t t = 0;
+    bool overflowed = false;
+    const double inv_per = 1.0 / (double)per;
+    auto tile_of = [&](uint32_t g_rel) { // g_rel / per; exact for the magnitudes here after one correction
+        uint32_t q = (uint32_t)((double)g_rel * inv_per);
+        while ((uint64_t)q * per > g_rel)
+            q--;
+        while ((uint64_t)(q + 1) * per <= g_rel)
+            q++;
+        return q;
+    };
+
+    while (t < s.ntiles && !overflowed) {
+        const uint32_t t1 = std::min(s.ntiles, t + kGroup);
+        for (uint32_t u = t1; u-- > t;) { // last flag first: the others are almost always set by then
+            if (!wait_for([&] { return (__atomic_load_n(&s.tile_dir[u], __ATOMIC_ACQUIRE) >> 63) != 0; }))
+                return d->fail("scan kernel finished without publishing tile %u of %u", u, s.ntiles);
+        }
+        // per-tile counts -> positions; how far `hand` must be read to hold all of them
+        start.resize(t1 - t + 1);
+        uint32_t total = 0, need = read_pos, t_ok = t1;
+        for (uint32_t u = t; u < t1; u++) {
+            const unsigned long long dw = s.tile_dir[u];
+            const uint32_t f = (uint32_t)(dw >> 32), base = (uint32_t)dw, n = f & 0xFFFFu;
+            if (f & 0x40000000u) { // some of its records went to the loose list: finish after completion
+                overflowed = true;
+                t_ok = u;
+                break;
+            }
+            start[u - t] = total;
+            total += n;
+            if (n && base + n > need)
+                need = base + n;
+        }
+        start[t_ok - t] = total;
+        order.assign(total, 0xFFFFFFFFu);
+        uint32_t placed = 0;
+        auto place = [&](uint32_t idx) -> bool { // false: the record's tile is beyond this group
+            const uint32_t tile = tile_of(recs[(size_t)idx * adsb::kCandWords]);
+            if (tile >= t_ok)
+                return false;
+            order[start[tile - t]++] = idx; // tile >= t: earlier groups were complete
+            placed++;
+            return true;
+        };
+        // early arrivals that belong to this group
+        size_t keep = 0;
+        for (size_t i = 0; i < early.size(); i++)
+            if (!place(early[i]))
+                early[keep++] = early[i];
+        early.resize(keep);
+        // sequential read of `hand`
+        if (need > read_pos) {
+            recs.resize((size_t)need * adsb::kCandWords);
+            uint32_t *gdst = recs.data() + (size_t)read_pos * adsb::kCandWords;
+            for (uint32_t k = read_pos; k < need; k++, gdst += adsb::kCandWords) {
+                const volatile uint32_t *r = s.hand + (size_t)k * adsb::kTileRecWords;
+                auto valid = [&] {
+                    const uint32_t w0 = r[0], w1 = r[1], w2 = r[2], w3 = r[3], w4 = r[4], w5 = r[5], w6 = r[6],
+                                   w7 = r[7];
+                    gdst[0] = w0, gdst[1] = w1, gdst[2] = w2, gdst[3] = w4, gdst[4] = w5, gdst[5] = w6;
+                    return w3 == adsb::granule_tag(w0, w1, w2, gen) && w7 == adsb::granule_tag(w4, w5, w6, gen);
+                };
+                if (!wait_for(valid))
+                    return d->fail("hand-off record %u never validated", k);
+                if (!place(k))
+                    early.push_back(k);
+            }
+            read_pos = need;
+        }
+        if (placed != total)
+            return d->fail("internal: %u of %u hand-off records placed for tiles %u..%u", placed, total, t, t_ok);
+        // within a tile the records are in arrival order: a handful, insertion sort
+        for (uint32_t u = t, lo = 0; u < t_ok; u++) {
+            const uint32_t hi = start[u - t]; // after placement: one past the tile's last position
+            for (uint32_t i = lo + 1; i < hi; i++) {
+                const uint32_t idx = order[i], key = recs[(size_t)idx * adsb::kCandWords];
+                uint32_t j = i;
+                while (j > lo && recs[(size_t)order[j - 1] * adsb::kCandWords] > key) {
+                    order[j] = order[j - 1];
+                    j--;
+                }
+                order[j] = idx;
+            }
+            lo = hi;
+        }
+        t = t_ok;
+        const uint64_t g_complete = std::min<uint64_t>(s.args.g_end, s.args.g_begin + (uint64_t)t * per);
+        deliver(d, s, recs.data(), order.data(), order.size(), nullptr, 0, g_complete);
+    }
+    const double total_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
+    d->prof.wait_ms += wait_ms;
+    d->prof.host_ms += total_ms - wait_ms;
+    *resume_tile = t;
+    return t < s.ntiles ? 1 : 0;
+}
+
 // Wait for the oldest scan in flight and hand its records on, in ascending g.
 int slot_collect(adsb_decoder *d)
 {
     ScanSlot &s = d->slots[d->slot_head];
     using clk = std::chrono::steady_clock;
+    uint32_t resume_tile = 0;
+    bool partial = false; // tiles below resume_tile were already delivered
+    if (s.streaming) {
+        const int rc = slot_collect_streaming(d, s, &resume_tile);
+        if (rc < 0)
+            return -1;
+        partial = rc == 1;
+    }
     const auto t_wait = clk::now();
     for (int attempt = 0;; attempt++) {
         HIP_TRY(d, hipEventSynchronize(s.ev_ready));
@@ -268,39 +506,39 @@ int slot_collect(adsb_decoder *d)
             return -1;
         if (slot_launch(d, s))
             return -1;
+        // the repeat is consumed after completion: tiles below resume_tile (if any)
+        // were delivered by the first run and are skipped by the gather below
     }
     const auto t_host = clk::now();
     d->prof.wait_ms += std::chrono::duration<double, std::milli>(t_host - t_wait).count();
     const size_t nc = s.h_counters[0], nt = s.h_counters[1];
-    sort_order(d, s.cands, nc);
-    if (nt)
-        sort_tries(d, s.tries, nt);
-    const auto t_sorted = clk::now();
-    d->prof.candidates += nc;
-    d->prof.tries += nt;
-    if (d->sink.cands) {
-        for (size_t i = 0; i < nc; i++) {
-            const uint32_t *r = s.cands + (size_t)d->order[i] * adsb::kCandWords;
-            adsb_candidate c;
-            std::memset(&c, 0, sizeof c);
-            c.g = s.args.g_begin + r[0];
-            c.pw = r[1];
-            std::memcpy(c.frame, &r[2], 14);
-            c.len = (uint8_t)((r[5] >> 16) & 0xFF);
-            c.reserved = (uint8_t)((r[5] >> 24) & 1u);
-            d->sink.cands->push_back(c);
+    if (!s.streaming) {
+        // collect-after-completion: everything is in the launch-wide lists, in arrival order
+        sort_order(d, s.cands, nc);
+        if (nt)
+            sort_tries(d, s.tries, nt);
+        deliver(d, s, s.cands, d->order.data(), nc, s.tries, nt, s.args.g_end);
+    } else if (partial) {
+        // a tile overflowed its hand-off region: gather what is left (regions of the
+        // tiles not yet delivered + the loose list) and sort it like the path above
+        d->gather.clear();
+        for (uint32_t t = resume_tile; t < s.ntiles; t++) { // the kernel has completed: all bytes are in
+            const unsigned long long dw = s.tile_dir[t];
+            const uint32_t n = (uint32_t)(dw >> 32) & 0xFFFFu, base = (uint32_t)dw;
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t *w = s.hand + ((size_t)base + i) * adsb::kTileRecWords;
+                const uint32_t rec[6] = {w[0], w[1], w[2], w[4], w[5], w[6]};
+                d->gather.insert(d->gather.end(), rec, rec + 6);
+            }
         }
-        for (size_t i = 0; i < nt; i++)
-            d->sink.tries->push_back((((uint64_t)(s.tries[i] >> 2) + s.args.g_begin) << 2) | (s.tries[i] & 3u));
-    } else {
-        d->res.feed_device(s.cands, d->order.data(), nc, adsb::kCandWords, s.args.g_begin, s.tries, nt);
-        d->res.advance(power_samples_produced(d->n_samples), s.args.g_end);
+        d->gather.insert(d->gather.end(), s.cands, s.cands + nc * adsb::kCandWords);
+        const size_t total = d->gather.size() / adsb::kCandWords;
+        sort_order(d, d->gather.data(), total);
+        deliver(d, s, d->gather.data(), d->order.data(), total, nullptr, 0, s.args.g_end);
+    } else if (nc != 0) {
+        return d->fail("internal: %zu loose records without a tile overflow flag", nc);
     }
     d->prof.host_ms += std::chrono::duration<double, std::milli>(clk::now() - t_host).count();
-    if (getenv("ADSB_DEBUG_HOST"))
-        fprintf(stderr, "collect: nc=%zu nt=%zu sort %.1f us, feed+resolve %.1f us\n", nc, nt,
-                std::chrono::duration<double, std::micro>(t_sorted - t_host).count(),
-                std::chrono::duration<double, std::micro>(clk::now() - t_sorted).count());
     s.busy = false;
     d->slot_head = (d->slot_head + 1) % kSlots;
     d->slot_count--;
@@ -492,9 +730,9 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         if ((e = hipMalloc(&d->stage[i], d->stage_cap * sizeof(uint16_t))) != hipSuccess)
             return bail("hipMalloc(stage)", e);
     for (ScanSlot &sl : d->slots) {
-        if ((e = hipMalloc(&sl.d_counters, 2 * sizeof(uint32_t))) != hipSuccess)
+        if ((e = hipMalloc(&sl.d_counters, 4 * sizeof(uint32_t))) != hipSuccess)
             return bail("hipMalloc(counters)", e);
-        if ((e = hipHostMalloc(&sl.h_counters, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+        if ((e = hipHostMalloc(&sl.h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
             return bail("hipHostMalloc(counters)", e);
         if ((e = hipEventCreate(&sl.ev_start)) != hipSuccess || (e = hipEventCreate(&sl.ev_done)) != hipSuccess ||
             (e = hipEventCreate(&sl.ev_ready)) != hipSuccess)
@@ -517,6 +755,7 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipMemcpy(fix)", e);
     }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    d->no_streaming = getenv("ADSB_NO_STREAMING") && atoi(getenv("ADSB_NO_STREAMING")) != 0;
     d->res.reset();
     return d;
 }
@@ -538,6 +777,8 @@ void adsb_destroy(adsb_decoder *d)
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
         if (sl.cands) (void)hipHostFree(sl.cands);
         if (sl.tries) (void)hipHostFree(sl.tries);
+        if (sl.tile_dir) (void)hipHostFree(sl.tile_dir);
+        if (sl.hand) (void)hipHostFree(sl.hand);
         if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
         if (sl.ev_ready) (void)hipEventDestroy(sl.ev_ready);

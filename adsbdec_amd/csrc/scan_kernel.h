@@ -33,6 +33,7 @@ constexpr int ADSB_DECOFFSET_K = 1200; // longest span an accepted frame jumps (
 constexpr int kCandWords = 6;   // {g_rel, pw, frame[0..13] | len<<16 in the last word}
 constexpr int kSyndWords = 14 * 256;
 constexpr int kFixSlots = 512;
+constexpr int kTileRecWords = 8; // two self-validating 16-byte granules
 
 constexpr int owned_runs(int passes) { return kPassRuns * passes - kReachRuns; }
 constexpr int tile_offsets(int passes) { return kRun * owned_runs(passes); }
@@ -41,6 +42,14 @@ constexpr size_t lds_bytes(int passes)
     return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 8 + kClistCap * 6);
 }
 constexpr uint64_t kMaxLaunchOffsets = (1ull << 30) - tile_offsets(kMaxPasses); // g_rel must fit 30 bits
+
+// Tag of one 16-byte hand-off granule (device writes it, host checks it).
+__host__ __device__ inline uint32_t granule_tag(uint32_t a, uint32_t b, uint32_t c, uint32_t gen)
+{
+    // gen differs between any two launches that can touch the same bytes, so a granule
+    // written whole by an earlier launch never validates; a torn one passes with 2^-32
+    return gen ^ a ^ (b << 11 | b >> 21) ^ (c << 22 | c >> 10);
+}
 
 struct ScanArgs {
     const uint32_t *x;   // (I,Q) pairs; x[0] is stream pair index pbuf0 (16-byte aligned, pbuf0 % 4 == 0)
@@ -52,10 +61,23 @@ struct ScanArgs {
     int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
     int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
     int all_candidates;  // 1: emit every CRC-valid offset (no never-visited filter)
+    // Streaming hand-off (tile_dir == null: off).  A tile reserves a contiguous range
+    // of the dense array `hand` for the records it keeps (one atomicAdd on
+    // counters[2]), writes them, and stores tile_dir[b] = {base, 0x80000000 |
+    // overflow << 30 | count} as one 8-byte granule, so that the host can consume
+    // tiles in order while the kernel is still running.  Nothing orders those stores
+    // on their way to host memory, so every 16-byte record store is SELF-VALIDATING:
+    // a record is two granules {g_rel, pw, w0, tag} {w1, w2, w3, tag} with tag =
+    // granule_tag(3 data words, gen); the host consumes a record only when both tags
+    // check (gen changes with every launch, so stale bytes never validate).
+    unsigned long long *tile_dir;
+    uint32_t *hand;        // kTileRecWords dwords per record
+    uint32_t hand_cap;     // records
+    uint32_t gen;
     const uint32_t *fix_tab; // EXTENSION (not in the reference): 512-entry perfect hash syndrome -> bit, or null
     uint32_t fix_mul;
     const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
-    uint32_t *counters;  // [0] candidates, [1] tries (may exceed the capacities)
+    uint32_t *counters;  // [0] loose candidates, [1] tries (may exceed the capacities), [2] hand-off records
     uint32_t *cands;     // kCandWords dwords per record
     uint32_t cand_cap;
     uint32_t *tries;     // (g_rel << 2) | code

@@ -269,6 +269,39 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     const int own = kPassRuns * K - kReachRuns;
     const int64_t t0 = (int64_t)args.g_begin + (int64_t)blockIdx.x * kRun * own; // first owned offset
 
+    uint32_t *tile_n = qcount + 4;    // records this tile keeps (ranked into its hand-off range)
+    uint32_t *tile_over = qcount + 5; // some records had to go to the loose list
+    uint32_t *tile_base = qcount + 6; // first index of the tile's range in args.hand
+    if (tid == 0) {
+        *tile_n = 0;
+        *tile_over = 0;
+        *tile_base = 0;
+    }
+    // A finished record goes to slot `hand_idx` of the dense hand-off array (two tagged
+    // 16-byte granules) or -- hand-off disabled, no slot (hand_idx = ~0u), array full --
+    // to the launch-wide loose list.
+    auto emit_record = [&](uint32_t hand_idx, uint32_t g_rel, uint32_t pw, const uint32_t (&wds)[4]) {
+        if (args.tile_dir) {
+            if (hand_idx < args.hand_cap) {
+                uint4 *dst = reinterpret_cast<uint4 *>(args.hand + (size_t)hand_idx * kTileRecWords);
+                dst[0] = make_uint4(g_rel, pw, wds[0], granule_tag(g_rel, pw, wds[0], args.gen));
+                dst[1] = make_uint4(wds[1], wds[2], wds[3], granule_tag(wds[1], wds[2], wds[3], args.gen));
+                return;
+            }
+            *tile_over = 1;
+        }
+        const uint32_t slot = atomicAdd(&args.counters[0], 1u);
+        if (slot < args.cand_cap) {
+            uint32_t *rec = args.cands + (size_t)slot * kCandWords;
+            rec[0] = g_rel;
+            rec[1] = pw;
+            rec[2] = wds[0];
+            rec[3] = wds[1];
+            rec[4] = wds[2];
+            rec[5] = wds[3];
+        }
+    };
+
     // plane words past the last computed run are read (never used) by Stage B
     if (tid < kPlanePad) {
         pl_d[kPassRuns * K + tid] = 0;
@@ -527,16 +560,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             columns_to_bytes(cw, code == 0, wds);
             wds[3] |= fixed << 24;
             const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, t0 + (int64_t)kRun * sv + sj);
-            const uint32_t slot = atomicAdd(&args.counters[0], 1u);
-            if (slot < args.cand_cap) {
-                uint32_t *rec = args.cands + (size_t)slot * kCandWords;
-                rec[0] = g_rel;
-                rec[1] = pw;
-                rec[2] = wds[0];
-                rec[3] = wds[1];
-                rec[4] = wds[2];
-                rec[5] = wds[3];
-            }
+            emit_record(~0u, g_rel, pw, wds); // unranked: loose list
         }
 
         if (stage_cands) {
@@ -549,11 +573,11 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             // list is complete), and none does, c is unreachable.  These are the +-1/2
             // sample shifted copies of every real frame: 3 of 4 records.
             __syncthreads();
-            const int ncl = min((int)*cl_n, kClistCap);
+            const int ncl = min((int)*cl_n, kClistCap); // <= kClistCap <= kThreads: one entry per thread
             const bool complete = *cl_over == 0;
-#pragma unroll 1
-            for (int i = tid; i < ncl; i += kThreads) {
-                uint32_t *ri = cl_rec + i * kCandWords;
+            bool keep = false;
+            const uint32_t *ri = cl_rec + tid * kCandWords;
+            if (tid < ncl) {
                 const int gi = (int)(ri[0] - tile_rel); // tile-local offset
                 bool drop = false;
                 if (complete) {
@@ -575,24 +599,24 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                         drop = !lands;
                     }
                 }
-                if (drop)
-                    continue;
+                keep = !drop;
+            }
+            // the kept records get a contiguous range of the dense hand-off array
+            uint32_t rank = 0;
+            if (keep)
+                rank = atomicAdd(tile_n, 1u);
+            __syncthreads();
+            if (tid == 0 && args.tile_dir && *tile_n)
+                *tile_base = atomicAdd(&args.counters[2], *tile_n);
+            __syncthreads();
+            if (keep) {
                 // finish the record: bytes in order, pw (demod.c:127,133), and emit
                 const uint32_t cw[4] = {ri[2], ri[3], ri[4], ri[5]};
                 uint32_t wds[4];
                 columns_to_bytes(cw, (ri[1] & 0xFFu) == 0, wds);
                 wds[3] |= (ri[1] >> 8) << 24; // repaired-by-extension flag
                 const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + ri[0]);
-                const uint32_t slot = atomicAdd(&args.counters[0], 1u);
-                if (slot < args.cand_cap) {
-                    uint32_t *rec = args.cands + (size_t)slot * kCandWords;
-                    rec[0] = ri[0];
-                    rec[1] = pw;
-                    rec[2] = wds[0];
-                    rec[3] = wds[1];
-                    rec[4] = wds[2];
-                    rec[5] = wds[3];
-                }
+                emit_record(*tile_base + rank, ri[0], pw, wds);
             }
         }
 
@@ -611,6 +635,22 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 break;
         }
         __syncthreads(); // queue is rewritten
+    }
+
+    if (args.tile_dir) {
+        // Publish the tile: {first record, flags | count} as ONE 8-byte store.  No fence:
+        // a system-scope release in every thread writes back the L2 per tile (measured:
+        // 4.5x slower kernel), and without one this store can overtake the records on
+        // the way to host memory (measured: it does) -- which is why the records
+        // validate themselves (scan_kernel.h).
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t base = *tile_base, nk = *tile_n;
+            const uint32_t fit = base >= args.hand_cap ? 0u : min(nk, args.hand_cap - base);
+            const unsigned long long word =
+                ((unsigned long long)(0x80000000u | (*tile_over ? 0x40000000u : 0u) | fit) << 32) | base;
+            __hip_atomic_store(&args.tile_dir[blockIdx.x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -303,6 +303,55 @@ def test_one_bit_repair_extension_vs_oracle(oracle, dec_factory):
     assert d0.stats() == pstats
 
 
+def _back_to_back(n_frames, seed):
+    from oracle import gen_signal as G
+    rng = np.random.default_rng(seed)
+    placed = [(10_000 + 2_400 * i, G.make_frame([17, 18, 17, 11][i % 4], rng), float(rng.uniform(500, 1500)), float(i))
+              for i in range(n_frames)]
+    return G.synth(10_000 + 2_400 * n_frames + 120_000, placed, 6.0, seed)
+
+
+def test_tile_region_overflow_falls_back_to_loose_list(capi, oracle, dec_factory, torch_cuda):
+    """Frames packed back to back put more finished records into one tile than its
+    64-record streaming region holds (all_candidates=1 quadruples them): the rest goes
+    to the loose list and the launch is finished after completion.  Same frames."""
+    x = _back_to_back(1500, 41)
+    want, wstats = oracle.decode(x, df18=True)
+    assert len(want) > 1000
+    t = _dev(torch_cuda, x)
+    for kw in (dict(all_candidates=True), dict()):
+        d = dec_factory(df18=True, **kw)
+        d.reset()
+        d.push_device_final(t.data_ptr(), t.numel())
+        assert records(d.drain()) == records(want)
+    # candidate-level: every CRC-valid offset survives the overflow path
+    a = oracle.power(x)
+    wc, _ = oracle.scan_all(a, 0, a.size - 1195, True)
+    d = dec_factory(df18=True, all_candidates=True)
+    cands, nc, _ = d.scan_shard(t.data_ptr(), 0, x.size, 0, a.size - 1195)
+    assert [(int(c.g), int(c.pw), bytes(c.frame[: c.len])) for c in cands[:nc]] == wc
+
+
+def test_streaming_handoff_is_stable_over_many_launches(oracle, dec_factory, torch_cuda):
+    """The host consumes tiles while the kernel runs (flags published with a system-scope
+    release); 300 back-to-back decodes of the same capture must all be identical."""
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture(1 << 22, seed=55, sigma=30.0, n_frames=1500, amp=(150, 1800))
+    want, _ = oracle.decode(x, df18=True)
+    t = _dev(torch_cuda, x)
+    d = dec_factory(df18=True)
+    exp = records(want)
+    for it in range(300):
+        d.reset()
+        d.push_device_final(t.data_ptr(), t.numel())
+        got = d.drain()
+        assert len(got) == len(exp), it
+        if it % 25 == 0:
+            assert records(got) == exp, it
+        else:
+            assert [f["g"] for f in got] == [e[0] for e in exp], it
+
+
 # ------------------------------------------------------------------ sharding on one device
 def test_shard_scan_and_host_gather(capi, oracle, dec_factory, torch_cuda):
     """SURVEY 8e with every shard on this one GPU: per-shard stateless scans over the
