@@ -342,8 +342,11 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
                 break;
             }
             __builtin_ia32_pause();
-            if ((spins & 0x3FF) == 0 && hipEventQuery(s.ev_ready) == hipSuccess && ++after_done > 2000)
-                break; // kernel and counter copy completed long ago: the bytes will not come
+            if ((spins & 0x3FF) == 0) {
+                const hipError_t q = hipEventQuery(s.ev_ready);
+                if (q != hipErrorNotReady && (q != hipSuccess || ++after_done > 2000))
+                    break; // the launch failed, or it completed long ago: the bytes will not come
+            }
         }
         wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t_w).count();
         return ok;
