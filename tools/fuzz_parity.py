@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Randomised parity fuzzer: HIP path vs the oracle over random captures and random
+ways of feeding them (host pushes in random chunk sizes, device pushes aligned or
+not, one-pass final, per-shard scans).  Runs until --seconds elapse; exits non-zero
+and prints the seed of the first mismatch.
+
+    python tools/fuzz_parity.py --seconds 240 [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from adsbdec_amd import capi  # noqa: E402
+from oracle import gen_signal as G  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def make_capture(rng):
+    kind = rng.integers(0, 5)
+    n = int(rng.integers(60_000, 3_000_000))
+    sigma = float(rng.choice([0.0, 3.0, 8.0, 30.0, 120.0, 300.0, 900.0]))
+    if kind == 0:      # silence / constant
+        return np.full(n, int(rng.integers(0, 4096)), np.uint16)
+    if kind == 1:      # uniform full-range noise
+        return rng.integers(0, int(rng.choice([4096, 12000, 30000])), n, dtype=np.uint16)
+    nf = int(rng.integers(0, max(1, n // 2500)))
+    frames = []
+    for _ in range(nf):
+        df = int(rng.choice([11, 17, 18]))
+        f = bytearray(G.make_frame(df, rng))
+        if rng.random() < 0.3:   # damaged frames (exercise CRC rejects / the repair extension)
+            for _ in range(int(rng.integers(1, 3))):
+                k = int(rng.integers(0, 8 * len(f)))
+                f[k >> 3] ^= 0x80 >> (k & 7)
+        start = int(rng.integers(0, max(1, n - 2400)))
+        frames.append((start, bytes(f), float(rng.uniform(40, 2000)), float(rng.uniform(0, 6.28))))
+    if kind == 2:      # packed back to back
+        frames = [(5_000 + 2_400 * i, fr, a, ph) for i, (_, fr, a, ph) in enumerate(frames) if 5_000 + 2_400 * (i + 1) < n]
+    return G.synth(n, frames, sigma, int(rng.integers(0, 1 << 30)))
+
+
+def key(fs):
+    return [(f["g"], f["ts"], f["pw"], f["frame"]) for f in fs]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    decs = {}
+
+    def dec(df18, stats, fix):
+        k = (df18, stats, fix)
+        if k not in decs:
+            decs[k] = capi.Decoder(df18=df18, collect_stats=stats, fix_1bit=fix,
+                                   stage_samples=int(1 << 17) if len(decs) % 2 else 0)
+        return decs[k]
+
+    t0, it, frames_total = time.time(), 0, 0
+    seed = args.seed
+    while time.time() - t0 < args.seconds:
+        rng = np.random.default_rng(seed)
+        x = make_capture(rng)
+        df18, stats, fix = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
+        want, wstats = O.decode(x, df18=df18, fix1=fix)
+        d = dec(df18, stats, fix)
+        mode = int(rng.integers(0, 5))
+        d.reset()
+        if mode == 0:      # host pushes, random chunking
+            pos = 0
+            while pos < x.size:
+                c = int(rng.choice([4, 1000, 4096, 65536, 1 << 20, x.size]))
+                d.push(x[pos:pos + c])
+                pos += c
+            d.finish()
+        else:
+            t = torch.from_numpy(x.view(np.int16)).cuda()
+            if mode == 1:
+                d.push_device_final(t.data_ptr(), t.numel())
+            elif mode == 2:  # two device pushes, aligned split
+                sp = 8 * int(rng.integers(1, max(2, x.size // 8)))
+                d.push_device(t.data_ptr(), sp)
+                d.push_device_final(t.data_ptr() + 2 * sp, x.size - sp)
+            elif mode == 3:  # unaligned split
+                sp = int(rng.integers(1, x.size))
+                d.push_device(t.data_ptr(), sp)
+                d.push_device(t.data_ptr() + 2 * sp, x.size - sp)
+                d.finish()
+            else:            # shard scans + host resolver
+                ns = int(rng.integers(1, 6))
+                r = capi.Resolver()
+                for s in capi.plan_shards(x.size, ns):
+                    cands, nc, tries = d.scan_shard(t.data_ptr() + 2 * s["first_sample"], s["first_sample"],
+                                                    s["n_samples"], s["g_begin"], s["g_end"])
+                    r.feed((cands, nc), tries)
+                m = 2 * (x.size // 4)
+                r.advance(2 * ((x.size + 3) // 4), max(0, m - 1195))
+                got = r.drain()
+                ok = key(got) == key(want)
+                if stats and ok:
+                    st = r.stats()
+                    ok = st["try"] == wstats["try"] and st["ok"] == wstats["ok"]
+                if not ok:
+                    print(f"MISMATCH seed={seed} mode=shards n={x.size} df18={df18} stats={stats} fix={fix}")
+                    sys.exit(1)
+                it += 1
+                seed += 1
+                frames_total += len(want)
+                continue
+        got = d.drain()
+        ok = key(got) == key(want)
+        if ok and stats:
+            ok = d.stats() == wstats
+        if ok and not stats and fix:
+            ok = d.stats()["fixed"] == wstats["fixed"]
+        if not ok:
+            print(f"MISMATCH seed={seed} mode={mode} n={x.size} df18={df18} stats={stats} fix={fix} "
+                  f"got={len(got)} want={len(want)}")
+            sys.exit(1)
+        it += 1
+        seed += 1
+        frames_total += len(want)
+    print(f"fuzz ok: {it} captures, {frames_total} frames, seeds {args.seed}..{seed - 1}, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
