@@ -65,17 +65,19 @@ struct ScanSlot {
 };
 
 constexpr int kSlots = 4;
-// offsets per pipelined launch (ADSB_CHUNK_MI overrides, for tuning runs)
-static uint64_t chunk_offsets()
+// Offsets per launch (ADSB_CHUNK_MI overrides, for tuning runs).  With the streaming
+// hand-off the host already overlaps a launch while it runs, so launches are as large
+// as the record buffers sensibly allow (each launch carries ~20 us of ramp and tail);
+// the collect-after-completion path needs several launches in flight to overlap at all.
+static uint64_t chunk_offsets(bool streaming)
 {
-    static const uint64_t v = [] {
+    static const uint64_t forced = [] {
         const char *e = getenv("ADSB_CHUNK_MI");
-        uint64_t mi = e ? strtoull(e, nullptr, 10) : 0;
-        if (mi < 1 || mi > 512)
-            mi = 64;
-        return 28ull * ((mi << 20) / 28);
+        const uint64_t mi = e ? strtoull(e, nullptr, 10) : 0;
+        return (mi >= 1 && mi <= 512) ? mi : 0;
     }();
-    return v;
+    const uint64_t mi = forced ? forced : (streaming ? 128 : 64);
+    return 28ull * ((mi << 20) / 28);
 }
 
 struct ScanSink { // where collected records go: a caller's vectors, or (null) the stream's resolver
@@ -565,7 +567,7 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
 {
     const bool stats = d->cfg.collect_stats != 0;
     while (g_begin < g_end) {
-        const uint64_t g_stop = std::min(g_end, g_begin + chunk_offsets());
+        const uint64_t g_stop = std::min(g_end, g_begin + chunk_offsets(!stats && !d->no_streaming));
         const uint64_t n_off = g_stop - g_begin;
         if (d->slot_count == kSlots && slot_collect(d))
             return -1;
