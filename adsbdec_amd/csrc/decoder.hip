@@ -369,12 +369,19 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
     uint32_t t = 0;
     bool overflowed = false;
     const double inv_per = 1.0 / (double)per;
-    auto tile_of = [&](uint32_t g_rel) { // g_rel / per; exact for the magnitudes here after one correction
-        uint32_t q = (uint32_t)((double)g_rel * inv_per);
+    uint32_t guess = 0; // consecutive records mostly belong to the same or a neighbouring tile
+    uint64_t guess_lo = 0, guess_hi = per;
+    auto tile_of = [&](uint32_t g_rel) {
+        if (g_rel >= guess_lo && g_rel < guess_hi)
+            return guess;
+        uint32_t q = (uint32_t)((double)g_rel * inv_per); // exact after at most one correction
         while ((uint64_t)q * per > g_rel)
             q--;
         while ((uint64_t)(q + 1) * per <= g_rel)
             q++;
+        guess = q;
+        guess_lo = (uint64_t)q * per;
+        guess_hi = guess_lo + per;
         return q;
     };
 
