@@ -42,7 +42,7 @@ def make_workload(torch, n_samples: int, n_frames: int | None = None, seed: int 
     """Synthetic capture built ON THE DEVICE: uint16 codes in [0,4095]
     around 2048, fs/4 carrier, PPM frames with valid CRC in ~1 ms slots, Gaussian noise.
     Returns (int16 cuda tensor viewed as the uint16 stream, truth [(start_sample, frame)])."""
-    from oracle import gen_signal as G  # generator only; not on the measured path
+    from tools import gen_signal as G  # the build's own generator; not on the measured path
 
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     rng = np.random.default_rng(seed)
@@ -124,7 +124,6 @@ def main():
 
     n = args.samples - args.samples % 28
     if args.dense:
-        from oracle import gen_signal as G  # generator only
         gen = torch.Generator(device="cuda")
         gen.manual_seed(100 + rank)
         x = torch.clamp(torch.round(torch.randn(n, generator=gen, device="cuda") * 300.0 + 2048.0), 0, 4095).to(torch.int16)
