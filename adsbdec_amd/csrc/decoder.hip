@@ -114,7 +114,7 @@ struct adsb_decoder {
 
     adsb_profile prof{};
     adsb::Resolver res;
-    std::vector<uint32_t> order, scratch_a, scratch_b, gather;
+    std::vector<uint32_t> order, scratch_a, scratch_b, gather, raw;
     bool no_streaming = false; // ADSB_NO_STREAMING=1: always collect after completion
     uint32_t launch_gen = 0;   // makes every launch's hand-off tags distinct
 
@@ -306,6 +306,9 @@ void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uin
         }
         for (size_t i = 0; i < nt; i++)
             d->sink.tries->push_back((((uint64_t)(tries[i] >> 2) + s.args.g_begin) << 2) | (tries[i] & 3u));
+    } else if (nt == 0) {
+        d->res.advance_device(recs, order, nc, adsb::kCandWords, s.args.g_begin,
+                              power_samples_produced(d->n_samples), g_complete);
     } else {
         d->res.feed_device(recs, order, nc, adsb::kCandWords, s.args.g_begin, tries, nt);
         d->res.advance(power_samples_produced(d->n_samples), g_complete);
@@ -359,72 +362,51 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
         const int v = e ? atoi(e) : 0;
         return (uint32_t)(v > 0 ? v : 512); // measured best of 128..1024 (ADSB_GROUP overrides)
     }();
-    std::vector<uint32_t> &recs = d->gather;   // every record read so far, compact, in `hand` order
-    std::vector<uint32_t> &early = d->scratch_a; // indices (into recs) of records whose tile is not in a group yet
-    std::vector<uint32_t> &order = d->order;     // the group's records in ascending g
-    std::vector<uint32_t> &start = d->scratch_b; // per tile of the group: next free position in `order`
+    std::vector<uint32_t> &recs = d->gather; // every record read so far, compact, in `hand` order
+    std::vector<uint32_t> &order = d->order; // the group's records in ascending g (indices into recs)
     recs.clear();
-    early.clear();
     uint32_t read_pos = 0; // records of `hand` consumed
     uint32_t t = 0;
     bool overflowed = false;
-    const double inv_per = 1.0 / (double)per;
-    uint32_t guess = 0; // consecutive records mostly belong to the same or a neighbouring tile
-    uint64_t guess_lo = 0, guess_hi = per;
-    auto tile_of = [&](uint32_t g_rel) {
-        if (g_rel >= guess_lo && g_rel < guess_hi)
-            return guess;
-        uint32_t q = (uint32_t)((double)g_rel * inv_per); // exact after at most one correction
-        while ((uint64_t)q * per > g_rel)
-            q--;
-        while ((uint64_t)(q + 1) * per <= g_rel)
-            q++;
-        guess = q;
-        guess_lo = (uint64_t)q * per;
-        guess_hi = guess_lo + per;
-        return q;
-    };
-
-    while (t < s.ntiles && !overflowed) {
-        const uint32_t t1 = std::min(s.ntiles, t + kGroup);
-        for (uint32_t u = t1; u-- > t;) { // last flag first: the others are almost always set by then
-            if (!wait_for([&] { return (__atomic_load_n(&s.tile_dir[u], __ATOMIC_ACQUIRE) >> 63) != 0; }))
-                return d->fail("scan kernel finished without publishing tile %u of %u", u, s.ntiles);
+    double dbg[4] = {0, 0, 0, 0};
+    const bool dbg_on = getenv("ADSB_DEBUG_HOST") != nullptr;
+    auto lap = [&](int k, clk::time_point &from) {
+        if (dbg_on) {
+            const auto now = clk::now();
+            dbg[k] += std::chrono::duration<double, std::micro>(now - from).count();
+            from = now;
         }
-        // per-tile counts -> positions; how far `hand` must be read to hold all of them
-        start.resize(t1 - t + 1);
-        uint32_t total = 0, need = read_pos, t_ok = t1;
+    };
+    while (t < s.ntiles && !overflowed) {
+        auto tp = clk::now();
+        const uint32_t t1 = std::min(s.ntiles, t + kGroup);
+        // wait on the group's LAST entry (the others are almost always published by then),
+        // then read the directory once, forwards; an entry that is still empty is waited for
+        if (!wait_for([&] { return (__atomic_load_n(&s.tile_dir[t1 - 1], __ATOMIC_ACQUIRE) >> 63) != 0; }))
+            return d->fail("scan kernel finished without publishing tile %u of %u", t1 - 1, s.ntiles);
+        // A tile's records sit in hand[base, base+n) in ascending g (the kernel ranks
+        // them), so the group's order is just its tiles' ranges one after the other.
+        order.clear();
+        uint32_t need = read_pos, t_ok = t1;
         for (uint32_t u = t; u < t1; u++) {
-            const unsigned long long dw = s.tile_dir[u];
+            unsigned long long dw = __atomic_load_n(&s.tile_dir[u], __ATOMIC_ACQUIRE);
+            if (!(dw >> 63) &&
+                !wait_for([&] { return ((dw = __atomic_load_n(&s.tile_dir[u], __ATOMIC_ACQUIRE)) >> 63) != 0; }))
+                return d->fail("scan kernel finished without publishing tile %u of %u", u, s.ntiles);
             const uint32_t f = (uint32_t)(dw >> 32), base = (uint32_t)dw, n = f & 0xFFFFu;
             if (f & 0x40000000u) { // some of its records went to the loose list: finish after completion
                 overflowed = true;
                 t_ok = u;
                 break;
             }
-            start[u - t] = total;
-            total += n;
+            for (uint32_t i = 0; i < n; i++)
+                order.push_back(base + i);
             if (n && base + n > need)
                 need = base + n;
         }
-        start[t_ok - t] = total;
-        order.assign(total, 0xFFFFFFFFu);
-        uint32_t placed = 0;
-        auto place = [&](uint32_t idx) -> bool { // false: the record's tile is beyond this group
-            const uint32_t tile = tile_of(recs[(size_t)idx * adsb::kCandWords]);
-            if (tile >= t_ok)
-                return false;
-            order[start[tile - t]++] = idx; // tile >= t: earlier groups were complete
-            placed++;
-            return true;
-        };
-        // early arrivals that belong to this group
-        size_t keep = 0;
-        for (size_t i = 0; i < early.size(); i++)
-            if (!place(early[i]))
-                early[keep++] = early[i];
-        early.resize(keep);
-        // sequential read of `hand`
+        lap(0, tp); // directory
+        // sequential read of `hand` (tiles reserve their ranges in completion order, so
+        // this also picks up records of tiles of later groups; they simply wait in recs)
         if (need > read_pos) {
             recs.resize((size_t)need * adsb::kCandWords);
             uint32_t *gdst = recs.data() + (size_t)read_pos * adsb::kCandWords;
@@ -438,31 +420,18 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
                 };
                 if (!wait_for(valid))
                     return d->fail("hand-off record %u never validated", k);
-                if (!place(k))
-                    early.push_back(k);
             }
             read_pos = need;
         }
-        if (placed != total)
-            return d->fail("internal: %u of %u hand-off records placed for tiles %u..%u", placed, total, t, t_ok);
-        // within a tile the records are in arrival order: a handful, insertion sort
-        for (uint32_t u = t, lo = 0; u < t_ok; u++) {
-            const uint32_t hi = start[u - t]; // after placement: one past the tile's last position
-            for (uint32_t i = lo + 1; i < hi; i++) {
-                const uint32_t idx = order[i], key = recs[(size_t)idx * adsb::kCandWords];
-                uint32_t j = i;
-                while (j > lo && recs[(size_t)order[j - 1] * adsb::kCandWords] > key) {
-                    order[j] = order[j - 1];
-                    j--;
-                }
-                order[j] = idx;
-            }
-            lo = hi;
-        }
+        lap(1, tp); // records
         t = t_ok;
         const uint64_t g_complete = std::min<uint64_t>(s.args.g_end, s.args.g_begin + (uint64_t)t * per);
         deliver(d, s, recs.data(), order.data(), order.size(), nullptr, 0, g_complete);
+        lap(2, tp); // resolve
     }
+    if (dbg_on)
+        fprintf(stderr, "stream collect: directory %.1f us, records %.1f us, resolve %.1f us (waits %.1f us inside)\n",
+                dbg[0], dbg[1], dbg[2], wait_ms * 1e3);
     const double total_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
     d->prof.wait_ms += wait_ms;
     d->prof.host_ms += total_ms - wait_ms;

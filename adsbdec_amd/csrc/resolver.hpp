@@ -71,6 +71,22 @@ public:
             tries_[tat + i] = (((uint64_t)(tries[i] >> 2) + g_base) << 2) | (tries[i] & 3u);
     }
 
+    // feed_device + advance in one step, without copying the records into the queue:
+    // the device batch is consumed in place; only what lies beyond the last executed
+    // deqframe call (normally nothing or a handful) is kept for later.
+    void advance_device(const uint32_t *recs, const uint32_t *order, size_t n, int words, uint64_t g_base,
+                        uint64_t power_samples, uint64_t g_complete)
+    {
+        compact();
+        batch_ = Batch{recs, order, n, 0, words, g_base};
+        advance(power_samples, g_complete);
+        for (; batch_.pos < batch_.n; batch_.pos++) { // leftovers: beyond the last call's limit
+            cands_.emplace_back();
+            batch_.load(batch_.pos, cands_.back());
+        }
+        batch_ = Batch{};
+    }
+
     // power_samples: samples the front end has produced so far (air.c `aidx` grows
     // by two per loop pass, so this is even); g_complete: every record with
     // g < g_complete has been fed.
@@ -148,35 +164,72 @@ private:
             stats_.try_[tries_[thead_++] & 3]++;
     }
 
+    // A batch of device records being consumed in place (advance_device).  Queue
+    // entries (older) always precede batch entries (newer) in g.
+    struct Batch {
+        const uint32_t *recs = nullptr;
+        const uint32_t *order = nullptr;
+        size_t n = 0, pos = 0;
+        int words = 0;
+        uint64_t g_base = 0;
+        uint64_t g(size_t i) const { return g_base + recs[(size_t)order[i] * words]; }
+        void load(size_t i, adsb_candidate &c) const
+        {
+            const uint32_t *r = recs + (size_t)order[i] * words;
+            c.g = g_base + r[0];
+            c.pw = r[1];
+            std::memcpy(c.frame, &r[2], 14);
+            c.len = (uint8_t)((r[5] >> 16) & 0xFF);
+            c.reserved = (uint8_t)((r[5] >> 24) & 1u);
+        }
+    };
+
     // One deqframe(ampbuff, len) call: visits offsets from base_ while < limit.
     void run_call(uint64_t limit)
     {
         uint64_t idx = base_;
-        const size_t n = cands_.size();
         while (idx < limit) {
-            while (chead_ < n && cands_[chead_].g < idx)
+            // next candidate at or after idx: the queue first, then the in-place batch
+            while (chead_ < cands_.size() && cands_[chead_].g < idx)
                 chead_++; // inside an accepted frame: never evaluated
-            if (chead_ == n || cands_[chead_].g >= limit) {
+            const bool from_queue = chead_ < cands_.size();
+            uint64_t g = ~0ull;
+            if (from_queue) {
+                g = cands_[chead_].g;
+            } else {
+                while (batch_.pos < batch_.n && batch_.g(batch_.pos) < idx)
+                    batch_.pos++;
+                if (batch_.pos < batch_.n)
+                    g = batch_.g(batch_.pos);
+            }
+            if (g >= limit) { // also: no candidate left
                 count_tries(idx, limit - 1);
                 idx = limit; // all remaining offsets advance by one (demod.c:141)
                 break;
             }
-            const adsb_candidate &c = cands_[chead_];
-            count_tries(idx, c.g);
-            const uint64_t span = 80 + 80 * (uint64_t)c.len; // demod.c:109,120,123: lidx
+            count_tries(idx, g);
             out_.emplace_back();
             adsb_frame &f = out_.back();
-            f.g = c.g;
-            f.ts = c.g + 1 - skipped_; // demod.c:99: one ts++ per visited offset
-            f.pw = c.pw;
-            f.len = c.len;
-            std::memcpy(f.frame, c.frame, 14);
-            f.reserved = c.reserved;
-            stats_.ok[df_slot(c.frame[0])]++;
-            stats_.fixed += c.reserved & 1u;
+            f.g = g;
+            f.ts = g + 1 - skipped_; // demod.c:99: one ts++ per visited offset
+            if (from_queue) {
+                const adsb_candidate &c = cands_[chead_++];
+                f.pw = c.pw;
+                f.len = c.len;
+                std::memcpy(f.frame, c.frame, 14);
+                f.reserved = c.reserved;
+            } else { // straight from the device record {g_rel, pw, frame[14] | len << 16 | flags << 24}
+                const uint32_t *r = batch_.recs + (size_t)batch_.order[batch_.pos++] * batch_.words;
+                f.pw = r[1];
+                std::memcpy(f.frame, &r[2], 14);
+                f.len = (uint8_t)((r[5] >> 16) & 0xFF);
+                f.reserved = (uint8_t)((r[5] >> 24) & 1u);
+            }
+            const uint64_t span = 80 + 80 * (uint64_t)f.len; // demod.c:109,120,123: lidx
+            stats_.ok[df_slot(f.frame[0])]++;
+            stats_.fixed += f.reserved & 1u;
             skipped_ += span - 1;
-            idx = c.g + span; // demod.c:128,134
-            chead_++;
+            idx = g + span; // demod.c:128,134
         }
         base_ = idx; // deqframe's return value; air.c:96-98 carries the rest
     }
@@ -185,6 +238,7 @@ private:
     uint64_t skipped_ = 0; // offsets jumped over by accepted frames
     std::vector<adsb_candidate> cands_;
     size_t chead_ = 0;
+    Batch batch_;
     std::vector<uint64_t> tries_;
     size_t thead_ = 0;
     std::vector<adsb_frame> out_;

@@ -601,20 +601,29 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 }
                 keep = !drop;
             }
-            // the kept records get a contiguous range of the dense hand-off array
-            uint32_t rank = 0;
-            if (keep)
-                rank = atomicAdd(tile_n, 1u);
+            // the kept records get a contiguous range of the dense hand-off array, in
+            // ascending g (rank = kept entries with a smaller offset), so that the host
+            // can take a tile's range as it is
+            if (keep) {
+                atomicAdd(tile_n, 1u);
+                cl_rec[tid * kCandWords + 1] |= 0x10000u; // staged word 1, bit 16: kept
+            }
             __syncthreads();
             if (tid == 0 && args.tile_dir && *tile_n)
                 *tile_base = atomicAdd(&args.counters[2], *tile_n);
+            uint32_t rank = 0;
+            if (keep) {
+                const uint32_t gi = ri[0];
+                for (int j = 0; j < ncl; j++)
+                    rank += ((cl_rec[j * kCandWords + 1] >> 16) & 1u) & (uint32_t)(cl_rec[j * kCandWords] < gi);
+            }
             __syncthreads();
             if (keep) {
                 // finish the record: bytes in order, pw (demod.c:127,133), and emit
                 const uint32_t cw[4] = {ri[2], ri[3], ri[4], ri[5]};
                 uint32_t wds[4];
                 columns_to_bytes(cw, (ri[1] & 0xFFu) == 0, wds);
-                wds[3] |= (ri[1] >> 8) << 24; // repaired-by-extension flag
+                wds[3] |= ((ri[1] >> 8) & 1u) << 24; // repaired-by-extension flag
                 const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + ri[0]);
                 emit_record(*tile_base + rank, ri[0], pw, wds);
             }
