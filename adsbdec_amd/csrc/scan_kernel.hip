@@ -127,7 +127,11 @@ __device__ __forceinline__ void power_block(const f32x2 (&vv)[34], float *a)
 #pragma unroll
         for (int k = 0; k < g; k++) {
             const f32x2 sq = s[k] * s[k];
-            a[J0 + k] = sq.x + sq.y; // air.c:76,91
+            // air.c:76,91.  A plain `sq.x + sq.y` gets SLP-packed across two outputs at
+            // the price of three transposing moves per pair; keep it one scalar add.
+            float r;
+            asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(sq.x), "v"(sq.y));
+            a[J0 + k] = r;
         }
         power_block<J0 + g, N - g, G>(vv, a);
     }

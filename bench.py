@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=256 << 20, help="input samples per GPU per step")
     ap.add_argument("--dense", action="store_true", help="configs[2]: wide-band noise, ~7%% preamble hits")
+    ap.add_argument("--stats", action="store_true", help="also reproduce valid.c's Try counters (collect_stats=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=0, help="oracle sample size (default: the whole capture)")
     ap.add_argument("--one-device-test", action="store_true",
@@ -135,7 +136,7 @@ def main():
                     f"sigma=8, device-resident (BASELINE configs[1]" + ("; one stream per GPU, configs[3])" if world > 1 else ")"))
     torch.cuda.synchronize()
 
-    dec = capi.Decoder(df18=args.dense, device=local_rank, profile=True)
+    dec = capi.Decoder(df18=args.dense, device=local_rank, profile=True, collect_stats=args.stats)
 
     xptr, xn = x.data_ptr(), x.numel()
 
