@@ -517,10 +517,13 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 const int pos = sj + 80 + 10 * cc;
                 const int wi = (pos * 2341) >> 16; // pos / 28 for pos < 5000
                 const int bp = pos - 28 * wi;
+                // bit b of the column = bit bp of word wi + 5b: move it to the sign
+                // position and shift it in (2 operations per bit), highest row first
                 uint32_t col = 0;
+                const int up = 31 - bp;
 #pragma unroll
-                for (int b = 0; b < 8; b++)
-                    col |= ((dcol[wi + 5 * b] >> bp) & 1u) << b;
+                for (int b = 7; b >= 0; b--)
+                    col = push_sign(col, dcol[wi + 5 * b] << up);
                 // short frames are bits 0..55 = rows b < 4; their syndromes are the
                 // long frame's 56 bits (4 rows) further on
                 const uint32_t idx = (code == 0) ? ((col & 15u) << 4) : col;
