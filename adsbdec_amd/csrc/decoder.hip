@@ -49,8 +49,10 @@ struct ScanSlot {
     uint32_t *d_counters = nullptr; // device: [0] candidates, [1] tries
     uint32_t *h_counters = nullptr; // pinned
     uint32_t *cands = nullptr;      // pinned, written by the kernel
-    uint32_t *tries = nullptr;      // pinned, written by the kernel
-    size_t cand_cap = 0, try_cap = 0;
+    uint32_t *tries = nullptr;      // pinned, written by the kernel (per-shard scans that return the list)
+    uint32_t *d_tries = nullptr;    // device: statistics runs of a stream count tries on the device
+    size_t cand_cap = 0, try_cap = 0, d_try_cap = 0;
+    bool tries_on_device = false;   // which of the two the launch in flight uses
     hipEvent_t ev_start = nullptr, ev_done = nullptr; // kernel timing (cfg.profile)
     hipEvent_t ev_ready = nullptr;                    // counters have landed in h_counters
     // streaming hand-off (scan_kernel.h): per-tile directory + dense record array, pinned
@@ -116,6 +118,19 @@ struct adsb_decoder {
     adsb::Resolver res;
     std::vector<uint32_t> order, scratch_a, scratch_b, gather, raw;
     bool no_streaming = false; // ADSB_NO_STREAMING=1: always collect after completion
+    // device-side visited-try count (scan_kernel.h TryCountArgs)
+    uint64_t *d_carry[2] = {nullptr, nullptr};
+    uint32_t n_carry = 0;
+    int carry_cur = 0;
+    uint64_t *d_frames_g = nullptr;
+    uint32_t *d_frames_span = nullptr;
+    size_t frames_cap = 0;
+    uint32_t *d_try_out = nullptr, *h_try_out = nullptr; // 4 words
+    uint64_t *h_frames_g = nullptr;                      // pinned upload buffers
+    uint32_t *h_frames_span = nullptr;
+    bool have_prev_frame = false; // last accepted frame of earlier passes (its span may cover later tries)
+    uint64_t prev_frame_g = 0;
+    uint32_t prev_frame_span = 0;
     uint32_t launch_gen = 0;   // makes every launch's hand-off tags distinct
 
     int fail(const char *fmt, ...)
@@ -143,6 +158,21 @@ namespace {
 inline uint64_t power_samples_produced(uint64_t n_samples)
 {
     return 2 * (n_samples / 4); // air.c:59-92: two power samples per four input samples
+}
+
+constexpr uint32_t kCarryCap = 1u << 20; // undecided tries carried between count passes (a few hundred in practice)
+
+int slot_reserve_device_tries(adsb_decoder *d, ScanSlot &s, size_t want)
+{
+    if (want > s.d_try_cap) {
+        if (s.d_tries)
+            HIP_TRY(d, hipFree(s.d_tries));
+        s.d_tries = nullptr;
+        s.d_try_cap = 0;
+        HIP_TRY(d, hipMalloc(&s.d_tries, want * sizeof(uint32_t)));
+        s.d_try_cap = want;
+    }
+    return 0;
 }
 
 int slot_reserve(adsb_decoder *d, ScanSlot &s, size_t want_cands, size_t want_tries)
@@ -200,9 +230,11 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     const bool stats = d->cfg.collect_stats != 0;
     const uint64_t per = (uint64_t)adsb::tile_offsets(s.args.passes);
     s.ntiles = (uint32_t)((s.args.g_end - s.args.g_begin + per - 1) / per);
-    // The try list (collect_stats) is only complete when the kernel has finished, so
-    // statistics runs take the collect-after-completion path.
-    s.streaming = !stats && !d->no_streaming;
+    // A stream's statistics run keeps the try words on the device (counted there after
+    // resolution); a per-shard scan hands the list back, sorted, so it needs the list
+    // complete on the host: collect after completion.
+    s.tries_on_device = stats && !d->sink.cands;
+    s.streaming = !d->no_streaming && (!stats || s.tries_on_device);
     if (s.streaming) {
         if (slot_reserve_tiles(d, s, s.ntiles, std::max<size_t>(s.hand_cap, s.cand_cap)))
             return -1;
@@ -219,8 +251,8 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.args.counters = s.d_counters;
     s.args.cands = s.cands;
     s.args.cand_cap = (uint32_t)std::min<size_t>(s.cand_cap, 0xFFFFFFFFu);
-    s.args.tries = s.tries;
-    s.args.try_cap = (uint32_t)std::min<size_t>(s.try_cap, 0xFFFFFFFFu);
+    s.args.tries = s.tries_on_device ? s.d_tries : s.tries;
+    s.args.try_cap = (uint32_t)std::min<size_t>(s.tries_on_device ? s.d_try_cap : s.try_cap, 0xFFFFFFFFu);
     HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d->stream));
     if (d->cfg.profile)
         HIP_TRY(d, hipEventRecord(s.ev_start, d->stream));
@@ -439,6 +471,84 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
     return t < s.ntiles ? 1 : 0;
 }
 
+// Device-side visited-try count of a statistics run (scan_kernel.h TryCountArgs):
+// decides every try below the resolver's position against the frames it accepted
+// since the previous pass (plus the last one before, whose span may reach further),
+// adds three counters to the statistics and carries the undecided tries.
+int count_tries_pass(adsb_decoder *d, const uint32_t *d_tries, uint32_t n_tries, uint64_t g_base, bool final)
+{
+    auto &log = d->res.accepted_log();
+    const size_t nf = log.size() + (d->have_prev_frame ? 1 : 0);
+    if (n_tries == 0 && d->n_carry == 0) {
+        if (!log.empty()) {
+            d->have_prev_frame = true;
+            d->prev_frame_g = log.back().first;
+            d->prev_frame_span = log.back().second;
+            log.clear();
+        }
+        return 0;
+    }
+    if (nf > d->frames_cap) {
+        const size_t cap = std::max<size_t>(nf + nf / 4, 4096);
+        if (d->d_frames_g) HIP_TRY(d, hipFree(d->d_frames_g));
+        if (d->d_frames_span) HIP_TRY(d, hipFree(d->d_frames_span));
+        if (d->h_frames_g) HIP_TRY(d, hipHostFree(d->h_frames_g));
+        if (d->h_frames_span) HIP_TRY(d, hipHostFree(d->h_frames_span));
+        d->d_frames_g = nullptr, d->d_frames_span = nullptr, d->h_frames_g = nullptr, d->h_frames_span = nullptr;
+        d->frames_cap = 0;
+        HIP_TRY(d, hipMalloc(&d->d_frames_g, cap * sizeof(uint64_t)));
+        HIP_TRY(d, hipMalloc(&d->d_frames_span, cap * sizeof(uint32_t)));
+        HIP_TRY(d, hipHostMalloc(&d->h_frames_g, cap * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_TRY(d, hipHostMalloc(&d->h_frames_span, cap * sizeof(uint32_t), hipHostMallocDefault));
+        d->frames_cap = cap;
+    }
+    size_t k = 0;
+    if (d->have_prev_frame) {
+        d->h_frames_g[k] = d->prev_frame_g;
+        d->h_frames_span[k++] = d->prev_frame_span;
+    }
+    for (const auto &f : log) {
+        d->h_frames_g[k] = f.first;
+        d->h_frames_span[k++] = f.second;
+    }
+    if (!log.empty()) {
+        d->have_prev_frame = true;
+        d->prev_frame_g = log.back().first;
+        d->prev_frame_span = log.back().second;
+        log.clear();
+    }
+    if (nf) {
+        HIP_TRY(d, hipMemcpyAsync(d->d_frames_g, d->h_frames_g, nf * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(d, hipMemcpyAsync(d->d_frames_span, d->h_frames_span, nf * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                  d->stream));
+    }
+    HIP_TRY(d, hipMemsetAsync(d->d_try_out, 0, 4 * sizeof(uint32_t), d->stream));
+    adsb::TryCountArgs a{};
+    a.tries = d_tries;
+    a.n_tries = n_tries;
+    a.g_base = g_base;
+    a.carry_in = d->d_carry[d->carry_cur];
+    a.n_carry = d->n_carry;
+    a.frames_g = d->d_frames_g;
+    a.frames_span = d->d_frames_span;
+    a.n_frames = (uint32_t)nf;
+    a.hi = d->res.base(); // every offset below has been visited or jumped over
+    a.final = final ? 1 : 0;
+    a.carry_out = d->d_carry[d->carry_cur ^ 1];
+    a.carry_cap = kCarryCap;
+    a.out = d->d_try_out;
+    HIP_TRY(d, adsb::launch_count_tries(a, d->stream));
+    HIP_TRY(d, hipMemcpyAsync(d->h_try_out, d->d_try_out, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    if (d->h_try_out[3] > kCarryCap)
+        return d->fail("%u undecided tries exceed the carry buffer", d->h_try_out[3]);
+    d->res.add_tries(d->h_try_out[0], d->h_try_out[1], d->h_try_out[2]);
+    d->prof.tries += n_tries;
+    d->n_carry = final ? 0 : d->h_try_out[3];
+    d->carry_cur ^= 1;
+    return 0;
+}
+
 // Wait for the oldest scan in flight and hand its records on, in ascending g.
 int slot_collect(adsb_decoder *d)
 {
@@ -475,7 +585,7 @@ int slot_collect(adsb_decoder *d)
         d->prof.offsets += s.args.g_end - s.args.g_begin;
         d->prof.last_offsets = s.args.g_end - s.args.g_begin;
         const size_t nc = s.h_counters[0], nt = s.h_counters[1];
-        if (nc <= s.cand_cap && nt <= s.try_cap)
+        if (nc <= s.cand_cap && nt <= (s.tries_on_device ? s.d_try_cap : s.try_cap))
             break;
         // Sparse output sized for far more than noise produces; the counters keep
         // counting past the capacity, so one repeat with exact sizes suffices.
@@ -483,7 +593,10 @@ int slot_collect(adsb_decoder *d)
             return d->fail("record buffers overflowed repeatedly (%zu candidates, %zu tries)", nc, nt);
         d->prof.relaunches++;
         HIP_TRY(d, hipStreamSynchronize(d->stream));
-        if (slot_reserve(d, s, std::max(s.cand_cap, nc + nc / 8 + 64), std::max(s.try_cap, nt + nt / 8 + 64)))
+        if (slot_reserve(d, s, std::max(s.cand_cap, nc + nc / 8 + 64),
+                         s.tries_on_device ? s.try_cap : std::max(s.try_cap, nt + nt / 8 + 64)))
+            return -1;
+        if (s.tries_on_device && slot_reserve_device_tries(d, s, std::max(s.d_try_cap, nt + nt / 8 + 64)))
             return -1;
         if (slot_launch(d, s))
             return -1;
@@ -496,9 +609,10 @@ int slot_collect(adsb_decoder *d)
     if (!s.streaming) {
         // collect-after-completion: everything is in the launch-wide lists, in arrival order
         sort_order(d, s.cands, nc);
-        if (nt)
+        if (nt && !s.tries_on_device)
             sort_tries(d, s.tries, nt);
-        deliver(d, s, s.cands, d->order.data(), nc, s.tries, nt, s.args.g_end);
+        const size_t nt_host = s.tries_on_device ? 0 : nt;
+        deliver(d, s, s.cands, d->order.data(), nc, s.tries, nt_host, s.args.g_end);
     } else if (partial) {
         // a tile overflowed its hand-off region: gather what is left (regions of the
         // tiles not yet delivered + the loose list) and sort it like the path above
@@ -519,6 +633,8 @@ int slot_collect(adsb_decoder *d)
     } else if (nc != 0) {
         return d->fail("internal: %zu loose records without a tile overflow flag", nc);
     }
+    if (s.tries_on_device && count_tries_pass(d, s.d_tries, (uint32_t)nt, s.args.g_begin, false))
+        return -1;
     d->prof.host_ms += std::chrono::duration<double, std::milli>(clk::now() - t_host).count();
     s.busy = false;
     d->slot_head = (d->slot_head + 1) % kSlots;
@@ -548,8 +664,12 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
         if (d->slot_count == kSlots && slot_collect(d))
             return -1;
         ScanSlot &s = d->slots[(d->slot_head + d->slot_count) % kSlots];
+        const bool host_tries = stats && d->sink.cands; // per-shard scans return the try list
         if (slot_reserve(d, s, std::max<size_t>(s.cand_cap, (size_t)(n_off / 128 + 32768)),
-                         stats ? std::max<size_t>(s.try_cap, (size_t)(n_off / 32 + 65536)) : s.try_cap))
+                         host_tries ? std::max<size_t>(s.try_cap, (size_t)(n_off / 32 + 65536)) : s.try_cap))
+            return -1;
+        if (stats && !host_tries &&
+            slot_reserve_device_tries(d, s, std::max<size_t>(s.d_try_cap, (size_t)(n_off / 32 + 65536))))
             return -1;
         adsb::ScanArgs &a = s.args;
         a = adsb::ScanArgs{};
@@ -735,6 +855,15 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         if ((e = hipMemcpy(d->d_fix, fix.data(), fix.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
             return bail("hipMemcpy(fix)", e);
     }
+    if (cfg.collect_stats) {
+        for (int i = 0; i < 2; i++)
+            if ((e = hipMalloc(&d->d_carry[i], (size_t)kCarryCap * sizeof(uint64_t))) != hipSuccess)
+                return bail("hipMalloc(try carry)", e);
+        if ((e = hipMalloc(&d->d_try_out, 4 * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipHostMalloc(&d->h_try_out, 4 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+            return bail("hipMalloc(try counters)", e);
+        d->res.log_accepted(true);
+    }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     d->no_streaming = getenv("ADSB_NO_STREAMING") && atoi(getenv("ADSB_NO_STREAMING")) != 0;
     d->res.reset();
@@ -753,11 +882,20 @@ void adsb_destroy(adsb_decoder *d)
             (void)hipFree(d->stage[i]);
     if (d->d_synd) (void)hipFree(d->d_synd);
     if (d->d_fix) (void)hipFree(d->d_fix);
+    for (int i = 0; i < 2; i++)
+        if (d->d_carry[i]) (void)hipFree(d->d_carry[i]);
+    if (d->d_frames_g) (void)hipFree(d->d_frames_g);
+    if (d->d_frames_span) (void)hipFree(d->d_frames_span);
+    if (d->h_frames_g) (void)hipHostFree(d->h_frames_g);
+    if (d->h_frames_span) (void)hipHostFree(d->h_frames_span);
+    if (d->d_try_out) (void)hipFree(d->d_try_out);
+    if (d->h_try_out) (void)hipHostFree(d->h_try_out);
     for (ScanSlot &sl : d->slots) {
         if (sl.d_counters) (void)hipFree(sl.d_counters);
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
         if (sl.cands) (void)hipHostFree(sl.cands);
         if (sl.tries) (void)hipHostFree(sl.tries);
+        if (sl.d_tries) (void)hipFree(sl.d_tries);
         if (sl.tile_dir) (void)hipHostFree(sl.tile_dir);
         if (sl.hand) (void)hipHostFree(sl.hand);
         if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
@@ -780,6 +918,9 @@ int adsb_reset(adsb_decoder *d)
     d->stage_fill = 0;
     d->cur = 0;
     d->res.reset();
+    d->res.log_accepted(d->cfg.collect_stats != 0);
+    d->n_carry = 0;
+    d->have_prev_frame = false;
     d->slot_head = 0;
     d->slot_count = 0;
     std::memset(&d->prof, 0, sizeof d->prof);
@@ -864,6 +1005,8 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
         if (scan_drain(d))
             return -1;
         d->res.advance(2 * ((total + 3) / 4), d->g_scanned); // EOF rule: see process_stage()
+        if (d->cfg.collect_stats && count_tries_pass(d, nullptr, 0, 0, true))
+            return -1; // tries beyond the final position are never visited
         d->stage_fill = 0;
         d->finished = true;
         return 0;
@@ -919,6 +1062,8 @@ int adsb_finish(adsb_decoder *d)
     HIP_TRY(d, hipSetDevice(d->device));
     if (process_stage(d, true))
         return -1;
+    if (d->cfg.collect_stats && count_tries_pass(d, nullptr, 0, 0, true))
+        return -1; // tries beyond the final position are never visited
     d->finished = true;
     return 0;
 }

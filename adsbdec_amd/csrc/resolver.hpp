@@ -17,6 +17,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/adsbdec_amd.h"
@@ -35,6 +36,7 @@ public:
         thead_ = 0;
         out_.clear();
         ohead_ = 0;
+        log_.clear();
         std::memset(&stats_, 0, sizeof stats_);
     }
 
@@ -106,6 +108,17 @@ public:
             // does every following call up to the next record (skip them in one step).
             run_call(limit);
         }
+    }
+
+    // Statistics runs that keep the try words on the device: log (g, span) of every
+    // accepted frame for the device-side visited-try count, and take the counts back.
+    void log_accepted(bool on) { log_on_ = on; }
+    std::vector<std::pair<uint64_t, uint32_t>> &accepted_log() { return log_; }
+    void add_tries(uint64_t df11, uint64_t df17, uint64_t df18)
+    {
+        stats_.try_[0] += df11;
+        stats_.try_[1] += df17;
+        stats_.try_[2] += df18;
     }
 
     size_t pending() const { return out_.size() - ohead_; }
@@ -229,6 +242,8 @@ private:
             stats_.ok[df_slot(f.frame[0])]++;
             stats_.fixed += f.reserved & 1u;
             skipped_ += span - 1;
+            if (log_on_)
+                log_.emplace_back(g, (uint32_t)span);
             idx = g + span; // demod.c:128,134
         }
         base_ = idx; // deqframe's return value; air.c:96-98 carries the rest
@@ -239,6 +254,8 @@ private:
     std::vector<adsb_candidate> cands_;
     size_t chead_ = 0;
     Batch batch_;
+    bool log_on_ = false;
+    std::vector<std::pair<uint64_t, uint32_t>> log_;
     std::vector<uint64_t> tries_;
     size_t thead_ = 0;
     std::vector<adsb_frame> out_;

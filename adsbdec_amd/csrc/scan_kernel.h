@@ -84,6 +84,29 @@ struct ScanArgs {
     uint32_t try_cap;
 };
 
+// Second, tiny kernel of statistics runs (valid.c:46,68 count a Try only for VISITED
+// offsets): the try words of a launch stay on the device; once the host has
+// resolved which frames were accepted, every try below `hi` (the resolver's position)
+// is looked up in the sorted accepted frames -- inside (g, g+span) of one means the
+// greedy scan jumped over it -- and only three counters come back.  Tries at or
+// beyond `hi` are not decided yet and are carried to the next pass.
+struct TryCountArgs {
+    const uint32_t *tries;     // this launch: (g_rel << 2) | code
+    uint32_t n_tries;
+    uint64_t g_base;
+    const uint64_t *carry_in;  // undecided tries of earlier passes: (g << 2) | code
+    uint32_t n_carry;
+    const uint64_t *frames_g;  // accepted frames, ascending
+    const uint32_t *frames_span;
+    uint32_t n_frames;
+    uint64_t hi;
+    int final;                 // 1: end of stream -- tries >= hi are dropped (never visited)
+    uint64_t *carry_out;
+    uint32_t carry_cap;
+    uint32_t *out;             // [0..2] visited tries per DF code, [3] entries written to carry_out
+};
+hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream);
+
 // Host: fill the 14 x 256 syndrome table (crc.h generator 0xFFF409).
 void make_syndrome_table(uint32_t *out /* kSyndWords */);
 // Host: perfect hash of the single-bit syndromes of bits 5..111 of a long frame:

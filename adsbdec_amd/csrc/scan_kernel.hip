@@ -52,6 +52,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "scan_kernel.h"
 
 namespace adsb {
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     uint32_t *tile_n = qcount + 4;    // records this tile keeps (ranked into its hand-off range)
     uint32_t *tile_over = qcount + 5; // some records had to go to the loose list
     uint32_t *tile_base = qcount + 6; // first index of the tile's range in args.hand
+    uint32_t *try_base = qcount + 7;  // first index of the round's range in args.tries (kStats)
     if (tid == 0) {
         *tile_n = 0;
         *tile_over = 0;
@@ -496,6 +499,11 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         __syncthreads();
         const bool over = *qover != 0;
         const int qn = over ? 0 : (int)*qcount;
+        if (kStats) { // one reservation of the launch-wide try list per round, not one per try
+            if (tid == 0)
+                *try_base = qn ? atomicAdd(&args.counters[1], (uint32_t)qn) : 0u;
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int q = tid; q < qn; q += kThreads) {
             const uint32_t ent = queue[q];
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             const uint32_t code = ent & 3u;
             const uint32_t g_rel = (uint32_t)(t0 - (int64_t)args.g_begin) + (uint32_t)(kRun * sv + sj);
             if (kStats) { // valid.c:46,68: every DF-gate pass that is visited is a Try
-                const uint32_t ts = atomicAdd(&args.counters[1], 1u);
+                const uint32_t ts = *try_base + (uint32_t)q;
                 if (ts < args.try_cap)
                     args.tries[ts] = (g_rel << 2) | code;
             }
@@ -668,6 +676,64 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             __hip_atomic_store(&args.tile_dir[blockIdx.x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void count_tries_kernel(const TryCountArgs a)
+{
+    uint32_t cnt[3] = {0, 0, 0};
+    const uint32_t total = a.n_tries + a.n_carry;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        uint64_t g;
+        uint32_t code;
+        if (i < a.n_tries) {
+            const uint32_t w = a.tries[i];
+            g = a.g_base + (w >> 2);
+            code = w & 3u;
+        } else {
+            const uint64_t w = a.carry_in[i - a.n_tries];
+            g = w >> 2;
+            code = (uint32_t)w & 3u;
+        }
+        if (g >= a.hi) { // the scan has not got there yet
+            if (!a.final) {
+                const uint32_t slot = atomicAdd(&a.out[3], 1u);
+                if (slot < a.carry_cap)
+                    a.carry_out[slot] = (g << 2) | code;
+            }
+            continue;
+        }
+        // last accepted frame that starts before g: is g inside it?  (The frame's own
+        // offset is a visited Try: strict inequality.)
+        uint32_t lo = 0, hi = a.n_frames;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.frames_g[mid] < g)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const bool shadowed = lo > 0 && g < a.frames_g[lo - 1] + a.frames_span[lo - 1];
+        if (!shadowed)
+            cnt[code < 3 ? code : 2]++;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t v = cnt[k];
+        for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v)
+            atomicAdd(&a.out[k], v);
+    }
+}
+
+hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream)
+{
+    const uint32_t total = args.n_tries + args.n_carry;
+    if (total == 0)
+        return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<uint32_t>((total + 255u) / 256u, 2048u);
+    hipLaunchKernelGGL(count_tries_kernel, dim3(blocks), dim3(256), 0, stream, args);
+    return hipGetLastError();
 }
 
 void make_syndrome_table(uint32_t *out)
