@@ -716,14 +716,22 @@ __global__ __launch_bounds__(256) void count_tries_kernel(const TryCountArgs a)
         if (!shadowed)
             cnt[code < 3 ? code : 2]++;
     }
+    // one atomic per block and counter: same-address atomics serialise in L2
+    __shared__ uint32_t part[3];
+    if (threadIdx.x < 3)
+        part[threadIdx.x] = 0;
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         uint32_t v = cnt[k];
         for (int off = 32; off > 0; off >>= 1)
             v += __shfl_down(v, off);
         if ((threadIdx.x & 63) == 0 && v)
-            atomicAdd(&a.out[k], v);
+            atomicAdd(&part[k], v);
     }
+    __syncthreads();
+    if (threadIdx.x < 3 && part[threadIdx.x])
+        atomicAdd(&a.out[threadIdx.x], part[threadIdx.x]);
 }
 
 hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream)
@@ -731,7 +739,7 @@ hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream)
     const uint32_t total = args.n_tries + args.n_carry;
     if (total == 0)
         return hipSuccess;
-    const unsigned blocks = (unsigned)std::min<uint32_t>((total + 255u) / 256u, 2048u);
+    const unsigned blocks = (unsigned)std::min<uint32_t>((total + 255u) / 256u, 512u);
     hipLaunchKernelGGL(count_tries_kernel, dim3(blocks), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
