@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -23,6 +24,8 @@
 #include <new>
 #include <string>
 #include <vector>
+
+#include <emmintrin.h>
 
 #include "../../include/adsbdec_amd.h"
 #include "resolver.hpp"
@@ -55,15 +58,14 @@ struct ScanSlot {
     bool tries_on_device = false;   // which of the two the launch in flight uses
     hipEvent_t ev_start = nullptr, ev_done = nullptr; // kernel timing (cfg.profile)
     hipEvent_t ev_ready = nullptr;                    // counters have landed in h_counters
-    // streaming hand-off (scan_kernel.h): per-tile directory + dense record array, pinned
-    unsigned long long *tile_dir = nullptr;
+    // streaming hand-off (scan_kernel.h): one stream of self-validating granules, pinned
     uint32_t *hand = nullptr;
-    size_t tile_alloc = 0; // tiles tile_dir can hold
-    size_t hand_cap = 0;   // records hand can hold
+    size_t hand_cap = 0;   // granules hand can hold
     uint32_t ntiles = 0;   // tiles of the launch in flight
     bool streaming = false;
     adsb::ScanArgs args{};
     bool busy = false;
+    bool prof_pending = false; // ev_start/ev_done of a collected launch not yet read (cfg.profile)
 };
 
 constexpr int kSlots = 4;
@@ -116,7 +118,7 @@ struct adsb_decoder {
 
     adsb_profile prof{};
     adsb::Resolver res;
-    std::vector<uint32_t> order, scratch_a, scratch_b, gather, raw;
+    std::vector<uint32_t> order, scratch_a, scratch_b, gather, raw, tile_start, tile_count;
     bool no_streaming = false; // ADSB_NO_STREAMING=1: always collect after completion
     // device-side visited-try count (scan_kernel.h TryCountArgs)
     uint64_t *d_carry[2] = {nullptr, nullptr};
@@ -196,7 +198,7 @@ int slot_reserve(adsb_decoder *d, ScanSlot &s, size_t want_cands, size_t want_tr
     return 0;
 }
 
-int slot_reserve_tiles(adsb_decoder *d, ScanSlot &s, size_t ntiles, size_t want_hand)
+int slot_reserve_hand(adsb_decoder *d, ScanSlot &s, size_t want_granules)
 {
     // fine-grained (coherent) so that the host sees the device's stores while the
     // kernel is still running
@@ -205,22 +207,39 @@ int slot_reserve_tiles(adsb_decoder *d, ScanSlot &s, size_t ntiles, size_t want_
         const int v = e ? atoi(e) : 0;
         return v == 1 ? hipHostMallocDefault : v == 2 ? hipHostMallocNonCoherent : hipHostMallocCoherent;
     }();
-    if (ntiles > s.tile_alloc) {
-        if (s.tile_dir)
-            HIP_TRY(d, hipHostFree(s.tile_dir));
-        s.tile_dir = nullptr;
-        s.tile_alloc = 0;
-        const size_t cap = ntiles + ntiles / 4 + 64;
-        HIP_TRY(d, hipHostMalloc(&s.tile_dir, cap * sizeof(unsigned long long), mem_flags));
-        s.tile_alloc = cap;
-    }
-    if (want_hand > s.hand_cap) {
+    if (want_granules > s.hand_cap) {
         if (s.hand)
             HIP_TRY(d, hipHostFree(s.hand));
         s.hand = nullptr;
         s.hand_cap = 0;
-        HIP_TRY(d, hipHostMalloc(&s.hand, want_hand * adsb::kTileRecWords * sizeof(uint32_t), mem_flags));
-        s.hand_cap = want_hand;
+        HIP_TRY(d, hipHostMalloc(&s.hand, want_granules * adsb::kGranuleWords * sizeof(uint32_t), mem_flags));
+        s.hand_cap = want_granules;
+    }
+    return 0;
+}
+
+// Kernel time of a collected launch, from its events.  Read lazily (next use of the
+// slot, adsb_get_profile): waiting for the events right after the last tile has been
+// consumed would put a device round trip on the critical path of every push.
+int slot_settle_profile(adsb_decoder *d, ScanSlot &s)
+{
+    if (!s.prof_pending)
+        return 0;
+    s.prof_pending = false;
+    HIP_TRY(d, hipEventSynchronize(s.ev_done));
+    float ms = 0;
+    HIP_TRY(d, hipEventElapsedTime(&ms, s.ev_start, s.ev_done));
+    d->prof.kernel_ms += ms;
+    d->prof.last_kernel_ms = ms;
+    const uint64_t no = s.args.g_end - s.args.g_begin;
+    if (no > d->prof.big_offsets) {
+        d->prof.big_offsets = no;
+        d->prof.big_launches = 0;
+        d->prof.big_ms = 0;
+    }
+    if (no == d->prof.big_offsets) {
+        d->prof.big_launches++;
+        d->prof.big_ms += ms;
     }
     return 0;
 }
@@ -228,6 +247,8 @@ int slot_reserve_tiles(adsb_decoder *d, ScanSlot &s, size_t ntiles, size_t want_
 int slot_launch(adsb_decoder *d, ScanSlot &s)
 {
     const bool stats = d->cfg.collect_stats != 0;
+    if (slot_settle_profile(d, s))
+        return -1;
     const uint64_t per = (uint64_t)adsb::tile_offsets(s.args.passes);
     s.ntiles = (uint32_t)((s.args.g_end - s.args.g_begin + per - 1) / per);
     // A stream's statistics run keeps the try words on the device (counted there after
@@ -236,15 +257,13 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.tries_on_device = stats && !d->sink.cands;
     s.streaming = !d->no_streaming && (!stats || s.tries_on_device);
     if (s.streaming) {
-        if (slot_reserve_tiles(d, s, s.ntiles, std::max<size_t>(s.hand_cap, s.cand_cap)))
+        // a marker per tile + two granules per record (sized like the loose list)
+        if (slot_reserve_hand(d, s, std::max<size_t>(s.hand_cap, 2 * s.cand_cap + s.ntiles + 64)))
             return -1;
-        std::memset(s.tile_dir, 0, (size_t)s.ntiles * sizeof(unsigned long long));
-        s.args.tile_dir = s.tile_dir;
         s.args.hand = s.hand;
         s.args.hand_cap = (uint32_t)std::min<size_t>(s.hand_cap, 0xFFFFFFFFu);
         s.args.gen = ++d->launch_gen * 0x9E3779B9u + 0x7F4A7C15u;
     } else {
-        s.args.tile_dir = nullptr;
         s.args.hand = nullptr;
         s.args.hand_cap = 0;
     }
@@ -253,7 +272,8 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.args.cand_cap = (uint32_t)std::min<size_t>(s.cand_cap, 0xFFFFFFFFu);
     s.args.tries = s.tries_on_device ? s.d_tries : s.tries;
     s.args.try_cap = (uint32_t)std::min<size_t>(s.tries_on_device ? s.d_try_cap : s.try_cap, 0xFFFFFFFFu);
-    HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d->stream));
+    // d_counters are zero here: cleared at creation and again behind every launch (below),
+    // so nothing sits between this call and the kernel's start
     if (d->cfg.profile)
         HIP_TRY(d, hipEventRecord(s.ev_start, d->stream));
     HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
@@ -261,6 +281,7 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
         HIP_TRY(d, hipEventRecord(s.ev_done, d->stream));
     HIP_TRY(d, hipMemcpyAsync(s.h_counters, s.d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(d, hipEventRecord(s.ev_ready, d->stream));
+    HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d->stream)); // for the slot's next launch
     s.busy = true;
     return 0;
 }
@@ -319,14 +340,17 @@ void sort_tries(adsb_decoder *d, uint32_t *t, size_t n)
 }
 
 // Hand sorted records to the sink (a caller's vectors or the stream's resolver).
-void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uint32_t *order, size_t nc,
-             const uint32_t *tries, size_t nt, uint64_t g_complete)
+// Record i is the 6 dwords {g_rel, pw, frame | len << 16 | flags << 24} at
+// recs[order[i] * words + off] (loose list / gathered copy: words 6, off 0; hand-off
+// stream consumed in place: words 4 = granule index, off 1).
+void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uint32_t *order, size_t nc, int words,
+             int off, const uint32_t *tries, size_t nt, uint64_t g_complete)
 {
     d->prof.candidates += nc;
     d->prof.tries += nt;
     if (d->sink.cands) {
         for (size_t i = 0; i < nc; i++) {
-            const uint32_t *r = recs + (size_t)order[i] * adsb::kCandWords;
+            const uint32_t *r = recs + (size_t)order[i] * words + off;
             adsb_candidate c;
             std::memset(&c, 0, sizeof c);
             c.g = s.args.g_begin + r[0];
@@ -339,33 +363,34 @@ void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uin
         for (size_t i = 0; i < nt; i++)
             d->sink.tries->push_back((((uint64_t)(tries[i] >> 2) + s.args.g_begin) << 2) | (tries[i] & 3u));
     } else if (nt == 0) {
-        d->res.advance_device(recs, order, nc, adsb::kCandWords, s.args.g_begin,
-                              power_samples_produced(d->n_samples), g_complete);
+        d->res.advance_device(recs, order, nc, words, off, s.args.g_begin, power_samples_produced(d->n_samples),
+                              g_complete);
     } else {
-        d->res.feed_device(recs, order, nc, adsb::kCandWords, s.args.g_begin, tries, nt);
+        d->res.feed_device(recs, order, nc, words, off, s.args.g_begin, tries, nt);
         d->res.advance(power_samples_produced(d->n_samples), g_complete);
     }
 }
 
 // Streaming collect: consume the oldest scan WHILE its kernel is still running, so
-// that sorting and resolving overlap the scan.
-//   * tile_dir says which tiles are complete and where their records are;
-//   * tiles reserve their ranges of `hand` in COMPLETION order, so `hand` is read
-//     strictly sequentially (one prefetchable stream; records validate themselves),
-//     and each record is dropped into its place in TILE order by a counting sort whose
-//     counts come from the directory; a record of a tile beyond the current group waits
-//     in `early`;
-//   * tiles are taken in groups: polling a directory line the device is still writing
-//     costs a coherence miss per poll.
-// Returns 1 if a tile reported records on the loose list: the caller then finishes
-// the launch through the collect-after-completion path, from tile *resume_tile on.
+// that resolving overlaps the scan.  The hand-off stream (scan_kernel.h) is read strictly
+// sequentially -- one prefetchable stream of device-written lines, no directory to poll:
+// a marker says which tile follows, how many records, and what their XOR must be; the
+// records are checked where they lie (16-byte loads) and later resolved in place.  Tiles reserve their ranges in COMPLETION
+// order, so a tile that finished early waits (start/count noted) until every tile before
+// it is in; the resolver is fed whenever the device leaves the host nothing to read, or
+// a group of tiles has accumulated.
+// Returns 1 if a tile reported records on the loose list (or the stream is full): the
+// caller then finishes the launch through the collect-after-completion path, from tile
+// *resume_tile on.
 int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
 {
     using clk = std::chrono::steady_clock;
     const uint64_t per = (uint64_t)adsb::tile_offsets(s.args.passes);
     const uint32_t gen = s.args.gen;
+    const uint32_t cap = s.args.hand_cap;
     double wait_ms = 0;
     const auto t_begin = clk::now();
+    auto t_last_wait = t_begin;
     // spin until `ready()`; gives up (with an error) once the kernel has long finished
     auto wait_for = [&](auto &&ready) -> bool {
         if (ready())
@@ -385,90 +410,123 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
                     break; // the launch failed, or it completed long ago: the bytes will not come
             }
         }
-        wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t_w).count();
+        t_last_wait = clk::now();
+        wait_ms += std::chrono::duration<double, std::milli>(t_last_wait - t_w).count();
         return ok;
     };
 
     static const uint32_t kGroup = [] {
         const char *e = getenv("ADSB_GROUP");
         const int v = e ? atoi(e) : 0;
-        return (uint32_t)(v > 0 ? v : 512); // measured best of 128..1024 (ADSB_GROUP overrides)
+        return (uint32_t)(v > 0 ? v : 512); // tiles resolved per batch while the host is behind the device
     }();
-    std::vector<uint32_t> &recs = d->gather; // every record read so far, compact, in `hand` order
-    std::vector<uint32_t> &order = d->order; // the group's records in ascending g (indices into recs)
-    recs.clear();
-    uint32_t read_pos = 0; // records of `hand` consumed
-    uint32_t t = 0;
+    std::vector<uint32_t> &order = d->order;     // a batch's records in ascending g (granule indices)
+    std::vector<uint32_t> &t_start = d->tile_start; // per tile: granule index of its first record ...
+    std::vector<uint32_t> &t_count = d->tile_count; // ... and its record count (~0u: not in yet)
+    t_start.assign(s.ntiles, 0u);
+    t_count.assign(s.ntiles, ~0u);
+    uint32_t pos = 0;       // granules of the stream consumed
+    uint32_t frontier = 0;  // every tile below is in
+    uint32_t delivered = 0; // every tile below has been handed to the resolver
     bool overflowed = false;
-    double dbg[4] = {0, 0, 0, 0};
+    double dbg[3] = {0, 0, 0};
     const bool dbg_on = getenv("ADSB_DEBUG_HOST") != nullptr;
-    auto lap = [&](int k, clk::time_point &from) {
-        if (dbg_on) {
-            const auto now = clk::now();
-            dbg[k] += std::chrono::duration<double, std::micro>(now - from).count();
-            from = now;
+    auto flush = [&](uint32_t upto) { // tiles [delivered, upto): their ranges, one after the other, are sorted
+        clk::time_point tp;
+        if (dbg_on)
+            tp = clk::now();
+        const uint64_t g_complete = std::min<uint64_t>(s.args.g_end, s.args.g_begin + (uint64_t)upto * per);
+        size_t nc = 0;
+        if (d->sink.cands) { // per-shard scan: the caller's vectors
+            order.clear();
+            for (uint32_t u = delivered; u < upto; u++)
+                for (uint32_t i = 0, b = t_start[u], n = t_count[u]; i < n; i++)
+                    order.push_back(b + 2 * i);
+            nc = order.size();
+            deliver(d, s, s.hand, order.data(), nc, adsb::kGranuleWords, 0, nullptr, 0, g_complete);
+        } else { // the stream's resolver walks the tile ranges where they lie
+            for (uint32_t u = delivered; u < upto; u++)
+                nc += t_count[u];
+            d->prof.candidates += nc;
+            d->res.advance_tiles(s.hand, t_start.data(), t_count.data(), delivered, upto, 0, s.args.g_begin,
+                                 power_samples_produced(d->n_samples), g_complete);
         }
+        delivered = upto;
+        if (dbg_on)
+            dbg[1] += std::chrono::duration<double, std::micro>(clk::now() - tp).count();
     };
-    while (t < s.ntiles && !overflowed) {
-        auto tp = clk::now();
-        const uint32_t t1 = std::min(s.ntiles, t + kGroup);
-        // wait on the group's LAST entry (the others are almost always published by then),
-        // then read the directory once, forwards; an entry that is still empty is waited for
-        if (!wait_for([&] { return (__atomic_load_n(&s.tile_dir[t1 - 1], __ATOMIC_ACQUIRE) >> 63) != 0; }))
-            return d->fail("scan kernel finished without publishing tile %u of %u", t1 - 1, s.ntiles);
-        // A tile's records sit in hand[base, base+n) in ascending g (the kernel ranks
-        // them), so the group's order is just its tiles' ranges one after the other.
-        order.clear();
-        uint32_t need = read_pos, t_ok = t1;
-        for (uint32_t u = t; u < t1; u++) {
-            unsigned long long dw = __atomic_load_n(&s.tile_dir[u], __ATOMIC_ACQUIRE);
-            if (!(dw >> 63) &&
-                !wait_for([&] { return ((dw = __atomic_load_n(&s.tile_dir[u], __ATOMIC_ACQUIRE)) >> 63) != 0; }))
-                return d->fail("scan kernel finished without publishing tile %u of %u", u, s.ntiles);
-            const uint32_t f = (uint32_t)(dw >> 32), base = (uint32_t)dw, n = f & 0xFFFFu;
-            if (f & 0x40000000u) { // some of its records went to the loose list: finish after completion
-                overflowed = true;
-                t_ok = u;
-                break;
-            }
-            for (uint32_t i = 0; i < n; i++)
-                order.push_back(base + i);
-            if (n && base + n > need)
-                need = base + n;
+    while (frontier < s.ntiles) {
+        if (pos >= cap) { // the stream is full: the rest of the launch is on the loose list
+            overflowed = true;
+            break;
         }
-        lap(0, tp); // directory
-        // sequential read of `hand` (tiles reserve their ranges in completion order, so
-        // this also picks up records of tiles of later groups; they simply wait in recs)
-        if (need > read_pos) {
-            recs.resize((size_t)need * adsb::kCandWords);
-            uint32_t *gdst = recs.data() + (size_t)read_pos * adsb::kCandWords;
-            for (uint32_t k = read_pos; k < need; k++, gdst += adsb::kCandWords) {
-                const volatile uint32_t *r = s.hand + (size_t)k * adsb::kTileRecWords;
-                auto valid = [&] {
-                    const uint32_t w0 = r[0], w1 = r[1], w2 = r[2], w3 = r[3], w4 = r[4], w5 = r[5], w6 = r[6],
-                                   w7 = r[7];
-                    gdst[0] = w0, gdst[1] = w1, gdst[2] = w2, gdst[3] = w4, gdst[4] = w5, gdst[5] = w6;
-                    return w3 == adsb::granule_tag(w0, w1, w2, gen) && w7 == adsb::granule_tag(w4, w5, w6, gen);
-                };
-                if (!wait_for(valid))
-                    return d->fail("hand-off record %u never validated", k);
+        // marker {tile, n | flags, check}: valid once it and the XOR of the 2n granules
+        // behind it agree (16-byte loads; the bytes are re-read on every poll)
+        const __m128i *gp = reinterpret_cast<const __m128i *>(s.hand) + pos;
+        uint32_t tile = 0, nf = 0;
+        auto tile_in = [&] {
+            std::atomic_signal_fence(std::memory_order_seq_cst); // compiler: re-read the bytes on every poll
+            const __m128i mk = _mm_load_si128(gp);
+            alignas(16) uint32_t mw[4], a[4];
+            _mm_store_si128(reinterpret_cast<__m128i *>(mw), mk);
+            tile = mw[0], nf = mw[1];
+            const uint32_t n = nf & 0xFFFFu;
+            const bool fits = !(nf & adsb::kMarkNoFit);
+            if (tile >= s.ntiles || (fits && (uint64_t)pos + 1 + 2ull * n > cap))
+                return false; // not a marker of this launch (yet)
+            __m128i acc = _mm_setzero_si128();
+            if (fits)
+                for (uint32_t k = 1; k <= 2 * n; k++)
+                    acc = _mm_xor_si128(acc, _mm_load_si128(gp + k));
+            _mm_store_si128(reinterpret_cast<__m128i *>(a), acc);
+            uint32_t lo, hi;
+            adsb::marker_check(tile, nf, gen, a[0], a[1], a[2], a[3], lo, hi);
+            return mw[2] == lo && mw[3] == hi;
+        };
+        clk::time_point tp;
+        if (dbg_on)
+            tp = clk::now();
+        if (!tile_in()) {
+            // the device is behind: use the time to resolve what is complete, then wait
+            if (frontier > delivered) {
+                flush(frontier);
+                continue;
             }
-            read_pos = need;
+            if (!wait_for(tile_in))
+                return d->fail("scan kernel finished without publishing granule %u (tile %u of %u pending)", pos, frontier,
+                               s.ntiles);
         }
-        lap(1, tp); // records
-        t = t_ok;
-        const uint64_t g_complete = std::min<uint64_t>(s.args.g_end, s.args.g_begin + (uint64_t)t * per);
-        deliver(d, s, recs.data(), order.data(), order.size(), nullptr, 0, g_complete);
-        lap(2, tp); // resolve
+        if (dbg_on)
+            dbg[0] += std::chrono::duration<double, std::micro>(clk::now() - tp).count();
+        const uint32_t n = nf & 0xFFFFu;
+        if (t_count[tile] != ~0u)
+            return d->fail("hand-off stream corrupt at granule %u (tile %u twice)", pos, tile);
+        if (nf & (adsb::kMarkOver | adsb::kMarkNoFit)) { // finish after completion
+            overflowed = true;
+            break;
+        }
+        t_start[tile] = pos + 1;
+        t_count[tile] = n;
+        pos += 1 + 2 * n;
+        while (frontier < s.ntiles && t_count[frontier] != ~0u)
+            frontier++;
+        // the tiles of the last resident round finish in a burst at the kernel's end: take
+        // them in small batches, so that little is left to do once the last one is in
+        constexpr uint32_t kTailTiles = 768, kTailGroup = 64;
+        if (frontier - delivered >= (s.ntiles - delivered > kTailTiles ? kGroup : kTailGroup))
+            flush(frontier);
     }
+    if (frontier > delivered)
+        flush(frontier);
     if (dbg_on)
-        fprintf(stderr, "stream collect: directory %.1f us, records %.1f us, resolve %.1f us (waits %.1f us inside)\n",
-                dbg[0], dbg[1], dbg[2], wait_ms * 1e3);
+        fprintf(stderr,
+                "stream collect: records %.1f us, resolve %.1f us, waits %.1f us; %.1f us after the last wait\n",
+                dbg[0], dbg[1], wait_ms * 1e3, std::chrono::duration<double, std::micro>(clk::now() - t_last_wait).count());
     const double total_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
     d->prof.wait_ms += wait_ms;
     d->prof.host_ms += total_ms - wait_ms;
-    *resume_tile = t;
-    return t < s.ntiles ? 1 : 0;
+    *resume_tile = delivered;
+    return overflowed ? 1 : 0;
 }
 
 // Device-side visited-try count of a statistics run (scan_kernel.h TryCountArgs):
@@ -562,25 +620,25 @@ int slot_collect(adsb_decoder *d)
             return -1;
         partial = rc == 1;
     }
+    if (s.streaming && !partial && !s.tries_on_device) {
+        // Every tile has been published and consumed and none used the loose list: the
+        // launch-wide counters have nothing to add, so do not wait for them (nor for the
+        // kernel's end event -- the profile reads that later).
+        s.prof_pending = d->cfg.profile != 0;
+        d->prof.launches++;
+        d->prof.offsets += s.args.g_end - s.args.g_begin;
+        d->prof.last_offsets = s.args.g_end - s.args.g_begin;
+        s.busy = false;
+        d->slot_head = (d->slot_head + 1) % kSlots;
+        d->slot_count--;
+        return 0;
+    }
     const auto t_wait = clk::now();
     for (int attempt = 0;; attempt++) {
         HIP_TRY(d, hipEventSynchronize(s.ev_ready));
-        if (d->cfg.profile) {
-            float ms = 0;
-            HIP_TRY(d, hipEventElapsedTime(&ms, s.ev_start, s.ev_done));
-            d->prof.kernel_ms += ms;
-            d->prof.last_kernel_ms = ms;
-            const uint64_t no = s.args.g_end - s.args.g_begin;
-            if (no > d->prof.big_offsets) {
-                d->prof.big_offsets = no;
-                d->prof.big_launches = 0;
-                d->prof.big_ms = 0;
-            }
-            if (no == d->prof.big_offsets) {
-                d->prof.big_launches++;
-                d->prof.big_ms += ms;
-            }
-        }
+        s.prof_pending = d->cfg.profile != 0;
+        if (slot_settle_profile(d, s))
+            return -1;
         d->prof.launches++;
         d->prof.offsets += s.args.g_end - s.args.g_begin;
         d->prof.last_offsets = s.args.g_end - s.args.g_begin;
@@ -612,24 +670,36 @@ int slot_collect(adsb_decoder *d)
         if (nt && !s.tries_on_device)
             sort_tries(d, s.tries, nt);
         const size_t nt_host = s.tries_on_device ? 0 : nt;
-        deliver(d, s, s.cands, d->order.data(), nc, s.tries, nt_host, s.args.g_end);
+        deliver(d, s, s.cands, d->order.data(), nc, adsb::kCandWords, 0, s.tries, nt_host, s.args.g_end);
     } else if (partial) {
-        // a tile overflowed its hand-off region: gather what is left (regions of the
-        // tiles not yet delivered + the loose list) and sort it like the path above
+        // Some records are on the loose list: gather what is left -- the hand-off stream's
+        // tiles not yet delivered (the kernel has completed: every granule that was ever
+        // written is in; a missing or non-fitting marker ends the stream) + the loose list
+        // -- and sort it like the path above.
         d->gather.clear();
-        for (uint32_t t = resume_tile; t < s.ntiles; t++) { // the kernel has completed: all bytes are in
-            const unsigned long long dw = s.tile_dir[t];
-            const uint32_t n = (uint32_t)(dw >> 32) & 0xFFFFu, base = (uint32_t)dw;
-            for (uint32_t i = 0; i < n; i++) {
-                const uint32_t *w = s.hand + ((size_t)base + i) * adsb::kTileRecWords;
-                const uint32_t rec[6] = {w[0], w[1], w[2], w[4], w[5], w[6]};
-                d->gather.insert(d->gather.end(), rec, rec + 6);
-            }
+        const uint32_t lim = (uint32_t)std::min<size_t>(s.h_counters[2], s.args.hand_cap);
+        for (uint32_t pos = 0; pos < lim;) {
+            const uint32_t *m = s.hand + (size_t)pos * adsb::kGranuleWords;
+            const uint32_t tile = m[0], nf = m[1], n = nf & 0xFFFFu;
+            if (tile >= s.ntiles || (nf & adsb::kMarkNoFit) || (uint64_t)pos + 1 + 2ull * n > lim)
+                break;
+            uint32_t a[4] = {0, 0, 0, 0}, lo, hi;
+            for (uint32_t k = 0; k < 8 * n; k++)
+                a[k & 3] ^= m[4 + k];
+            adsb::marker_check(tile, nf, s.args.gen, a[0], a[1], a[2], a[3], lo, hi);
+            if (m[2] != lo || m[3] != hi)
+                break;
+            if (tile >= resume_tile)
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t *w = m + (size_t)(1 + 2 * i) * adsb::kGranuleWords;
+                    d->gather.insert(d->gather.end(), w, w + 6); // {g_rel, pw, w0..w3}
+                }
+            pos += 1 + 2 * n;
         }
         d->gather.insert(d->gather.end(), s.cands, s.cands + nc * adsb::kCandWords);
         const size_t total = d->gather.size() / adsb::kCandWords;
         sort_order(d, d->gather.data(), total);
-        deliver(d, s, d->gather.data(), d->order.data(), total, nullptr, 0, s.args.g_end);
+        deliver(d, s, d->gather.data(), d->order.data(), total, adsb::kCandWords, 0, nullptr, 0, s.args.g_end);
     } else if (nc != 0) {
         return d->fail("internal: %zu loose records without a tile overflow flag", nc);
     }
@@ -833,6 +903,8 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
     for (ScanSlot &sl : d->slots) {
         if ((e = hipMalloc(&sl.d_counters, 4 * sizeof(uint32_t))) != hipSuccess)
             return bail("hipMalloc(counters)", e);
+        if ((e = hipMemset(sl.d_counters, 0, 4 * sizeof(uint32_t))) != hipSuccess)
+            return bail("hipMemset(counters)", e);
         if ((e = hipHostMalloc(&sl.h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
             return bail("hipHostMalloc(counters)", e);
         if ((e = hipEventCreate(&sl.ev_start)) != hipSuccess || (e = hipEventCreate(&sl.ev_done)) != hipSuccess ||
@@ -896,7 +968,6 @@ void adsb_destroy(adsb_decoder *d)
         if (sl.cands) (void)hipHostFree(sl.cands);
         if (sl.tries) (void)hipHostFree(sl.tries);
         if (sl.d_tries) (void)hipFree(sl.d_tries);
-        if (sl.tile_dir) (void)hipHostFree(sl.tile_dir);
         if (sl.hand) (void)hipHostFree(sl.hand);
         if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
@@ -924,6 +995,8 @@ int adsb_reset(adsb_decoder *d)
     d->slot_head = 0;
     d->slot_count = 0;
     std::memset(&d->prof, 0, sizeof d->prof);
+    for (auto &sl : d->slots)
+        sl.prof_pending = false; // belongs to the profile that was just cleared
     d->err.clear();
     return 0;
 }
@@ -997,18 +1070,28 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
         g_end = round_down(g_end, 28);
     d->n_samples = total;
     if (final) {
+        using clk = std::chrono::steady_clock;
+        const bool dbg_on = getenv("ADSB_DEBUG_HOST") != nullptr;
+        const auto t0 = clk::now();
         if (g_end > d->g_scanned) {
             if (scan_submit(d, p, first, n, d->g_scanned, g_end))
                 return -1;
             d->g_scanned = g_end;
         }
+        const auto t1 = clk::now();
         if (scan_drain(d))
             return -1;
+        const auto t2 = clk::now();
         d->res.advance(2 * ((total + 3) / 4), d->g_scanned); // EOF rule: see process_stage()
         if (d->cfg.collect_stats && count_tries_pass(d, nullptr, 0, 0, true))
             return -1; // tries beyond the final position are never visited
         d->stage_fill = 0;
         d->finished = true;
+        if (dbg_on) {
+            auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            fprintf(stderr, "push_device_final: submit %.1f us, drain %.1f us, finish %.1f us\n", us(t0, t1), us(t1, t2),
+                    us(t2, clk::now()));
+        }
         return 0;
     }
     // Tail first: what the next push (or adsb_finish) still needs goes to the staging
@@ -1092,6 +1175,10 @@ int adsb_get_profile(const adsb_decoder *d, adsb_profile *out)
 {
     if (!d || !out)
         return -1;
+    adsb_decoder *m = const_cast<adsb_decoder *>(d); // kernel times are read from their events on demand
+    for (auto &sl : m->slots)
+        if (slot_settle_profile(m, sl))
+            return -1;
     *out = d->prof;
     return 0;
 }

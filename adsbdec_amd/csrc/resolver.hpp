@@ -50,16 +50,17 @@ public:
             tries_.insert(tries_.end(), tries, tries + nt);
     }
 
-    // Device records: kWords dwords each {g_rel, pw, frame bytes 0..13, len in byte 14},
-    // visited through `order` (ascending g_rel); tries ascending ((g_rel << 2) | code).
-    void feed_device(const uint32_t *recs, const uint32_t *order, size_t n, int words, uint64_t g_base,
+    // Device records: {g_rel, pw, frame bytes 0..13, len in byte 14} = 6 dwords starting
+    // at recs[order[i] * words + off], visited through `order` (ascending g_rel); tries
+    // ascending ((g_rel << 2) | code).
+    void feed_device(const uint32_t *recs, const uint32_t *order, size_t n, int words, int off, uint64_t g_base,
                      const uint32_t *tries, size_t nt)
     {
         compact();
         const size_t at = cands_.size();
         cands_.resize(at + n);
         for (size_t i = 0; i < n; i++) {
-            const uint32_t *r = recs + (size_t)order[i] * words;
+            const uint32_t *r = recs + (size_t)order[i] * words + off;
             adsb_candidate &c = cands_[at + i];
             c.g = g_base + r[0];
             c.pw = r[1];
@@ -76,17 +77,38 @@ public:
     // feed_device + advance in one step, without copying the records into the queue:
     // the device batch is consumed in place; only what lies beyond the last executed
     // deqframe call (normally nothing or a handful) is kept for later.
-    void advance_device(const uint32_t *recs, const uint32_t *order, size_t n, int words, uint64_t g_base,
+    void advance_device(const uint32_t *recs, const uint32_t *order, size_t n, int words, int off, uint64_t g_base,
                         uint64_t power_samples, uint64_t g_complete)
     {
         compact();
-        batch_ = Batch{recs, order, n, 0, words, g_base};
-        advance(power_samples, g_complete);
-        for (; batch_.pos < batch_.n; batch_.pos++) { // leftovers: beyond the last call's limit
-            cands_.emplace_back();
-            batch_.load(batch_.pos, cands_.back());
-        }
         batch_ = Batch{};
+        batch_.recs = recs + off;
+        batch_.order = order;
+        batch_.n = n;
+        batch_.words = words;
+        batch_.g_base = g_base;
+        batch_.cur = n ? batch_.recs + (size_t)order[0] * words : nullptr;
+        advance(power_samples, g_complete);
+        keep_leftovers();
+    }
+
+    // The same for tiles [t0, t1) of a hand-off stream (scan_kernel.h): tile u's records
+    // are the counts[u] consecutive 8-dword records from granule starts[u] on, each
+    // {g_rel, pw, frame | len << 16 | flags << 24} from dword `off`, ascending inside a
+    // tile and from tile to tile.
+    void advance_tiles(const uint32_t *stream, const uint32_t *starts, const uint32_t *counts, uint32_t t0, uint32_t t1,
+                       int off, uint64_t g_base, uint64_t power_samples, uint64_t g_complete)
+    {
+        compact();
+        batch_ = Batch{};
+        batch_.recs = stream + off;
+        batch_.starts = starts;
+        batch_.counts = counts;
+        batch_.u_end = t1;
+        batch_.g_base = g_base;
+        batch_.seek_tile(t0);
+        advance(power_samples, g_complete);
+        keep_leftovers();
     }
 
     // power_samples: samples the front end has produced so far (air.c `aidx` grows
@@ -180,22 +202,54 @@ private:
     // A batch of device records being consumed in place (advance_device).  Queue
     // entries (older) always precede batch entries (newer) in g.
     struct Batch {
-        const uint32_t *recs = nullptr;
+        const uint32_t *cur = nullptr;  // {g_rel, pw, w0..w3} of the next record; null: exhausted
+        const uint32_t *recs = nullptr; // dword 0 of index 0 (the layout's offset already applied)
+        uint64_t g_base = 0;
+        // either: records visited through an index list
         const uint32_t *order = nullptr;
         size_t n = 0, pos = 0;
         int words = 0;
-        uint64_t g_base = 0;
-        uint64_t g(size_t i) const { return g_base + recs[(size_t)order[i] * words]; }
-        void load(size_t i, adsb_candidate &c) const
+        // or: tile ranges of a granule stream
+        const uint32_t *starts = nullptr, *counts = nullptr;
+        uint32_t u = 0, u_end = 0, left = 0;
+
+        void seek_tile(uint32_t t)
         {
-            const uint32_t *r = recs + (size_t)order[i] * words;
-            c.g = g_base + r[0];
+            for (u = t; u < u_end; u++)
+                if (counts[u]) {
+                    left = counts[u];
+                    cur = recs + (size_t)starts[u] * 4;
+                    return;
+                }
+            cur = nullptr;
+        }
+        void next()
+        {
+            if (order) {
+                pos++;
+                cur = pos < n ? recs + (size_t)order[pos] * words : nullptr;
+            } else if (--left) {
+                cur += 8; // two granules per record
+            } else {
+                seek_tile(u + 1);
+            }
+        }
+    };
+
+    void keep_leftovers() // records beyond the last executed call's limit wait in the queue
+    {
+        for (; batch_.cur; batch_.next()) {
+            const uint32_t *r = batch_.cur;
+            cands_.emplace_back();
+            adsb_candidate &c = cands_.back();
+            c.g = batch_.g_base + r[0];
             c.pw = r[1];
             std::memcpy(c.frame, &r[2], 14);
             c.len = (uint8_t)((r[5] >> 16) & 0xFF);
             c.reserved = (uint8_t)((r[5] >> 24) & 1u);
         }
-    };
+        batch_ = Batch{};
+    }
 
     // One deqframe(ampbuff, len) call: visits offsets from base_ while < limit.
     void run_call(uint64_t limit)
@@ -210,10 +264,10 @@ private:
             if (from_queue) {
                 g = cands_[chead_].g;
             } else {
-                while (batch_.pos < batch_.n && batch_.g(batch_.pos) < idx)
-                    batch_.pos++;
-                if (batch_.pos < batch_.n)
-                    g = batch_.g(batch_.pos);
+                while (batch_.cur && batch_.g_base + batch_.cur[0] < idx)
+                    batch_.next();
+                if (batch_.cur)
+                    g = batch_.g_base + batch_.cur[0];
             }
             if (g >= limit) { // also: no candidate left
                 count_tries(idx, limit - 1);
@@ -232,7 +286,8 @@ private:
                 std::memcpy(f.frame, c.frame, 14);
                 f.reserved = c.reserved;
             } else { // straight from the device record {g_rel, pw, frame[14] | len << 16 | flags << 24}
-                const uint32_t *r = batch_.recs + (size_t)batch_.order[batch_.pos++] * batch_.words;
+                const uint32_t *r = batch_.cur;
+                batch_.next();
                 f.pw = r[1];
                 std::memcpy(f.frame, &r[2], 14);
                 f.len = (uint8_t)((r[5] >> 16) & 0xFF);

@@ -33,22 +33,29 @@ constexpr int ADSB_DECOFFSET_K = 1200; // longest span an accepted frame jumps (
 constexpr int kCandWords = 6;   // {g_rel, pw, frame[0..13] | len<<16 in the last word}
 constexpr int kSyndWords = 14 * 256;
 constexpr int kFixSlots = 512;
-constexpr int kTileRecWords = 8; // two self-validating 16-byte granules
+// hand-off stream (ScanArgs::hand): 16-byte granules
+constexpr int kGranuleWords = 4;
+constexpr uint32_t kMarkOver = 0x10000u;  // marker flag: some records of the tile are on the loose list
+constexpr uint32_t kMarkNoFit = 0x20000u; // marker flag: the tile's range ran past the array (records are loose)
 
 constexpr int owned_runs(int passes) { return kPassRuns * passes - kReachRuns; }
 constexpr int tile_offsets(int passes) { return kRun * owned_runs(passes); }
 constexpr size_t lds_bytes(int passes)
 {
-    return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 8 + kClistCap * 6);
+    return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6);
 }
 constexpr uint64_t kMaxLaunchOffsets = (1ull << 30) - tile_offsets(kMaxPasses); // g_rel must fit 30 bits
 
-// Tag of one 16-byte hand-off granule (device writes it, host checks it).
-__host__ __device__ inline uint32_t granule_tag(uint32_t a, uint32_t b, uint32_t c, uint32_t gen)
+// Check words of a tile marker (device writes them, host checks them): a0..a3 = XOR,
+// word by word, of the 2n record granules that follow the marker.  gen differs
+// between any two launches that can touch the same bytes, so a marker written by an
+// earlier launch never validates, and a range in which some granule has not landed yet
+// (stale bytes) passes with probability 2^-64.
+__host__ __device__ inline void marker_check(uint32_t tile, uint32_t nf, uint32_t gen, uint32_t a0, uint32_t a1, uint32_t a2,
+                                             uint32_t a3, uint32_t &lo, uint32_t &hi)
 {
-    // gen differs between any two launches that can touch the same bytes, so a granule
-    // written whole by an earlier launch never validates; a torn one passes with 2^-32
-    return gen ^ a ^ (b << 11 | b >> 21) ^ (c << 22 | c >> 10);
+    lo = a0 ^ (a2 << 16 | a2 >> 16) ^ gen ^ tile ^ (nf << 11 | nf >> 21);
+    hi = a1 ^ (a3 << 16 | a3 >> 16) ^ ~gen ^ (tile << 7 | tile >> 25) ^ nf;
 }
 
 struct ScanArgs {
@@ -61,23 +68,24 @@ struct ScanArgs {
     int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
     int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
     int all_candidates;  // 1: emit every CRC-valid offset (no never-visited filter)
-    // Streaming hand-off (tile_dir == null: off).  A tile reserves a contiguous range
-    // of the dense array `hand` for the records it keeps (one atomicAdd on
-    // counters[2]), writes them, and stores tile_dir[b] = {base, 0x80000000 |
-    // overflow << 30 | count} as one 8-byte granule, so that the host can consume
-    // tiles in order while the kernel is still running.  Nothing orders those stores
-    // on their way to host memory, so every 16-byte record store is SELF-VALIDATING:
-    // a record is two granules {g_rel, pw, w0, tag} {w1, w2, w3, tag} with tag =
-    // granule_tag(3 data words, gen); the host consumes a record only when both tags
-    // check (gen changes with every launch, so stale bytes never validate).
-    unsigned long long *tile_dir;
-    uint32_t *hand;        // kTileRecWords dwords per record
-    uint32_t hand_cap;     // records
+    // Streaming hand-off (hand == null: off).  `hand` is ONE stream of 16-byte granules
+    // that the host reads strictly sequentially while the kernel runs.  A tile reserves
+    // 1 + 2n consecutive granules with one atomicAdd on counters[2] (so ranges appear in
+    // tile COMPLETION order) and writes
+    //     marker  {tile, n | flags, check_lo, check_hi}
+    //     n x     {g_rel, pw, w0, w1} {w2, w3, 0, 0}            (ascending g_rel)
+    // Nothing orders these stores on their way to host memory, so the marker carries
+    // marker_check() of the records: the host consumes a tile only when the marker and
+    // the XOR of the 2n granules behind it agree (gen changes with every launch, so
+    // stale bytes never validate).  A tile whose range does not fit writes no records
+    // there (they go to the loose list) and says so in its marker, if that fits.
+    uint32_t *hand;
+    uint32_t hand_cap;     // granules
     uint32_t gen;
     const uint32_t *fix_tab; // EXTENSION (not in the reference): 512-entry perfect hash syndrome -> bit, or null
     uint32_t fix_mul;
     const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
-    uint32_t *counters;  // [0] loose candidates, [1] tries (may exceed the capacities), [2] hand-off records
+    uint32_t *counters;  // [0] loose candidates, [1] tries (may exceed the capacities), [2] hand-off granules
     uint32_t *cands;     // kCandWords dwords per record
     uint32_t cand_cap;
     uint32_t *tries;     // (g_rel << 2) | code

@@ -277,22 +277,32 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
 
     uint32_t *tile_n = qcount + 4;    // records this tile keeps (ranked into its hand-off range)
     uint32_t *tile_over = qcount + 5; // some records had to go to the loose list
-    uint32_t *tile_base = qcount + 6; // first index of the tile's range in args.hand
+    uint32_t *tile_base = qcount + 6; // granule index of the tile's marker in args.hand
     uint32_t *try_base = qcount + 7;  // first index of the round's range in args.tries (kStats)
+    uint32_t *tile_res = qcount + 8;  // the tile has reserved its range of args.hand
+    uint32_t *tile_fit = qcount + 9;  // ... and the whole range lies inside the array
+    uint32_t *tile_chk = qcount + 10; // [4]: XOR of the granules the tile wrote there, word by word
     if (tid == 0) {
         *tile_n = 0;
         *tile_over = 0;
         *tile_base = 0;
+        *tile_res = 0;
+        *tile_fit = 0;
+        tile_chk[0] = tile_chk[1] = tile_chk[2] = tile_chk[3] = 0;
     }
-    // A finished record goes to slot `hand_idx` of the dense hand-off array (two tagged
-    // 16-byte granules) or -- hand-off disabled, no slot (hand_idx = ~0u), array full --
-    // to the launch-wide loose list.
-    auto emit_record = [&](uint32_t hand_idx, uint32_t g_rel, uint32_t pw, const uint32_t (&wds)[4]) {
-        if (args.tile_dir) {
-            if (hand_idx < args.hand_cap) {
-                uint4 *dst = reinterpret_cast<uint4 *>(args.hand + (size_t)hand_idx * kTileRecWords);
-                dst[0] = make_uint4(g_rel, pw, wds[0], granule_tag(g_rel, pw, wds[0], args.gen));
-                dst[1] = make_uint4(wds[1], wds[2], wds[3], granule_tag(wds[1], wds[2], wds[3], args.gen));
+    // A finished record goes to granules `gran`, `gran + 1` of the hand-off stream (and
+    // into the tile's checksum) or -- hand-off disabled, unranked record (gran = ~0u),
+    // stream full -- to the launch-wide loose list.
+    auto emit_record = [&](uint32_t gran, uint32_t g_rel, uint32_t pw, const uint32_t (&wds)[4]) {
+        if (args.hand) {
+            if (gran != ~0u && *tile_fit) {
+                uint4 *dst = reinterpret_cast<uint4 *>(args.hand) + gran;
+                dst[0] = make_uint4(g_rel, pw, wds[0], wds[1]);
+                dst[1] = make_uint4(wds[2], wds[3], 0u, 0u);
+                atomicXor(&tile_chk[0], g_rel ^ wds[2]);
+                atomicXor(&tile_chk[1], pw ^ wds[3]);
+                atomicXor(&tile_chk[2], wds[0]);
+                atomicXor(&tile_chk[3], wds[1]);
                 return;
             }
             *tile_over = 1;
@@ -397,21 +407,48 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         // (a single rounding cannot change the sign of a non-zero difference and an
         // exact zero stays zero).  These are the only FMAs in the kernel; the signal
         // arithmetic above is mul-then-add.
-        float c[34];
+        //
+        // Packing: every operation here combines index k with k + 5 or k + 10, so the
+        // usual (k, k+1) register pairs cannot feed v_pk_* on both sides (5 is odd).
+        // Pairs (k, k+2) for k mod 5 in {0, 1} can -- the partner set is closed under
+        // +5 -- and leave k mod 5 == 4 as scalar operations: 4 of 5 values are packed.
+        float c[34], dv[28], e1v[28], e2v[28];
 #pragma unroll
-        for (int k = 0; k < 34; k += 2) {
-            const f32x2 lo = {a[k], a[k + 1]}, hi = {a[k + 10], a[k + 11]};
-            const f32x2 sum = lo + hi;
-            c[k] = __builtin_truncf(sum.x);
-            c[k + 1] = __builtin_truncf(sum.y);
+        for (int k = 0; k < 33; k++) {
+            if (k % 5 < 2) {
+                const f32x2 lo = {a[k], a[k + 2]}, hi = {a[k + 10], a[k + 12]};
+                const f32x2 sum = lo + hi;
+                c[k] = __builtin_truncf(sum.x);
+                c[k + 2] = __builtin_truncf(sum.y);
+            } else if (k % 5 == 4) {
+                c[k] = __builtin_truncf(a[k] + a[k + 10]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 28; m++) {
+            if (m % 5 < 2 && m + 2 < 28) {
+                const f32x2 am = {a[m], a[m + 2]}, an = {a[m + 5], a[m + 7]};
+                const f32x2 cm = {c[m], c[m + 2]}, cn = {c[m + 5], c[m + 7]};
+                const f32x2 two = {2.0f, 2.0f};
+                const f32x2 dd = an - am;
+                const f32x2 x1 = __builtin_elementwise_fma(cn, two, -cm);
+                const f32x2 x2 = __builtin_elementwise_fma(cm, two, -cn);
+                dv[m] = dd.x, dv[m + 2] = dd.y;
+                e1v[m] = x1.x, e1v[m + 2] = x1.y;
+                e2v[m] = x2.x, e2v[m + 2] = x2.y;
+            } else if (m % 5 == 4 || (m % 5 < 2 && m + 2 >= 28)) {
+                dv[m] = a[m + 5] - a[m];
+                e1v[m] = __builtin_fmaf(c[m + 5], 2.0f, -c[m]);
+                e2v[m] = __builtin_fmaf(c[m], 2.0f, -c[m + 5]);
+            }
         }
 
         uint32_t d = 0, e1 = 0, e2 = 0;
 #pragma unroll
         for (int m = 27; m >= 0; m--) { // bit m of each word <-> sample m of the run
-            d = push_sign(d, __float_as_uint(a[m + 5] - a[m]));                           // a[m] > a[m+5]   (demod.c:34)
-            e1 = push_sign(e1, __float_as_uint(__builtin_fmaf(c[m + 5], 2.0f, -c[m])));  // c[m] > 2 c[m+5] (SN = 2, demod.c:83)
-            e2 = push_sign(e2, __float_as_uint(__builtin_fmaf(c[m], 2.0f, -c[m + 5])));  // c[m+5] > 2 c[m]
+            d = push_sign(d, __float_as_uint(dv[m]));    // a[m+5] - a[m] < 0:  a[m] > a[m+5]   (demod.c:34)
+            e1 = push_sign(e1, __float_as_uint(e1v[m])); // 2 c[m+5] - c[m] < 0: c[m] > 2 c[m+5] (SN = 2, demod.c:83)
+            e2 = push_sign(e2, __float_as_uint(e2v[m])); // 2 c[m] - c[m+5] < 0: c[m+5] > 2 c[m]
         }
         if (lane < kWaveRuns) { // lane 63 only feeds lane 62
             pl_d[v] = d;
@@ -439,7 +476,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     uint32_t *qover = qcount + 1;
     uint32_t *cl_n = qcount + 2;    // CRC-valid candidates staged in LDS this round
     uint32_t *cl_over = qcount + 3; // some were emitted directly: the staged list is incomplete
-    uint32_t *cl_rec = qcount + 8;  // kClistCap records of kCandWords
+    uint32_t *cl_rec = qcount + 16; // kClistCap records of kCandWords
     const uint32_t qcap = (uint32_t)args.queue_cap;
     const uint32_t tile_rel = (uint32_t)(t0 - (int64_t)args.g_begin);
 
@@ -616,16 +653,21 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 }
                 keep = !drop;
             }
-            // the kept records get a contiguous range of the dense hand-off array, in
-            // ascending g (rank = kept entries with a smaller offset), so that the host
-            // can take a tile's range as it is
+            // the tile reserves one marker granule plus two per kept record of the hand-off
+            // stream; the records follow the marker in ascending g (rank = kept entries
+            // with a smaller offset), so that the host can take the range as it is
             if (keep) {
                 atomicAdd(tile_n, 1u);
                 cl_rec[tid * kCandWords + 1] |= 0x10000u; // staged word 1, bit 16: kept
             }
             __syncthreads();
-            if (tid == 0 && args.tile_dir && *tile_n)
-                *tile_base = atomicAdd(&args.counters[2], *tile_n);
+            if (tid == 0 && args.hand) {
+                const uint32_t need = 1u + 2u * *tile_n;
+                const uint32_t b = atomicAdd(&args.counters[2], need);
+                *tile_base = b;
+                *tile_fit = (b < args.hand_cap && need <= args.hand_cap - b) ? 1u : 0u;
+                *tile_res = 1;
+            }
             uint32_t rank = 0;
             if (keep) {
                 const uint32_t gi = ri[0];
@@ -640,7 +682,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 columns_to_bytes(cw, (ri[1] & 0xFFu) == 0, wds);
                 wds[3] |= ((ri[1] >> 8) & 1u) << 24; // repaired-by-extension flag
                 const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + ri[0]);
-                emit_record(*tile_base + rank, ri[0], pw, wds);
+                emit_record(*tile_base + 1u + 2u * rank, ri[0], pw, wds);
             }
         }
 
@@ -661,19 +703,26 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         __syncthreads(); // queue is rewritten
     }
 
-    if (args.tile_dir) {
-        // Publish the tile: {first record, flags | count} as ONE 8-byte store.  No fence:
-        // a system-scope release in every thread writes back the L2 per tile (measured:
-        // 4.5x slower kernel), and without one this store can overtake the records on
-        // the way to host memory (measured: it does) -- which is why the records
-        // validate themselves (scan_kernel.h).
+    if (args.hand) {
+        // Publish the tile: its marker granule {tile, count | flags, checksum} in front of
+        // its records.  No fence: a system-scope release in every thread writes back the
+        // L2 per tile (measured: 4.5x slower kernel), and without one nothing orders these
+        // stores on their way to host memory (measured: a flag does overtake the records)
+        // -- which is why the marker carries a checksum of the records (scan_kernel.h).
         __syncthreads();
         if (tid == 0) {
-            const uint32_t base = *tile_base, nk = *tile_n;
-            const uint32_t fit = base >= args.hand_cap ? 0u : min(nk, args.hand_cap - base);
-            const unsigned long long word =
-                ((unsigned long long)(0x80000000u | (*tile_over ? 0x40000000u : 0u) | fit) << 32) | base;
-            __hip_atomic_store(&args.tile_dir[blockIdx.x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            uint32_t b = *tile_base, fit = *tile_fit;
+            if (!*tile_res) { // no whole-tile round staged anything (all_candidates, fallback rounds)
+                b = atomicAdd(&args.counters[2], 1u);
+                fit = b < args.hand_cap;
+            }
+            if (b < args.hand_cap) {
+                const uint32_t nf = *tile_n | (*tile_over ? kMarkOver : 0u) | (fit ? 0u : kMarkNoFit);
+                uint32_t lo, hi;
+                marker_check(blockIdx.x, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
+                uint4 *dst = reinterpret_cast<uint4 *>(args.hand) + b;
+                *dst = make_uint4(blockIdx.x, nf, lo, hi);
+            }
         }
     }
 }

@@ -48,7 +48,7 @@ int main(int argc, char **argv)
     a.counters = counters; a.cands = cands; a.cand_cap = 1u << 20; a.tries = nullptr; a.try_cap = 0;
     std::vector<uint32_t> synd(adsb::kSyndWords); adsb::make_syndrome_table(synd.data());
     uint32_t *dsynd; CK(hipMalloc(&dsynd, synd.size() * 4)); CK(hipMemcpy(dsynd, synd.data(), synd.size() * 4, hipMemcpyHostToDevice));
-    a.synd = dsynd; a.queue_cap = adsb::kQueueCap; a.all_candidates = 0; a.fix_tab = nullptr; a.fix_mul = 0; a.tile_dir = nullptr; a.hand = nullptr; a.hand_cap = 0; a.gen = 0;
+    a.synd = dsynd; a.queue_cap = adsb::kQueueCap; a.all_candidates = 0; a.fix_tab = nullptr; a.fix_mul = 0; a.hand = nullptr; a.hand_cap = 0; a.gen = 0;
     a.passes = argc > 3 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++) { CK(hipMemset(counters, 0, 8)); CK(adsb::launch_scan(a, false, 0)); }
