@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if force or _newer(obj, [src] + hdrs):
             if verbose:
                 print("hipcc", s)
-            _run([HIPCC] + HIP_FLAGS + ["-c", src, "-o", obj])
+            _run([HIPCC] + HIP_FLAGS + os.environ.get("ADSB_EXTRA_HIPFLAGS", "").split() + ["-c", src, "-o", obj])
         objs.append(obj)
     for s in C_SOURCES:
         src = os.path.join(CSRC, s)

@@ -249,8 +249,7 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     const bool stats = d->cfg.collect_stats != 0;
     if (slot_settle_profile(d, s))
         return -1;
-    const uint64_t per = (uint64_t)adsb::tile_offsets(s.args.passes);
-    s.ntiles = (uint32_t)((s.args.g_end - s.args.g_begin + per - 1) / per);
+    s.ntiles = adsb::tile_count(s.args.g_end - s.args.g_begin, s.args.stagger, s.args.passes);
     // A stream's statistics run keeps the try words on the device (counted there after
     // resolution); a per-shard scan hands the list back, sorted, so it needs the list
     // complete on the host: collect after completion.
@@ -385,7 +384,6 @@ void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uin
 int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
 {
     using clk = std::chrono::steady_clock;
-    const uint64_t per = (uint64_t)adsb::tile_offsets(s.args.passes);
     const uint32_t gen = s.args.gen;
     const uint32_t cap = s.args.hand_cap;
     double wait_ms = 0;
@@ -435,7 +433,8 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
         clk::time_point tp;
         if (dbg_on)
             tp = clk::now();
-        const uint64_t g_complete = std::min<uint64_t>(s.args.g_end, s.args.g_begin + (uint64_t)upto * per);
+        const uint64_t g_complete = std::min<uint64_t>(
+            s.args.g_end, s.args.g_begin + adsb::kRun * adsb::tile_first_run(upto, s.args.stagger, s.args.passes));
         size_t nc = 0;
         if (d->sink.cands) { // per-shard scan: the caller's vectors
             order.clear();
@@ -452,8 +451,13 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
                                  power_samples_produced(d->n_samples), g_complete);
         }
         delivered = upto;
-        if (dbg_on)
+        if (dbg_on) {
             dbg[1] += std::chrono::duration<double, std::micro>(clk::now() - tp).count();
+            dbg[2] += 1;
+            if (getenv("ADSB_DEBUG_TIMELINE"))
+                fprintf(stderr, "  t=%.1f us: tiles < %u resolved (%zu records), waited %.1f us so far\n",
+                        std::chrono::duration<double, std::micro>(clk::now() - t_begin).count(), upto, nc, wait_ms * 1e3);
+        }
     };
     while (frontier < s.ntiles) {
         if (pos >= cap) { // the stream is full: the rest of the launch is on the loose list
@@ -483,9 +487,6 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
             adsb::marker_check(tile, nf, gen, a[0], a[1], a[2], a[3], lo, hi);
             return mw[2] == lo && mw[3] == hi;
         };
-        clk::time_point tp;
-        if (dbg_on)
-            tp = clk::now();
         if (!tile_in()) {
             // the device is behind: use the time to resolve what is complete, then wait
             if (frontier > delivered) {
@@ -496,8 +497,6 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
                 return d->fail("scan kernel finished without publishing granule %u (tile %u of %u pending)", pos, frontier,
                                s.ntiles);
         }
-        if (dbg_on)
-            dbg[0] += std::chrono::duration<double, std::micro>(clk::now() - tp).count();
         const uint32_t n = nf & 0xFFFFu;
         if (t_count[tile] != ~0u)
             return d->fail("hand-off stream corrupt at granule %u (tile %u twice)", pos, tile);
@@ -520,8 +519,9 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
         flush(frontier);
     if (dbg_on)
         fprintf(stderr,
-                "stream collect: records %.1f us, resolve %.1f us, waits %.1f us; %.1f us after the last wait\n",
-                dbg[0], dbg[1], wait_ms * 1e3, std::chrono::duration<double, std::micro>(clk::now() - t_last_wait).count());
+                "stream collect: %.1f us in all, resolve %.1f us in %d batches, waits %.1f us; %.1f us after the last wait\n",
+                std::chrono::duration<double, std::micro>(clk::now() - t_begin).count(), dbg[1], (int)dbg[2], wait_ms * 1e3,
+                std::chrono::duration<double, std::micro>(clk::now() - t_last_wait).count());
     const double total_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
     d->prof.wait_ms += wait_ms;
     d->prof.host_ms += total_ms - wait_ms;
@@ -620,6 +620,22 @@ int slot_collect(adsb_decoder *d)
             return -1;
         partial = rc == 1;
     }
+#if ADSB_TILE_CLOCK
+    if (const char *path = getenv("ADSB_CLOCK_OUT")) {
+        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        std::vector<uint32_t> h((size_t)s.ntiles * 4);
+        HIP_TRY(d, hipMemcpy(h.data(), s.args.tile_clock, h.size() * 4, hipMemcpyDeviceToHost));
+        uint32_t t0c = ~0u;
+        for (uint32_t i = 0; i < s.ntiles; i++)
+            t0c = std::min(t0c, h[4 * i]);
+        if (FILE *f = fopen(path, "w")) {
+            for (uint32_t i = 0; i < s.ntiles; i++)
+                fprintf(f, "%u %.2f %.2f %u %u %u\n", i, (h[4 * i] - t0c) * 0.01, (h[4 * i + 1] - t0c) * 0.01, h[4 * i + 3] & 15u,
+                        (h[4 * i + 2] >> 8) & 15u, (h[4 * i + 2] >> 13) & 7u);
+            fclose(f);
+        }
+    }
+#endif
     if (s.streaming && !partial && !s.tries_on_device) {
         // Every tile has been published and consumed and none used the loose list: the
         // launch-wide counters have nothing to add, so do not wait for them (nor for the
@@ -751,6 +767,15 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
         a.g_end = g_stop;
         a.df18 = d->cfg.df18 ? 1 : 0;
         a.passes = adsb::choose_passes(n_off, d->n_cus);
+        a.stagger = adsb::choose_stagger(n_off, d->n_cus, a.passes);
+#if ADSB_TILE_CLOCK
+        {   // tuning builds: per-tile device timestamps of the LAST launch, dumped at collect
+            static uint32_t *dclk = nullptr;
+            if (!dclk)
+                HIP_TRY(d, hipMalloc(&dclk, (size_t)(1u << 20) * 16));
+            a.tile_clock = dclk;
+        }
+#endif
         a.synd = d->d_synd;
         a.queue_cap = (d->cfg.debug_queue_cap >= 256 && d->cfg.debug_queue_cap <= adsb::kQueueCap)
                           ? d->cfg.debug_queue_cap

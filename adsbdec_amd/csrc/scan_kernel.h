@@ -44,6 +44,35 @@ constexpr size_t lds_bytes(int passes)
 {
     return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6);
 }
+
+// Tile geometry of a launch.  Every tile takes K = `passes` passes, except that the first
+// `stagger` tiles (a multiple of 4, K >= 5; 0 = off, the default) cycle through K-3, K-2,
+// K-1, K -- an experiment in spreading tile completions that did not pay (choose_stagger).
+__host__ __device__ inline int tile_passes(uint32_t tile, uint32_t stagger, int k)
+{
+    return tile < stagger ? k - 3 + (int)(tile & 3u) : k;
+}
+__host__ __device__ inline uint64_t tile_first_run(uint32_t tile, uint32_t stagger, int k)
+{
+    const uint64_t quad = 4ull * (uint64_t)owned_runs(k) - 6ull * kPassRuns; // K-3, K-2, K-1, K passes
+    if (tile < stagger) {
+        const uint32_t q = tile >> 2, r = tile & 3u;
+        return q * quad + (uint64_t)r * (uint64_t)owned_runs(k - 3) + (uint64_t)kPassRuns * (r * (r - 1u) / 2u);
+    }
+    return (uint64_t)(stagger >> 2) * quad + (uint64_t)(tile - stagger) * (uint64_t)owned_runs(k);
+}
+inline uint32_t tile_count(uint64_t n_offsets, uint32_t stagger, int k)
+{
+    const uint64_t runs = (n_offsets + kRun - 1) / kRun;
+    const uint64_t head = tile_first_run(stagger, stagger, k);
+    if (runs >= head)
+        return stagger + (uint32_t)((runs - head + owned_runs(k) - 1) / owned_runs(k));
+    uint32_t t = (uint32_t)(runs / (tile_first_run(4, 4, k))) * 4u; // whole quads, then at most four more
+    while (tile_first_run(t, stagger, k) < runs)
+        t++;
+    return t;
+}
+
 constexpr uint64_t kMaxLaunchOffsets = (1ull << 30) - tile_offsets(kMaxPasses); // g_rel must fit 30 bits
 
 // Check words of a tile marker (device writes them, host checks them): a0..a3 = XOR,
@@ -58,6 +87,10 @@ __host__ __device__ inline void marker_check(uint32_t tile, uint32_t nf, uint32_
     hi = a1 ^ (a3 << 16 | a3 >> 16) ^ ~gen ^ (tile << 7 | tile >> 25) ^ nf;
 }
 
+#ifndef ADSB_TILE_CLOCK
+#define ADSB_TILE_CLOCK 0 // tools/kbench: per-tile timestamps
+#endif
+
 struct ScanArgs {
     const uint32_t *x;   // (I,Q) pairs; x[0] is stream pair index pbuf0 (16-byte aligned, pbuf0 % 4 == 0)
     int64_t pbuf0;
@@ -66,6 +99,8 @@ struct ScanArgs {
     uint64_t g_end;      // one past the last offset
     int df18;            // demod.c:26
     int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
+    uint32_t *tile_clock; // ADSB_TILE_CLOCK builds only: 4 dwords per tile {begin, end (100 MHz), HW_ID, XCC_ID}
+    uint32_t stagger;    // the first `stagger` tiles take K-3..K passes in turn (tile_passes)
     int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
     int all_candidates;  // 1: emit every CRC-valid offset (no never-visited filter)
     // Streaming hand-off (hand == null: off).  `hand` is ONE stream of 16-byte granules
@@ -123,6 +158,9 @@ uint32_t make_fix_table(uint32_t *tab /* kFixSlots */);
 // Host: choose the passes-per-tile for a launch of n_offsets on a device with
 // `slots` resident workgroups (balances halo overhead against tail quantisation).
 int choose_passes(uint64_t n_offsets, int cus);
+// Host: how many leading tiles to stagger (tile_passes): 0 unless ADSB_STAGGER is set
+// (measured: no gain, see choose_stagger).
+uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes);
 hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream);
 
 } // namespace adsb

@@ -227,6 +227,22 @@ __device__ __forceinline__ void columns_to_bytes(const uint32_t (&cw)[4], bool i
     wds[3] |= (is_short ? 7u : 14u) << 16;
 }
 
+// One 16-byte granule of the hand-off stream, written THROUGH to host memory (sc0 sc1).
+// A plain store may sit in the L2 until its line is evicted or the kernel ends (measured:
+// single tiles reaching the host ~30 us after their neighbours, which stalls the host's
+// in-order resolver and leaves it a burst of work at the very end).  Write-through
+// stores are a scarce resource, though -- the device retires only ~40 M of them per
+// second, whatever their size (measured: two 8-byte ones per granule from the threads
+// that finish the records made the kernel 11x slower) -- so a tile writes its whole range
+// with ONE instruction of adjacent lanes: a few line-sized requests per tile.
+// No ordering is implied or needed: the tile's checksum validates the bytes.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_granule_through(uint32_t *hand, uint32_t gran, u32x4 v)
+{
+    u32x4 *dst = reinterpret_cast<u32x4 *>(hand) + gran;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v) : "memory");
+}
+
 // acc = (acc << 1) | sign(v): one v_alignbit_b32
 __device__ __forceinline__ uint32_t push_sign(uint32_t acc, uint32_t v)
 {
@@ -256,7 +272,7 @@ template <bool kStats>
 __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const ScanArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int K = args.passes;
+    const int K = tile_passes(blockIdx.x, args.stagger, args.passes);
     const int nplane = kPassRuns * K + kPlanePad;
     uint32_t *pl_d = smem;
     uint32_t *pl_e1 = smem + nplane;
@@ -270,10 +286,15 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     const int64_t pbuf0 = args.pbuf0, p_lo = args.p_lo, p_hi = args.p_hi;
 
     const int tid = threadIdx.x;
+#if ADSB_TILE_CLOCK
+    // kbench only: when and where each tile ran (100 MHz clock, HW_ID, XCC_ID) -> args.tile_clock[4 * tile ..]
+    const uint64_t clk_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int own = kPassRuns * K - kReachRuns;
-    const int64_t t0 = (int64_t)args.g_begin + (int64_t)blockIdx.x * kRun * own; // first owned offset
+    const int64_t t0 = // first owned offset
+        (int64_t)args.g_begin + (int64_t)kRun * (int64_t)tile_first_run(blockIdx.x, args.stagger, args.passes);
 
     uint32_t *tile_n = qcount + 4;    // records this tile keeps (ranked into its hand-off range)
     uint32_t *tile_over = qcount + 5; // some records had to go to the loose list
@@ -290,23 +311,12 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         *tile_fit = 0;
         tile_chk[0] = tile_chk[1] = tile_chk[2] = tile_chk[3] = 0;
     }
-    // A finished record goes to granules `gran`, `gran + 1` of the hand-off stream (and
-    // into the tile's checksum) or -- hand-off disabled, unranked record (gran = ~0u),
-    // stream full -- to the launch-wide loose list.
-    auto emit_record = [&](uint32_t gran, uint32_t g_rel, uint32_t pw, const uint32_t (&wds)[4]) {
-        if (args.hand) {
-            if (gran != ~0u && *tile_fit) {
-                uint4 *dst = reinterpret_cast<uint4 *>(args.hand) + gran;
-                dst[0] = make_uint4(g_rel, pw, wds[0], wds[1]);
-                dst[1] = make_uint4(wds[2], wds[3], 0u, 0u);
-                atomicXor(&tile_chk[0], g_rel ^ wds[2]);
-                atomicXor(&tile_chk[1], pw ^ wds[3]);
-                atomicXor(&tile_chk[2], wds[0]);
-                atomicXor(&tile_chk[3], wds[1]);
-                return;
-            }
+    // A finished record that cannot go through the hand-off stream (hand-off disabled,
+    // record emitted outside the whole-tile round, stream full) goes to the launch-wide
+    // loose list; the tile's marker then tells the host to collect after completion.
+    auto emit_loose = [&](uint32_t g_rel, uint32_t pw, const uint32_t (&wds)[4]) {
+        if (args.hand)
             *tile_over = 1;
-        }
         const uint32_t slot = atomicAdd(&args.counters[0], 1u);
         if (slot < args.cand_cap) {
             uint32_t *rec = args.cands + (size_t)slot * kCandWords;
@@ -612,7 +622,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             columns_to_bytes(cw, code == 0, wds);
             wds[3] |= fixed << 24;
             const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, t0 + (int64_t)kRun * sv + sj);
-            emit_record(~0u, g_rel, pw, wds); // unranked: loose list
+            emit_loose(g_rel, pw, wds);
         }
 
         if (stage_cands) {
@@ -675,14 +685,55 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                     rank += ((cl_rec[j * kCandWords + 1] >> 16) & 1u) & (uint32_t)(cl_rec[j * kCandWords] < gi);
             }
             __syncthreads();
+            const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
+            uint32_t fin[6];
             if (keep) {
-                // finish the record: bytes in order, pw (demod.c:127,133), and emit
+                // finish the record: bytes in order, pw (demod.c:127,133)
                 const uint32_t cw[4] = {ri[2], ri[3], ri[4], ri[5]};
                 uint32_t wds[4];
                 columns_to_bytes(cw, (ri[1] & 0xFFu) == 0, wds);
                 wds[3] |= ((ri[1] >> 8) & 1u) << 24; // repaired-by-extension flag
                 const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + ri[0]);
-                emit_record(*tile_base + 1u + 2u * rank, ri[0], pw, wds);
+                if (to_stream) {
+                    fin[0] = ri[0], fin[1] = pw, fin[2] = wds[0], fin[3] = wds[1], fin[4] = wds[2], fin[5] = wds[3];
+                    atomicXor(&tile_chk[0], ri[0] ^ wds[2]); // word-wise XOR of its two granules
+                    atomicXor(&tile_chk[1], pw ^ wds[3]);
+                    atomicXor(&tile_chk[2], wds[0]);
+                    atomicXor(&tile_chk[3], wds[1]);
+                } else {
+                    emit_loose(ri[0], pw, wds);
+                }
+            }
+            if (to_stream) {
+                // the finished records replace the staged list, in rank order, and the
+                // tile's range {marker, records} leaves as one store of adjacent lanes
+                __syncthreads(); // every staged entry has been read
+                if (keep) {
+                    uint32_t *o = cl_rec + rank * kCandWords;
+#pragma unroll
+                    for (int k = 0; k < 6; k++)
+                        o[k] = fin[k];
+                }
+                __syncthreads();
+                const uint32_t nk = *tile_n;
+                // no fallback rounds will follow (they emit loose records): the marker is final
+                const bool marker_now = !over;
+                for (uint32_t L = tid; L < 1u + 2u * nk; L += kThreads) {
+                    u32x4 gv;
+                    if (L == 0) {
+                        if (!marker_now)
+                            continue;
+                        const uint32_t nf = nk | (*tile_over ? kMarkOver : 0u);
+                        uint32_t lo, hi;
+                        marker_check(blockIdx.x, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
+                        gv = u32x4{blockIdx.x, nf, lo, hi};
+                        *tile_res = 2; // marker written
+                    } else {
+                        const uint32_t *r = cl_rec + ((L - 1u) >> 1) * kCandWords;
+                        gv = ((L - 1u) & 1u) ? u32x4{r[4], r[5], 0u, 0u} : u32x4{r[0], r[1], r[2], r[3]};
+                    }
+                    store_granule_through(args.hand, *tile_base + L, gv);
+                }
             }
         }
 
@@ -703,6 +754,17 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         __syncthreads(); // queue is rewritten
     }
 
+#if ADSB_TILE_CLOCK
+    __syncthreads();
+    if (tid == 0 && args.tile_clock) {
+        const uint64_t clk_end = __builtin_amdgcn_s_memrealtime();
+        uint32_t *o = args.tile_clock + 4 * (size_t)blockIdx.x;
+        o[0] = (uint32_t)clk_begin;
+        o[1] = (uint32_t)clk_end;
+        o[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
+        o[3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID[3:0]
+    }
+#endif
     if (args.hand) {
         // Publish the tile: its marker granule {tile, count | flags, checksum} in front of
         // its records.  No fence: a system-scope release in every thread writes back the
@@ -710,7 +772,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         // stores on their way to host memory (measured: a flag does overtake the records)
         // -- which is why the marker carries a checksum of the records (scan_kernel.h).
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0 && *tile_res != 2) {
             uint32_t b = *tile_base, fit = *tile_fit;
             if (!*tile_res) { // no whole-tile round staged anything (all_candidates, fallback rounds)
                 b = atomicAdd(&args.counters[2], 1u);
@@ -720,8 +782,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 const uint32_t nf = *tile_n | (*tile_over ? kMarkOver : 0u) | (fit ? 0u : kMarkNoFit);
                 uint32_t lo, hi;
                 marker_check(blockIdx.x, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
-                uint4 *dst = reinterpret_cast<uint4 *>(args.hand) + b;
-                *dst = make_uint4(blockIdx.x, nf, lo, hi);
+                store_granule_through(args.hand, b, u32x4{blockIdx.x, nf, lo, hi});
             }
         }
     }
@@ -845,6 +906,11 @@ int choose_passes(uint64_t n_offsets, int cus)
     // long tiles amortise the 44-run halo, short ones fill the last round better.
     if (cus <= 0)
         cus = 256;
+    if (const char *e = getenv("ADSB_PASSES")) { // tuning and tests
+        const int k = atoi(e);
+        if (k >= 2 && k <= kMaxPasses)
+            return k;
+    }
     int best = 2;
     double best_cost = 1e300;
     for (int k = 2; k <= 6; k++) { // measured: 4..6 passes are best at every launch size (tools/kbench)
@@ -869,13 +935,30 @@ int choose_passes(uint64_t n_offsets, int cus)
     return best;
 }
 
+uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes)
+{
+    // Off unless ADSB_STAGGER asks for it (read per launch: tests switch it).  Measured on
+    // MI355X with per-tile device timestamps (tools/kbench -DADSB_TILE_CLOCK): equal tiles
+    // already complete at a steady 25.6 tiles/us in index order -- each CU favours its
+    // older workgroups, so a round's tiles finish spread over ~20 us -- and a staggered
+    // first round only added smaller tiles (kernel +4 %).
+    (void)cus;
+    const char *e = getenv("ADSB_STAGGER");
+    const int forced = e ? atoi(e) : 0;
+    if (passes < 5 || forced <= 0)
+        return 0;
+    const uint32_t st = (uint32_t)forced & ~3u;
+    const uint64_t tiles = (n_offsets + tile_offsets(passes) - 1) / tile_offsets(passes);
+    return tiles >= 2ull * st ? st : 0u;
+}
+
 hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream)
 {
     if (args.g_end <= args.g_begin)
         return hipSuccess;
     const uint64_t n = args.g_end - args.g_begin;
     const uint64_t per = (uint64_t)tile_offsets(args.passes);
-    const uint64_t blocks = (n + per - 1) / per;
+    const uint64_t blocks = tile_count(n, args.stagger, args.passes);
     const size_t lds = lds_bytes(args.passes);
     if (getenv("ADSB_DEBUG_LAUNCH"))
         fprintf(stderr, "launch_scan: n=%llu passes=%d per=%llu blocks=%llu lds=%zu prior_err=%d\n",

@@ -450,3 +450,24 @@ def test_cli_matches_golden_avr_mlat_beast(capi, tmp_path):
         assert [int(v) for v in err[2].split(":")[1].split()] == [rec["stats"]["ok"][k] for k in (11, 17, 18)]
     # unknown flags print the usage text and exit 1 (main.c:85-87)
     assert subprocess.run([capi.CLI_PATH, "-e"], capture_output=True).returncode == 1
+
+
+def test_staggered_tile_sizes(oracle, dec_factory, torch_cuda, monkeypatch):
+    """Large launches give their first resident round of tiles K-3..K passes in turn
+    (scan_kernel.h tile_passes) so that tiles do not complete in bursts; that only
+    happens from ~140 M samples on, so force it here on a small capture (ADSB_PASSES /
+    ADSB_STAGGER are read per launch) and compare with the oracle, statistics included."""
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture(1 << 22, seed=77, sigma=25.0, n_frames=1200, amp=(150, 1800))
+    want, wstats = oracle.decode(x, df18=True)
+    t = _dev(torch_cuda, x)
+    for passes, stagger in ((5, 8), (6, 16), (5, 60)):
+        monkeypatch.setenv("ADSB_PASSES", str(passes))
+        monkeypatch.setenv("ADSB_STAGGER", str(stagger))
+        for stats in (False, True):
+            d = dec_factory(df18=True, collect_stats=stats)
+            d.reset()
+            d.push_device_final(t.data_ptr(), t.numel())
+            assert records(d.drain()) == records(want)
+            if stats:
+                assert d.stats() == wstats

@@ -8,7 +8,7 @@ n = (256<<20); n -= n % 28
 x, truth = make_workload(torch, n, seed=1)
 torch.cuda.synchronize()
 dec = capi.Decoder(profile=True)
-for it in range(8):
+for it in range(int(os.environ.get("ADSB_STEPS", "8"))):
     t0=time.perf_counter(); dec.reset()
     t1=time.perf_counter(); dec.push_device_final(x.data_ptr(), x.numel())
     t2=time.perf_counter()

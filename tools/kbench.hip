@@ -49,7 +49,8 @@ int main(int argc, char **argv)
     std::vector<uint32_t> synd(adsb::kSyndWords); adsb::make_syndrome_table(synd.data());
     uint32_t *dsynd; CK(hipMalloc(&dsynd, synd.size() * 4)); CK(hipMemcpy(dsynd, synd.data(), synd.size() * 4, hipMemcpyHostToDevice));
     a.synd = dsynd; a.queue_cap = adsb::kQueueCap; a.all_candidates = 0; a.fix_tab = nullptr; a.fix_mul = 0; a.hand = nullptr; a.hand_cap = 0; a.gen = 0;
-    a.passes = argc > 3 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256);
+    a.passes = argc > 3 && atoi(argv[3]) > 0 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256);
+    a.stagger = adsb::choose_stagger(a.g_end - a.g_begin, 256, a.passes); // ADSB_STAGGER=0 turns it off
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++) { CK(hipMemset(counters, 0, 8)); CK(adsb::launch_scan(a, false, 0)); }
     CK(hipDeviceSynchronize());
@@ -59,11 +60,27 @@ int main(int argc, char **argv)
         CK(hipEventRecord(e0, 0)); CK(adsb::launch_scan(a, false, 0)); CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms);
     }
+#if ADSB_TILE_CLOCK
+    {   // one more launch with the per-tile clock buffer; dump "tile begin_us end_us xcc cu" to stdout
+        const uint32_t nt = adsb::tile_count(a.g_end - a.g_begin, a.stagger, a.passes);
+        uint32_t *dclk; CK(hipMalloc(&dclk, (size_t)nt * 16)); CK(hipMemset(dclk, 0, (size_t)nt * 16));
+        a.tile_clock = dclk;
+        CK(hipMemsetAsync(counters, 0, 8, 0)); CK(adsb::launch_scan(a, false, 0)); CK(hipDeviceSynchronize());
+        std::vector<uint32_t> h((size_t)nt * 4); CK(hipMemcpy(h.data(), dclk, h.size() * 4, hipMemcpyDeviceToHost));
+        uint32_t t0c = ~0u; for (uint32_t i = 0; i < nt; i++) t0c = std::min(t0c, h[4 * i]);
+        FILE *f = fopen(getenv("ADSB_CLOCK_OUT") ? getenv("ADSB_CLOCK_OUT") : "tile_clock.txt", "w");
+        for (uint32_t i = 0; i < nt; i++)
+            fprintf(f, "%u %.2f %.2f %u %u %u\n", i, (h[4 * i] - t0c) * 0.01, (h[4 * i + 1] - t0c) * 0.01, h[4 * i + 3] & 15u,
+                    (h[4 * i + 2] >> 8) & 15u, (h[4 * i + 2] >> 13) & 7u); // xcc, cu_id, sh/se bits
+        fclose(f);
+        a.tile_clock = nullptr;
+    }
+#endif
     std::sort(t.begin(), t.end());
     uint32_t hc[2]; CK(hipMemcpy(hc, counters, 8, hipMemcpyDeviceToHost));
     double med = t[t.size() / 2];
-    printf("passes=%d ablate=%d minwaves=%d tile=%d lds=%zu | median %.4f ms min %.4f | %.1f GB/s alg | %.1f Gsamples/s | cands=%u\n",
-           a.passes, ADSB_ABLATE, ADSB_MIN_WAVES, adsb::tile_offsets(a.passes), adsb::lds_bytes(a.passes), med, t[0],
+    printf("passes=%d stagger=%u ablate=%d minwaves=%d tile=%d lds=%zu | median %.4f ms min %.4f | %.1f GB/s alg | %.1f Gsamples/s | cands=%u\n",
+           a.passes, a.stagger, ADSB_ABLATE, ADSB_MIN_WAVES, adsb::tile_offsets(a.passes), adsb::lds_bytes(a.passes), med, t[0],
            2.0 * n / med / 1e6, n / med / 1e6, hc[0]);
     return 0;
 }
