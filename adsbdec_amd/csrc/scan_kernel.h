@@ -87,6 +87,9 @@ __host__ __device__ inline void marker_check(uint32_t tile, uint32_t nf, uint32_
     hi = a1 ^ (a3 << 16 | a3 >> 16) ^ ~gen ^ (tile << 7 | tile >> 25) ^ nf;
 }
 
+#ifndef ADSB_SAME_DATA
+#define ADSB_SAME_DATA 0 // tools/kbench: all tiles read the same samples
+#endif
 #ifndef ADSB_TILE_CLOCK
 #define ADSB_TILE_CLOCK 0 // tools/kbench: per-tile timestamps
 #endif

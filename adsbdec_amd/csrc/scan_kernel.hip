@@ -337,17 +337,48 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     }
 
     // ------------------------------ Stage A ------------------------------
-    // the 36 pairs (8 of pre-halo + 28) of this lane's run in pass `ps`
-    auto load_pass = [&](int ps, uint32_t (&w)[36]) {
-        const int lv0 = kWaveRuns * (4 * ps + wave);
-        const int64_t pr0 = t0 + (int64_t)kRun * (lv0 + lane) - 8; // first pair loaded; multiple of 4
-        // wave-uniform: every pair this wave loads lies inside the buffer
-        const int64_t wlo = t0 + (int64_t)kRun * lv0 - 8;
-        const bool interior = (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
-        if (interior) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(xin + (pr0 - pbuf0));
+    // The 36 pairs (8 of pre-halo + 28) of this lane's run in pass `ps` are nine 16-byte
+    // loads.  ADSB_PREFETCH = P > 0 issues the first P of them one pass ahead (4 P more
+    // registers), so that a pass starts computing its first outputs at once while the
+    // other 9 - P loads are in flight.
+    auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * (kWaveRuns * (4 * ps + wave) + lane) - 8; };
+    auto pass_interior = [&](int ps) { // wave-uniform: every pair this wave loads lies inside the buffer
+        const int64_t wlo = t0 + (int64_t)kRun * (kWaveRuns * (4 * ps + wave)) - 8;
+        return (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
+    };
+#if ADSB_SAME_DATA // kbench only: every tile reads the first tile's samples (cache-resident): compute without HBM
+    auto pass_src = [&](int ps) { return reinterpret_cast<const uint4 *>(xin + (pass_first_pair(ps) - t0 + 8)); };
+#else
+    auto pass_src = [&](int ps) { return reinterpret_cast<const uint4 *>(xin + (pass_first_pair(ps) - pbuf0)); };
+#endif
+    constexpr int kPre = ADSB_PREFETCH;
+    uint32_t wpre[kPre > 0 ? 4 * kPre : 1];
+    bool have_pre = false;
+    if (kPre > 0 && pass_interior(0)) {
+        const uint4 *src = pass_src(0);
+#pragma unroll
+        for (int k = 0; k < kPre; k++) {
+            const uint4 q = src[k];
+            wpre[4 * k + 0] = q.x, wpre[4 * k + 1] = q.y, wpre[4 * k + 2] = q.z, wpre[4 * k + 3] = q.w;
+        }
+        have_pre = true;
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < K; pass++) {
+        const int v0 = kWaveRuns * (4 * pass + wave); // first run of this wave in this pass
+        const int v = v0 + lane;
+        uint32_t w[36];
+        if (pass_interior(pass)) {
+            const uint4 *src = pass_src(pass);
+            if (kPre > 0 && have_pre) {
+#pragma unroll
+                for (int k = 0; k < 4 * kPre; k++)
+                    w[k] = wpre[k];
+            }
 #pragma unroll
             for (int k = 0; k < 9; k++) {
+                if (kPre > 0 && k < kPre && have_pre)
+                    continue;
                 const uint4 q = src[k];
                 w[4 * k + 0] = q.x;
                 w[4 * k + 1] = q.y;
@@ -357,29 +388,24 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         } else {
             // Stream start (the ring is zero-initialised, air.c:33: a missing pair
             // is 0x0800,0x0800 -> v = 0) and the ragged end of a buffer.
+            const int64_t pr0 = pass_first_pair(pass);
 #pragma unroll
             for (int k = 0; k < 36; k++) {
                 const int64_t pr = pr0 + k;
                 w[k] = (pr >= p_lo && pr < p_hi) ? xin[pr - pbuf0] : 0x08000800u;
             }
         }
-    };
-#if ADSB_PREFETCH
-    uint32_t w[36];
-    load_pass(0, w);
-#endif
-#pragma unroll 1
-    for (int pass = 0; pass < K; pass++) {
-        const int v0 = kWaveRuns * (4 * pass + wave); // first run of this wave in this pass
-        const int v = v0 + lane;
-#if ADSB_PREFETCH
-        uint32_t wn[36]; // next pass's samples, in flight while this pass computes
-        if (pass + 1 < K)
-            load_pass(pass + 1, wn);
-#else
-        uint32_t w[36];
-        load_pass(pass, w);
-#endif
+        if (kPre > 0) {
+            have_pre = (pass + 1 < K) && pass_interior(pass + 1);
+            if (have_pre) {
+                const uint4 *src = pass_src(pass + 1);
+#pragma unroll
+                for (int k = 0; k < kPre; k++) {
+                    const uint4 q = src[k];
+                    wpre[4 * k + 0] = q.x, wpre[4 * k + 1] = q.y, wpre[4 * k + 2] = q.z, wpre[4 * k + 3] = q.w;
+                }
+            }
+        }
 #if ADSB_ABLATE == 1
         {   // kbench: price the loads alone
             uint32_t acc = 0;
@@ -465,11 +491,6 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             pl_e1[v] = e1;
             pl_e2[v] = e2;
         }
-#if ADSB_PREFETCH
-#pragma unroll
-        for (int k = 0; k < 36; k++)
-            w[k] = wn[k];
-#endif
     }
     __syncthreads();
 #if ADSB_ABLATE != 0
