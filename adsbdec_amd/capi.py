@@ -183,10 +183,18 @@ class Decoder:
     def pending(self) -> int:
         return int(self._L.adsb_pending(self._h))
 
-    def drain_raw(self):
-        """All pending frames as one ctypes Frame array (no per-frame Python work)."""
+    def drain_raw(self, reuse: bool = False):
+        """All pending frames as one ctypes Frame array (no per-frame Python work).
+        reuse=True hands out the handle's own output array (valid until the next such
+        call) instead of allocating -- and page-faulting in -- a fresh one every time."""
         n = self.pending()
-        buf = (Frame * max(1, n))()
+        if reuse:
+            if getattr(self, "_out_cap", 0) < max(1, n):
+                self._out_cap = max(1, n + n // 4)
+                self._out_buf = (Frame * self._out_cap)()
+            buf = self._out_buf
+        else:
+            buf = (Frame * max(1, n))()
         got = self._L.adsb_drain(self._h, buf, n) if n else 0
         if got < 0:
             raise AdsbError("adsb_drain failed")

@@ -56,7 +56,11 @@ struct ScanSlot {
     uint32_t *d_tries = nullptr;    // device: statistics runs of a stream count tries on the device
     size_t cand_cap = 0, try_cap = 0, d_try_cap = 0;
     bool tries_on_device = false;   // which of the two the launch in flight uses
-    hipEvent_t ev_start = nullptr, ev_done = nullptr; // kernel timing (cfg.profile)
+    // kernel timing (cfg.profile): two pairs used in turn, so that a launch's duration can
+    // be read while the slot's NEXT launch runs instead of in front of it
+    hipEvent_t ev_start[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    int ev_cur = 0;                  // pair of the launch in flight
+    uint64_t ev_offsets[2] = {0, 0}; // offsets of the launch each pair timed
     hipEvent_t ev_ready = nullptr;                    // counters have landed in h_counters
     // streaming hand-off (scan_kernel.h): one stream of self-validating granules, pinned
     uint32_t *hand = nullptr;
@@ -65,7 +69,7 @@ struct ScanSlot {
     bool streaming = false;
     adsb::ScanArgs args{};
     bool busy = false;
-    bool prof_pending = false; // ev_start/ev_done of a collected launch not yet read (cfg.profile)
+    bool prof_pending[2] = {false, false}; // pair of a collected launch not read yet
 };
 
 constexpr int kSlots = 4;
@@ -221,17 +225,17 @@ int slot_reserve_hand(adsb_decoder *d, ScanSlot &s, size_t want_granules)
 // Kernel time of a collected launch, from its events.  Read lazily (next use of the
 // slot, adsb_get_profile): waiting for the events right after the last tile has been
 // consumed would put a device round trip on the critical path of every push.
-int slot_settle_profile(adsb_decoder *d, ScanSlot &s)
+int slot_settle_profile(adsb_decoder *d, ScanSlot &s, int pair)
 {
-    if (!s.prof_pending)
+    if (!s.prof_pending[pair])
         return 0;
-    s.prof_pending = false;
-    HIP_TRY(d, hipEventSynchronize(s.ev_done));
+    s.prof_pending[pair] = false;
+    HIP_TRY(d, hipEventSynchronize(s.ev_done[pair]));
     float ms = 0;
-    HIP_TRY(d, hipEventElapsedTime(&ms, s.ev_start, s.ev_done));
+    HIP_TRY(d, hipEventElapsedTime(&ms, s.ev_start[pair], s.ev_done[pair]));
     d->prof.kernel_ms += ms;
     d->prof.last_kernel_ms = ms;
-    const uint64_t no = s.args.g_end - s.args.g_begin;
+    const uint64_t no = s.ev_offsets[pair];
     if (no > d->prof.big_offsets) {
         d->prof.big_offsets = no;
         d->prof.big_launches = 0;
@@ -247,8 +251,10 @@ int slot_settle_profile(adsb_decoder *d, ScanSlot &s)
 int slot_launch(adsb_decoder *d, ScanSlot &s)
 {
     const bool stats = d->cfg.collect_stats != 0;
-    if (slot_settle_profile(d, s))
+    s.ev_cur ^= 1;
+    if (slot_settle_profile(d, s, s.ev_cur)) // two launches old: normally read long ago
         return -1;
+    s.ev_offsets[s.ev_cur] = s.args.g_end - s.args.g_begin;
     s.ntiles = adsb::tile_count(s.args.g_end - s.args.g_begin, s.args.stagger, s.args.passes);
     // A stream's statistics run keeps the try words on the device (counted there after
     // resolution); a per-shard scan hands the list back, sorted, so it needs the list
@@ -274,13 +280,17 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     // d_counters are zero here: cleared at creation and again behind every launch (below),
     // so nothing sits between this call and the kernel's start
     if (d->cfg.profile)
-        HIP_TRY(d, hipEventRecord(s.ev_start, d->stream));
+        HIP_TRY(d, hipEventRecord(s.ev_start[s.ev_cur], d->stream));
     HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
     if (d->cfg.profile)
-        HIP_TRY(d, hipEventRecord(s.ev_done, d->stream));
+        HIP_TRY(d, hipEventRecord(s.ev_done[s.ev_cur], d->stream));
     HIP_TRY(d, hipMemcpyAsync(s.h_counters, s.d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(d, hipEventRecord(s.ev_ready, d->stream));
     HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d->stream)); // for the slot's next launch
+    for (ScanSlot &o : d->slots) // kernel times of earlier launches: read now, behind this launch
+        for (int pair = 0; pair < 2; pair++)
+            if (!(&o == &s && pair == s.ev_cur) && slot_settle_profile(d, o, pair))
+                return -1;
     s.busy = true;
     return 0;
 }
@@ -640,7 +650,7 @@ int slot_collect(adsb_decoder *d)
         // Every tile has been published and consumed and none used the loose list: the
         // launch-wide counters have nothing to add, so do not wait for them (nor for the
         // kernel's end event -- the profile reads that later).
-        s.prof_pending = d->cfg.profile != 0;
+        s.prof_pending[s.ev_cur] = d->cfg.profile != 0;
         d->prof.launches++;
         d->prof.offsets += s.args.g_end - s.args.g_begin;
         d->prof.last_offsets = s.args.g_end - s.args.g_begin;
@@ -652,8 +662,8 @@ int slot_collect(adsb_decoder *d)
     const auto t_wait = clk::now();
     for (int attempt = 0;; attempt++) {
         HIP_TRY(d, hipEventSynchronize(s.ev_ready));
-        s.prof_pending = d->cfg.profile != 0;
-        if (slot_settle_profile(d, s))
+        s.prof_pending[s.ev_cur] = d->cfg.profile != 0;
+        if (slot_settle_profile(d, s, s.ev_cur))
             return -1;
         d->prof.launches++;
         d->prof.offsets += s.args.g_end - s.args.g_begin;
@@ -932,7 +942,8 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipMemset(counters)", e);
         if ((e = hipHostMalloc(&sl.h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
             return bail("hipHostMalloc(counters)", e);
-        if ((e = hipEventCreate(&sl.ev_start)) != hipSuccess || (e = hipEventCreate(&sl.ev_done)) != hipSuccess ||
+        if ((e = hipEventCreate(&sl.ev_start[0])) != hipSuccess || (e = hipEventCreate(&sl.ev_done[0])) != hipSuccess ||
+            (e = hipEventCreate(&sl.ev_start[1])) != hipSuccess || (e = hipEventCreate(&sl.ev_done[1])) != hipSuccess ||
             (e = hipEventCreate(&sl.ev_ready)) != hipSuccess)
             return bail("hipEventCreate", e);
     }
@@ -994,8 +1005,10 @@ void adsb_destroy(adsb_decoder *d)
         if (sl.tries) (void)hipHostFree(sl.tries);
         if (sl.d_tries) (void)hipFree(sl.d_tries);
         if (sl.hand) (void)hipHostFree(sl.hand);
-        if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
-        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        for (int pair = 0; pair < 2; pair++) {
+            if (sl.ev_start[pair]) (void)hipEventDestroy(sl.ev_start[pair]);
+            if (sl.ev_done[pair]) (void)hipEventDestroy(sl.ev_done[pair]);
+        }
         if (sl.ev_ready) (void)hipEventDestroy(sl.ev_ready);
     }
     if (d->own_stream && d->stream)
@@ -1019,9 +1032,6 @@ int adsb_reset(adsb_decoder *d)
     d->have_prev_frame = false;
     d->slot_head = 0;
     d->slot_count = 0;
-    std::memset(&d->prof, 0, sizeof d->prof);
-    for (auto &sl : d->slots)
-        sl.prof_pending = false; // belongs to the profile that was just cleared
     d->err.clear();
     return 0;
 }
@@ -1202,8 +1212,9 @@ int adsb_get_profile(const adsb_decoder *d, adsb_profile *out)
         return -1;
     adsb_decoder *m = const_cast<adsb_decoder *>(d); // kernel times are read from their events on demand
     for (auto &sl : m->slots)
-        if (slot_settle_profile(m, sl))
-            return -1;
+        for (int pair = 0; pair < 2; pair++)
+            if (slot_settle_profile(m, sl, pair))
+                return -1;
     *out = d->prof;
     return 0;
 }

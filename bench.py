@@ -143,7 +143,7 @@ def main():
     def step():
         dec.reset()
         dec.push_device_final(xptr, xn)  # == push_device + finish, in one pass
-        return dec.drain_raw()  # frames stay in a C array; converted once, after timing
+        return dec.drain_raw(reuse=True)  # frames land in one C array; converted once, after timing
 
     for _ in range(args.warmup):
         raw = step()
@@ -154,19 +154,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    kernel_ms = 0.0
-    kernel_offsets = 0
-    big = {}  # offsets-per-launch of the dominant launches -> [count, sum of ms]
     fence()
+    p0 = dec.profile()  # counters accumulate over the handle's life: take differences
     t0 = time.perf_counter()
     for _ in range(args.steps):
         raw = step()
-        p = dec.profile()  # reset() clears it, so read per step
-        kernel_ms += p["kernel_ms"]
-        kernel_offsets += p["offsets"]
-        b = big.setdefault(p["big_offsets"], [0, 0.0])
-        b[0] += p["big_launches"]
-        b[1] += p["big_ms"]
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -184,8 +176,13 @@ def main():
     # the library on the launching stream.  traffic = HBM bytes of one such launch
     # from the committed rocprofv3 PMC passes over this same command (FETCH_SIZE x 2 on
     # gfx950 + WRITE_SIZE), when the launch size matches.
-    big_off = max(big) if big else 0
-    n_big, ms_big = big.get(big_off, (0, 0.0))
+    p1 = dec.profile()
+    kernel_ms = p1["kernel_ms"] - p0["kernel_ms"]
+    big_off = p1["big_offsets"]
+    if p0["big_offsets"] == big_off:  # the warm-up already ran launches of the dominant size
+        n_big, ms_big = p1["big_launches"] - p0["big_launches"], p1["big_ms"] - p0["big_ms"]
+    else:
+        n_big, ms_big = p1["big_launches"], p1["big_ms"]
     avg_ms = ms_big / n_big if n_big else 0.0
     achieved = 4.0 * big_off / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None

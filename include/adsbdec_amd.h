@@ -80,8 +80,10 @@ typedef struct adsb_config {
                                   in [5,112). Off by default; no reference parity exists for it. */
 } adsb_config;
 
+/* Counters accumulate over the life of the handle (adsb_reset keeps them: a caller that
+ * decodes many captures takes differences). */
 typedef struct adsb_profile {
-    uint64_t launches;         /* scan-kernel launches since create/reset           */
+    uint64_t launches;         /* scan-kernel launches since adsb_create            */
     uint64_t relaunches;       /* launches repeated after a record-buffer overflow  */
     uint64_t offsets;          /* preamble offsets those launches covered           */
     double kernel_ms;          /* sum of their HIP-event durations (profile=1 only)  */
@@ -103,7 +105,8 @@ void adsb_config_default(adsb_config *cfg);
 adsb_decoder *adsb_create(const adsb_config *cfg);
 void adsb_destroy(adsb_decoder *d);
 
-/* Restart the stream on the same handle (fresh ring, ts, stats), keeping device buffers. */
+/* Restart the stream on the same handle (fresh ring, ts, stats), keeping device buffers
+ * and the adsb_profile counters. */
 int adsb_reset(adsb_decoder *d);
 
 /* Sample ingress; replaces `decodeiq(const unsigned short *r, const int len)`
