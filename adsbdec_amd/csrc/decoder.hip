@@ -279,11 +279,13 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.args.try_cap = (uint32_t)std::min<size_t>(s.tries_on_device ? s.d_try_cap : s.try_cap, 0xFFFFFFFFu);
     // d_counters are zero here: cleared at creation and again behind every launch (below),
     // so nothing sits between this call and the kernel's start
+    // profile: the events take the kernel's own start/end timestamps (hipExtLaunchKernel), which
+    // is what rocprofv3 reports; two hipEventRecord markers around a plain launch read ~8 us
+    // (4 %) long here, and the extended launch costs the host ~4 us more per call
     if (d->cfg.profile)
-        HIP_TRY(d, hipEventRecord(s.ev_start[s.ev_cur], d->stream));
-    HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
-    if (d->cfg.profile)
-        HIP_TRY(d, hipEventRecord(s.ev_done[s.ev_cur], d->stream));
+        HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream, s.ev_start[s.ev_cur], s.ev_done[s.ev_cur]));
+    else
+        HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
     HIP_TRY(d, hipMemcpyAsync(s.h_counters, s.d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(d, hipEventRecord(s.ev_ready, d->stream));
     HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d->stream)); // for the slot's next launch

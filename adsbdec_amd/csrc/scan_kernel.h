@@ -164,6 +164,8 @@ int choose_passes(uint64_t n_offsets, int cus);
 // Host: how many leading tiles to stagger (tile_passes): 0 unless ADSB_STAGGER is set
 // (measured: no gain, see choose_stagger).
 uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes);
-hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream);
+// ev_start / ev_stop (both or neither): events that receive the kernel's start and end times.
+hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                       hipEvent_t ev_stop = nullptr);
 
 } // namespace adsb

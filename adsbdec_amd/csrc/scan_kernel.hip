@@ -47,6 +47,7 @@
 //
 // Arithmetic is strict binary32: multiply, then add (built with -ffp-contract=off;
 // tests/test_build_flags.py checks the ISA for the absence of v_fma/v_mac).
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -973,7 +974,7 @@ uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes)
     return tiles >= 2ull * st ? st : 0u;
 }
 
-hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream)
+hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (args.g_end <= args.g_begin)
         return hipSuccess;
@@ -985,10 +986,14 @@ hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream)
         fprintf(stderr, "launch_scan: n=%llu passes=%d per=%llu blocks=%llu lds=%zu prior_err=%d\n",
                 (unsigned long long)n, args.passes, (unsigned long long)per, (unsigned long long)blocks, lds,
                 (int)hipPeekAtLastError());
+    // the events (if any) take the kernel's own start and end timestamps -- what rocprofv3
+    // reports -- rather than the times the stream reaches two extra markers
     if (stats)
-        hipLaunchKernelGGL(scan_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args);
+        hipExtLaunchKernelGGL(scan_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), (uint32_t)lds, stream, ev_start,
+                              ev_stop, 0u, args);
     else
-        hipLaunchKernelGGL(scan_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args);
+        hipExtLaunchKernelGGL(scan_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), (uint32_t)lds, stream, ev_start,
+                              ev_stop, 0u, args);
     return hipGetLastError();
 }
 
