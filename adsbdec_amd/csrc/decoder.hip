@@ -134,6 +134,10 @@ struct adsb_decoder {
     uint32_t *d_try_out = nullptr, *h_try_out = nullptr; // 4 words
     uint64_t *h_frames_g = nullptr;                      // pinned upload buffers
     uint32_t *h_frames_span = nullptr;
+    bool final_follows = false;   // adsb_push_device_final: the end-of-stream count pass comes next
+    const uint32_t *deferred_tries = nullptr; // try list of the last launch, left for that pass
+    uint32_t deferred_n = 0;
+    uint64_t deferred_base = 0;
     bool have_prev_frame = false; // last accepted frame of earlier passes (its span may cover later tries)
     uint64_t prev_frame_g = 0;
     uint32_t prev_frame_span = 0;
@@ -731,8 +735,17 @@ int slot_collect(adsb_decoder *d)
     } else if (nc != 0) {
         return d->fail("internal: %zu loose records without a tile overflow flag", nc);
     }
-    if (s.tries_on_device && count_tries_pass(d, s.d_tries, (uint32_t)nt, s.args.g_begin, false))
-        return -1;
+    if (s.tries_on_device) {
+        if (d->final_follows && d->slot_count == 1) {
+            // last launch of the stream: its tries are counted by the end-of-stream pass, which
+            // runs right after the final resolver step -- one device round trip instead of two
+            d->deferred_tries = s.d_tries;
+            d->deferred_n = (uint32_t)nt;
+            d->deferred_base = s.args.g_begin;
+        } else if (count_tries_pass(d, s.d_tries, (uint32_t)nt, s.args.g_begin, false)) {
+            return -1;
+        }
+    }
     d->prof.host_ms += std::chrono::duration<double, std::milli>(clk::now() - t_host).count();
     s.busy = false;
     d->slot_head = (d->slot_head + 1) % kSlots;
@@ -757,7 +770,8 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
 {
     const bool stats = d->cfg.collect_stats != 0;
     while (g_begin < g_end) {
-        const uint64_t g_stop = std::min(g_end, g_begin + chunk_offsets(!stats && !d->no_streaming));
+        // streamed launches: everything but a per-shard scan that hands the try list back
+        const uint64_t g_stop = std::min(g_end, g_begin + chunk_offsets(!d->no_streaming && !(stats && d->sink.cands)));
         const uint64_t n_off = g_stop - g_begin;
         if (d->slot_count == kSlots && slot_collect(d))
             return -1;
@@ -1116,11 +1130,15 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
             d->g_scanned = g_end;
         }
         const auto t1 = clk::now();
-        if (scan_drain(d))
+        d->final_follows = true;
+        d->deferred_tries = nullptr, d->deferred_n = 0;
+        const int rc = scan_drain(d);
+        d->final_follows = false;
+        if (rc)
             return -1;
         const auto t2 = clk::now();
         d->res.advance(2 * ((total + 3) / 4), d->g_scanned); // EOF rule: see process_stage()
-        if (d->cfg.collect_stats && count_tries_pass(d, nullptr, 0, 0, true))
+        if (d->cfg.collect_stats && count_tries_pass(d, d->deferred_tries, d->deferred_n, d->deferred_base, true))
             return -1; // tries beyond the final position are never visited
         d->stage_fill = 0;
         d->finished = true;
