@@ -1,0 +1,161 @@
+// resolver_paths.cpp -- the three ways records reach adsb::Resolver must agree:
+//   (a) adsb_candidate queue   feed() + advance()          (pinned against the oracle and the
+//                                                           real deqframe by tests/test_host_logic.py)
+//   (b) device records through an index list, in place      advance_device()
+//   (c) tile ranges of a hand-off stream, in place          advance_tiles()
+// Random candidate sets with the shifted copies, overlaps and chains the device really
+// emits, fed in random batch sizes; frames (g, ts, pw, len, bytes, flag) and Ok counters
+// must be identical.  Built and run by tests/test_host_logic.py (g++, no GPU).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../adsbdec_amd/csrc/resolver.hpp"
+
+struct Rec {
+    uint64_t g;
+    uint32_t pw, w[4];
+};
+
+static std::vector<adsb_frame> drain_all(adsb::Resolver &r)
+{
+    std::vector<adsb_frame> out(r.pending());
+    if (!out.empty())
+        r.drain(out.data(), out.size());
+    return out;
+}
+
+int main(int argc, char **argv)
+{
+    const int rounds = argc > 1 ? atoi(argv[1]) : 200;
+    std::mt19937_64 rng(12345);
+    for (int round = 0; round < rounds; round++) {
+        // a stream of `total` offsets; candidates in clusters (a frame + shifted copies + overlapping others)
+        const uint64_t total = 200000 + rng() % 2000000;
+        std::vector<Rec> recs;
+        for (uint64_t g = rng() % 5000; g + 1300 < total;) {
+            const int copies = 1 + (int)(rng() % 4);
+            for (int c = 0; c < copies; c++) {
+                Rec r;
+                r.g = g + (uint64_t)c * (1 + rng() % 3);
+                r.pw = (uint32_t)(rng() % 100000);
+                const bool is_short = rng() % 4 == 0;
+                for (auto &w : r.w)
+                    w = (uint32_t)rng();
+                r.w[0] = (r.w[0] & ~0xFFu) | (is_short ? (11u << 3) : ((rng() & 1) ? (17u << 3) : (18u << 3))) | (rng() & 7u);
+                r.w[3] = (r.w[3] & 0xFFFFu) | ((is_short ? 7u : 14u) << 16) | ((uint32_t)(rng() & 1) << 24);
+                if (is_short)
+                    r.w[1] &= 0x00FFFFFFu, r.w[2] = 0, r.w[3] &= 0xFFFF0000u;
+                if (recs.empty() || r.g > recs.back().g)
+                    recs.push_back(r);
+            }
+            g += (rng() % 3 == 0) ? 200 + rng() % 1200 : 1500 + rng() % 60000; // some overlap chains
+        }
+        const uint64_t power_samples = total + 1195 + (rng() % 2) * 2; // even
+        // (a) queue path
+        adsb::Resolver ra, rb, rc;
+        ra.reset(), rb.reset(), rc.reset();
+        std::vector<adsb_frame> fa, fb, fc;
+        {
+            size_t i = 0;
+            uint64_t gc = 0;
+            while (gc < total) {
+                gc = std::min<uint64_t>(total, gc + 1 + rng() % 300000);
+                std::vector<adsb_candidate> batch;
+                for (; i < recs.size() && recs[i].g < gc; i++) {
+                    adsb_candidate c;
+                    std::memset(&c, 0, sizeof c);
+                    c.g = recs[i].g, c.pw = recs[i].pw;
+                    std::memcpy(c.frame, recs[i].w, 14);
+                    c.len = (uint8_t)((recs[i].w[3] >> 16) & 0xFF);
+                    c.reserved = (uint8_t)((recs[i].w[3] >> 24) & 1u);
+                    batch.push_back(c);
+                }
+                ra.feed(batch.data(), batch.size(), nullptr, 0);
+                ra.advance(power_samples, gc);
+                auto f = drain_all(ra);
+                fa.insert(fa.end(), f.begin(), f.end());
+            }
+        }
+        // (b) 6-word records through an index list (shuffled storage), with a launch base
+        {
+            size_t i = 0;
+            uint64_t gc = 0;
+            while (gc < total) {
+                const uint64_t base = gc - gc % 28;
+                gc = std::min<uint64_t>(total, gc + 1 + rng() % 300000);
+                std::vector<uint32_t> words, order;
+                std::vector<size_t> idx;
+                for (; i < recs.size() && recs[i].g < gc; i++)
+                    idx.push_back(i);
+                std::vector<size_t> slot(idx.size());
+                for (size_t k = 0; k < slot.size(); k++)
+                    slot[k] = k;
+                std::shuffle(slot.begin(), slot.end(), rng);
+                words.resize(idx.size() * 6);
+                order.resize(idx.size());
+                for (size_t k = 0; k < idx.size(); k++) {
+                    uint32_t *w = &words[slot[k] * 6];
+                    w[0] = (uint32_t)(recs[idx[k]].g - base), w[1] = recs[idx[k]].pw;
+                    std::memcpy(w + 2, recs[idx[k]].w, 16);
+                    order[k] = (uint32_t)slot[k];
+                }
+                rb.advance_device(words.data(), order.data(), order.size(), 6, 0, base, power_samples, gc);
+                auto f = drain_all(rb);
+                fb.insert(fb.end(), f.begin(), f.end());
+            }
+        }
+        // (c) tile ranges of a granule stream: tiles of `per` offsets, stored in shuffled tile order
+        {
+            const uint32_t per = 12880 + 7056 * (uint32_t)(rng() % 4);
+            const uint32_t ntiles = (uint32_t)((total + per - 1) / per);
+            std::vector<std::vector<size_t>> by_tile(ntiles);
+            for (size_t i = 0; i < recs.size(); i++)
+                by_tile[recs[i].g / per].push_back(i);
+            std::vector<uint32_t> tile_order(ntiles), starts(ntiles), counts(ntiles), stream;
+            for (uint32_t t = 0; t < ntiles; t++)
+                tile_order[t] = t;
+            for (uint32_t t = 0; t + 1 < ntiles; t += 2) // neighbours complete out of order
+                if (rng() & 1)
+                    std::swap(tile_order[t], tile_order[t + 1]);
+            for (uint32_t t : tile_order) {
+                stream.insert(stream.end(), 4, 0xDEADBEEFu); // the marker granule
+                starts[t] = (uint32_t)(stream.size() / 4);
+                counts[t] = (uint32_t)by_tile[t].size();
+                for (size_t i : by_tile[t]) {
+                    const uint32_t w[8] = {(uint32_t)recs[i].g, recs[i].pw, recs[i].w[0], recs[i].w[1], recs[i].w[2], recs[i].w[3], 0, 0};
+                    stream.insert(stream.end(), w, w + 8);
+                }
+            }
+            for (uint32_t t = 0; t < ntiles;) {
+                const uint32_t t1 = std::min<uint32_t>(ntiles, t + 1 + (uint32_t)(rng() % 40));
+                rc.advance_tiles(stream.data(), starts.data(), counts.data(), t, t1, 0, 0, power_samples,
+                                 std::min<uint64_t>(total, (uint64_t)t1 * per));
+                auto f = drain_all(rc);
+                fc.insert(fc.end(), f.begin(), f.end());
+                t = t1;
+            }
+        }
+        auto same = [](const std::vector<adsb_frame> &x, const std::vector<adsb_frame> &y) {
+            if (x.size() != y.size())
+                return false;
+            for (size_t i = 0; i < x.size(); i++)
+                if (x[i].g != y[i].g || x[i].ts != y[i].ts || x[i].pw != y[i].pw || x[i].len != y[i].len ||
+                    std::memcmp(x[i].frame, y[i].frame, x[i].len) || x[i].reserved != y[i].reserved)
+                    return false;
+            return true;
+        };
+        const bool ok = same(fa, fb) && same(fa, fc) && !std::memcmp(&ra.stats(), &rb.stats(), sizeof(adsb_stats)) &&
+                        !std::memcmp(&ra.stats(), &rc.stats(), sizeof(adsb_stats));
+        if (!ok || fa.empty()) {
+            printf("round %d: MISMATCH (%zu / %zu / %zu frames of %zu candidates)\n", round, fa.size(), fb.size(), fc.size(),
+                   recs.size());
+            return 1;
+        }
+    }
+    printf("ok: %d rounds\n", rounds);
+    return 0;
+}
