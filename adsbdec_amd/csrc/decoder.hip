@@ -49,19 +49,18 @@ inline uint64_t round_down(uint64_t v, uint64_t q) { return v - v % q; }
 // PCIe posted writes are free next to the sample traffic), so collecting a chunk is
 // one event wait -- no device-to-host copy and no second synchronisation.
 struct ScanSlot {
-    uint32_t *d_counters = nullptr; // device: [0] candidates, [1] tries
-    uint32_t *h_counters = nullptr; // pinned
+    uint32_t *d_counters = nullptr; // device: adsb::kCounterWords (ScanArgs::counters)
+    uint32_t *h_counters = nullptr; // pinned: two copies used in turn (ev_cur), so that a launch's kernel
+                                    // time can be read behind the slot's NEXT launch instead of in front of it
     uint32_t *cands = nullptr;      // pinned, written by the kernel
     uint32_t *tries = nullptr;      // pinned, written by the kernel (per-shard scans that return the list)
     uint32_t *d_tries = nullptr;    // device: statistics runs of a stream count tries on the device
     size_t cand_cap = 0, try_cap = 0, d_try_cap = 0;
     bool tries_on_device = false;   // which of the two the launch in flight uses
-    // kernel timing (cfg.profile): two pairs used in turn, so that a launch's duration can
-    // be read while the slot's NEXT launch runs instead of in front of it
-    hipEvent_t ev_start[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    int ev_cur = 0;                  // pair of the launch in flight
-    uint64_t ev_offsets[2] = {0, 0}; // offsets of the launch each pair timed
-    hipEvent_t ev_ready = nullptr;                    // counters have landed in h_counters
+    int ev_cur = 0;                  // copy of the launch in flight
+    uint64_t ev_offsets[2] = {0, 0}; // offsets of the launch each copy belongs to
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}; // the counters have landed in h_counters[copy]
+    uint32_t *hc() { return h_counters + ev_cur * adsb::kCounterWords; }
     // streaming hand-off (scan_kernel.h): one stream of self-validating granules, pinned
     uint32_t *hand = nullptr;
     size_t hand_cap = 0;   // granules hand can hold
@@ -69,7 +68,7 @@ struct ScanSlot {
     bool streaming = false;
     adsb::ScanArgs args{};
     bool busy = false;
-    bool prof_pending[2] = {false, false}; // pair of a collected launch not read yet
+    bool prof_pending[2] = {false, false}; // kernel time of a collected launch not read yet
 };
 
 constexpr int kSlots = 4;
@@ -226,20 +225,23 @@ int slot_reserve_hand(adsb_decoder *d, ScanSlot &s, size_t want_granules)
     return 0;
 }
 
-// Kernel time of a collected launch, from its events.  Read lazily (next use of the
-// slot, adsb_get_profile): waiting for the events right after the last tile has been
-// consumed would put a device round trip on the critical path of every push.
-int slot_settle_profile(adsb_decoder *d, ScanSlot &s, int pair)
+// Kernel time of a collected launch (cfg.profile): the tiles leave the earliest start and
+// the latest end of the device's 100 MHz clock in the counters -- no events, no extended
+// launch.  Read lazily (behind the slot's next launch, or in adsb_get_profile): waiting for
+// the counters right after the last tile has been consumed would put a device round trip on
+// the critical path of every push.
+int slot_settle_profile(adsb_decoder *d, ScanSlot &s, int copy)
 {
-    if (!s.prof_pending[pair])
+    if (!s.prof_pending[copy])
         return 0;
-    s.prof_pending[pair] = false;
-    HIP_TRY(d, hipEventSynchronize(s.ev_done[pair]));
-    float ms = 0;
-    HIP_TRY(d, hipEventElapsedTime(&ms, s.ev_start[pair], s.ev_done[pair]));
+    s.prof_pending[copy] = false;
+    HIP_TRY(d, hipEventSynchronize(s.ev_ready[copy]));
+    const uint32_t *c = s.h_counters + copy * adsb::kCounterWords;
+    const uint64_t t_begin = ~((uint64_t)c[5] << 32 | c[4]), t_end = (uint64_t)c[7] << 32 | c[6];
+    const double ms = t_end > t_begin ? (double)(t_end - t_begin) * 1e-5 : 0.0; // 10 ns ticks
     d->prof.kernel_ms += ms;
     d->prof.last_kernel_ms = ms;
-    const uint64_t no = s.ev_offsets[pair];
+    const uint64_t no = s.ev_offsets[copy];
     if (no > d->prof.big_offsets) {
         d->prof.big_offsets = no;
         d->prof.big_launches = 0;
@@ -266,8 +268,8 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.tries_on_device = stats && !d->sink.cands;
     s.streaming = !d->no_streaming && (!stats || s.tries_on_device);
     if (s.streaming) {
-        // a marker per tile + two granules per record (sized like the loose list)
-        if (slot_reserve_hand(d, s, std::max<size_t>(s.hand_cap, 2 * s.cand_cap + s.ntiles + 64)))
+        // a line per tile (marker + padding) + two granules per record (sized like the loose list)
+        if (slot_reserve_hand(d, s, std::max<size_t>(s.hand_cap, 2 * s.cand_cap + 4 * (size_t)s.ntiles + 64)))
             return -1;
         s.args.hand = s.hand;
         s.args.hand_cap = (uint32_t)std::min<size_t>(s.hand_cap, 0xFFFFFFFFu);
@@ -283,16 +285,12 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.args.try_cap = (uint32_t)std::min<size_t>(s.tries_on_device ? s.d_try_cap : s.try_cap, 0xFFFFFFFFu);
     // d_counters are zero here: cleared at creation and again behind every launch (below),
     // so nothing sits between this call and the kernel's start
-    // profile: the events take the kernel's own start/end timestamps (hipExtLaunchKernel), which
-    // is what rocprofv3 reports; two hipEventRecord markers around a plain launch read ~8 us
-    // (4 %) long here, and the extended launch costs the host ~4 us more per call
-    if (d->cfg.profile)
-        HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream, s.ev_start[s.ev_cur], s.ev_done[s.ev_cur]));
-    else
-        HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
-    HIP_TRY(d, hipMemcpyAsync(s.h_counters, s.d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(d, hipEventRecord(s.ev_ready, d->stream));
-    HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, 4 * sizeof(uint32_t), d->stream)); // for the slot's next launch
+    s.args.profile = d->cfg.profile ? 1 : 0;
+    HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
+    HIP_TRY(d, hipMemcpyAsync(s.hc(), s.d_counters, adsb::kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              d->stream));
+    HIP_TRY(d, hipEventRecord(s.ev_ready[s.ev_cur], d->stream));
+    HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, adsb::kCounterWords * sizeof(uint32_t), d->stream)); // for the next launch
     for (ScanSlot &o : d->slots) // kernel times of earlier launches: read now, behind this launch
         for (int pair = 0; pair < 2; pair++)
             if (!(&o == &s && pair == s.ev_cur) && slot_settle_profile(d, o, pair))
@@ -406,6 +404,11 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
     const auto t_begin = clk::now();
     auto t_last_wait = t_begin;
     // spin until `ready()`; gives up (with an error) once the kernel has long finished
+    static const int kPollPause = [] {
+        const char *e = getenv("ADSB_POLL_PAUSE");
+        const int v = e ? atoi(e) : -1;
+        return v >= 0 ? v : 4; // measured: 0..256 make no difference to the kernel or the step
+    }();
     auto wait_for = [&](auto &&ready) -> bool {
         if (ready())
             return true;
@@ -417,9 +420,12 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
                 ok = true;
                 break;
             }
-            __builtin_ia32_pause();
-            if ((spins & 0x3FF) == 0) {
-                const hipError_t q = hipEventQuery(s.ev_ready);
+            // a few pauses between polls: the line being re-read has to be pulled out of this
+            // core's cache by the very device write that is awaited
+            for (int k = 0; k < kPollPause; k++)
+                __builtin_ia32_pause();
+            if ((spins & 0x3F) == 0) {
+                const hipError_t q = hipEventQuery(s.ev_ready[s.ev_cur]);
                 if (q != hipErrorNotReady && (q != hipSuccess || ++after_done > 2000))
                     break; // the launch failed, or it completed long ago: the bytes will not come
             }
@@ -522,7 +528,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
         }
         t_start[tile] = pos + 1;
         t_count[tile] = n;
-        pos += 1 + 2 * n;
+        pos += adsb::stream_granules(n);
         while (frontier < s.ntiles && t_count[frontier] != ~0u)
             frontier++;
         // the tiles of the last resident round finish in a burst at the kernel's end: take
@@ -667,14 +673,14 @@ int slot_collect(adsb_decoder *d)
     }
     const auto t_wait = clk::now();
     for (int attempt = 0;; attempt++) {
-        HIP_TRY(d, hipEventSynchronize(s.ev_ready));
+        HIP_TRY(d, hipEventSynchronize(s.ev_ready[s.ev_cur]));
         s.prof_pending[s.ev_cur] = d->cfg.profile != 0;
         if (slot_settle_profile(d, s, s.ev_cur))
             return -1;
         d->prof.launches++;
         d->prof.offsets += s.args.g_end - s.args.g_begin;
         d->prof.last_offsets = s.args.g_end - s.args.g_begin;
-        const size_t nc = s.h_counters[0], nt = s.h_counters[1];
+        const size_t nc = s.hc()[0], nt = s.hc()[1];
         if (nc <= s.cand_cap && nt <= (s.tries_on_device ? s.d_try_cap : s.try_cap))
             break;
         // Sparse output sized for far more than noise produces; the counters keep
@@ -695,7 +701,7 @@ int slot_collect(adsb_decoder *d)
     }
     const auto t_host = clk::now();
     d->prof.wait_ms += std::chrono::duration<double, std::milli>(t_host - t_wait).count();
-    const size_t nc = s.h_counters[0], nt = s.h_counters[1];
+    const size_t nc = s.hc()[0], nt = s.hc()[1];
     if (!s.streaming) {
         // collect-after-completion: everything is in the launch-wide lists, in arrival order
         sort_order(d, s.cands, nc);
@@ -709,7 +715,7 @@ int slot_collect(adsb_decoder *d)
         // written is in; a missing or non-fitting marker ends the stream) + the loose list
         // -- and sort it like the path above.
         d->gather.clear();
-        const uint32_t lim = (uint32_t)std::min<size_t>(s.h_counters[2], s.args.hand_cap);
+        const uint32_t lim = (uint32_t)std::min<size_t>(s.hc()[2], s.args.hand_cap);
         for (uint32_t pos = 0; pos < lim;) {
             const uint32_t *m = s.hand + (size_t)pos * adsb::kGranuleWords;
             const uint32_t tile = m[0], nf = m[1], n = nf & 0xFFFFu;
@@ -726,7 +732,7 @@ int slot_collect(adsb_decoder *d)
                     const uint32_t *w = m + (size_t)(1 + 2 * i) * adsb::kGranuleWords;
                     d->gather.insert(d->gather.end(), w, w + 6); // {g_rel, pw, w0..w3}
                 }
-            pos += 1 + 2 * n;
+            pos += adsb::stream_granules(n);
         }
         d->gather.insert(d->gather.end(), s.cands, s.cands + nc * adsb::kCandWords);
         const size_t total = d->gather.size() / adsb::kCandWords;
@@ -952,15 +958,13 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         if ((e = hipMalloc(&d->stage[i], d->stage_cap * sizeof(uint16_t))) != hipSuccess)
             return bail("hipMalloc(stage)", e);
     for (ScanSlot &sl : d->slots) {
-        if ((e = hipMalloc(&sl.d_counters, 4 * sizeof(uint32_t))) != hipSuccess)
+        if ((e = hipMalloc(&sl.d_counters, adsb::kCounterWords * sizeof(uint32_t))) != hipSuccess)
             return bail("hipMalloc(counters)", e);
-        if ((e = hipMemset(sl.d_counters, 0, 4 * sizeof(uint32_t))) != hipSuccess)
+        if ((e = hipMemset(sl.d_counters, 0, adsb::kCounterWords * sizeof(uint32_t))) != hipSuccess)
             return bail("hipMemset(counters)", e);
-        if ((e = hipHostMalloc(&sl.h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+        if ((e = hipHostMalloc(&sl.h_counters, 2 * adsb::kCounterWords * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
             return bail("hipHostMalloc(counters)", e);
-        if ((e = hipEventCreate(&sl.ev_start[0])) != hipSuccess || (e = hipEventCreate(&sl.ev_done[0])) != hipSuccess ||
-            (e = hipEventCreate(&sl.ev_start[1])) != hipSuccess || (e = hipEventCreate(&sl.ev_done[1])) != hipSuccess ||
-            (e = hipEventCreate(&sl.ev_ready)) != hipSuccess)
+        if ((e = hipEventCreate(&sl.ev_ready[0])) != hipSuccess || (e = hipEventCreate(&sl.ev_ready[1])) != hipSuccess)
             return bail("hipEventCreate", e);
     }
     {
@@ -1021,11 +1025,8 @@ void adsb_destroy(adsb_decoder *d)
         if (sl.tries) (void)hipHostFree(sl.tries);
         if (sl.d_tries) (void)hipFree(sl.d_tries);
         if (sl.hand) (void)hipHostFree(sl.hand);
-        for (int pair = 0; pair < 2; pair++) {
-            if (sl.ev_start[pair]) (void)hipEventDestroy(sl.ev_start[pair]);
-            if (sl.ev_done[pair]) (void)hipEventDestroy(sl.ev_done[pair]);
-        }
-        if (sl.ev_ready) (void)hipEventDestroy(sl.ev_ready);
+        for (hipEvent_t ev : sl.ev_ready)
+            if (ev) (void)hipEventDestroy(ev);
     }
     if (d->own_stream && d->stream)
         (void)hipStreamDestroy(d->stream);

@@ -35,8 +35,13 @@ constexpr int kSyndWords = 14 * 256;
 constexpr int kFixSlots = 512;
 // hand-off stream (ScanArgs::hand): 16-byte granules
 constexpr int kGranuleWords = 4;
+constexpr int kCounterWords = 8; // ScanArgs::counters
 constexpr uint32_t kMarkOver = 0x10000u;  // marker flag: some records of the tile are on the loose list
 constexpr uint32_t kMarkNoFit = 0x20000u; // marker flag: the tile's range ran past the array (records are loose)
+// Granules a tile with n records reserves: marker + 2 n, rounded up to whole 64-byte lines, so
+// that the host never reads (and caches) a line the device has yet to write another tile into
+// -- every later device write to such a line has to pull it out of the CPU's cache first.
+__host__ __device__ constexpr uint32_t stream_granules(uint32_t n) { return (1u + 2u * n + 3u) & ~3u; }
 
 constexpr int owned_runs(int passes) { return kPassRuns * passes - kReachRuns; }
 constexpr int tile_offsets(int passes) { return kRun * owned_runs(passes); }
@@ -108,8 +113,8 @@ struct ScanArgs {
     int all_candidates;  // 1: emit every CRC-valid offset (no never-visited filter)
     // Streaming hand-off (hand == null: off).  `hand` is ONE stream of 16-byte granules
     // that the host reads strictly sequentially while the kernel runs.  A tile reserves
-    // 1 + 2n consecutive granules with one atomicAdd on counters[2] (so ranges appear in
-    // tile COMPLETION order) and writes
+    // stream_granules(n) consecutive granules (whole 64-byte lines) with one atomicAdd on
+    // counters[2] (so ranges appear in tile COMPLETION order) and writes
     //     marker  {tile, n | flags, check_lo, check_hi}
     //     n x     {g_rel, pw, w0, w1} {w2, w3, 0, 0}            (ascending g_rel)
     // Nothing orders these stores on their way to host memory, so the marker carries
@@ -123,7 +128,11 @@ struct ScanArgs {
     const uint32_t *fix_tab; // EXTENSION (not in the reference): 512-entry perfect hash syndrome -> bit, or null
     uint32_t fix_mul;
     const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
-    uint32_t *counters;  // [0] loose candidates, [1] tries (may exceed the capacities), [2] hand-off granules
+    // [0] loose candidates, [1] tries (may exceed the capacities), [2] hand-off granules, [3] spare;
+    // with `profile`: [4..5] max over tiles of ~(start), [6..7] max of end, on the device's
+    // 100 MHz clock (64-bit; zero-initialised like the rest)
+    uint32_t *counters;
+    int profile;
     uint32_t *cands;     // kCandWords dwords per record
     uint32_t cand_cap;
     uint32_t *tries;     // (g_rel << 2) | code
@@ -164,8 +173,6 @@ int choose_passes(uint64_t n_offsets, int cus);
 // Host: how many leading tiles to stagger (tile_passes): 0 unless ADSB_STAGGER is set
 // (measured: no gain, see choose_stagger).
 uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes);
-// ev_start / ev_stop (both or neither): events that receive the kernel's start and end times.
-hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream, hipEvent_t ev_start = nullptr,
-                       hipEvent_t ev_stop = nullptr);
+hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream);
 
 } // namespace adsb

@@ -47,7 +47,6 @@
 //
 // Arithmetic is strict binary32: multiply, then add (built with -ffp-contract=off;
 // tests/test_build_flags.py checks the ISA for the absence of v_fma/v_mac).
-#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -287,6 +286,8 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     const int64_t pbuf0 = args.pbuf0, p_lo = args.p_lo, p_hi = args.p_hi;
 
     const int tid = threadIdx.x;
+    // cfg.profile: the launch's duration is (latest tile end) - (earliest tile start)
+    const uint64_t prof_begin = args.profile ? __builtin_amdgcn_s_memrealtime() : 0;
 #if ADSB_TILE_CLOCK
     // kbench only: when and where each tile ran (100 MHz clock, HW_ID, XCC_ID) -> args.tile_clock[4 * tile ..]
     const uint64_t clk_begin = __builtin_amdgcn_s_memrealtime();
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             }
             __syncthreads();
             if (tid == 0 && args.hand) {
-                const uint32_t need = 1u + 2u * *tile_n;
+                const uint32_t need = stream_granules(*tile_n);
                 const uint32_t b = atomicAdd(&args.counters[2], need);
                 *tile_base = b;
                 *tile_fit = (b < args.hand_cap && need <= args.hand_cap - b) ? 1u : 0u;
@@ -776,6 +777,14 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         __syncthreads(); // queue is rewritten
     }
 
+    if (args.profile) {
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long *c64 = reinterpret_cast<unsigned long long *>(args.counters);
+            atomicMax(&c64[2], ~(unsigned long long)prof_begin);
+            atomicMax(&c64[3], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        }
+    }
 #if ADSB_TILE_CLOCK
     __syncthreads();
     if (tid == 0 && args.tile_clock) {
@@ -797,7 +806,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         if (tid == 0 && *tile_res != 2) {
             uint32_t b = *tile_base, fit = *tile_fit;
             if (!*tile_res) { // no whole-tile round staged anything (all_candidates, fallback rounds)
-                b = atomicAdd(&args.counters[2], 1u);
+                b = atomicAdd(&args.counters[2], stream_granules(0));
                 fit = b < args.hand_cap;
             }
             if (b < args.hand_cap) {
@@ -974,7 +983,7 @@ uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes)
     return tiles >= 2ull * st ? st : 0u;
 }
 
-hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
+hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream)
 {
     if (args.g_end <= args.g_begin)
         return hipSuccess;
@@ -986,14 +995,10 @@ hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream, hip
         fprintf(stderr, "launch_scan: n=%llu passes=%d per=%llu blocks=%llu lds=%zu prior_err=%d\n",
                 (unsigned long long)n, args.passes, (unsigned long long)per, (unsigned long long)blocks, lds,
                 (int)hipPeekAtLastError());
-    // the events (if any) take the kernel's own start and end timestamps -- what rocprofv3
-    // reports -- rather than the times the stream reaches two extra markers
     if (stats)
-        hipExtLaunchKernelGGL(scan_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), (uint32_t)lds, stream, ev_start,
-                              ev_stop, 0u, args);
+        hipLaunchKernelGGL(scan_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args);
     else
-        hipExtLaunchKernelGGL(scan_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), (uint32_t)lds, stream, ev_start,
-                              ev_stop, 0u, args);
+        hipLaunchKernelGGL(scan_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args);
     return hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
-"""Print the library's own per-launch kernel time (HIP events of hipExtLaunchKernel) for a few
-bench-sized steps; run it under `rocprofv3 --kernel-trace` and compare with the trace's durations."""
+"""Print the library's own per-launch kernel time (cfg.profile: in-kernel clock, latest tile end -
+earliest tile start) for a few bench-sized steps; run it under `rocprofv3 --kernel-trace` and
+compare with the trace's durations."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch

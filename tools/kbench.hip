@@ -38,7 +38,7 @@ int main(int argc, char **argv)
     n -= n % 28;
     uint16_t *x; uint32_t *counters, *cands;
     CK(hipMalloc(&x, n * 2));
-    CK(hipMalloc(&counters, 16));
+    CK(hipMalloc(&counters, 32));
     CK(hipMalloc(&cands, (1u << 20) * 24));
     fill_noise<<<4096, 256>>>(x, n, 12345, argc > 4 ? (float)atof(argv[4]) : 8.0f);
     CK(hipDeviceSynchronize());
@@ -49,14 +49,19 @@ int main(int argc, char **argv)
     std::vector<uint32_t> synd(adsb::kSyndWords); adsb::make_syndrome_table(synd.data());
     uint32_t *dsynd; CK(hipMalloc(&dsynd, synd.size() * 4)); CK(hipMemcpy(dsynd, synd.data(), synd.size() * 4, hipMemcpyHostToDevice));
     a.synd = dsynd; a.queue_cap = adsb::kQueueCap; a.all_candidates = 0; a.fix_tab = nullptr; a.fix_mul = 0; a.hand = nullptr; a.hand_cap = 0; a.gen = 0;
+    if (getenv("KB_HAND")) { // hand-off stream into pinned host memory, nobody reading it
+        uint32_t *hand; const size_t gran = 4u << 20;
+        CK(hipHostMalloc(&hand, gran * 16, hipHostMallocCoherent));
+        a.hand = hand; a.hand_cap = (uint32_t)gran; a.gen = 12345;
+    }
     a.passes = argc > 3 && atoi(argv[3]) > 0 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256);
     a.stagger = adsb::choose_stagger(a.g_end - a.g_begin, 256, a.passes); // ADSB_STAGGER=0 turns it off
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) { CK(hipMemset(counters, 0, 8)); CK(adsb::launch_scan(a, false, 0)); }
+    for (int i = 0; i < 3; i++) { CK(hipMemset(counters, 0, 32)); CK(adsb::launch_scan(a, false, 0)); }
     CK(hipDeviceSynchronize());
     std::vector<float> t;
     for (int i = 0; i < iters; i++) {
-        CK(hipMemsetAsync(counters, 0, 8, 0));
+        CK(hipMemsetAsync(counters, 0, 32, 0));
         CK(hipEventRecord(e0, 0)); CK(adsb::launch_scan(a, false, 0)); CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms);
     }
@@ -65,7 +70,7 @@ int main(int argc, char **argv)
         const uint32_t nt = adsb::tile_count(a.g_end - a.g_begin, a.stagger, a.passes);
         uint32_t *dclk; CK(hipMalloc(&dclk, (size_t)nt * 16)); CK(hipMemset(dclk, 0, (size_t)nt * 16));
         a.tile_clock = dclk;
-        CK(hipMemsetAsync(counters, 0, 8, 0)); CK(adsb::launch_scan(a, false, 0)); CK(hipDeviceSynchronize());
+        CK(hipMemsetAsync(counters, 0, 32, 0)); CK(adsb::launch_scan(a, false, 0)); CK(hipDeviceSynchronize());
         std::vector<uint32_t> h((size_t)nt * 4); CK(hipMemcpy(h.data(), dclk, h.size() * 4, hipMemcpyDeviceToHost));
         uint32_t t0c = ~0u; for (uint32_t i = 0; i < nt; i++) t0c = std::min(t0c, h[4 * i]);
         FILE *f = fopen(getenv("ADSB_CLOCK_OUT") ? getenv("ADSB_CLOCK_OUT") : "tile_clock.txt", "w");
