@@ -6,9 +6,14 @@
 //              [stage_first, stage_first+stage_fill): the unscanned tail plus the
 //              newest push.  stage_first is a multiple of 8 samples so that pair
 //              index/4 alignment and 16-byte loads line up with the stream.
-//   cands      kCandWords dwords per CRC-valid candidate, appended with one atomic
-//   tries      one dword per DF-gate pass (only with collect_stats)
-//   counters   2 dwords
+//   d_tries    one dword per DF-gate pass (collect_stats of a stream: counted on the device)
+//   counters   adsb::kCounterWords dwords per launch slot
+// and in pinned host memory, written by the kernel
+//   hand       the hand-off stream: a marker + the kept records of every tile (scan_kernel.h),
+//              consumed while the kernel runs
+//   cands      "loose" list, kCandWords dwords per record, appended with one atomic: records
+//              that could not go through the stream; collected after completion
+//   tries      try words of per-shard scans, which hand the list back to the caller
 // A buffer pushed with adsb_push_device() at a stream position that is a multiple
 // of 8 samples and a 16-byte aligned address is scanned IN PLACE: only the ~4 KiB
 // seam with the previous push and the ~5 KiB tail go through the staging buffer.
@@ -44,10 +49,9 @@ inline uint64_t round_down(uint64_t v, uint64_t q) { return v - v % q; }
 
 } // namespace
 
-// One scan in flight: the kernel of a chunk of offsets appends its records straight
-// into this slot's PINNED HOST buffers (the records are tens of bytes per frame;
-// PCIe posted writes are free next to the sample traffic), so collecting a chunk is
-// one event wait -- no device-to-host copy and no second synchronisation.
+// One scan in flight: the kernel of a chunk of offsets writes its records straight into
+// this slot's PINNED HOST buffers (the records are tens of bytes per frame; PCIe writes
+// are free next to the sample traffic) -- no device-to-host copy of records, ever.
 struct ScanSlot {
     uint32_t *d_counters = nullptr; // device: adsb::kCounterWords (ScanArgs::counters)
     uint32_t *h_counters = nullptr; // pinned: two copies used in turn (ev_cur), so that a launch's kernel
@@ -121,7 +125,7 @@ struct adsb_decoder {
 
     adsb_profile prof{};
     adsb::Resolver res;
-    std::vector<uint32_t> order, scratch_a, scratch_b, gather, raw, tile_start, tile_count;
+    std::vector<uint32_t> order, scratch_a, scratch_b, gather, tile_start, tile_count;
     bool no_streaming = false; // ADSB_NO_STREAMING=1: always collect after completion
     // device-side visited-try count (scan_kernel.h TryCountArgs)
     uint64_t *d_carry[2] = {nullptr, nullptr};
