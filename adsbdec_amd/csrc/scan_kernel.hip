@@ -13,7 +13,8 @@
 // The greedy skip, ts and the end-of-file horizon are sequential and are replayed
 // on the host over these sparse records (resolver.hpp).
 //
-// Structure (HBM-bound integer+f32 scan; no MFMA -- there is no contraction):
+// Structure (a streaming integer+f32 scan, VALU-bound on gfx950; no MFMA -- there is no
+// contraction, and every product and sum must be rounded separately):
 //
 //  Stage A (all the arithmetic; no barriers, no divergence).  A thread computes a
 //  RUN of 28 consecutive power samples in registers.  28 = 4 x 7 keeps the FIR's
@@ -40,13 +41,17 @@
 //  +5b at a fixed bit position, because 140 = 5 x 28) and checks the CRC as the XOR
 //  of 14 syndrome-table lookups; only CRC-valid offsets (~1e-4) take the slow path
 //  that rebuilds the bytes in order and recomputes pw from the input samples.
+//  CRC-valid candidates of the tile are filtered (never-visited rule), ranked, and leave
+//  as one write-through store of adjacent lanes into the host's hand-off stream
+//  (scan_kernel.h), or -- fallbacks -- through the launch-wide loose list.
 //
 //  A workgroup owns owned_runs(K) = 252 K - 44 runs and computes 252 K (+1): the halo
 //  (the 1196-sample reach of a long frame) costs 44 runs of planes per tile (2 % at
 //  K = 8) instead of 1204 float samples of LDS.
 //
 // Arithmetic is strict binary32: multiply, then add (built with -ffp-contract=off;
-// tests/test_build_flags.py checks the ISA for the absence of v_fma/v_mac).
+// tests/test_build_flags.py checks the ISA: the only fused operations are the 56 exact
+// sign tests of the preamble comparison).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
