@@ -54,8 +54,9 @@ inline uint64_t round_down(uint64_t v, uint64_t q) { return v - v % q; }
 // are free next to the sample traffic) -- no device-to-host copy of records, ever.
 struct ScanSlot {
     uint32_t *d_counters = nullptr; // device: adsb::kCounterWords (ScanArgs::counters)
-    uint32_t *h_counters = nullptr; // pinned: two copies used in turn (ev_cur), so that a launch's kernel
-                                    // time can be read behind the slot's NEXT launch instead of in front of it
+    uint32_t *h_counters = nullptr; // pinned, written by the launch's last tile (ScanArgs::report): two copies
+                                    // used in turn (ev_cur), so that a launch's kernel time can be read
+                                    // behind the slot's NEXT launch instead of in front of it
     uint32_t *cands = nullptr;      // pinned, written by the kernel
     uint32_t *tries = nullptr;      // pinned, written by the kernel (per-shard scans that return the list)
     uint32_t *d_tries = nullptr;    // device: statistics runs of a stream count tries on the device
@@ -63,7 +64,7 @@ struct ScanSlot {
     bool tries_on_device = false;   // which of the two the launch in flight uses
     int ev_cur = 0;                  // copy of the launch in flight
     uint64_t ev_offsets[2] = {0, 0}; // offsets of the launch each copy belongs to
-    hipEvent_t ev_ready[2] = {nullptr, nullptr}; // the counters have landed in h_counters[copy]
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}; // the kernel has completed (report and loose list are in)
     uint32_t *hc() { return h_counters + ev_cur * adsb::kCounterWords; }
     // streaming hand-off (scan_kernel.h): one stream of self-validating granules, pinned
     uint32_t *hand = nullptr;
@@ -271,13 +272,13 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     // complete on the host: collect after completion.
     s.tries_on_device = stats && !d->sink.cands;
     s.streaming = !d->no_streaming && (!stats || s.tries_on_device);
+    s.args.gen = ++d->launch_gen * 0x9E3779B9u + 0x7F4A7C15u;
     if (s.streaming) {
         // a line per tile (marker + padding) + two granules per record (sized like the loose list)
         if (slot_reserve_hand(d, s, std::max<size_t>(s.hand_cap, 2 * s.cand_cap + 4 * (size_t)s.ntiles + 64)))
             return -1;
         s.args.hand = s.hand;
         s.args.hand_cap = (uint32_t)std::min<size_t>(s.hand_cap, 0xFFFFFFFFu);
-        s.args.gen = ++d->launch_gen * 0x9E3779B9u + 0x7F4A7C15u;
     } else {
         s.args.hand = nullptr;
         s.args.hand_cap = 0;
@@ -287,14 +288,11 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.args.cand_cap = (uint32_t)std::min<size_t>(s.cand_cap, 0xFFFFFFFFu);
     s.args.tries = s.tries_on_device ? s.d_tries : s.tries;
     s.args.try_cap = (uint32_t)std::min<size_t>(s.tries_on_device ? s.d_try_cap : s.try_cap, 0xFFFFFFFFu);
-    // d_counters are zero here: cleared at creation and again behind every launch (below),
-    // so nothing sits between this call and the kernel's start
+    // d_counters are zero here: cleared at creation, and every launch's last tile leaves them so
     s.args.profile = d->cfg.profile ? 1 : 0;
+    s.args.report = s.hc();
     HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
-    HIP_TRY(d, hipMemcpyAsync(s.hc(), s.d_counters, adsb::kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                              d->stream));
     HIP_TRY(d, hipEventRecord(s.ev_ready[s.ev_cur], d->stream));
-    HIP_TRY(d, hipMemsetAsync(s.d_counters, 0, adsb::kCounterWords * sizeof(uint32_t), d->stream)); // for the next launch
     for (ScanSlot &o : d->slots) // kernel times of earlier launches: read now, behind this launch
         for (int pair = 0; pair < 2; pair++)
             if (!(&o == &s && pair == s.ev_cur) && slot_settle_profile(d, o, pair))
@@ -966,7 +964,7 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipMalloc(counters)", e);
         if ((e = hipMemset(sl.d_counters, 0, adsb::kCounterWords * sizeof(uint32_t))) != hipSuccess)
             return bail("hipMemset(counters)", e);
-        if ((e = hipHostMalloc(&sl.h_counters, 2 * adsb::kCounterWords * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+        if ((e = hipHostMalloc(&sl.h_counters, 2 * adsb::kCounterWords * sizeof(uint32_t), hipHostMallocCoherent)) != hipSuccess)
             return bail("hipHostMalloc(counters)", e);
         if ((e = hipEventCreate(&sl.ev_ready[0])) != hipSuccess || (e = hipEventCreate(&sl.ev_ready[1])) != hipSuccess)
             return bail("hipEventCreate", e);

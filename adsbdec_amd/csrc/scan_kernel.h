@@ -128,10 +128,13 @@ struct ScanArgs {
     const uint32_t *fix_tab; // EXTENSION (not in the reference): 512-entry perfect hash syndrome -> bit, or null
     uint32_t fix_mul;
     const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
-    // [0] loose candidates, [1] tries (may exceed the capacities), [2] hand-off granules, [3] spare;
-    // with `profile`: [4..5] max over tiles of ~(start), [6..7] max of end, on the device's
-    // 100 MHz clock (64-bit; zero-initialised like the rest)
+    // Device counters, zero at launch: [0] loose candidates, [1] tries (may exceed the
+    // capacities), [2] hand-off granules, [3] spare; with `profile` [4..5] max over tiles of
+    // ~(start) and [6..7] max of end on the device's 100 MHz clock (64-bit).  launch_scan
+    // puts one wave behind the scan (report_kernel) that writes them to `report` (pinned
+    // host, same layout, word [3] = gen; null: no report) and zeroes them.
     uint32_t *counters;
+    uint32_t *report;
     int profile;
     uint32_t *cands;     // kCandWords dwords per record
     uint32_t cand_cap;

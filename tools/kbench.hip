@@ -45,7 +45,8 @@ int main(int argc, char **argv)
     adsb::ScanArgs a{};
     a.x = (const uint32_t *)x; a.pbuf0 = 0; a.p_lo = 0; a.p_hi = n / 2;
     a.g_begin = 0; a.g_end = (n / 2 - 1195) / 28 * 28; a.df18 = 0;
-    a.counters = counters; a.cands = cands; a.cand_cap = 1u << 20; a.tries = nullptr; a.try_cap = 0;
+    uint32_t *report; CK(hipHostMalloc(&report, 32, hipHostMallocCoherent));
+    a.report = report; a.counters = counters; a.cands = cands; a.cand_cap = 1u << 20; a.tries = nullptr; a.try_cap = 0;
     std::vector<uint32_t> synd(adsb::kSyndWords); adsb::make_syndrome_table(synd.data());
     uint32_t *dsynd; CK(hipMalloc(&dsynd, synd.size() * 4)); CK(hipMemcpy(dsynd, synd.data(), synd.size() * 4, hipMemcpyHostToDevice));
     a.synd = dsynd; a.queue_cap = adsb::kQueueCap; a.all_candidates = 0; a.fix_tab = nullptr; a.fix_mul = 0; a.hand = nullptr; a.hand_cap = 0; a.gen = 0;
@@ -61,7 +62,7 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
     std::vector<float> t;
     for (int i = 0; i < iters; i++) {
-        CK(hipMemsetAsync(counters, 0, 32, 0));
+        
         CK(hipEventRecord(e0, 0)); CK(adsb::launch_scan(a, false, 0)); CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms);
     }
@@ -70,7 +71,7 @@ int main(int argc, char **argv)
         const uint32_t nt = adsb::tile_count(a.g_end - a.g_begin, a.stagger, a.passes);
         uint32_t *dclk; CK(hipMalloc(&dclk, (size_t)nt * 16)); CK(hipMemset(dclk, 0, (size_t)nt * 16));
         a.tile_clock = dclk;
-        CK(hipMemsetAsync(counters, 0, 32, 0)); CK(adsb::launch_scan(a, false, 0)); CK(hipDeviceSynchronize());
+         CK(adsb::launch_scan(a, false, 0)); CK(hipDeviceSynchronize());
         std::vector<uint32_t> h((size_t)nt * 4); CK(hipMemcpy(h.data(), dclk, h.size() * 4, hipMemcpyDeviceToHost));
         uint32_t t0c = ~0u; for (uint32_t i = 0; i < nt; i++) t0c = std::min(t0c, h[4 * i]);
         FILE *f = fopen(getenv("ADSB_CLOCK_OUT") ? getenv("ADSB_CLOCK_OUT") : "tile_clock.txt", "w");
@@ -82,7 +83,8 @@ int main(int argc, char **argv)
     }
 #endif
     std::sort(t.begin(), t.end());
-    uint32_t hc[2]; CK(hipMemcpy(hc, counters, 8, hipMemcpyDeviceToHost));
+    CK(hipDeviceSynchronize());
+    const uint32_t hc[2] = {report[0], report[1]}; // the last tile's report (the device counters are zero again)
     double med = t[t.size() / 2];
     printf("passes=%d stagger=%u ablate=%d minwaves=%d tile=%d lds=%zu | median %.4f ms min %.4f | %.1f GB/s alg | %.1f Gsamples/s | cands=%u\n",
            a.passes, a.stagger, ADSB_ABLATE, ADSB_MIN_WAVES, adsb::tile_offsets(a.passes), adsb::lds_bytes(a.passes), med, t[0],
