@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libadsbdec_amd.so")
+LIB_PATH = os.environ.get("ADSB_LIB_PATH") or os.path.join(PKG, "lib", "libadsbdec_amd.so")  # override: A/B runs
 CLI_PATH = os.path.join(PKG, "lib", "adsbdec_amd_cli")
 
 

@@ -699,12 +699,11 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 cl_rec[tid * kCandWords + 1] |= 0x10000u; // staged word 1, bit 16: kept
             }
             __syncthreads();
-            if (tid == 0 && args.hand) {
-                const uint32_t need = stream_granules(*tile_n);
-                const uint32_t b = atomicAdd(&args.counters[2], need);
-                *tile_base = b;
-                *tile_fit = (b < args.hand_cap && need <= args.hand_cap - b) ? 1u : 0u;
-                *tile_res = 1;
+            uint32_t res_need = 0, res_base = 0;
+            const bool reserves = tid == 0 && args.hand;
+            if (reserves) { // the result is not looked at before this thread's own record is finished
+                res_need = stream_granules(*tile_n);
+                res_base = atomicAdd(&args.counters[2], res_need);
             }
             uint32_t rank = 0;
             if (keep) {
@@ -712,36 +711,42 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 for (int j = 0; j < ncl; j++)
                     rank += ((cl_rec[j * kCandWords + 1] >> 16) & 1u) & (uint32_t)(cl_rec[j * kCandWords] < gi);
             }
-            __syncthreads();
-            const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
+            // finish the record: bytes in order, pw (demod.c:127,133).  The loads of pw_at
+            // run while thread 0's reservation above is still on its way back.
             uint32_t fin[6];
             if (keep) {
-                // finish the record: bytes in order, pw (demod.c:127,133)
                 const uint32_t cw[4] = {ri[2], ri[3], ri[4], ri[5]};
                 uint32_t wds[4];
                 columns_to_bytes(cw, (ri[1] & 0xFFu) == 0, wds);
                 wds[3] |= ((ri[1] >> 8) & 1u) << 24; // repaired-by-extension flag
                 const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + ri[0]);
-                if (to_stream) {
-                    fin[0] = ri[0], fin[1] = pw, fin[2] = wds[0], fin[3] = wds[1], fin[4] = wds[2], fin[5] = wds[3];
-                    atomicXor(&tile_chk[0], ri[0] ^ wds[2]); // word-wise XOR of its two granules
-                    atomicXor(&tile_chk[1], pw ^ wds[3]);
-                    atomicXor(&tile_chk[2], wds[0]);
-                    atomicXor(&tile_chk[3], wds[1]);
-                } else {
-                    emit_loose(ri[0], pw, wds);
-                }
+                fin[0] = ri[0], fin[1] = pw, fin[2] = wds[0], fin[3] = wds[1], fin[4] = wds[2], fin[5] = wds[3];
             }
-            if (to_stream) {
-                // the finished records replace the staged list, in rank order, and the
-                // tile's range {marker, records} leaves as one store of adjacent lanes
-                __syncthreads(); // every staged entry has been read
-                if (keep) {
+            if (reserves) {
+                *tile_base = res_base;
+                *tile_fit = (res_base < args.hand_cap && res_need <= args.hand_cap - res_base) ? 1u : 0u;
+                *tile_res = 1;
+            }
+            __syncthreads(); // tile_base / tile_fit are in, and every staged entry has been read
+            const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
+            if (keep) {
+                if (to_stream) {
+                    // the finished records replace the staged list, in rank order
                     uint32_t *o = cl_rec + rank * kCandWords;
 #pragma unroll
                     for (int k = 0; k < 6; k++)
                         o[k] = fin[k];
+                    atomicXor(&tile_chk[0], fin[0] ^ fin[4]); // word-wise XOR of its two granules
+                    atomicXor(&tile_chk[1], fin[1] ^ fin[5]);
+                    atomicXor(&tile_chk[2], fin[2]);
+                    atomicXor(&tile_chk[3], fin[3]);
+                } else {
+                    const uint32_t wds[4] = {fin[2], fin[3], fin[4], fin[5]};
+                    emit_loose(fin[0], fin[1], wds);
                 }
+            }
+            if (to_stream) {
+                // the tile's range {marker, records} leaves as one store of adjacent lanes
                 __syncthreads();
                 const uint32_t nk = *tile_n;
                 // no fallback rounds will follow (they emit loose records): the marker is final
