@@ -471,3 +471,42 @@ def test_staggered_tile_sizes(oracle, dec_factory, torch_cuda, monkeypatch):
             assert records(d.drain()) == records(want)
             if stats:
                 assert d.stats() == wstats
+
+
+def test_two_streams_interleaved_on_one_gpu(oracle, dec_factory, torch_cuda):
+    """one adsb_decoder per stream, several may live in one process.  Two
+    handles (own HIP streams, launch slots and resolvers) are fed their captures in
+    interleaved pushes of unequal sizes -- host pushes into one, device pushes into the
+    other -- and each must equal its own stream decoded alone; then both are reset and
+    swap captures."""
+    from oracle import gen_signal as G
+    xa, _ = G.dense_capture(1 << 21, seed=201, sigma=20.0, n_frames=500, amp=(150, 1800))
+    xb, _ = G.dense_capture((1 << 21) + 4096, seed=202, sigma=60.0, n_frames=300, amp=(200, 1500))
+    wa, sa = oracle.decode(xa, df18=True)
+    wb, sb = oracle.decode(xb, df18=True)
+    da = dec_factory(df18=True, collect_stats=True)
+    db = dec_factory(df18=True, collect_stats=True)
+    for first, second, wf, ws, sf, ss in ((xa, xb, wa, wb, sa, sb), (xb, xa, wb, wa, sb, sa)):
+        da.reset()
+        db.reset()
+        t2 = _dev(torch_cuda, second)
+        got_a, got_b = [], []
+        pa = pb = 0
+        rng = np.random.default_rng(9)
+        while pa < first.size or pb < second.size:
+            na = int(min(first.size - pa, rng.integers(1, 300_000)))
+            if na:
+                da.push(first[pa: pa + na])
+                pa += na
+                got_a += da.drain()
+            nb = int(min(second.size - pb, 8 * rng.integers(1, 40_000)))
+            if nb:
+                db.push_device(t2.data_ptr() + 2 * pb, nb)
+                pb += nb
+                got_b += db.drain()
+        da.finish()
+        db.finish()
+        got_a += da.drain()
+        got_b += db.drain()
+        assert records(got_a) == records(wf) and da.stats() == sf
+        assert records(got_b) == records(ws) and db.stats() == ss
