@@ -971,6 +971,12 @@ int choose_passes(uint64_t n_offsets, int cus)
         if (k >= 2 && k <= kMaxPasses)
             return k;
     }
+    // Large launches: tiles retire at a steady rate in index order (each CU favours its older
+    // workgroups, so there are no "rounds" to quantise), and a longer tile only amortises its
+    // 44-run halo better.  Measured in bench.py at 128 Mi offsets: K = 5 / 6 / 7 / 8 / 10 ->
+    // 0.214 / 0.212 / 0.208 / 0.211 / 0.211 ms per step.
+    if (n_offsets >= (96ull << 20))
+        return 7;
     int best = 2;
     double best_cost = 1e300;
     for (int k = 2; k <= 6; k++) { // measured: 4..6 passes are best at every launch size (tools/kbench)
