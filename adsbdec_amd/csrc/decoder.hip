@@ -54,7 +54,7 @@ inline uint64_t round_down(uint64_t v, uint64_t q) { return v - v % q; }
 // are free next to the sample traffic) -- no device-to-host copy of records, ever.
 struct ScanSlot {
     uint32_t *d_counters = nullptr; // device: adsb::kCounterWords (ScanArgs::counters)
-    uint32_t *h_counters = nullptr; // pinned, written by the launch's last tile (ScanArgs::report): two copies
+    uint32_t *h_counters = nullptr; // pinned, written by the launch's report kernel (ScanArgs::report): two copies
                                     // used in turn (ev_cur), so that a launch's kernel time can be read
                                     // behind the slot's NEXT launch instead of in front of it
     uint32_t *cands = nullptr;      // pinned, written by the kernel
@@ -288,7 +288,7 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.args.cand_cap = (uint32_t)std::min<size_t>(s.cand_cap, 0xFFFFFFFFu);
     s.args.tries = s.tries_on_device ? s.d_tries : s.tries;
     s.args.try_cap = (uint32_t)std::min<size_t>(s.tries_on_device ? s.d_try_cap : s.try_cap, 0xFFFFFFFFu);
-    // d_counters are zero here: cleared at creation, and every launch's last tile leaves them so
+    // d_counters are zero here: cleared at creation, and the report kernel behind every scan leaves them so
     s.args.profile = d->cfg.profile ? 1 : 0;
     s.args.report = s.hc();
     HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
@@ -390,10 +390,10 @@ void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uin
 // that resolving overlaps the scan.  The hand-off stream (scan_kernel.h) is read strictly
 // sequentially -- one prefetchable stream of device-written lines, no directory to poll:
 // a marker says which tile follows, how many records, and what their XOR must be; the
-// records are checked where they lie (16-byte loads) and later resolved in place.  Tiles reserve their ranges in COMPLETION
-// order, so a tile that finished early waits (start/count noted) until every tile before
-// it is in; the resolver is fed whenever the device leaves the host nothing to read, or
-// a group of tiles has accumulated.
+// records are checked where they lie (16-byte loads) and later resolved in place.  Tiles
+// reserve their ranges in COMPLETION order, so a tile that finished early waits (start and
+// count noted) until every tile before it is in; the resolver is fed whenever the device
+// leaves the host nothing to read, or a group of tiles has accumulated.
 // Returns 1 if a tile reported records on the loose list (or the stream is full): the
 // caller then finishes the launch through the collect-after-completion path, from tile
 // *resume_tile on.
