@@ -63,6 +63,7 @@ SYMBOLS = {
     "adsb_host_alloc": (C.c_void_p, [C.c_size_t]),
     "adsb_host_free": (None, [C.c_void_p]),
     "adsb_drain": (C.c_long, [C.c_void_p, C.POINTER(Frame), C.c_size_t]),
+    "adsb_take": (C.c_long, [C.c_void_p, C.POINTER(C.POINTER(Frame))]),
     "adsb_pending": (C.c_size_t, [C.c_void_p]),
     "adsb_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "adsb_get_profile": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
@@ -199,6 +200,15 @@ class Decoder:
         if got < 0:
             raise AdsbError("adsb_drain failed")
         return buf, int(got)
+
+    def take_raw(self):
+        """All pending frames in place (adsb_take): (pointer to Frame, count); valid until the
+        next push / finish / reset of this decoder."""
+        p = C.POINTER(Frame)()
+        n = self._L.adsb_take(self._h, C.byref(p))
+        if n < 0:
+            raise AdsbError("adsb_take failed")
+        return p, int(n)
 
     def drain(self):
         buf, n = self.drain_raw()

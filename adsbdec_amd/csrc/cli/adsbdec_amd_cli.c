@@ -43,15 +43,13 @@ static void usage(void)
 
 static int flush_frames(adsb_decoder *dec, int outformat)
 {
-    adsb_frame fr[256];
+    const adsb_frame *fr; /* the handle's own queue: formatted where it lies */
     char pkt[256];
-    long n;
-    while ((n = adsb_drain(dec, fr, 256)) > 0) {
-        for (long i = 0; i < n; i++) {
-            int len = adsb_format_frame(&fr[i], outformat, pkt);
-            if (fwrite(pkt, 1, (size_t)len, stdout) != (size_t)len)
-                return -1;
-        }
+    const long n = adsb_take(dec, &fr);
+    for (long i = 0; i < n; i++) {
+        int len = adsb_format_frame(&fr[i], outformat, pkt);
+        if (fwrite(pkt, 1, (size_t)len, stdout) != (size_t)len)
+            return -1;
     }
     return n < 0 ? -1 : 0;
 }

@@ -1216,6 +1216,13 @@ long adsb_drain(adsb_decoder *d, adsb_frame *out, size_t cap)
     return (long)d->res.drain(out, cap);
 }
 
+long adsb_take(adsb_decoder *d, const adsb_frame **frames)
+{
+    if (!d || !frames)
+        return -1;
+    return (long)d->res.take(frames);
+}
+
 size_t adsb_pending(const adsb_decoder *d)
 {
     return d ? d->res.pending() : 0;

@@ -158,6 +158,15 @@ public:
         }
         return n;
     }
+    // drain without the copy: the pending frames where they lie (valid until the next feed /
+    // advance / reset, which recycles the storage); they count as drained
+    size_t take(const adsb_frame **p)
+    {
+        const size_t n = out_.size() - ohead_;
+        *p = n ? out_.data() + ohead_ : nullptr;
+        ohead_ = out_.size();
+        return n;
+    }
     const adsb_stats &stats() const { return stats_; }
     uint64_t base() const { return base_; }
 
@@ -173,6 +182,10 @@ private:
 
     void compact()
     {
+        if (ohead_ && ohead_ == out_.size()) { // everything handed out (take): recycle
+            out_.clear();
+            ohead_ = 0;
+        }
         if (chead_ && chead_ == cands_.size()) {
             cands_.clear();
             chead_ = 0;

@@ -8,7 +8,7 @@
 A "step" is one full pass of the hot path over one synthetic capture that is
 already resident in HBM: adsb_reset -> adsb_push_device_final (fused scan kernel
 over every preamble offset, record gather, greedy resolution, end-of-file rule)
--> adsb_drain (frames in reference order).  Workload = BASELINE.json configs[1]:
+-> adsb_take (frames in reference order, in place).  Workload = BASELINE.json configs[1]:
 256 Mi uint16 samples @ 20 MS/s, sparse frames (~1 k frames/s, DF17 with some
 DF11), sigma = 8 noise.  With N > 1 every rank decodes its own independent stream
 of that size (configs[3]); no data-path collective exists, so scaling is "weak".
@@ -143,7 +143,7 @@ def main():
     def step():
         dec.reset()
         dec.push_device_final(xptr, xn)  # == push_device + finish, in one pass
-        return dec.drain_raw(reuse=True)  # frames land in one C array; converted once, after timing
+        return dec.take_raw()  # adsb_take: the frames where the library queued them; converted after timing
 
     for _ in range(args.warmup):
         raw = step()

@@ -139,6 +139,11 @@ int adsb_finish(adsb_decoder *d);
 /* Frame egress; the records the reference hands to netout() (output.c:159), in
  * the same order. Returns the number copied (<= cap), or -1. */
 long adsb_drain(adsb_decoder *d, adsb_frame *out, size_t cap);
+/* The same without the copy: every pending frame, in place. *frames points into the
+ * handle's own queue and stays valid until the next call that pushes samples into,
+ * finishes, resets or destroys this handle; the frames count as drained. Returns their
+ * number (0: *frames is NULL). */
+long adsb_take(adsb_decoder *d, const adsb_frame **frames);
 /* Number of frames currently waiting in the handle. */
 size_t adsb_pending(const adsb_decoder *d);
 

@@ -510,3 +510,31 @@ def test_two_streams_interleaved_on_one_gpu(oracle, dec_factory, torch_cuda):
         got_b += db.drain()
         assert records(got_a) == records(wf) and da.stats() == sf
         assert records(got_b) == records(ws) and db.stats() == ss
+
+
+def capi_frames(p, n):
+    from adsbdec_amd import capi
+    return capi._frames_to_dicts(p, n)
+
+
+def test_take_is_drain_without_the_copy(oracle, dec_factory):
+    """adsb_take hands out the queued frames in place; mixing it with adsb_drain and with
+    further pushes must neither lose nor repeat a frame."""
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture(1 << 21, seed=303, sigma=20.0, n_frames=400, amp=(150, 1800))
+    want, _ = oracle.decode(x, df18=True)
+    d = dec_factory(df18=True)
+    got = []
+    cuts = [0, 300_000, 300_004, 900_000, 1_500_000, x.size]
+    for i, (a, b) in enumerate(zip(cuts, cuts[1:])):
+        d.push(x[a:b])
+        if i % 2:
+            got += d.drain()
+        else:
+            p, n = d.take_raw()
+            got += capi_frames(p, n)
+            assert d.take_raw()[1] == 0 and d.drain() == []
+    d.finish()
+    p, n = d.take_raw()
+    got += capi_frames(p, n)
+    assert records(got) == records(want)

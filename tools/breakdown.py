@@ -12,7 +12,7 @@ for it in range(int(os.environ.get("ADSB_STEPS", "8"))):
     t0=time.perf_counter(); dec.reset()
     t1=time.perf_counter(); dec.push_device_final(x.data_ptr(), x.numel())
     t2=time.perf_counter()
-    t3=time.perf_counter(); raw = dec.drain_raw(reuse=True)
+    t3=time.perf_counter(); raw = dec.take_raw()
     t4=time.perf_counter()
     p = dec.profile()
     q = prev if 'prev' in dir() and prev else {k: 0 for k in p}
