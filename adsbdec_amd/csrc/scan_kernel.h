@@ -10,9 +10,6 @@ namespace adsb {
 #ifndef ADSB_ABLATE
 #define ADSB_ABLATE 0 // kbench only: 1 = loads only, 2 = front end + bit planes only
 #endif
-#ifndef ADSB_PREFETCH
-#define ADSB_PREFETCH 0 // P in 1..9: issue the first P of a pass's nine loads one pass ahead (measured: slower)
-#endif
 #ifndef ADSB_FIR_GROUP
 #define ADSB_FIR_GROUP 4 // FIR outputs advanced together (independent chains interleaved)
 #endif

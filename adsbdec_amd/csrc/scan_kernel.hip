@@ -344,83 +344,78 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     }
 
     // ------------------------------ Stage A ------------------------------
-    // The 36 pairs (8 of pre-halo + 28) of this lane's run in pass `ps` are nine 16-byte
-    // loads.  ADSB_PREFETCH = P > 0 issues the first P of them one pass ahead (4 P more
-    // registers), so that a pass starts computing its first outputs at once while the
-    // other 9 - P loads are in flight.
-    auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * (kWaveRuns * (4 * ps + wave) + lane) - 8; };
-    auto pass_interior = [&](int ps) { // wave-uniform: every pair this wave loads lies inside the buffer
-        const int64_t wlo = t0 + (int64_t)kRun * (kWaveRuns * (4 * ps + wave)) - 8;
-        return (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
-    };
-#if ADSB_SAME_DATA // kbench only: every tile reads the first tile's samples (cache-resident): compute without HBM
-    auto pass_src = [&](int ps) { return reinterpret_cast<const uint4 *>(xin + (pass_first_pair(ps) - t0 + 8)); };
-#else
-    auto pass_src = [&](int ps) { return reinterpret_cast<const uint4 *>(xin + (pass_first_pair(ps) - pbuf0)); };
-#endif
-    constexpr int kPre = ADSB_PREFETCH;
-    uint32_t wpre[kPre > 0 ? 4 * kPre : 1];
-    bool have_pre = false;
-    if (kPre > 0 && pass_interior(0)) {
-        const uint4 *src = pass_src(0);
-#pragma unroll
-        for (int k = 0; k < kPre; k++) {
-            const uint4 q = src[k];
-            wpre[4 * k + 0] = q.x, wpre[4 * k + 1] = q.y, wpre[4 * k + 2] = q.z, wpre[4 * k + 3] = q.w;
-        }
-        have_pre = true;
-    }
+    // Input: the 34 pairs (6 of pre-halo + 28) a run needs are 17 TYPED buffer loads of 8
+    // bytes per lane (buffer_load_format_xyzw, data format 16_16_16_16, number format
+    // USCALED): the load path itself converts the four uint16 to four floats -- exactly, and
+    // for free next to 66 v_cvt_f32_u32 per run (4.4 cycles each; kernel -4.5 % with the chip
+    // cool, -2 % throttled).  Lanes are 112 bytes apart; the buffer resource is rebuilt per
+    // wave and pass around the wave's own 7 KiB window, so no buffer size limit applies.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * (kWaveRuns * (4 * ps + wave)) - 8; }; // lane 0's
 #pragma unroll 1
     for (int pass = 0; pass < K; pass++) {
         const int v0 = kWaveRuns * (4 * pass + wave); // first run of this wave in this pass
         const int v = v0 + lane;
-        uint32_t w[36];
-        if (pass_interior(pass)) {
-            const uint4 *src = pass_src(pass);
-            if (kPre > 0 && have_pre) {
-#pragma unroll
-                for (int k = 0; k < 4 * kPre; k++)
-                    w[k] = wpre[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                if (kPre > 0 && k < kPre && have_pre)
-                    continue;
-                const uint4 q = src[k];
-                w[4 * k + 0] = q.x;
-                w[4 * k + 1] = q.y;
-                w[4 * k + 2] = q.z;
-                w[4 * k + 3] = q.w;
-            }
+        const int64_t wlo = pass_first_pair(pass);
+        // wave-uniform: every pair this wave loads lies inside the buffer
+        const bool interior = (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
+        f32x4 tl[17]; // tl[k]: pairs 2k+2, 2k+3 of the lane's 36 = slots 2k, 2k+1
+        if (interior) {
+#if ADSB_SAME_DATA // kbench only: every tile reads the first tile's samples (cache-resident): compute without HBM
+            const uint64_t wbase = (uint64_t)(xin + (wlo - t0 + 8));
+#else
+            const uint64_t wbase = (uint64_t)(xin + (wlo - pbuf0));
+#endif
+            i32x4 rs;
+            rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)wbase);
+            rs.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(wbase >> 32) & 0xFFFFu)); // stride 0: raw buffer
+            rs.z = 64 * kRun * 4 + 64;                                                        // bytes
+            rs.w = (int)(4u | 5u << 3 | 6u << 6 | 7u << 9 /* dst_sel xyzw */ | 2u << 12 /* USCALED */ | 12u << 15 /* 16_16_16_16 */);
+            const int voff = lane * (kRun * 4);
+            asm volatile("buffer_load_format_xyzw %0, %17, %18, 0 offen offset:8\n\t"
+                         "buffer_load_format_xyzw %1, %17, %18, 0 offen offset:16\n\t"
+                         "buffer_load_format_xyzw %2, %17, %18, 0 offen offset:24\n\t"
+                         "buffer_load_format_xyzw %3, %17, %18, 0 offen offset:32\n\t"
+                         "buffer_load_format_xyzw %4, %17, %18, 0 offen offset:40\n\t"
+                         "buffer_load_format_xyzw %5, %17, %18, 0 offen offset:48\n\t"
+                         "buffer_load_format_xyzw %6, %17, %18, 0 offen offset:56\n\t"
+                         "buffer_load_format_xyzw %7, %17, %18, 0 offen offset:64\n\t"
+                         "buffer_load_format_xyzw %8, %17, %18, 0 offen offset:72\n\t"
+                         "buffer_load_format_xyzw %9, %17, %18, 0 offen offset:80\n\t"
+                         "buffer_load_format_xyzw %10, %17, %18, 0 offen offset:88\n\t"
+                         "buffer_load_format_xyzw %11, %17, %18, 0 offen offset:96\n\t"
+                         "buffer_load_format_xyzw %12, %17, %18, 0 offen offset:104\n\t"
+                         "buffer_load_format_xyzw %13, %17, %18, 0 offen offset:112\n\t"
+                         "buffer_load_format_xyzw %14, %17, %18, 0 offen offset:120\n\t"
+                         "buffer_load_format_xyzw %15, %17, %18, 0 offen offset:128\n\t"
+                         "buffer_load_format_xyzw %16, %17, %18, 0 offen offset:136\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(tl[0]), "=&v"(tl[1]), "=&v"(tl[2]), "=&v"(tl[3]), "=&v"(tl[4]), "=&v"(tl[5]), "=&v"(tl[6]),
+                           "=&v"(tl[7]), "=&v"(tl[8]), "=&v"(tl[9]), "=&v"(tl[10]), "=&v"(tl[11]), "=&v"(tl[12]),
+                           "=&v"(tl[13]), "=&v"(tl[14]), "=&v"(tl[15]), "=&v"(tl[16])
+                         : "v"(voff), "s"(rs)
+                         : "memory");
         } else {
-            // Stream start (the ring is zero-initialised, air.c:33: a missing pair
-            // is 0x0800,0x0800 -> v = 0) and the ragged end of a buffer.
-            const int64_t pr0 = pass_first_pair(pass);
+            // Stream start (the ring is zero-initialised, air.c:33: a missing pair is
+            // 0x0800,0x0800 -> v = 0) and the ragged end of a buffer: plain loads, converted here
+            const int64_t pr0 = wlo + (int64_t)kRun * lane;
 #pragma unroll
-            for (int k = 0; k < 36; k++) {
-                const int64_t pr = pr0 + k;
-                w[k] = (pr >= p_lo && pr < p_hi) ? xin[pr - pbuf0] : 0x08000800u;
-            }
-        }
-        if (kPre > 0) {
-            have_pre = (pass + 1 < K) && pass_interior(pass + 1);
-            if (have_pre) {
-                const uint4 *src = pass_src(pass + 1);
-#pragma unroll
-                for (int k = 0; k < kPre; k++) {
-                    const uint4 q = src[k];
-                    wpre[4 * k + 0] = q.x, wpre[4 * k + 1] = q.y, wpre[4 * k + 2] = q.z, wpre[4 * k + 3] = q.w;
-                }
+            for (int k = 0; k < 17; k++) {
+                const int64_t pa = pr0 + 2 * k + 2, pb = pa + 1;
+                const uint32_t d0 = (pa >= p_lo && pa < p_hi) ? xin[pa - pbuf0] : 0x08000800u;
+                const uint32_t d1 = (pb >= p_lo && pb < p_hi) ? xin[pb - pbuf0] : 0x08000800u;
+                tl[k] = f32x4{(float)(d0 & 0xFFFFu), (float)(d0 >> 16), (float)(d1 & 0xFFFFu), (float)(d1 >> 16)};
             }
         }
 #if ADSB_ABLATE == 1
         {   // kbench: price the loads alone
-            uint32_t acc = 0;
+            float acc = 0;
 #pragma unroll
-            for (int k = 0; k < 36; k++)
-                acc ^= w[k];
+            for (int k = 0; k < 17; k++)
+                acc += tl[k].x + tl[k].y + tl[k].z + tl[k].w;
             if (lane < kWaveRuns)
-                pl_d[v] = acc;
+                pl_d[v] = __float_as_uint(acc);
             continue;
         }
 #endif
@@ -430,8 +425,8 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         f32x2 vv[34];
 #pragma unroll
         for (int s = 0; s < 34; s++) {
-            const uint32_t d = w[s + 2];
-            const f32x2 f = {(float)(d & 0xFFFFu), (float)(d >> 16)};
+            const f32x4 q = tl[s >> 1];
+            const f32x2 f = (s & 1) ? f32x2{q.z, q.w} : f32x2{q.x, q.y};
             const f32x2 mid = {2048.0f, 2048.0f};
             vv[s] = ((s & 1) == 0) ? (f - mid) : (mid - f); // slot s <-> rel pair s-6: same parity
         }

@@ -5,7 +5,7 @@ mkdir -p tools/bin
 for cfg in "$@"; do
   set -- $cfg
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -I adsbdec_amd/csrc \
-     -DADSB_ABLATE=$1 -DADSB_MIN_WAVES=$2 -DADSB_FIR_GROUP=${3:-4} -DADSB_PREFETCH=${4:-0} tools/kbench.hip -o tools/bin/kb_a$1_w$2_g${3:-4}_p${4:-0} 2>&1 | grep -E "error" &
+     -DADSB_ABLATE=$1 -DADSB_MIN_WAVES=$2 -DADSB_FIR_GROUP=${3:-4} tools/kbench.hip -o tools/bin/kb_a$1_w$2_g${3:-4} 2>&1 | grep -E "error" &
 done
 wait
 ls tools/bin
