@@ -186,7 +186,7 @@ def main():
     avg_ms = ms_big / n_big if n_big else 0.0
     achieved = 4.0 * big_off / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_v10_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r1_v11_pmc.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
