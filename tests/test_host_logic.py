@@ -148,6 +148,13 @@ def test_resolver_input_paths_agree(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", src, "-o", str(exe)], check=True)
     out = subprocess.run([str(exe), "150"], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+    # and once more under AddressSanitizer + UBSan (the in-place batch paths juggle raw pointers)
+    san = tmp_path / "resolver_paths_san"
+    built = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            src, "-o", str(san)], capture_output=True, text=True)
+    if built.returncode == 0:  # sanitizer runtimes present in this image
+        out = subprocess.run([str(san), "40"], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
 
 
 def test_tile_geometry_is_consistent(tmp_path):
