@@ -8,7 +8,7 @@ namespace adsb {
 
 // Tuning knobs; the defaults are what ships. tools/kbench.hip overrides them with -D.
 #ifndef ADSB_ABLATE
-#define ADSB_ABLATE 0 // kbench only: 1 = loads only, 2 = front end + bit planes only
+#define ADSB_ABLATE 0 // kbench only: 1 = loads only, 2 = front end + bit planes only, 3 = no loads (arithmetic alone)
 #endif
 #ifndef ADSB_FIR_GROUP
 #define ADSB_FIR_GROUP 4 // FIR outputs advanced together (independent chains interleaved)

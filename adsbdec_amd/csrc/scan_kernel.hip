@@ -361,6 +361,15 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         // wave-uniform: every pair this wave loads lies inside the buffer
         const bool interior = (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
         f32x4 tl[17]; // tl[k]: pairs 2k+2, 2k+3 of the lane's 36 = slots 2k, 2k+1
+#if ADSB_ABLATE == 3 // kbench: no loads at all -- the arithmetic alone
+        if (interior) {
+#pragma unroll
+            for (int k = 0; k < 17; k++) {
+                const float q = (float)((lane * 17 + k + pass) & 4095);
+                tl[k] = f32x4{q, q + 1.0f, 2048.0f, q + 3.0f};
+            }
+        } else
+#endif
         if (interior) {
 #if ADSB_SAME_DATA // kbench only: every tile reads the first tile's samples (cache-resident): compute without HBM
             const uint64_t wbase = (uint64_t)(xin + (wlo - t0 + 8));
