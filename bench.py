@@ -196,7 +196,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": "adsb::scan_kernel", "launch_offsets": big_off, "launch_bytes": 4 * big_off,
                 "launch_ms": round(avg_ms, 5), "launches_per_step": round(n_big / args.steps, 2),
-                "kernel_ms_per_step": round(kernel_ms / args.steps, 4)}
+                "kernel_ms_per_step": round(kernel_ms / args.steps, 4),
+                "limited_by": "VALU issue (every product and sum of the 14-tap FIR is rounded separately: "
+                              "784 flops per 28 outputs), not HBM: DESIGN.md section 4"}
 
     # ---- CPU baseline + correctness gate (rank 0 only, N == 1 only) ----
     cpu = None
