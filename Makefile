@@ -1,0 +1,41 @@
+# Plain-make build of the C-ABI library and the C host program, for users who do not want
+# Python in the loop (python -m adsbdec_amd._build runs the same commands; keep them in step).
+# hipcc cross-compiles the gfx950 code object without a GPU.
+HIPCC    ?= /opt/rocm/bin/hipcc
+CC       ?= gcc
+# -ffp-contract=off: the reference arithmetic is binary32 multiply THEN add
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function
+CSRC     := adsbdec_amd/csrc
+LIBDIR   := adsbdec_amd/lib
+LIB      := $(LIBDIR)/libadsbdec_amd.so
+CLI      := $(LIBDIR)/adsbdec_amd_cli
+HDRS     := $(CSRC)/scan_kernel.h $(CSRC)/resolver.hpp include/adsbdec_amd.h
+
+all: $(LIB) $(CLI)
+
+$(LIBDIR)/%.hip.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/format.c.o: $(CSRC)/format.c $(HDRS)
+	@mkdir -p $(LIBDIR)
+	$(CC) -O2 -fPIC -Wall -c $< -o $@
+
+$(LIB): $(LIBDIR)/scan_kernel.hip.o $(LIBDIR)/decoder.hip.o $(LIBDIR)/format.c.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm
+
+$(CLI): $(CSRC)/cli/adsbdec_amd_cli.c $(LIB) include/adsbdec_amd.h
+	$(CC) -O2 -Wall -o $@ $< -Iinclude -L$(LIBDIR) -ladsbdec_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+
+# test infrastructure (never linked into the library): the CPU oracle, and the reference
+# objects it is pinned against when /root/reference is present
+oracle:
+	$(MAKE) -C oracle
+
+check: all
+	python -m pytest tests -q -m "not gpu"
+
+clean:
+	rm -f $(LIBDIR)/*.o $(LIB) $(CLI)
+
+.PHONY: all oracle check clean
