@@ -130,14 +130,19 @@ struct adsb_decoder {
     bool no_streaming = false; // ADSB_NO_STREAMING=1: always collect after completion
     // device-side visited-try count (scan_kernel.h TryCountArgs)
     uint64_t *d_carry[2] = {nullptr, nullptr};
-    uint32_t n_carry = 0;
+    uint32_t *d_carry_n = nullptr; // device: three counts in rotation (in, out, next: TryCountArgs)
+    int carry_n_cur = 0;
+    bool carry_maybe = false;      // a non-final pass has run since the last final one: its carry may be non-empty
     int carry_cur = 0;
-    uint64_t *d_frames_g = nullptr;
-    uint32_t *d_frames_span = nullptr;
+    adsb::TryFrame *d_frames = nullptr;
     size_t frames_cap = 0;
-    uint32_t *d_try_out = nullptr, *h_try_out = nullptr; // 4 words
-    uint64_t *h_frames_g = nullptr;                      // pinned upload buffers
-    uint32_t *h_frames_span = nullptr;
+    unsigned long long *d_try_acc = nullptr; // device: visited tries per DF code since reset + overflow flag
+    bool tries_unread = false;               // passes have been enqueued since the statistics were last read
+    bool acc_dirty = false;                  // ... since d_try_acc was last zeroed
+    adsb::TryFrame *h_frames[2] = {nullptr, nullptr}; // pinned upload buffers, used in turn (a pass is never waited for)
+    hipEvent_t ev_frames[2] = {nullptr, nullptr};
+    bool frames_pending[2] = {false, false};
+    int frames_buf = 0;
     bool final_follows = false;   // adsb_push_device_final: the end-of-stream count pass comes next
     const uint32_t *deferred_tries = nullptr; // try list of the last launch, left for that pass
     uint32_t deferred_n = 0;
@@ -174,6 +179,7 @@ inline uint64_t power_samples_produced(uint64_t n_samples)
     return 2 * (n_samples / 4); // air.c:59-92: two power samples per four input samples
 }
 
+constexpr size_t kTryStateBytes = 4 * sizeof(unsigned long long) + 4 * sizeof(uint32_t); // d_try_acc + d_carry_n
 constexpr uint32_t kCarryCap = 1u << 20; // undecided tries carried between count passes (a few hundred in practice)
 
 int slot_reserve_device_tries(adsb_decoder *d, ScanSlot &s, size_t want)
@@ -561,73 +567,87 @@ int count_tries_pass(adsb_decoder *d, const uint32_t *d_tries, uint32_t n_tries,
 {
     auto &log = d->res.accepted_log();
     const size_t nf = log.size() + (d->have_prev_frame ? 1 : 0);
-    if (n_tries == 0 && d->n_carry == 0) {
+    auto remember_last = [&] {
         if (!log.empty()) {
             d->have_prev_frame = true;
             d->prev_frame_g = log.back().first;
             d->prev_frame_span = log.back().second;
             log.clear();
         }
+    };
+    if (n_tries == 0 && !d->carry_maybe) {
+        remember_last();
         return 0;
     }
-    if (nf > d->frames_cap) {
+    if (nf > d->frames_cap) { // rare: grow the frame arrays (passes in flight use them: drain the stream first)
+        HIP_TRY(d, hipStreamSynchronize(d->stream));
         const size_t cap = std::max<size_t>(nf + nf / 4, 4096);
-        if (d->d_frames_g) HIP_TRY(d, hipFree(d->d_frames_g));
-        if (d->d_frames_span) HIP_TRY(d, hipFree(d->d_frames_span));
-        if (d->h_frames_g) HIP_TRY(d, hipHostFree(d->h_frames_g));
-        if (d->h_frames_span) HIP_TRY(d, hipHostFree(d->h_frames_span));
-        d->d_frames_g = nullptr, d->d_frames_span = nullptr, d->h_frames_g = nullptr, d->h_frames_span = nullptr;
+        if (d->d_frames) HIP_TRY(d, hipFree(d->d_frames));
+        d->d_frames = nullptr;
         d->frames_cap = 0;
-        HIP_TRY(d, hipMalloc(&d->d_frames_g, cap * sizeof(uint64_t)));
-        HIP_TRY(d, hipMalloc(&d->d_frames_span, cap * sizeof(uint32_t)));
-        HIP_TRY(d, hipHostMalloc(&d->h_frames_g, cap * sizeof(uint64_t), hipHostMallocDefault));
-        HIP_TRY(d, hipHostMalloc(&d->h_frames_span, cap * sizeof(uint32_t), hipHostMallocDefault));
+        for (int b = 0; b < 2; b++) {
+            if (d->h_frames[b]) HIP_TRY(d, hipHostFree(d->h_frames[b]));
+            d->h_frames[b] = nullptr;
+            d->frames_pending[b] = false;
+            HIP_TRY(d, hipHostMalloc(&d->h_frames[b], cap * sizeof(adsb::TryFrame), hipHostMallocDefault));
+        }
+        HIP_TRY(d, hipMalloc(&d->d_frames, cap * sizeof(adsb::TryFrame)));
         d->frames_cap = cap;
     }
+    const int b = d->frames_buf ^= 1;
+    if (d->frames_pending[b]) { // the pass before last has long copied this buffer
+        HIP_TRY(d, hipEventSynchronize(d->ev_frames[b]));
+        d->frames_pending[b] = false;
+    }
     size_t k = 0;
-    if (d->have_prev_frame) {
-        d->h_frames_g[k] = d->prev_frame_g;
-        d->h_frames_span[k++] = d->prev_frame_span;
-    }
-    for (const auto &f : log) {
-        d->h_frames_g[k] = f.first;
-        d->h_frames_span[k++] = f.second;
-    }
-    if (!log.empty()) {
-        d->have_prev_frame = true;
-        d->prev_frame_g = log.back().first;
-        d->prev_frame_span = log.back().second;
-        log.clear();
-    }
+    if (d->have_prev_frame)
+        d->h_frames[b][k++] = adsb::TryFrame{d->prev_frame_g, d->prev_frame_span, 0};
+    for (const auto &f : log)
+        d->h_frames[b][k++] = adsb::TryFrame{f.first, f.second, 0};
+    remember_last();
     if (nf) {
-        HIP_TRY(d, hipMemcpyAsync(d->d_frames_g, d->h_frames_g, nf * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
-        HIP_TRY(d, hipMemcpyAsync(d->d_frames_span, d->h_frames_span, nf * sizeof(uint32_t), hipMemcpyHostToDevice,
-                                  d->stream));
+        HIP_TRY(d, hipMemcpyAsync(d->d_frames, d->h_frames[b], nf * sizeof(adsb::TryFrame), hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(d, hipEventRecord(d->ev_frames[b], d->stream));
+        d->frames_pending[b] = true;
     }
-    HIP_TRY(d, hipMemsetAsync(d->d_try_out, 0, 4 * sizeof(uint32_t), d->stream));
+    const int c_in = d->carry_n_cur, c_out = (c_in + 1) % 3, c_next = (c_in + 2) % 3;
     adsb::TryCountArgs a{};
     a.tries = d_tries;
     a.n_tries = n_tries;
     a.g_base = g_base;
     a.carry_in = d->d_carry[d->carry_cur];
-    a.n_carry = d->n_carry;
-    a.frames_g = d->d_frames_g;
-    a.frames_span = d->d_frames_span;
+    a.n_carry = d->d_carry_n + c_in;
+    a.frames = d->d_frames;
     a.n_frames = (uint32_t)nf;
     a.hi = d->res.base(); // every offset below has been visited or jumped over
     a.final = final ? 1 : 0;
     a.carry_out = d->d_carry[d->carry_cur ^ 1];
     a.carry_cap = kCarryCap;
-    a.out = d->d_try_out;
-    HIP_TRY(d, adsb::launch_count_tries(a, d->stream));
-    HIP_TRY(d, hipMemcpyAsync(d->h_try_out, d->d_try_out, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(d, hipStreamSynchronize(d->stream));
-    if (d->h_try_out[3] > kCarryCap)
-        return d->fail("%u undecided tries exceed the carry buffer", d->h_try_out[3]);
-    d->res.add_tries(d->h_try_out[0], d->h_try_out[1], d->h_try_out[2]);
+    a.n_carry_out = d->d_carry_n + c_out; // zero: cleared at creation / reset, or by the pass before last
+    a.n_carry_next = d->d_carry_n + c_next;
+    a.acc = d->d_try_acc;
+    HIP_TRY(d, adsb::launch_count_tries(a, d->stream)); // enqueued and forgotten: read_tries() collects
     d->prof.tries += n_tries;
-    d->n_carry = final ? 0 : d->h_try_out[3];
     d->carry_cur ^= 1;
+    d->carry_n_cur = c_out;
+    d->carry_maybe = !final;
+    d->tries_unread = true;
+    d->acc_dirty = true;
+    return 0;
+}
+
+// The statistics are asked for: wait for the count passes and take the device's totals.
+int read_tries(adsb_decoder *d)
+{
+    if (!d->tries_unread)
+        return 0;
+    unsigned long long acc[4];
+    HIP_TRY(d, hipMemcpyAsync(acc, d->d_try_acc, sizeof acc, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    d->tries_unread = false;
+    if (acc[3])
+        return d->fail("undecided tries exceeded the carry buffer (%u entries)", kCarryCap);
+    d->res.set_tries(acc[0], acc[1], acc[2]);
     return 0;
 }
 
@@ -675,7 +695,16 @@ int slot_collect(adsb_decoder *d)
     }
     const auto t_wait = clk::now();
     for (int attempt = 0;; attempt++) {
-        HIP_TRY(d, hipEventSynchronize(s.ev_ready[s.ev_cur]));
+        if (s.streaming && !partial) {
+            // every tile has been consumed: the kernel is ending and its report is microseconds
+            // away -- poll for it instead of going to sleep in hipEventSynchronize
+            hipError_t q;
+            while ((q = hipEventQuery(s.ev_ready[s.ev_cur])) == hipErrorNotReady)
+                __builtin_ia32_pause();
+            HIP_TRY(d, q);
+        } else {
+            HIP_TRY(d, hipEventSynchronize(s.ev_ready[s.ev_cur]));
+        }
         s.prof_pending[s.ev_cur] = d->cfg.profile != 0;
         if (slot_settle_profile(d, s, s.ev_cur))
             return -1;
@@ -989,9 +1018,12 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         for (int i = 0; i < 2; i++)
             if ((e = hipMalloc(&d->d_carry[i], (size_t)kCarryCap * sizeof(uint64_t))) != hipSuccess)
                 return bail("hipMalloc(try carry)", e);
-        if ((e = hipMalloc(&d->d_try_out, 4 * sizeof(uint32_t))) != hipSuccess ||
-            (e = hipHostMalloc(&d->h_try_out, 4 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+        // one allocation, so that adsb_reset clears both with one fill: 4 accumulators + 3 (4) carry counts
+        if ((e = hipMalloc(&d->d_try_acc, kTryStateBytes)) != hipSuccess ||
+            (e = hipMemset(d->d_try_acc, 0, kTryStateBytes)) != hipSuccess ||
+            (e = hipEventCreate(&d->ev_frames[0])) != hipSuccess || (e = hipEventCreate(&d->ev_frames[1])) != hipSuccess)
             return bail("hipMalloc(try counters)", e);
+        d->d_carry_n = reinterpret_cast<uint32_t *>(d->d_try_acc + 4);
         d->res.log_accepted(true);
     }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1014,12 +1046,12 @@ void adsb_destroy(adsb_decoder *d)
     if (d->d_fix) (void)hipFree(d->d_fix);
     for (int i = 0; i < 2; i++)
         if (d->d_carry[i]) (void)hipFree(d->d_carry[i]);
-    if (d->d_frames_g) (void)hipFree(d->d_frames_g);
-    if (d->d_frames_span) (void)hipFree(d->d_frames_span);
-    if (d->h_frames_g) (void)hipHostFree(d->h_frames_g);
-    if (d->h_frames_span) (void)hipHostFree(d->h_frames_span);
-    if (d->d_try_out) (void)hipFree(d->d_try_out);
-    if (d->h_try_out) (void)hipHostFree(d->h_try_out);
+    if (d->d_frames) (void)hipFree(d->d_frames);
+    for (int b = 0; b < 2; b++) {
+        if (d->h_frames[b]) (void)hipHostFree(d->h_frames[b]);
+        if (d->ev_frames[b]) (void)hipEventDestroy(d->ev_frames[b]);
+    }
+    if (d->d_try_acc) (void)hipFree(d->d_try_acc);
     for (ScanSlot &sl : d->slots) {
         if (sl.d_counters) (void)hipFree(sl.d_counters);
         if (sl.h_counters) (void)hipHostFree(sl.h_counters);
@@ -1047,7 +1079,13 @@ int adsb_reset(adsb_decoder *d)
     d->cur = 0;
     d->res.reset();
     d->res.log_accepted(d->cfg.collect_stats != 0);
-    d->n_carry = 0;
+    if (d->acc_dirty) { // behind any count pass still queued
+        HIP_TRY(d, hipSetDevice(d->device));
+        HIP_TRY(d, hipMemsetAsync(d->d_try_acc, 0, kTryStateBytes, d->stream));
+    }
+    d->acc_dirty = false;
+    d->tries_unread = false;
+    d->carry_maybe = false;
     d->have_prev_frame = false;
     d->slot_head = 0;
     d->slot_count = 0;
@@ -1231,6 +1269,9 @@ size_t adsb_pending(const adsb_decoder *d)
 int adsb_get_stats(const adsb_decoder *d, adsb_stats *out)
 {
     if (!d || !out)
+        return -1;
+    adsb_decoder *m = const_cast<adsb_decoder *>(d); // the try counters live on the device until asked for
+    if (m->cfg.collect_stats && (hipSetDevice(m->device) != hipSuccess || read_tries(m)))
         return -1;
     *out = d->res.stats();
     return 0;

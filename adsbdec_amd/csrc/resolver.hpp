@@ -136,11 +136,11 @@ public:
     // accepted frame for the device-side visited-try count, and take the counts back.
     void log_accepted(bool on) { log_on_ = on; }
     std::vector<std::pair<uint64_t, uint32_t>> &accepted_log() { return log_; }
-    void add_tries(uint64_t df11, uint64_t df17, uint64_t df18)
+    void set_tries(uint64_t df11, uint64_t df17, uint64_t df18)
     {
-        stats_.try_[0] += df11;
-        stats_.try_[1] += df17;
-        stats_.try_[2] += df18;
+        stats_.try_[0] = df11;
+        stats_.try_[1] = df17;
+        stats_.try_[2] = df18;
     }
 
     size_t pending() const { return out_.size() - ohead_; }

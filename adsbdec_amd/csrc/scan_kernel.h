@@ -143,22 +143,29 @@ struct ScanArgs {
 // offsets): the try words of a launch stay on the device; once the host has
 // resolved which frames were accepted, every try below `hi` (the resolver's position)
 // is looked up in the sorted accepted frames -- inside (g, g+span) of one means the
-// greedy scan jumped over it -- and only three counters come back.  Tries at or
-// beyond `hi` are not decided yet and are carried to the next pass.
+// greedy scan jumped over it -- and three device-side counters accumulate.  Tries at or
+// beyond `hi` are not decided yet and are carried to the next pass.  Nothing comes back to
+// the host until statistics are asked for: a pass is enqueued and forgotten.
+struct TryFrame { // an accepted frame as the count kernel needs it (one upload per pass)
+    uint64_t g;
+    uint32_t span, pad;
+};
 struct TryCountArgs {
     const uint32_t *tries;     // this launch: (g_rel << 2) | code
     uint32_t n_tries;
     uint64_t g_base;
     const uint64_t *carry_in;  // undecided tries of earlier passes: (g << 2) | code
-    uint32_t n_carry;
-    const uint64_t *frames_g;  // accepted frames, ascending
-    const uint32_t *frames_span;
+    const uint32_t *n_carry;   // device: how many (left there by the previous pass)
+    const TryFrame *frames;    // accepted frames, ascending
     uint32_t n_frames;
     uint64_t hi;
     int final;                 // 1: end of stream -- tries >= hi are dropped (never visited)
     uint64_t *carry_out;
     uint32_t carry_cap;
-    uint32_t *out;             // [0..2] visited tries per DF code, [3] entries written to carry_out
+    uint32_t *n_carry_out;     // device, zero at launch: entries appended to carry_out (may exceed carry_cap)
+    uint32_t *n_carry_next;    // device: the count the NEXT pass will append to; this pass zeroes it
+    unsigned long long *acc;   // device: [0..2] visited tries per DF code, accumulated over the stream's passes;
+                               // [3] != 0: a carry list overflowed.  The host reads it when statistics are asked for.
 };
 hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream);
 

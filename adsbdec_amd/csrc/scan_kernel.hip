@@ -855,7 +855,10 @@ __global__ __launch_bounds__(64) void report_kernel(uint32_t *counters, uint32_t
 __global__ __launch_bounds__(256) void count_tries_kernel(const TryCountArgs a)
 {
     uint32_t cnt[3] = {0, 0, 0};
-    const uint32_t total = a.n_tries + a.n_carry;
+    const uint32_t n_carry = min(*a.n_carry, a.carry_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *a.n_carry_next = 0; // three counts in rotation: nobody reads or appends to this one during this pass
+    const uint32_t total = a.n_tries + n_carry;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         uint64_t g;
         uint32_t code;
@@ -870,9 +873,11 @@ __global__ __launch_bounds__(256) void count_tries_kernel(const TryCountArgs a)
         }
         if (g >= a.hi) { // the scan has not got there yet
             if (!a.final) {
-                const uint32_t slot = atomicAdd(&a.out[3], 1u);
+                const uint32_t slot = atomicAdd(a.n_carry_out, 1u);
                 if (slot < a.carry_cap)
                     a.carry_out[slot] = (g << 2) | code;
+                else
+                    a.acc[3] = 1; // reported when the statistics are read
             }
             continue;
         }
@@ -881,12 +886,12 @@ __global__ __launch_bounds__(256) void count_tries_kernel(const TryCountArgs a)
         uint32_t lo = 0, hi = a.n_frames;
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (a.frames_g[mid] < g)
+            if (a.frames[mid].g < g)
                 lo = mid + 1;
             else
                 hi = mid;
         }
-        const bool shadowed = lo > 0 && g < a.frames_g[lo - 1] + a.frames_span[lo - 1];
+        const bool shadowed = lo > 0 && g < a.frames[lo - 1].g + a.frames[lo - 1].span;
         if (!shadowed)
             cnt[code < 3 ? code : 2]++;
     }
@@ -905,15 +910,14 @@ __global__ __launch_bounds__(256) void count_tries_kernel(const TryCountArgs a)
     }
     __syncthreads();
     if (threadIdx.x < 3 && part[threadIdx.x])
-        atomicAdd(&a.out[threadIdx.x], part[threadIdx.x]);
+        atomicAdd(&a.acc[threadIdx.x], (unsigned long long)part[threadIdx.x]);
 }
 
 hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream)
 {
-    const uint32_t total = args.n_tries + args.n_carry;
-    if (total == 0)
-        return hipSuccess;
-    const unsigned blocks = (unsigned)std::min<uint32_t>((total + 255u) / 256u, 512u);
+    // the carry count lives on the device: a fixed grid, grid-stride over whatever there is
+    const uint32_t guess = args.n_tries + 65536u;
+    const unsigned blocks = (unsigned)std::min<uint32_t>((guess + 255u) / 256u, 2048u);
     hipLaunchKernelGGL(count_tries_kernel, dim3(blocks), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
