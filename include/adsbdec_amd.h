@@ -147,7 +147,8 @@ long adsb_take(adsb_decoder *d, const adsb_frame **frames);
 /* Number of frames currently waiting in the handle. */
 size_t adsb_pending(const adsb_decoder *d);
 
-/* print_stats() counters (valid.c:84-100); needs collect_stats=1 for try_. */
+/* print_stats() counters (valid.c:84-100); needs collect_stats=1 for try_, which are counted
+ * on the device and fetched by this call (it waits for the count passes still queued). */
 int adsb_get_stats(const adsb_decoder *d, adsb_stats *out);
 int adsb_get_profile(const adsb_decoder *d, adsb_profile *out);
 
