@@ -347,8 +347,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     // Input: the 34 pairs (6 of pre-halo + 28) a run needs are 17 TYPED buffer loads of 8
     // bytes per lane (buffer_load_format_xyzw, data format 16_16_16_16, number format
     // USCALED): the load path itself converts the four uint16 to four floats -- exactly, and
-    // for free next to 66 v_cvt_f32_u32 per run (4.4 cycles each; kernel -4.5 % with the chip
-    // cool, -2 % throttled).  Lanes are 112 bytes apart; the buffer resource is rebuilt per
+    // for free next to 66 v_cvt_f32_u32 per run (4.4 cycles each; kernel -2 .. -4.5 %).  Lanes are 112 bytes apart; the buffer resource is rebuilt per
     // wave and pass around the wave's own 7 KiB window, so no buffer size limit applies.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));

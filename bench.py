@@ -87,8 +87,11 @@ def make_workload(torch, n_samples: int, n_frames: int | None = None, seed: int 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preroll-ms", type=float, default=60.0,
+                    help="run the step untimed for this long before the warm-up steps: the GPU's clock governor "
+                         "needs ~20 ms of load to settle (tools/kernel_time_course.py); 0 = off")
     ap.add_argument("--samples", type=int, default=256 << 20, help="input samples per GPU per step")
     ap.add_argument("--dense", action="store_true", help="configs[2]: wide-band noise, ~7%% preamble hits")
     ap.add_argument("--stats", action="store_true", help="also reproduce valid.c's Try counters (collect_stats=1)")
@@ -145,6 +148,14 @@ def main():
         dec.push_device_final(xptr, xn)  # == push_device + finish, in one pass
         return dec.take_raw()  # adsb_take: the frames where the library queued them; converted after timing
 
+    # Clock pre-roll (disclosed in the JSON line): on MI355X the first ~40 steps after an idle
+    # period run 15 % slower than the steady state while the clock governor settles -- 185 us
+    # per kernel against 159 us from ~20 ms of continuous load on (tools/kernel_time_course.py).
+    # A service decoding captures back to back lives in the steady state, so that is what the
+    # warm-up + timed steps below measure, whatever K and W the caller picked.
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+        step()
     for _ in range(args.warmup):
         raw = step()
 
@@ -186,7 +197,7 @@ def main():
     avg_ms = ms_big / n_big if n_big else 0.0
     achieved = 4.0 * big_off / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_v11_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r1_v12_pmc.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
@@ -227,7 +238,7 @@ def main():
         line = {
             "metric": "Msamples/s demodulated (20MSPS uint16 real), whole job",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "warmup": args.warmup, "preroll_ms": args.preroll_ms, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "samples_per_gpu": n, "frames_decoded_rank0": len(frames),

@@ -29,7 +29,7 @@ big = max(grid)  # dominant launch = the largest grid
 for r in rows_all:
     if int(r["Grid_Size"]) == big:
         vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"what": "rocprofv3 --pmc passes over `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline` (MI355X, ROCm 7.2), "
+out = {"what": "rocprofv3 --pmc passes over `python3 bench.py --steps 5 --warmup 1 --preroll-ms 0 --no-cpu-baseline` (MI355X, ROCm 7.2), "
                "adsb::scan_kernel dispatches of the dominant launch size only; one pass per counter group as "
                "MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE cannot share a pass)",
        "grid_size": big, "counters": {}}
