@@ -7,7 +7,7 @@ from adsbdec_amd import capi
 from bench import make_workload
 torch.cuda.set_device(0)
 n = (256 << 20); n -= n % 28
-x, _ = make_workload(torch, n, seed=1)
+x, _ = make_workload(torch, n, seed=1, n_frames=int(os.environ["KTC_FRAMES"]) if "KTC_FRAMES" in os.environ else None)
 torch.cuda.synchronize()
 dec = capi.Decoder(profile=True)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
