@@ -13,10 +13,14 @@ over every preamble offset, record gather, greedy resolution, end-of-file rule)
 DF11), sigma = 8 noise.  With N > 1 every rank decodes its own independent stream
 of that size (configs[3]); no data-path collective exists, so scaling is "weak".
 
+Before the W warm-up steps the step is run untimed for --preroll-ms (default 60 ms, in
+the JSON line as `preroll_ms`): the GPU's clock governor needs ~20 ms of load to settle,
+and a service decoding captures back to back lives in that steady state.
+
 Rank 0 prints ONE JSON line.  `value` is whole-job Msamples/s.  `roofline` prices
 the scan kernel against HBM (algorithmic traffic = 2 B per input sample = 4 B per
-preamble offset; kernel time from HIP events recorded inside the library on the
-stream it launches on).  `cpu_baseline` is the oracle (C restatement of the
+preamble offset; kernel time = latest tile end - earliest tile start on the device's
+own clock, taken inside the kernel over the timed steps: within 1 % of rocprofv3).  `cpu_baseline` is the oracle (C restatement of the
 reference path, 1 thread) timed on this host on the same capture; it also gates
 the run: every frame the GPU path returned must equal the oracle's.
 """
