@@ -7,14 +7,16 @@
  * HIP path against the reference's algorithm.  Nothing under adsbdec_amd/ (the
  * product) may include, link, import or execute anything in oracle/.
  *
- * Parity pinning status (see DESIGN.md "Oracle"):
- *   - demod.c / valid.c / crc.h / output.c:formatpkt  -> PINNED against the real
- *     reference objects built into oracle/_ref/ (oracle/Makefile) and against the
- *     committed fixtures in tests/golden/ minted through them.
- *   - air.c:decodeiq (fs/4 + FIR + power + accumulate/carry) -> PARITY UNPINNED:
- *     air.c needs <libairspy/airspy.h>, which this image lacks, so it cannot be
- *     built here without writing a stand-in header; the restatement below follows
- *     air.c:54-101 line by line and is checked only by known-answer/property tests.
+ * Parity pinning status (see DESIGN.md "Oracle"): PINNED, every stage, against the
+ * reference's own code EXECUTED here.  oracle/Makefile compiles air.c:29-101
+ * (fbuff/fidx, dsfilter, ampbuff/aidx, decodeiq -- the part of air.c that uses no
+ * libairspy symbol), demod.c, valid.c (+ crc.h) and output.c:formatpkt from
+ * /root/reference into oracle/_ref/; tests/test_oracle_vs_ref.py requires this
+ * restatement to agree with that chain bit for bit (power samples, frames, ts, pw,
+ * Try/Ok, AVR/MLAT/Beast bytes) over > 2000 seeded uint16 captures, and the
+ * fixtures in tests/golden/ are minted through it (oracle/make_golden.py).
+ * The 1-bit repair EXTENSION (orc_decode_fix1) has no reference counterpart and
+ * stays "parity unpinned" by nature.
  */
 #ifndef ADSB_ORACLE_H
 #define ADSB_ORACLE_H

@@ -7,15 +7,17 @@ Run in the build container (needs /root/reference for oracle/_ref):
 For every case it writes <name>.npz (the uint16 input) and <name>.json (expected
 records).  How the expectation is produced, precisely:
 
-  input x --(oracle front end, restated from air.c:54-92: NOT the reference, which
-             cannot be built here for lack of libairspy)--> power samples
-          --(REAL reference deqframe/getdf/getabyte/validShort/validLong/CrcStep/
-             formatpkt/print_stats, oracle/_ref/ref_demod)--> frames, ts, pw,
-             AVR / AVR-MLAT / Beast bytes, Try/Ok table.
+  input x (uint16 file) --> oracle/_ref/ref_adsbdec = the REAL reference code,
+      compiled from /root/reference by oracle/Makefile and executed here:
+      decodeiq + ampbuff carry (air.c:29-101) -> deqframe/getdf/getabyte (demod.c)
+      -> validShort/validLong/CrcStep/CrcEnd/print_stats (valid.c, crc.h)
+      -> formatpkt (output.c), behind a fileInput-shaped read loop (air.c:217-246)
+  --> frames, ts, pw, AVR / AVR-MLAT / Beast bytes, Try/Ok table.
 
-So the fixtures pin everything downstream of the power samples to the real
-reference and everything upstream to the restatement (DESIGN.md "Oracle").  The
-script asserts that the all-restatement oracle gives identical records.
+Nothing in a fixture comes from the restatement except `g` (the preamble's power-
+sample index, which the reference never materialises): the script asserts that the
+restatement's records equal the reference's and that g is consistent with the
+reference's ts through ts = g + 1 - sum(span - 1) (demod.c:86,99,128,134).
 The reference's own tests hold no vectors for this path; the
 public CRC known answers it cites are in crc_kat.json.
 """
@@ -53,6 +55,17 @@ def cases():
     # too short for deqframe ever to fire: no output at all
     x, _ = G.sparse_capture(81000, 5, seed=17)
     yield "too_short", "too_short", x, False
+    # frames across the first calls' T-1200 horizons: deqframe returns mid-buffer after a
+    # jump, so the carry base turns odd (air.c:94-99); length % 4 == 1
+    rng = np.random.default_rng(23)
+    frames = [(2 * (40980 * c - 1200) + d, G.make_frame(df, rng), 900.0, 0.3 * c)
+              for c, d, df in ((1, -2300, 17), (1, 2601, 11), (2, -1101, 18), (2, 1501, 17), (3, -2399, 11),
+                               (3, 201, 17), (4, -301, 18))]
+    x = G.synth(5 * 81960 + 4 * 300 + 1, frames, 6.0, 23)
+    yield "odd_carry_base_a", "odd_carry_base", x, True
+    # codes beyond 12 bits (still inside the domain where the reference's float->int is defined)
+    x = np.random.default_rng(29).integers(0, 30000, 3 * 81960 + 2, dtype=np.uint16)
+    yield "wide_codes_noise", "wide_codes_noise", x, True
 
 
 def main():
@@ -60,15 +73,20 @@ def main():
         raise SystemExit("oracle/_ref is not available (needs /root/reference)")
     os.makedirs(OUT, exist_ok=True)
     for name, input_name, x, df18 in cases():
-        a = O.power(x)
-        rf, rstats = O.ref_demod(a, df18=df18)
+        rf, rstats = O.ref_decode(x, df18=df18)
         of, ostats = O.decode(x, df18=df18)
         assert ostats == rstats, (name, ostats, rstats)
         assert [(f["ts"], f["pw"], f["frame"]) for f in of] == [(f["ts"], f["pw"], f["frame"]) for f in rf], name
+        skipped = 0
+        for r, o in zip(rf, of):   # g is the restatement's; tie it to the reference's ts
+            assert r["ts"] == o["g"] + 1 - skipped, name
+            skipped += (80 + 80 * len(r["frame"])) - 1
         rec = dict(
             name=name, input=input_name + ".npz", df18=df18, n_samples=int(x.size),
-            provenance="power samples from oracle front end; records from the real reference "
-                       "demod.c/valid.c/output.c objects (oracle/_ref/ref_demod)",
+            provenance="every record from the REAL reference chain executed on the uint16 input "
+                       "(oracle/_ref/ref_adsbdec: air.c:29-101 decodeiq, demod.c, valid.c, output.c "
+                       "formatpkt, compiled from /root/reference); g from the restatement, checked "
+                       "against the reference's ts",
             stats={k: {str(d): int(v) for d, v in rstats[k].items()} for k in rstats},
             frames=[dict(g=o["g"], ts=r["ts"], pw=r["pw"], frame=r["frame"].hex().upper(),
                          avr=r["avr"].decode(), mlat=r["mlat"].decode(), beast=r["beast"].hex().upper())

@@ -1,7 +1,8 @@
 """oracle.py -- TEST INFRASTRUCTURE ONLY.
 
 ctypes front for oracle/liboracle.so (the C restatement of the reference path) and
-for oracle/_ref/ref_demod (the real reference demod.c/valid.c/output.c objects).
+runner of oracle/_ref/ref_adsbdec / ref_power (the REAL reference code: air.c:29-101,
+demod.c, valid.c, output.c:formatpkt compiled from /root/reference, oracle/Makefile).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module; the product (adsbdec_amd/) never does.
 """
@@ -16,7 +17,11 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle.so")
-REF_DEMOD = os.path.join(HERE, "_ref", "ref_demod")
+REF_ADSBDEC = os.path.join(HERE, "_ref", "ref_adsbdec")
+REF_ADSBDEC_NATIVE = os.path.join(HERE, "_ref", "ref_adsbdec_native")
+REF_POWER = os.path.join(HERE, "_ref", "ref_power")
+# captures handed to the reference binaries go through files; /dev/shm keeps them in memory
+_TMP = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
 
 
 class OrcFrame(C.Structure):
@@ -36,7 +41,7 @@ def build(force: bool = False) -> None:
 def build_ref() -> bool:
     """Build oracle/_ref from /root/reference when that tree is present."""
     if not os.path.isdir("/root/reference"):
-        return os.path.exists(REF_DEMOD)
+        return ref_available()
     subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
     return True
 
@@ -170,21 +175,15 @@ def avr_lines(frames, outformat: int = 0) -> bytes:
 
 
 # --------------------------------------------------------------------------
-# the real reference objects (oracle/_ref), driven on a power-sample buffer
+# the REAL reference code (oracle/_ref): one process per run, because the
+# reference keeps its stream state in statics (air.c:33-34,49-50; demod.c:86;
+# valid.c:30-31)
 # --------------------------------------------------------------------------
 def ref_available() -> bool:
-    return os.path.exists(REF_DEMOD)
+    return os.path.exists(REF_ADSBDEC) and os.path.exists(REF_POWER)
 
 
-def ref_demod(a: np.ndarray, df18: bool = False):
-    """Run the REAL deqframe/validShort/validLong/formatpkt/print_stats on power
-    samples `a`.  Returns (frames, stats); frames carry ts, pw, frame and the three
-    formatpkt renderings (avr, mlat, beast)."""
-    assert a.dtype == np.float32
-    with tempfile.NamedTemporaryFile(suffix=".f32", dir="/tmp") as tf:
-        a.tofile(tf.name)
-        cmd = [REF_DEMOD] + (["-a"] if df18 else []) + [tf.name]
-        p = subprocess.run(cmd, capture_output=True, check=True)
+def _parse_ref_output(p):
     frames = []
     for line in p.stdout.decode().splitlines():
         ts, pw, ln, avr, rest = line.split(" ", 4)
@@ -199,3 +198,44 @@ def ref_demod(a: np.ndarray, df18: bool = False):
     ok = [int(v) for v in err[2].split(":")[1].split()]
     stats = {"try": {11: tr[0], 17: tr[1], 18: tr[2]}, "ok": {11: ok[0], 17: ok[1], 18: ok[2]}}
     return frames, stats
+
+
+def ref_decode(x, df18: bool = False, chunk: int | None = None, native: bool = False, path: str | None = None):
+    """The whole REAL chain on a uint16 capture: decodeiq (air.c:54-101) -> deqframe
+    (demod.c) -> validShort/Long (valid.c, crc.h) -> formatpkt (output.c), fed by a
+    fileInput-shaped read loop (1 Mi samples per decodeiq call unless `chunk`).
+    Returns (frames, stats); frames carry ts, pw, frame and the three formatpkt
+    renderings (avr, mlat, beast) -- no g: the reference does not know it.
+    native=True runs the build with the reference's own -O3 -march=native flags.
+    path: decode this file instead of writing x to a temporary one."""
+    exe = REF_ADSBDEC_NATIVE if native else REF_ADSBDEC
+    opts = (["-a"] if df18 else []) + (["-c", str(chunk)] if chunk else [])
+    if path is not None:
+        return _parse_ref_output(subprocess.run([exe] + opts + [path], capture_output=True, check=True))
+    x = _as_u16(x)
+    with tempfile.NamedTemporaryFile(suffix=".u16", dir=_TMP) as tf:
+        x.tofile(tf.name)
+        return _parse_ref_output(subprocess.run([exe] + opts + [tf.name], capture_output=True, check=True))
+
+
+def ref_power(x, chunk: int | None = None) -> np.ndarray:
+    """Power samples produced by the REAL decodeiq (air.c:54-92) for capture x: one
+    per 2 input samples, 2*ceil(n/4) of them (a ragged tail's last pair is computed
+    from whatever the read buffer held, like the reference)."""
+    x = _as_u16(x)
+    with tempfile.NamedTemporaryFile(suffix=".u16", dir=_TMP) as ti, \
+            tempfile.NamedTemporaryFile(suffix=".f32", dir=_TMP) as to:
+        x.tofile(ti.name)
+        subprocess.run([REF_POWER] + (["-c", str(chunk)] if chunk else []) + [ti.name, to.name], check=True)
+        return np.fromfile(to.name, dtype=np.float32)
+
+
+def ref_demod(a: np.ndarray, df18: bool = False):
+    """The REAL deqframe/validShort/validLong/formatpkt/print_stats on POWER samples
+    `a` (synthetic power fuzz of getdf/getabyte; the carry loop around deqframe is
+    the harness's restatement of air.c:94-99 in this mode -- pinning uses ref_decode)."""
+    assert a.dtype == np.float32
+    with tempfile.NamedTemporaryFile(suffix=".f32", dir=_TMP) as tf:
+        a.tofile(tf.name)
+        cmd = [REF_ADSBDEC] + (["-a"] if df18 else []) + ["-p", tf.name]
+        return _parse_ref_output(subprocess.run(cmd, capture_output=True, check=True))

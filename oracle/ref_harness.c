@@ -1,19 +1,26 @@
 /*
  * ref_harness.c -- TEST INFRASTRUCTURE ONLY.
  *
- * Driver around the REAL reference objects (compiled by oracle/Makefile from the
+ * Driver around the REAL reference code (compiled by oracle/Makefile from the
  * sources where they lie under /root/reference, outputs only in oracle/_ref/):
+ *     air.c:29-101 -> fbuff/fidx, dsfilter, ampbuff/aidx, decodeiq  (the slice that
+ *                 uses no libairspy symbol; see ref_chain_tail.c for how it is built)
  *     demod.c  -> deqframe/getdf/getabyte        (demod.c:31-144)
  *     valid.c  -> validShort/validLong/print_stats + crc.h   (valid.c:39-101)
  *     output.c -> formatpkt                       (output.c:204-262), linked as
  *                 _ref/libref_format.so with everything else garbage-collected.
- * air.c is NOT built (needs <libairspy/airspy.h>, absent from this image; writing a
- * stand-in header is not allowed), so this driver takes POWER samples (float32,
- * one per 10 MS/s sample) and replays air.c:94-99's accumulate/carry around the
- * real deqframe.  It implements the egress seam netout() (valid.c:26) as a
- * collector: it is the consumer of that callback, exactly like output.c's writer.
+ * What this file adds is only what stands on the OUTER side of the reference's own
+ * seams: a read loop shaped like fileInput (air.c:217-246: one reused buffer,
+ * IQBUFFSZ = 1 Mi samples per call of decodeiq) and the egress callback netout()
+ * (valid.c:26) as a collector, exactly like output.c's writer.
  *
- * usage: ref_demod [-a] power.f32   -> stdout: one line per accepted frame
+ * usage: ref_adsbdec [-a] [-c chunk_samples] capture.u16
+ *            the real chain decodeiq -> deqframe -> validShort/Long -> formatpkt
+ *        ref_adsbdec [-a] -p power.f32
+ *            POWER samples (float32, one per 10 MS/s sample) fed through a
+ *            restatement of air.c:94-99's accumulate/carry into the real deqframe:
+ *            used to fuzz getdf/getabyte on synthetic power, not for pinning
+ *   -> stdout: one line per accepted frame
  *        "<ts> <pw> <len> <avr line> <mlat line> <beast hex>"; stderr: print_stats().
  */
 #include <inttypes.h>
@@ -37,6 +44,7 @@ typedef struct ref_blk_s {
     struct ref_blk_s *next;
 } ref_blk;
 extern int formatpkt(ref_blk *blk, char *pkt);          /* output.c:204 */
+extern void ref_decodeiq(const unsigned short *r, int len); /* ref_chain_tail.c -> air.c:54 */
 
 #define APBUFFSZ (8196 * 5)                             /* air.c:47 */
 
@@ -72,20 +80,11 @@ void netout(const uint8_t *frame, const int len, const uint64_t ts, const uint32
     putchar('\n');
 }
 
-int main(int argc, char **argv)
+static int run_power(const char *path)
 {
-    int argi = 1;
-    if (argi < argc && strcmp(argv[argi], "-a") == 0) {
-        df = 1; /* main.c:76-78 */
-        argi++;
-    }
-    if (argi >= argc) {
-        fprintf(stderr, "usage: ref_demod [-a] power.f32\n");
-        return 2;
-    }
-    FILE *f = fopen(argv[argi], "rb");
+    FILE *f = fopen(path, "rb");
     if (!f) {
-        perror(argv[argi]);
+        perror(path);
         return 2;
     }
     static float ampbuff[APBUFFSZ + 4]; /* air.c:49 */
@@ -103,6 +102,49 @@ int main(int argc, char **argv)
         }
     }
     fclose(f);
+    return 0;
+}
+
+/* fileInput (air.c:217-246): read() into one reused buffer, decodeiq(iqbuff, n/2).
+ * The buffer has 4 spare samples so that a ragged last read over-reads inside the
+ * allocation (the reference reads whatever the buffer held there). */
+static int run_capture(const char *path, size_t chunk)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        perror(path);
+        return 2;
+    }
+    unsigned short *iqbuff = calloc(chunk + 4, sizeof *iqbuff);
+    size_t n;
+    while ((n = fread(iqbuff, sizeof *iqbuff, chunk, f)) > 0)
+        ref_decodeiq(iqbuff, (int)n);
+    free(iqbuff);
+    fclose(f);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    int argi = 1, power = 0;
+    size_t chunk = 1024 * 1024; /* IQBUFFSZ, air.c:218 */
+    for (; argi < argc && argv[argi][0] == '-'; argi++) {
+        if (strcmp(argv[argi], "-a") == 0)
+            df = 1; /* main.c:76-78 */
+        else if (strcmp(argv[argi], "-p") == 0)
+            power = 1;
+        else if (strcmp(argv[argi], "-c") == 0 && argi + 1 < argc)
+            chunk = strtoull(argv[++argi], NULL, 0);
+        else
+            break;
+    }
+    if (argi + 1 != argc || chunk == 0) {
+        fprintf(stderr, "usage: ref_adsbdec [-a] [-c chunk_samples] capture.u16 | [-a] -p power.f32\n");
+        return 2;
+    }
+    int rc = power ? run_power(argv[argi]) : run_capture(argv[argi], chunk);
+    if (rc)
+        return rc;
     fflush(stdout);
     print_stats();
     return 0;

@@ -1,11 +1,13 @@
 """CPU tests of the oracle itself: it must be pinned before it is trusted.
 
  - CRC table and known answers (crc.h)
- - the restatement against the REAL reference objects in oracle/_ref (skipped on
-   machines without them) on power buffers, including random ones that fuzz getdf
- - the restatement against the committed golden fixtures
- - known-answer / property tests of the front end (air.c:54-92), which is the one
-   part that cannot be pinned against the reference (air.c is unbuildable here)
+ - the restatement against the REAL reference deqframe/valid/formatpkt in oracle/_ref
+   (skipped on machines without it) on synthetic POWER buffers that fuzz getdf
+ - the restatement against the committed golden fixtures (minted through the real
+   chain, oracle/make_golden.py)
+ - known-answer / property tests of the front end (air.c:54-92)
+The pin of the whole chain on uint16 input, real decodeiq included, is
+tests/test_oracle_vs_ref.py.
 """
 import json
 import os
@@ -50,7 +52,7 @@ def test_oracle_reproduces_golden(oracle, name):
         assert oracle.formatpkt(f["frame"], f["ts"], f["pw"], 2) == bytes.fromhex(g["beast"])
 
 
-needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "ref_demod")),
+needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "ref_adsbdec")),
                                reason="oracle/_ref not built (needs /root/reference)")
 
 
