@@ -66,7 +66,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cli_src = os.path.join(CSRC, "cli", "adsbdec_amd_cli.c")
     if os.path.exists(cli_src) and (force or _newer(CLI, [cli_src, LIB] + hdrs)):
         _run(["gcc", "-O2", "-Wall", "-o", CLI, cli_src, "-I", os.path.join(ROOT, "include"),
-              "-L", LIBDIR, "-ladsbdec_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
+              "-L", LIBDIR, "-ladsbdec_amd", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 
 

@@ -39,7 +39,8 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("df18", C.c_int32), ("device", C.c_int32),
                 ("collect_stats", C.c_int32), ("profile", C.c_int32), ("debug_queue_cap", C.c_int32),
                 ("stage_samples", C.c_uint64), ("stream", C.c_void_p), ("all_candidates", C.c_int32),
-                ("fix_1bit", C.c_int32)]
+                ("fix_1bit", C.c_int32), ("debug_cand_cap", C.c_int32), ("debug_try_cap", C.c_int32),
+                ("debug_clist_cap", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -57,6 +58,10 @@ SYMBOLS = {
     "adsb_destroy": (None, [C.c_void_p]),
     "adsb_reset": (C.c_int, [C.c_void_p]),
     "adsb_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "adsb_push_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "adsb_sync": (C.c_int, [C.c_void_p]),
+    "adsb_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "adsb_host_unregister": (C.c_int, [C.c_void_p]),
     "adsb_push_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_push_device_final": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_finish": (C.c_int, [C.c_void_p]),
@@ -130,7 +135,8 @@ class Decoder:
 
     def __init__(self, df18: bool = False, device: int = -1, collect_stats: bool = False,
                  profile: bool = False, stage_samples: int = 0, stream: int | None = None,
-                 debug_queue_cap: int = 0, all_candidates: bool = False, fix_1bit: bool = False):
+                 debug_queue_cap: int = 0, all_candidates: bool = False, fix_1bit: bool = False,
+                 debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0):
         L = load()
         cfg = Config()
         L.adsb_config_default(C.byref(cfg))
@@ -143,6 +149,9 @@ class Decoder:
         cfg.debug_queue_cap = debug_queue_cap
         cfg.all_candidates = int(all_candidates)
         cfg.fix_1bit = int(fix_1bit)
+        cfg.debug_cand_cap = debug_cand_cap
+        cfg.debug_try_cap = debug_try_cap
+        cfg.debug_clist_cap = debug_clist_cap
         self._L = L
         self._fix = bool(fix_1bit)
         self._h = L.adsb_create(C.byref(cfg))
@@ -171,6 +180,18 @@ class Decoder:
         x = np.ascontiguousarray(x)
         assert x.dtype == np.uint16
         self._check(self._L.adsb_push(self._h, x.ctypes.data, x.size), "adsb_push")
+
+    def push_async(self, x):
+        """adsb_push_async: x (ndarray or (ptr, n)) stays borrowed until the next push/finish/sync returns."""
+        if isinstance(x, tuple):
+            ptr, n = x
+        else:
+            assert x.dtype == np.uint16 and x.flags["C_CONTIGUOUS"]
+            ptr, n = x.ctypes.data, x.size
+        self._check(self._L.adsb_push_async(self._h, ptr, n), "adsb_push_async")
+
+    def sync(self):
+        self._check(self._L.adsb_sync(self._h), "adsb_sync")
 
     def push_device(self, ptr: int, n: int):
         self._check(self._L.adsb_push_device(self._h, ptr, n), "adsb_push_device")
@@ -240,9 +261,13 @@ class Decoder:
             self._check(rc, "adsb_scan_shard")
             return cands, nc.value, tries[: nt.value].copy()
 
-    def decode(self, x: np.ndarray, chunk: int | None = None):
-        """Whole-buffer convenience: push (optionally in chunks), finish, drain."""
+    def decode(self, x: np.ndarray, chunk: int | None = None, mode: str = "sync"):
+        """Whole-buffer convenience: push (optionally in chunks), finish, drain.
+        mode "async": adsb_push_async from two alternating page-locked buffers, the
+        double-buffered read loop of the C host program."""
         self.reset()
+        if mode == "async":
+            return self._decode_async(x, chunk or x.size)
         if chunk is None:
             self.push(x)
         else:
@@ -250,6 +275,42 @@ class Decoder:
                 self.push(x[i:i + chunk])
         self.finish()
         return self.drain()
+
+    def _decode_async(self, x: np.ndarray, chunk: int):
+        out = []
+        with PinnedBuffers(2, max(1, min(chunk, max(1, x.size)))) as bufs:
+            for k, i in enumerate(range(0, x.size, chunk)):
+                piece = x[i:i + chunk]
+                b = bufs[k % 2][: piece.size]
+                b[:] = piece                # the previous push from this buffer was two calls ago: free again
+                self.push_async(b)
+                out += self.drain()         # frames of the previous piece
+            self.finish()
+            out += self.drain()
+        return out
+
+
+class PinnedBuffers:
+    """n page-locked uint16 buffers from adsb_host_alloc, as numpy views."""
+
+    def __init__(self, n: int, samples: int):
+        L = load()
+        self._L, self._ptrs, self.views = L, [], []
+        for _ in range(n):
+            p = L.adsb_host_alloc(2 * samples)
+            if not p:
+                raise AdsbError("adsb_host_alloc failed")
+            self._ptrs.append(p)
+            self.views.append(np.ctypeslib.as_array((C.c_uint16 * samples).from_address(p)))
+
+    def __enter__(self):
+        return self.views
+
+    def __exit__(self, *exc):
+        self.views = []
+        for p in self._ptrs:
+            self._L.adsb_host_free(p)
+        self._ptrs = []
 
 
 class Resolver:

@@ -22,13 +22,75 @@
  * The stderr statistics table has the reference's format (valid.c:84-100).
  */
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "adsbdec_amd.h"
 
-#define READ_SAMPLES (16u * 1024u * 1024u) /* 32 MiB per read(); the reference reads 2 MiB */
+/* fileInput (air.c:217-246) reads 2 MiB at a time into one buffer and decodes it before the
+ * next read().  Here a reader thread fills a ring of 32 MiB buffers from the moment the
+ * program starts -- so the file is being read while the GPU runtime initialises (~0.2 s) --
+ * and the main thread hands each filled buffer to adsb_push_async(), which overlaps the
+ * host-to-device copy of one buffer with the scan of the previous one. */
+#define BUF_SAMPLES (16u * 1024u * 1024u)
+#define RING_MAX_BYTES (1024ull * 1024ull * 1024ull)
+
+typedef struct {
+    uint16_t *buf;
+    size_t bytes; /* valid bytes once filled */
+    int filled;
+    int registered;
+} ring_slot;
+
+typedef struct {
+    int fd, nbuf, failed;
+    ring_slot *slot;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} ring;
+
+static void *reader_main(void *arg)
+{
+    ring *r = (ring *)arg;
+    const size_t cap = (size_t)BUF_SAMPLES * 2;
+    for (int k = 0;; k++) {
+        ring_slot *s = &r->slot[k % r->nbuf];
+        pthread_mutex_lock(&r->mu);
+        while (s->filled)
+            pthread_cond_wait(&r->cv, &r->mu);
+        pthread_mutex_unlock(&r->mu);
+        if (!s->buf && posix_memalign((void **)&s->buf, 4096, cap) != 0) {
+            s->buf = NULL;
+            r->failed = 1;
+        }
+        size_t got = 0;
+        while (s->buf && got < cap) { /* fill the buffer: only the last one of a file is short */
+            ssize_t n = read(r->fd, (char *)s->buf + got, cap - got);
+            if (n <= 0)
+                break;
+            got += (size_t)n;
+        }
+        pthread_mutex_lock(&r->mu);
+        s->bytes = got;
+        s->filled = 1;
+        pthread_cond_broadcast(&r->cv);
+        pthread_mutex_unlock(&r->mu);
+        if (got < cap)
+            return NULL; /* end of file (or an error: the run ends there, air.c:236-237) */
+    }
+}
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 static void usage(void)
 {
@@ -38,7 +100,8 @@ static void usage(void)
     printf("\t-m : output avrmlat format (ie : with 12Mhz timestamp)\n");
     printf("\t-b : output binary beast format\n");
     printf("\t-x : (extension) repair 1-bit CRC errors in DF17/18 frames\n");
-    printf("\t-f : input from filename (raw 16 bits real, 12-bit ADC code centred on 2048)\n");
+    printf("\t-f : input from filename (raw 16 bits real: uint16 carrying the 12-bit ADC code centred on 2048;\n");
+    printf("\t     bit-identical to adsbdec for codes 0..4095, see adsbdec_amd.h for the wider domain)\n");
 }
 
 static int flush_frames(adsb_decoder *dec, int outformat)
@@ -88,6 +151,30 @@ int main(int argc, char **argv)
         return 1;
     }
 
+    const int timing = getenv("ADSB_CLI_TIMING") != NULL;
+    const int use_register = !(getenv("ADSB_CLI_REGISTER") && atoi(getenv("ADSB_CLI_REGISTER")) == 0);
+    const double t_start = now_ms();
+
+    /* start reading before anything touches the GPU */
+    ring rg;
+    memset(&rg, 0, sizeof rg);
+    pthread_t reader;
+    int have_reader = 0;
+    rg.fd = open(filename, O_RDONLY);
+    if (rg.fd >= 0) { /* an unopenable file ends the run silently (air.c:225-228) */
+        struct stat sb;
+        unsigned long long size = (fstat(rg.fd, &sb) == 0 && sb.st_size > 0) ? (unsigned long long)sb.st_size : 0;
+        if (size > RING_MAX_BYTES || size == 0)
+            size = RING_MAX_BYTES; /* pipes and huge files: a bounded ring, the reader waits for free buffers */
+        rg.nbuf = (int)(size / ((unsigned long long)BUF_SAMPLES * 2)) + 2;
+        if (rg.nbuf < 3)
+            rg.nbuf = 3;
+        rg.slot = (ring_slot *)calloc((size_t)rg.nbuf, sizeof *rg.slot);
+        pthread_mutex_init(&rg.mu, NULL);
+        pthread_cond_init(&rg.cv, NULL);
+        have_reader = rg.slot && pthread_create(&reader, NULL, reader_main, &rg) == 0;
+    }
+
     adsb_config cfg;
     adsb_config_default(&cfg);
     cfg.df18 = df18;
@@ -98,43 +185,72 @@ int main(int argc, char **argv)
         fprintf(stderr, "adsb_create() failed: %s\n", adsb_last_error(NULL));
         return 255; /* runOutput() == -1 -> exit status 255 (main.c:101-105) */
     }
+    const double t_init = now_ms();
+    double t_reg = 0;
 
     int rc = 0;
-    int fd = open(filename, O_RDONLY);
-    if (fd >= 0) { /* an unopenable file ends the run silently (air.c:225-228) */
-        /* page-locked, so that adsb_push() is one DMA (air.c:230 uses malloc) */
-        uint16_t *buf = (uint16_t *)adsb_host_alloc((size_t)READ_SAMPLES * sizeof(uint16_t));
-        if (!buf) {
-            fprintf(stderr, "adsb_host_alloc() failed\n");
-            adsb_destroy(dec);
-            return 255;
-        }
-        size_t have = 0; /* bytes carried when read() returns an odd count */
-        for (;;) {
-            ssize_t n = read(fd, (char *)buf + have, (size_t)READ_SAMPLES * 2 - have);
-            if (n <= 0)
-                break;
-            size_t bytes = have + (size_t)n;
-            if (adsb_push(dec, buf, bytes / 2) != 0) {
-                fprintf(stderr, "adsb_push() failed: %s\n", adsb_last_error(dec));
+    if (have_reader) {
+        int prev = -1;
+        for (int k = 0;; k++) {
+            ring_slot *s = &rg.slot[k % rg.nbuf];
+            pthread_mutex_lock(&rg.mu);
+            while (!s->filled)
+                pthread_cond_wait(&rg.cv, &rg.mu);
+            pthread_mutex_unlock(&rg.mu);
+            if (rg.failed) {
+                fprintf(stderr, "out of memory for the read buffers\n");
                 rc = 255;
                 break;
             }
-            have = bytes & 1;
-            if (have)
-                ((char *)buf)[0] = ((char *)buf)[bytes - 1];
-            if (flush_frames(dec, outformat) != 0)
-                break;
+            const size_t bytes = s->bytes;
+            if (bytes >= 2) {
+                if (use_register && !s->registered) { /* page-lock it: the push is then a direct DMA */
+                    const double t0 = now_ms();
+                    s->registered = adsb_host_register(s->buf, (size_t)BUF_SAMPLES * 2) == 0;
+                    t_reg += now_ms() - t0;
+                }
+                /* a trailing odd byte is dropped, like decodeiq(iqbuff, n / 2) (air.c:239) */
+                const int prc = s->registered ? adsb_push_async(dec, s->buf, bytes / 2) : adsb_push(dec, s->buf, bytes / 2);
+                if (prc != 0) {
+                    fprintf(stderr, "adsb_push() failed: %s\n", adsb_last_error(dec));
+                    rc = 255;
+                    break;
+                }
+                if (flush_frames(dec, outformat) != 0)
+                    break;
+            }
+            if (prev >= 0) { /* the buffer of the previous push is free again (adsb_push_async's contract) */
+                pthread_mutex_lock(&rg.mu);
+                rg.slot[prev].filled = 0;
+                pthread_cond_broadcast(&rg.cv);
+                pthread_mutex_unlock(&rg.mu);
+            }
+            prev = k % rg.nbuf;
+            if (bytes < (size_t)BUF_SAMPLES * 2)
+                break; /* that was the last buffer */
         }
-        adsb_host_free(buf);
-        close(fd);
         if (rc == 0 && adsb_finish(dec) != 0) {
             fprintf(stderr, "adsb_finish() failed: %s\n", adsb_last_error(dec));
             rc = 255;
         }
         flush_frames(dec, outformat);
         fflush(stdout);
+        if (rc != 0) { /* let the reader run out: hand every buffer back */
+            pthread_mutex_lock(&rg.mu);
+            for (int i = 0; i < rg.nbuf; i++)
+                rg.slot[i].filled = 0;
+            pthread_cond_broadcast(&rg.cv);
+            pthread_mutex_unlock(&rg.mu);
+            close(rg.fd); /* read() fails from here on */
+        }
+        pthread_join(reader, NULL);
+        if (rc == 0)
+            close(rg.fd);
     }
+    const double t_done = now_ms();
+    if (timing)
+        fprintf(stderr, "timing: runtime init %.1f ms, decode %.1f ms (of which page-locking %.1f ms), total %.1f ms\n",
+                t_init - t_start, t_done - t_init, t_reg, t_done - t_start);
 
     adsb_stats st;
     if (adsb_get_stats(dec, &st) == 0) { /* valid.c:84-100 */
@@ -146,6 +262,8 @@ int main(int argc, char **argv)
                 (unsigned long long)st.ok[1], (unsigned long long)st.ok[2]);
         fprintf(stderr, "Total :\t%10llu\n", tot); /* tot_fi is uninitialised there */
     }
-    adsb_destroy(dec);
-    return rc;
+    /* no adsb_destroy / unregister / free: the process ends here, and tearing the GPU runtime
+     * down cleanly costs tens of milliseconds that an offline decode has no use for */
+    fflush(stderr);
+    _exit(rc);
 }

@@ -73,6 +73,7 @@ struct ScanSlot {
     bool streaming = false;
     adsb::ScanArgs args{};
     bool busy = false;
+    uint64_t piece = 0; // adsb_push_async: the launch belongs to this push piece (collected one piece later)
     bool prof_pending[2] = {false, false}; // kernel time of a collected launch not read yet
 };
 
@@ -151,6 +152,10 @@ struct adsb_decoder {
     uint64_t prev_frame_g = 0;
     uint32_t prev_frame_span = 0;
     uint32_t launch_gen = 0;   // makes every launch's hand-off tags distinct
+    // adsb_push_async: host-to-device copies run on their own stream, one event per piece
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy = nullptr;
+    uint64_t piece = 0;        // pieces pushed asynchronously so far
 
     int fail(const char *fmt, ...)
     {
@@ -765,7 +770,15 @@ int slot_collect(adsb_decoder *d)
                 }
             pos += adsb::stream_granules(n);
         }
-        d->gather.insert(d->gather.end(), s.cands, s.cands + nc * adsb::kCandWords);
+        // The loose list may also hold records of tiles the streamed part has already
+        // delivered: after a relaunch (record buffers regrown) every tile runs again, and
+        // whether a tile's range fits the hand-off stream depends on completion order.
+        const uint64_t resume_rel = (uint64_t)adsb::kRun * adsb::tile_first_run(resume_tile, s.args.stagger, s.args.passes);
+        for (size_t i = 0; i < nc; i++) {
+            const uint32_t *w = s.cands + i * adsb::kCandWords;
+            if (w[0] >= resume_rel)
+                d->gather.insert(d->gather.end(), w, w + adsb::kCandWords);
+        }
         const size_t total = d->gather.size() / adsb::kCandWords;
         sort_order(d, d->gather.data(), total);
         deliver(d, s, d->gather.data(), d->order.data(), total, adsb::kCandWords, 0, nullptr, 0, s.args.g_end);
@@ -814,11 +827,13 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
             return -1;
         ScanSlot &s = d->slots[(d->slot_head + d->slot_count) % kSlots];
         const bool host_tries = stats && d->sink.cands; // per-shard scans return the try list
-        if (slot_reserve(d, s, std::max<size_t>(s.cand_cap, (size_t)(n_off / 128 + 32768)),
-                         host_tries ? std::max<size_t>(s.try_cap, (size_t)(n_off / 32 + 65536)) : s.try_cap))
+        // test knobs: start from buffers that are too small, so that the relaunch path runs
+        const size_t cand_want = d->cfg.debug_cand_cap > 0 ? (size_t)d->cfg.debug_cand_cap : (size_t)(n_off / 128 + 32768);
+        const size_t try_want = d->cfg.debug_try_cap > 0 ? (size_t)d->cfg.debug_try_cap : (size_t)(n_off / 32 + 65536);
+        if (slot_reserve(d, s, std::max<size_t>(s.cand_cap, cand_want),
+                         host_tries ? std::max<size_t>(s.try_cap, try_want) : s.try_cap))
             return -1;
-        if (stats && !host_tries &&
-            slot_reserve_device_tries(d, s, std::max<size_t>(s.d_try_cap, (size_t)(n_off / 32 + 65536))))
+        if (stats && !host_tries && slot_reserve_device_tries(d, s, std::max<size_t>(s.d_try_cap, try_want)))
             return -1;
         adsb::ScanArgs &a = s.args;
         a = adsb::ScanArgs{};
@@ -844,10 +859,13 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
                           ? d->cfg.debug_queue_cap
                           : adsb::kQueueCap;
         a.all_candidates = d->cfg.all_candidates ? 1 : 0;
+        a.clist_cap = (d->cfg.debug_clist_cap >= 1 && d->cfg.debug_clist_cap <= adsb::kClistCap) ? d->cfg.debug_clist_cap
+                                                                                                  : adsb::kClistCap;
         a.fix_tab = d->cfg.fix_1bit ? d->d_fix : nullptr;
         a.fix_mul = d->fix_mul;
         if (slot_launch(d, s))
             return -1;
+        s.piece = d->piece;
         d->slot_count++;
         g_begin = g_stop;
     }
@@ -855,7 +873,9 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
 }
 
 // Scan what the staged samples allow, resolve, and keep only the unscanned tail.
-int process_stage(adsb_decoder *d, bool final)
+// in_flight (adsb_push_async): the launches submitted here are left running; only those
+// of earlier pieces are collected.
+int process_stage(adsb_decoder *d, bool final, bool in_flight = false)
 {
     const uint64_t m_real = power_samples_produced(d->n_samples);
     uint64_t g_end = m_real >= ADSB_WINDOW ? m_real - ADSB_WINDOW + 1 : 0;
@@ -866,13 +886,19 @@ int process_stage(adsb_decoder *d, bool final)
             return -1;
         d->g_scanned = g_end;
     }
-    if (scan_drain(d)) // frames become drainable within the call that supplied their samples
+    if (in_flight) {
+        while (d->slot_count && d->slots[d->slot_head].piece < d->piece)
+            if (slot_collect(d))
+                return -1;
+    } else if (scan_drain(d)) { // frames become drainable within the call that supplied their samples
         return -1;
+    }
     // At EOF a trailing partial quad still makes the reference produce two (garbage)
     // power samples (air.c:59 loop bound); they can never be read by a visited
     // offset but they count for the `aidx >= APBUFFSZ` test.
     const uint64_t m_ref = final ? 2 * ((d->n_samples + 3) / 4) : m_real;
-    d->res.advance(m_ref, d->g_scanned);
+    if (!in_flight) // (in flight: the records below g_scanned are not all in yet; slot_collect advanced as far as they are)
+        d->res.advance(m_ref, d->g_scanned);
     if (final)
         return 0;
 
@@ -891,7 +917,15 @@ int process_stage(adsb_decoder *d, bool final)
     return 0;
 }
 
-int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind)
+// async (adsb_push_async): the copy of a piece goes to the copy stream and the scan stream
+// waits for it by event, so that the copy engine moves piece k+1 while piece k is scanned;
+// the launches of a piece are collected while the NEXT piece is on its way.  Why no other
+// synchronisation is needed: piece k is copied behind the unscanned tail of the staging
+// buffer that becomes current after piece k-1's tail copy, [left, left + take) -- a region
+// that the tail copy (it writes [0, left)) does not touch, that scan k-1 does not read (it
+// reads the other buffer, or this one below `left`), and whose previous reader, scan k-2,
+// was collected while piece k-1 was pushed.
+int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind, bool async = false)
 {
     const uint16_t *p = static_cast<const uint16_t *>(src);
     while (n) {
@@ -899,13 +933,19 @@ int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind)
         if (room == 0)
             return d->fail("staging buffer exhausted (stage_samples too small)");
         const size_t take = (size_t)std::min<uint64_t>(room, n);
-        HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind,
-                                  d->stream));
+        if (async) {
+            d->piece++;
+            HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind, d->copy_stream));
+            HIP_TRY(d, hipEventRecord(d->ev_copy, d->copy_stream));
+            HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_copy, 0));
+        } else {
+            HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind, d->stream));
+        }
         d->stage_fill += take;
         d->n_samples += take;
         p += take;
         n -= take;
-        if (process_stage(d, false))
+        if (process_stage(d, false, async))
             return -1;
     }
     return 0;
@@ -985,6 +1025,9 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipStreamCreate", e);
         d->own_stream = true;
     }
+    if ((e = hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&d->ev_copy, hipEventDisableTiming)) != hipSuccess)
+        return bail("hipStreamCreate(copy)", e);
     for (int i = 0; i < 2; i++)
         if ((e = hipMalloc(&d->stage[i], d->stage_cap * sizeof(uint16_t))) != hipSuccess)
             return bail("hipMalloc(stage)", e);
@@ -1037,8 +1080,12 @@ void adsb_destroy(adsb_decoder *d)
     if (!d)
         return;
     (void)hipSetDevice(d->device);
+    if (d->copy_stream)
+        (void)hipStreamSynchronize(d->copy_stream);
     if (d->stream)
         (void)hipStreamSynchronize(d->stream);
+    if (d->ev_copy) (void)hipEventDestroy(d->ev_copy);
+    if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
     for (int i = 0; i < 2; i++)
         if (d->stage[i])
             (void)hipFree(d->stage[i]);
@@ -1071,6 +1118,25 @@ int adsb_reset(adsb_decoder *d)
 {
     if (!d)
         return -1;
+    bool busy = d->slot_count != 0;
+    for (const ScanSlot &sl : d->slots)
+        busy |= sl.busy;
+    if (busy) {
+        // launches still in flight (a push failed half-way, or adsb_push_async without adsb_sync):
+        // let them end before their slots are reused -- their records are dropped with the stream
+        HIP_TRY(d, hipSetDevice(d->device));
+        HIP_TRY(d, hipStreamSynchronize(d->copy_stream));
+        HIP_TRY(d, hipStreamSynchronize(d->stream)); // the report kernel behind each scan has zeroed its counters
+        for (ScanSlot &sl : d->slots) {
+            sl.busy = false;
+            sl.prof_pending[0] = sl.prof_pending[1] = false;
+        }
+    }
+    d->final_follows = false;
+    d->deferred_tries = nullptr;
+    d->deferred_n = 0;
+    d->deferred_base = 0;
+    d->sink = ScanSink{};
     d->n_samples = 0;
     d->g_scanned = 0;
     d->finished = false;
@@ -1110,6 +1176,44 @@ int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n)
     return 0;
 }
 
+int adsb_push_async(adsb_decoder *d, const uint16_t *samples, size_t n)
+{
+    if (!d)
+        return -1;
+    if (d->finished)
+        return d->fail("adsb_push_async after adsb_finish");
+    if (n == 0)
+        return 0;
+    if (!samples)
+        return d->fail("adsb_push_async: NULL samples");
+    HIP_TRY(d, hipSetDevice(d->device));
+    return push_copy(d, samples, n, hipMemcpyHostToDevice, true);
+}
+
+int adsb_sync(adsb_decoder *d)
+{
+    if (!d)
+        return -1;
+    HIP_TRY(d, hipSetDevice(d->device));
+    if (scan_drain(d))
+        return -1;
+    if (!d->finished)
+        d->res.advance(power_samples_produced(d->n_samples), d->g_scanned);
+    HIP_TRY(d, hipStreamSynchronize(d->copy_stream));
+    HIP_TRY(d, hipStreamSynchronize(d->stream)); // tail copies: every borrowed buffer is free
+    return 0;
+}
+
+int adsb_host_register(void *p, size_t bytes)
+{
+    return (p && bytes && hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) ? 0 : -1;
+}
+
+int adsb_host_unregister(void *p)
+{
+    return (p && hipHostUnregister(p) == hipSuccess) ? 0 : -1;
+}
+
 void *adsb_host_alloc(size_t bytes)
 {
     void *p = nullptr;
@@ -1145,7 +1249,12 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
     if (!aligned || n < kInPlaceMinSamples) {
         if (n && push_copy(d, p, n, hipMemcpyDeviceToDevice))
             return -1;
-        return final ? adsb_finish(d) : 0;
+        if (final)
+            return adsb_finish(d);
+        // the staging copy may still be queued when no scan was launched behind it (and
+        // collected): the caller is free to reuse or free the buffer on return
+        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        return 0;
     }
 
     // In-place scan.  First the seam: offsets whose window starts in earlier data.

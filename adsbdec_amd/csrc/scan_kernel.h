@@ -108,6 +108,7 @@ struct ScanArgs {
     uint32_t stagger;    // the first `stagger` tiles take K-3..K passes in turn (tile_passes)
     int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
     int all_candidates;  // 1: emit every CRC-valid offset (no never-visited filter)
+    int clist_cap;       // CRC-valid candidates staged per tile: 1..kClistCap (kClistCap unless testing)
     // Streaming hand-off (hand == null: off).  `hand` is ONE stream of 16-byte granules
     // that the host reads strictly sequentially while the kernel runs.  A tile reserves
     // stream_granules(n) consecutive granules (whole 64-byte lines) with one atomicAdd on

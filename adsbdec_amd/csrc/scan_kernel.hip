@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             // {g_rel, code, columns} -- and finished below with dense lanes.
             if (stage_cands) {
                 const uint32_t ci = atomicAdd(cl_n, 1u);
-                if (ci < (uint32_t)kClistCap) {
+                if (ci < (uint32_t)args.clist_cap) {
                     uint32_t *rec = cl_rec + ci * kCandWords;
                     rec[0] = g_rel;
                     rec[1] = code | (fixed << 8);
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             // list is complete), and none does, c is unreachable.  These are the +-1/2
             // sample shifted copies of every real frame: 3 of 4 records.
             __syncthreads();
-            const int ncl = min((int)*cl_n, kClistCap); // <= kClistCap <= kThreads: one entry per thread
+            const int ncl = min((int)*cl_n, args.clist_cap); // <= kClistCap <= kThreads: one entry per thread
             const bool complete = *cl_over == 0;
             bool keep = false;
             const uint32_t *ri = cl_rec + tid * kCandWords;

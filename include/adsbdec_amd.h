@@ -15,6 +15,16 @@
  *
  * The HIP path is the only implementation behind these symbols: there is no CPU
  * fallback, and adsb_create() fails loudly when no gfx950 device is usable.
+ *
+ * Input domain.  Samples are uint16 carrying the Airspy's 12-bit ADC code centred on
+ * 2048 (air.c:64 `(float)r[i]-0x800`).  Results are bit-identical to the reference for
+ * every code in [0, 4095] and, beyond the ADC's range, for codes up to ~25 000
+ * (tested to 32 000 with |x-2048| <= ~23 000): there the preamble sums still fit an
+ * int.  Larger codes make the reference's `int p1 = float + float` (demod.c:102-105)
+ * and `2*s1` overflow -- undefined behaviour in C that happens to wrap with gcc --
+ * while this library compares the un-wrapped values; adsb_push accepts such samples
+ * but no parity is claimed for them.  Streams are limited to < 2^32
+ * samples (the reference's `fidx` wraps there).
  */
 #ifndef ADSBDEC_AMD_H
 #define ADSBDEC_AMD_H
@@ -26,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADSB_ABI_VERSION 1
+#define ADSB_ABI_VERSION 2
 
 /* Constants of the path (adsbdec.h:1-3, air.c:32,47). */
 #define ADSB_PULSEW 5
@@ -69,7 +79,8 @@ typedef struct adsb_config {
     int32_t df18;              /* demod.c:26 `df`, set by -a (main.c:76-78)        */
     int32_t device;            /* HIP device ordinal; -1 = the current device     */
     int32_t collect_stats;     /* reproduce valid.c's Try counters (costs a try list) */
-    int32_t profile;           /* time the scan kernel with HIP events on its stream */
+    int32_t profile;           /* time every scan launch on the device's own 100 MHz clock (latest tile
+                                  end - earliest tile start, taken inside the kernel): adsb_profile */
     int32_t debug_queue_cap;   /* test knob: survivor-queue entries per workgroup round (256..1024); 0 = default */
     uint64_t stage_samples;    /* device staging capacity for adsb_push(); 0 = default (32 Mi) */
     void *stream;              /* hipStream_t to launch on; NULL = a stream owned by the handle */
@@ -78,6 +89,12 @@ typedef struct adsb_config {
     int32_t fix_1bit;          /* EXTENSION, not in the reference (its -e flag does nothing):
                                   repair DF17/18 frames whose CRC residual is the syndrome of one bit
                                   in [5,112). Off by default; no reference parity exists for it. */
+    /* test knobs (0 = default): shrink the launch-wide record buffers / the per-tile staged list so
+     * that tests can force every overflow path (relaunch with regrown buffers, loose list) */
+    int32_t debug_cand_cap;    /* loose-list records per launch slot                         */
+    int32_t debug_try_cap;     /* try words per launch slot (collect_stats)                  */
+    int32_t debug_clist_cap;   /* CRC-valid candidates staged per tile (1..192)              */
+    int32_t reserved0;
 } adsb_config;
 
 /* Counters accumulate over the life of the handle (adsb_reset keeps them: a caller that
@@ -86,7 +103,7 @@ typedef struct adsb_profile {
     uint64_t launches;         /* scan-kernel launches since adsb_create            */
     uint64_t relaunches;       /* launches repeated after a record-buffer overflow  */
     uint64_t offsets;          /* preamble offsets those launches covered           */
-    double kernel_ms;          /* sum of their HIP-event durations (profile=1 only)  */
+    double kernel_ms;          /* sum of their durations on the device clock (profile=1 only) */
     double last_kernel_ms;
     uint64_t last_offsets;
     uint64_t candidates;       /* CRC-valid candidates received from the device     */
@@ -95,7 +112,7 @@ typedef struct adsb_profile {
     double wait_ms;            /* host time blocked waiting for the device          */
     uint64_t big_offsets;      /* offsets per launch of the largest launch size seen */
     uint64_t big_launches;     /* launches of that size                             */
-    double big_ms;             /* sum of their HIP-event durations (profile=1)       */
+    double big_ms;             /* sum of their durations on the device clock (profile=1) */
 } adsb_profile;
 
 void adsb_config_default(adsb_config *cfg);
@@ -115,6 +132,21 @@ int adsb_reset(adsb_decoder *d);
  * concatenation of all pushes (the reference requires n % 4 == 0). */
 int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n);
 
+/* Overlapped ingress: the same stream semantics as adsb_push, but the call
+ * returns as soon as the host-to-device copy and the scan of this chunk are ENQUEUED (copy
+ * engine and scan kernel on separate HIP streams); it then collects and resolves the scan
+ * of the PREVIOUS chunk, which has been running meanwhile.  Consequences for the caller:
+ *   - `samples` stays borrowed until the NEXT adsb_push_async / adsb_push / adsb_finish /
+ *     adsb_sync on this handle returns: alternate two buffers, like a double-buffered
+ *     read() loop (fileInput's single iqbuff, air.c:230-239, becomes two);
+ *   - frames become drainable one call later than with adsb_push (never reordered);
+ *   - the buffers should come from adsb_host_alloc() or be adsb_host_register()ed:
+ *     pageable memory works but the runtime then copies synchronously (no overlap).
+ * adsb_sync() waits for everything in flight: all frames of the samples pushed so far
+ * are drainable and every borrowed buffer is free again. */
+int adsb_push_async(adsb_decoder *d, const uint16_t *samples, size_t n);
+int adsb_sync(adsb_decoder *d);
+
 /* Same, for samples already resident in HBM (device pointer valid on cfg.device).
  * A 16-byte aligned pointer at a stream position that is a multiple of 8 samples
  * is scanned in place; anything else goes through the staging buffer. */
@@ -131,6 +163,10 @@ int adsb_push_device_final(adsb_decoder *d, const void *device_samples, size_t n
  * DMA; ordinary malloc'd memory works too, through the driver's bounce buffers. */
 void *adsb_host_alloc(size_t bytes);
 void adsb_host_free(void *p);
+/* Page-lock memory the caller already owns (e.g. buffers a reader thread filled before
+ * the GPU runtime was up) so that pushes from it are direct DMA.  0 / -1. */
+int adsb_host_register(void *p, size_t bytes);
+int adsb_host_unregister(void *p);
 
 /* End of input (fileInput's EOF, air.c:241-244): runs the remaining offsets and
  * applies the reference's end-of-file horizon. */

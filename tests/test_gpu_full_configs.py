@@ -1,0 +1,135 @@
+"""BASELINE.json's configurations at their STATED single-GPU sizes, through the C-ABI,
+bit for bit against the oracle (and, where the compiled reference travelled with the
+snapshot, against the real chain too):
+
+  configs[1]  256 Mi samples, sparse frames (~1 k frames/s)           one stream, one pass
+  configs[2]  256 Mi samples of dense noise (~7 % preamble hits), -a  statistics included
+  configs[4]  ONE 2 Gi-sample stream time-sharded 8 ways  all 8 shards on this one
+              GPU, one host resolver; 1-bit repair extension off (reference parity) and on
+
+configs[0] is tests/golden/config1_1Mi_100xDF17 (every test file uses it); configs[3]
+(8 independent streams) is configs[1] once per GPU -- bench.py --gpus N.
+These take a minute or two of CPU oracle time in all; they are ordinary `gpu` tests.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, records
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _host(t):
+    return t.cpu().numpy().view(np.uint16)
+
+
+def _ts_checksum(frames):
+    """ts == g + 1 - sum(span - 1): a checksum of the whole greedy replay (demod.c:86,99,128,134)."""
+    skipped = 0
+    for f in frames:
+        assert f["ts"] == f["g"] + 1 - skipped
+        skipped += 80 + 80 * len(f["frame"]) - 1
+
+
+def test_config1_256Mi_sparse(capi, oracle, torch_cuda):
+    from bench import make_workload
+    n = (256 << 20) - (256 << 20) % 28
+    t, truth = make_workload(torch_cuda, n, seed=1)
+    d = capi.Decoder(df18=False, collect_stats=True)
+    try:
+        d.push_device_final(t.data_ptr(), t.numel())
+        got, gstats = d.drain(), d.stats()
+        x = _host(t)
+        want, wstats = oracle.decode(x, df18=False)
+        assert records(got) == records(want)
+        assert gstats == wstats
+        assert len(got) > 12_000
+        _ts_checksum(got)
+        sent = iter(fr for _, fr in truth)       # every decoded frame is one that was sent, in order
+        assert all(any(f["frame"] == s for s in sent) for f in got)
+        if oracle.ref_available():               # the real reference chain on the same 512 MiB
+            path = "/dev/shm/adsb_cfg1.u16" if os.access("/dev/shm", os.W_OK) else "/tmp/adsb_cfg1.u16"
+            x.tofile(path)
+            try:
+                rf, rstats = oracle.ref_decode(None, False, path=path)
+            finally:
+                os.unlink(path)
+            assert [(f["ts"], f["pw"], f["frame"]) for f in got] == [(f["ts"], f["pw"], f["frame"]) for f in rf]
+            assert gstats == rstats
+        # the same capture through the overlapped host path, 1 Mi samples per call (air.c:218)
+        d2 = capi.Decoder(df18=False)
+        try:
+            assert records(d2.decode(x[: 64 << 20], chunk=1 << 20, mode="async")) == \
+                records(oracle.decode(x[: 64 << 20], df18=False)[0])
+        finally:
+            d2.close()
+    finally:
+        d.close()
+
+
+def test_config2_256Mi_dense_noise(capi, oracle, torch_cuda):
+    torch = torch_cuda
+    n = (256 << 20) - (256 << 20) % 28
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(100)
+    t = torch.clamp(torch.round(torch.randn(n, generator=gen, device="cuda") * 300.0 + 2048.0), 0, 4095).to(torch.int16)
+    d = capi.Decoder(df18=True, collect_stats=True)
+    try:
+        d.push_device_final(t.data_ptr(), t.numel())
+        got, gstats = d.drain(), d.stats()
+        want, wstats = oracle.decode(_host(t), df18=True)
+        assert records(got) == records(want)
+        assert gstats == wstats
+        assert sum(wstats["try"].values()) > 500_000      # ~0.65 % of 128 Mi offsets pass the DF gate
+        _ts_checksum(got)
+    finally:
+        d.close()
+
+
+def test_config4_2Gi_one_stream_in_8_shards(capi, oracle, torch_cuda):
+    """contiguous shards starting on multiples of 28 offsets, halo = 8 pairs
+    before + one 1196-sample window after (adsb_plan_shards), stateless per-shard scans
+    (adsb_scan_shard), candidates gathered in shard order into ONE resolver that replays
+    the sequential rules (greedy skip demod.c:128,134; ts demod.c:86,99; deqframe call
+    pattern and EOF horizon air.c:94-99).  Here all eight shards run on this GPU."""
+    from bench import make_workload
+    n = (2 << 30) - (2 << 30) % 28
+    t, _ = make_workload(torch_cuda, n, seed=9, damage_share=0.2)
+    x = _host(t)
+    for fix in (False, True):
+        want, wstats = oracle.decode(x, df18=True, fix1=fix)
+        d = capi.Decoder(df18=True, collect_stats=True, fix_1bit=fix)
+        r = capi.Resolver()
+        try:
+            for s in capi.plan_shards(x.size, 8):
+                cands, nc, tries = d.scan_shard(t.data_ptr() + 2 * s["first_sample"], s["first_sample"],
+                                                s["n_samples"], s["g_begin"], s["g_end"])
+                r.feed((cands, nc), tries)
+            m = 2 * (x.size // 4)
+            r.advance(2 * ((x.size + 3) // 4), m - 1195)
+            got = r.drain()
+            assert records(got) == records(want)
+            st = r.stats()
+            assert st["try"] == wstats["try"] and st["ok"] == wstats["ok"]
+            assert len(got) > 80_000
+            if fix:
+                assert wstats["fixed"] > 5_000 and sum(1 for _ in got) > n_plain
+            else:
+                n_plain = len(got)
+            _ts_checksum(got)
+        finally:
+            d.close()
+            r.close()

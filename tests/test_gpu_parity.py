@@ -143,16 +143,75 @@ def test_beyond_12_bit_codes_vs_oracle(oracle, dec_factory, hi):
     assert len(want) >= 30 and float((a[:-10] + a[10:]).max()) > 2.0 ** 24   # pair sums beyond 2^24
 
 
+@pytest.mark.parametrize("mode", ["sync", "async"])
 @pytest.mark.parametrize("chunk", [4, 1000, 4096, 65536 + 12, 1 << 18])
-def test_chunked_pushes_equal_one_shot(oracle, dec_factory, chunk):
-    """The stream is the concatenation of pushes (decodeiq's statics, air.c:33-34,49-50)."""
+def test_chunked_pushes_equal_one_shot(oracle, dec_factory, chunk, mode):
+    """The stream is the concatenation of pushes (decodeiq's statics, air.c:33-34,49-50),
+    with adsb_push and with the overlapped adsb_push_async (copy of chunk k+1 beside the
+    scan of chunk k, frames one call later) alike."""
     from oracle import gen_signal as G
     n = 200_000 if chunk < 1000 else 600_000
     x, _ = G.dense_capture(n, seed=5, sigma=35.0, n_frames=100)
     want, wstats = oracle.decode(x, df18=True)
     d = dec_factory(df18=True, collect_stats=True)
-    assert records(d.decode(x, chunk=chunk)) == records(want)
+    assert records(d.decode(x, chunk=chunk, mode=mode)) == records(want)
     assert d.stats() == wstats
+
+
+@pytest.mark.parametrize("stage", [0, 1 << 16])
+def test_async_pushes_reference_call_size_and_mixed_calls(capi, oracle, dec_factory, torch_cuda, stage):
+    """adsb_push_async at the reference's own call size (IQBUFFSZ = 1 Mi samples,
+    air.c:218) from two alternating page-locked buffers; then the same stream with
+    async, sync and device pushes mixed and an adsb_sync in the middle.  A small staging
+    buffer makes every push several pieces."""
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture((5 << 20) + 6, seed=61, sigma=30.0, n_frames=1200, amp=(150, 1800))
+    want, wstats = oracle.decode(x, df18=True)
+    d = dec_factory(df18=True, collect_stats=True, stage_samples=stage)
+    assert records(d.decode(x, chunk=1 << 20, mode="async")) == records(want)
+    assert d.stats() == wstats
+    t = _dev(torch_cuda, x)
+    d.reset()
+    got = []
+    with capi.PinnedBuffers(2, 1 << 20) as bufs:
+        cuts = [0, 1 << 20, (1 << 20) + 4096, 2 << 20, 3 << 20, (3 << 20) + 70_000, 4 << 20, x.size]
+        kinds = ["async", "async", "sync", "async", "device", "async", "async"]
+        for k, (a, b, kind) in enumerate(zip(cuts, cuts[1:], kinds)):
+            if kind == "device":
+                d.push_device(t.data_ptr() + 2 * a, b - a)
+            elif kind == "sync":
+                d.push(x[a:b])
+            else:
+                buf = bufs[k % 2][: b - a]
+                buf[:] = x[a:b]
+                d.push_async(buf)
+            if k == 3:
+                d.sync()
+                n_mid = d.pending()
+                assert n_mid > 0
+            got += d.drain()
+        d.finish()
+        got += d.drain()
+    assert records(got) == records(want)
+    assert d.stats() == wstats
+
+
+def test_reset_with_launches_in_flight(oracle, dec_factory, capi):
+    """adsb_reset right after adsb_push_async (scans and copies still running): the old
+    stream's records are dropped and the next stream decodes cleanly on the same slots."""
+    from oracle import gen_signal as G
+    xa, _ = G.dense_capture(3 << 20, seed=71, sigma=30.0, n_frames=700)
+    xb, _ = G.dense_capture((1 << 20) + 4, seed=72, sigma=50.0, n_frames=300)
+    want, wstats = oracle.decode(xb, df18=True)
+    d = dec_factory(df18=True, collect_stats=True)
+    with capi.PinnedBuffers(1, xa.size) as bufs:
+        bufs[0][:] = xa
+        for _ in range(3):
+            d.reset()
+            d.push_async(bufs[0])
+            d.reset()                       # launches of the push above are in flight
+            assert records(d.decode(xb)) == records(want)
+            assert d.stats() == wstats
 
 
 def test_streaming_frames_available_before_eof(oracle, dec_factory):
@@ -254,14 +313,48 @@ def test_saturated_and_dc_inputs(oracle, dec_factory):
 
 
 def test_record_buffer_overflow_is_regrown(oracle, dec_factory):
-    """Many more DF-gate passes than the initial try-list capacity: the launch is
-    repeated with larger buffers and nothing is lost."""
+    """More DF-gate passes / loose records than the (shrunken: cfg.debug_*_cap) launch
+    buffers hold: the launch is repeated with regrown buffers and nothing is lost or
+    delivered twice.  adsb_profile.relaunches proves the path ran."""
     rng = np.random.default_rng(12)
     x = rng.integers(0, 4096, 1 << 22, dtype=np.uint16)   # ~0.65 % of 2 Mi offsets pass the DF gate
     want, wstats = oracle.decode(x, df18=True)
-    d = dec_factory(df18=True, collect_stats=True)
+    assert sum(wstats["try"].values()) > 10_000
+    # (a) the device-side try list overflows (statistics run of a stream)
+    d = dec_factory(df18=True, collect_stats=True, debug_try_cap=1000)
     assert records(d.decode(x)) == records(want)
     assert d.stats() == wstats
+    assert d.profile()["relaunches"] >= 1
+    # (b) the loose list overflows: all_candidates sends every record there
+    from oracle import gen_signal as G
+    xb = _back_to_back(600, 43)
+    wb, wbstats = oracle.decode(xb, df18=True)
+    d = dec_factory(df18=True, all_candidates=True, debug_cand_cap=64)
+    assert records(d.decode(xb)) == records(wb) and len(wb) > 400
+    assert d.profile()["relaunches"] >= 1
+
+
+@pytest.mark.parametrize("clist", [1, 2, 7])
+def test_staged_list_overflow_and_partial_relaunch(oracle, dec_factory, torch_cuda, clist):
+    """cfg.debug_clist_cap shrinks the per-tile staged candidate list: tiles with more
+    CRC-valid offsets than that emit the surplus straight to the loose list (cl_over),
+    flag their marker, and the launch is finished after completion -- part streamed, part
+    gathered.  With the loose list shrunk too, the gather needs a relaunch, after which
+    records of tiles that the streamed part had already delivered must not be fed twice."""
+    x = _back_to_back(400, 47)
+    want, wstats = oracle.decode(x, df18=True)
+    assert len(want) > 300
+    t = _dev(torch_cuda, x)
+    for kw in (dict(), dict(debug_cand_cap=16), dict(collect_stats=True, debug_cand_cap=16, debug_try_cap=64)):
+        d = dec_factory(df18=True, debug_clist_cap=clist, **kw)
+        for _ in range(2):
+            d.reset()
+            d.push_device_final(t.data_ptr(), t.numel())
+            assert records(d.drain()) == records(want)
+            if kw.get("collect_stats"):
+                assert d.stats() == wstats
+        if "debug_cand_cap" in kw:
+            assert d.profile()["relaunches"] >= 1
 
 
 def test_survivor_queue_overflow_fallback(oracle, dec_factory):
@@ -312,9 +405,9 @@ def _back_to_back(n_frames, seed):
 
 
 def test_tile_region_overflow_falls_back_to_loose_list(capi, oracle, dec_factory, torch_cuda):
-    """Frames packed back to back put more finished records into one tile than its
-    64-record streaming region holds (all_candidates=1 quadruples them): the rest goes
-    to the loose list and the launch is finished after completion.  Same frames."""
+    """Frames packed back to back, all_candidates=1 (every CRC-valid offset is reported,
+    ~4 per frame, emitted outside the whole-tile round): the records travel through the
+    launch-wide loose list and the launch is finished after completion.  Same frames."""
     x = _back_to_back(1500, 41)
     want, wstats = oracle.decode(x, df18=True)
     assert len(want) > 1000
@@ -333,23 +426,118 @@ def test_tile_region_overflow_falls_back_to_loose_list(capi, oracle, dec_factory
 
 
 def test_streaming_handoff_is_stable_over_many_launches(oracle, dec_factory, torch_cuda):
-    """The host consumes tiles while the kernel runs (flags published with a system-scope
-    release); 300 back-to-back decodes of the same capture must all be identical."""
+    """The host consumes a launch's tiles WHILE the kernel runs, out of pinned memory that
+    still holds the previous launch's bytes: a tile is taken when its marker's 64-bit check
+    word matches the XOR of the record granules behind it, mixed with a per-launch `gen`
+    (scan_kernel.h; nothing orders the device's stores).  To be able to fail, the test
+    alternates DIFFERENT captures of different sizes on one handle -- the same hand-off
+    buffers are rewritten with different records at different positions every launch, so
+    a marker or a granule left over from the previous launch is a wrong record here, not
+    the same one -- and compares every record of every launch."""
     from oracle import gen_signal as G
-    x, _ = G.dense_capture(1 << 22, seed=55, sigma=30.0, n_frames=1500, amp=(150, 1800))
-    want, _ = oracle.decode(x, df18=True)
-    t = _dev(torch_cuda, x)
+    caps = []
+    for seed, n, nfr in ((55, 1 << 22, 1500), (56, (1 << 22) - 300_000, 900), (57, (1 << 21) + 4096, 1100)):
+        x, _ = G.dense_capture(n, seed=seed, sigma=30.0, n_frames=nfr, amp=(150, 1800))
+        caps.append((_dev(torch_cuda, x), records(oracle.decode(x, df18=True)[0])))
     d = dec_factory(df18=True)
-    exp = records(want)
     for it in range(300):
+        t, exp = caps[(it * 7 + it // 5) % 3]
         d.reset()
         d.push_device_final(t.data_ptr(), t.numel())
-        got = d.drain()
-        assert len(got) == len(exp), it
-        if it % 25 == 0:
-            assert records(got) == exp, it
-        else:
-            assert [f["g"] for f in got] == [e[0] for e in exp], it
+        assert records(d.drain()) == exp, it
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_without_streaming_handoff(capi, dec_factory, torch_cuda, monkeypatch, name):
+    """ADSB_NO_STREAMING=1 (read by adsb_create): every launch is collected after completion
+    from the launch-wide lists -- the fallback the streaming path drops to on overflow."""
+    monkeypatch.setenv("ADSB_NO_STREAMING", "1")
+    x, rec = load_golden(name)
+    d = dec_factory(df18=rec["df18"], collect_stats=True)
+    assert records(d.decode(x)) == golden_records(rec)
+    assert d.stats() == rec["stats"]
+    t = _dev(torch_cuda, x)
+    d.reset()
+    d.push_device_final(t.data_ptr(), t.numel())
+    assert records(d.drain()) == golden_records(rec)
+    assert d.stats() == rec["stats"]
+
+
+@pytest.mark.parametrize("seed,sigma,nfr,df18", [(111, 8.0, 80, False), (112, 300.0, 60, True)])
+def test_seeded_without_streaming_handoff(oracle, dec_factory, monkeypatch, seed, sigma, nfr, df18):
+    from oracle import gen_signal as G
+    monkeypatch.setenv("ADSB_NO_STREAMING", "1")
+    x, _ = G.dense_capture((3 << 20) + 4 * seed, seed=seed, sigma=sigma, n_frames=nfr, amp=(150, 1900))
+    want, wstats = oracle.decode(x, df18=df18)
+    d = dec_factory(df18=df18, collect_stats=True)
+    assert records(d.decode(x, chunk=1 << 20)) == records(want)
+    assert d.stats() == wstats
+    assert records(d.decode(x, chunk=1 << 20, mode="async")) == records(want)
+
+
+# ------------------------------------------------------------------ against the REAL reference, executed
+def _ref_or_skip(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref (the compiled reference) did not travel with this snapshot")
+
+
+@pytest.mark.parametrize("seed,n,sigma,nfr,df18", [(201, 1 << 20, 8.0, 100, False), (202, (1 << 21) + 6, 45.0, 500, True),
+                                                   (203, 1 << 20, 300.0, 40, True), (204, 3 * 81_960 + 3, 20.0, 60, True)])
+def test_hip_equals_real_reference_chain(capi, oracle, dec_factory, seed, n, sigma, nfr, df18):
+    """The HIP path against the reference's own code EXECUTED on this box: oracle/_ref/
+    ref_adsbdec = air.c:29-101 decodeiq + demod.c + valid.c + output.c:formatpkt, compiled
+    from /root/reference in the build container (the binary travels, the sources do not).
+    No restatement in between: ts, pw, frame bytes, Try/Ok and all three output formats."""
+    _ref_or_skip(oracle)
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture(n, seed=seed, sigma=sigma, n_frames=nfr, amp=(150, 1900))
+    rf, rstats = oracle.ref_decode(x, df18)
+    d = dec_factory(df18=df18, collect_stats=True)
+    got = d.decode(x, chunk=1 << 20)            # the reference's own call size
+    assert [(f["ts"], f["pw"], f["frame"]) for f in got] == [(f["ts"], f["pw"], f["frame"]) for f in rf]
+    assert d.stats() == rstats
+    assert len(rf) > 5
+    for f, r in zip(got, rf):
+        assert capi.format_frame(f, 0) == r["avr"]
+        assert capi.format_frame(f, 1) == r["mlat"]
+        assert capi.format_frame(f, 2) == r["beast"]
+
+
+def test_cli_equals_real_reference_chain_on_a_file(capi, oracle, tmp_path):
+    """The C host program on a file against the real chain on the same file: stdout bytes
+    (AVR, AVR-MLAT) and the stderr Try/Ok table."""
+    _ref_or_skip(oracle)
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture((40 << 20) + 2, seed=207, sigma=25.0, n_frames=4000, amp=(150, 1800))  # > 2 ring buffers
+    path = str(tmp_path / "capture.u16")
+    x.tofile(path)
+    rf, rstats = oracle.ref_decode(None, True, path=path)
+    for flag, key in (([], "avr"), (["-m"], "mlat")):
+        for env in ({}, {"ADSB_CLI_REGISTER": "0"}):
+            p = subprocess.run([capi.CLI_PATH, "-a"] + flag + ["-f", path], capture_output=True, timeout=600,
+                               env={**os.environ, **env})
+            assert p.returncode == 0, p.stderr
+            assert p.stdout == b"".join(f[key] for f in rf)
+            err = p.stderr.decode().splitlines()
+            assert [int(v) for v in err[1].split(":")[1].split()] == [rstats["try"][k] for k in (11, 17, 18)]
+            assert [int(v) for v in err[2].split(":")[1].split()] == [rstats["ok"][k] for k in (11, 17, 18)]
+
+
+def test_fuzz_30s(oracle):
+    """tools/fuzz_parity.py for 30 s: random captures x random ways of feeding them (host
+    pushes sync/async, device pushes aligned or not, one-pass final, shard scans), each
+    compared with the oracle, every 4th also oracle-vs-real-chain.  The summary line is
+    kept (gpurun_out/ -> profiles/)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import fuzz_parity
+    summary = fuzz_parity.run(30.0, seed=20_000)
+    assert summary["captures"] > 50 and summary["frames"] > 1000
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "fuzz_gpu_test_summary.json"), "w") as f:
+            json.dump(summary, f, indent=1)
 
 
 # ------------------------------------------------------------------ sharding on one device

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(capi):
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/adsbdec_amd.h but not exported"
     assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
-    assert L.adsb_abi_version() == 1
+    assert L.adsb_abi_version() == 2
 
 
 def test_struct_layouts_match_header(capi):

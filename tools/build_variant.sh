@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B builds of the library: tools/build_variant.sh <name> "<extra hipcc flags>"
+#   -> adsbdec_amd/lib_var/<name>/libadsbdec_amd.so   (load it with ADSB_LIB_PATH=...)
+cd "$(dirname "$0")/.." || exit 1
+name=$1; shift
+out=adsbdec_amd/lib_var/$name
+mkdir -p "$out"
+FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wno-unused-function $*"
+for s in scan_kernel decoder; do
+  /opt/rocm/bin/hipcc $FLAGS -c adsbdec_amd/csrc/$s.hip -o "$out/$s.o" || exit 1
+done
+gcc -O2 -fPIC -c adsbdec_amd/csrc/format.c -o "$out/format.o" || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libadsbdec_amd.so" "$out"/scan_kernel.o "$out"/decoder.o "$out"/format.o -lm || exit 1
+echo "$out/libadsbdec_amd.so"

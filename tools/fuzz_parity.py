@@ -49,13 +49,13 @@ def key(fs):
     return [(f["g"], f["ts"], f["pw"], f["frame"]) for f in fs]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=120)
-    ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+def run(seconds: float, seed: int = 1, log=print):
+    """Fuzz for `seconds`; returns a summary dict; raises AssertionError naming the seed of a mismatch.
+    Besides the oracle, every capture whose mode allows it is also compared with the REAL
+    reference chain (oracle/_ref/ref_adsbdec) when that binary is present."""
     torch.cuda.set_device(0)
     decs = {}
+    with_ref = O.ref_available()
 
     def dec(df18, stats, fix):
         k = (df18, stats, fix)
@@ -64,16 +64,25 @@ def main():
                                    stage_samples=int(1 << 17) if len(decs) % 2 else 0)
         return decs[k]
 
-    t0, it, frames_total = time.time(), 0, 0
-    seed = args.seed
-    while time.time() - t0 < args.seconds:
+    t0, it, frames_total, ref_checked = time.time(), 0, 0, 0
+    modes = [0] * 6
+    first_seed = seed
+    while time.time() - t0 < seconds:
         rng = np.random.default_rng(seed)
         x = make_capture(rng)
         df18, stats, fix = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
         want, wstats = O.decode(x, df18=df18, fix1=fix)
+        if with_ref and not fix and seed % 4 == 0:   # the restatement itself against the real chain, on this capture
+            rf, rstats = O.ref_decode(x, df18)
+            assert [(f["ts"], f["pw"], f["frame"]) for f in rf] == [(f["ts"], f["pw"], f["frame"]) for f in want], \
+                f"oracle != real reference chain, seed={seed}"
+            assert rstats == {k: wstats[k] for k in ("try", "ok")}, f"oracle stats != real reference chain, seed={seed}"
+            ref_checked += 1
         d = dec(df18, stats, fix)
-        mode = int(rng.integers(0, 5))
+        mode = int(rng.integers(0, 6))
+        modes[mode] += 1
         d.reset()
+        what = f"seed={seed} mode={mode} n={x.size} df18={df18} stats={stats} fix={fix}"
         if mode == 0:      # host pushes, random chunking
             pos = 0
             while pos < x.size:
@@ -81,6 +90,9 @@ def main():
                 d.push(x[pos:pos + c])
                 pos += c
             d.finish()
+            got = d.drain()
+        elif mode == 5:    # overlapped host pushes (adsb_push_async), random chunking, frames drained as they come
+            got = d.decode(x, chunk=int(rng.choice([1000, 4096, 65536 + 4, 1 << 18, 1 << 20, max(1, x.size)])), mode="async")
         else:
             t = torch.from_numpy(x.view(np.int16)).cuda()
             if mode == 1:
@@ -104,31 +116,49 @@ def main():
                 m = 2 * (x.size // 4)
                 r.advance(2 * ((x.size + 3) // 4), max(0, m - 1195))
                 got = r.drain()
-                ok = key(got) == key(want)
-                if stats and ok:
+                assert key(got) == key(want), "MISMATCH (shards) " + what
+                if stats:
                     st = r.stats()
-                    ok = st["try"] == wstats["try"] and st["ok"] == wstats["ok"]
-                if not ok:
-                    print(f"MISMATCH seed={seed} mode=shards n={x.size} df18={df18} stats={stats} fix={fix}")
-                    sys.exit(1)
+                    assert st["try"] == wstats["try"] and st["ok"] == wstats["ok"], "MISMATCH (shard stats) " + what
                 it += 1
                 seed += 1
                 frames_total += len(want)
                 continue
-        got = d.drain()
-        ok = key(got) == key(want)
-        if ok and stats:
-            ok = d.stats() == wstats
-        if ok and not stats and fix:
-            ok = d.stats()["fixed"] == wstats["fixed"]
-        if not ok:
-            print(f"MISMATCH seed={seed} mode={mode} n={x.size} df18={df18} stats={stats} fix={fix} "
-                  f"got={len(got)} want={len(want)}")
-            sys.exit(1)
+            got = d.drain()
+        assert key(got) == key(want), f"MISMATCH {what} got={len(got)} want={len(want)}"
+        if stats:
+            assert d.stats() == wstats, "MISMATCH (stats) " + what
+        elif fix:
+            assert d.stats()["fixed"] == wstats["fixed"], "MISMATCH (fixed) " + what
         it += 1
         seed += 1
         frames_total += len(want)
-    print(f"fuzz ok: {it} captures, {frames_total} frames, seeds {args.seed}..{seed - 1}, {time.time() - t0:.0f} s")
+    for d in decs.values():
+        d.close()
+    summary = dict(captures=it, frames=frames_total, first_seed=first_seed, last_seed=seed - 1,
+                   seconds=round(time.time() - t0, 1), mismatches=0,
+                   captures_by_mode=dict(host_push=modes[0], device_final=modes[1], device_split_aligned=modes[2],
+                                         device_split_unaligned=modes[3], shards=modes[4], host_push_async=modes[5]),
+                   also_checked_against_real_reference_chain=ref_checked)
+    log(f"fuzz ok: {summary}")
+    return summary
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default="", help="write the summary as JSON here")
+    args = ap.parse_args()
+    try:
+        summary = run(args.seconds, args.seed)
+    except AssertionError as e:
+        print(e)
+        sys.exit(1)
+    if args.out:
+        import json
+        with open(args.out, "w") as f:
+            json.dump(summary, f, indent=1)
 
 
 if __name__ == "__main__":
