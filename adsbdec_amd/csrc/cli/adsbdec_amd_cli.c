@@ -45,10 +45,12 @@ typedef struct {
     size_t bytes; /* valid bytes once filled */
     int filled;
     int registered;
+    int ready;    /* filled, and page-locked if that was asked for: the main thread may push it */
 } ring_slot;
 
 typedef struct {
-    int fd, nbuf, failed;
+    int fd, nbuf, failed, use_register;
+    double t_reg;
     ring_slot *slot;
     pthread_mutex_t mu;
     pthread_cond_t cv;
@@ -90,6 +92,32 @@ static double now_ms(void)
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+/* Started once the GPU runtime is up: page-locks the filled buffers in ring order (each one
+ * once), so that buffer k+1 is being locked while buffer k is pushed. */
+static void *locker_main(void *arg)
+{
+    ring *r = (ring *)arg;
+    for (int k = 0;; k++) {
+        ring_slot *s = &r->slot[k % r->nbuf];
+        pthread_mutex_lock(&r->mu);
+        while (!s->filled || s->ready)
+            pthread_cond_wait(&r->cv, &r->mu);
+        pthread_mutex_unlock(&r->mu);
+        const size_t bytes = s->bytes;
+        if (r->use_register && !s->registered && s->buf && bytes >= 2) {
+            const double t0 = now_ms();
+            s->registered = adsb_host_register(s->buf, (size_t)BUF_SAMPLES * 2) == 0;
+            r->t_reg += now_ms() - t0;
+        }
+        pthread_mutex_lock(&r->mu);
+        s->ready = 1;
+        pthread_cond_broadcast(&r->cv);
+        pthread_mutex_unlock(&r->mu);
+        if (bytes < (size_t)BUF_SAMPLES * 2)
+            return NULL;
+    }
 }
 
 static void usage(void)
@@ -186,15 +214,18 @@ int main(int argc, char **argv)
         return 255; /* runOutput() == -1 -> exit status 255 (main.c:101-105) */
     }
     const double t_init = now_ms();
-    double t_reg = 0;
 
     int rc = 0;
+    pthread_t locker;
+    rg.use_register = use_register;
+    if (have_reader && pthread_create(&locker, NULL, locker_main, &rg) != 0)
+        have_reader = 0;
     if (have_reader) {
         int prev = -1;
         for (int k = 0;; k++) {
             ring_slot *s = &rg.slot[k % rg.nbuf];
             pthread_mutex_lock(&rg.mu);
-            while (!s->filled)
+            while (!s->ready)
                 pthread_cond_wait(&rg.cv, &rg.mu);
             pthread_mutex_unlock(&rg.mu);
             if (rg.failed) {
@@ -204,11 +235,6 @@ int main(int argc, char **argv)
             }
             const size_t bytes = s->bytes;
             if (bytes >= 2) {
-                if (use_register && !s->registered) { /* page-lock it: the push is then a direct DMA */
-                    const double t0 = now_ms();
-                    s->registered = adsb_host_register(s->buf, (size_t)BUF_SAMPLES * 2) == 0;
-                    t_reg += now_ms() - t0;
-                }
                 /* a trailing odd byte is dropped, like decodeiq(iqbuff, n / 2) (air.c:239) */
                 const int prc = s->registered ? adsb_push_async(dec, s->buf, bytes / 2) : adsb_push(dec, s->buf, bytes / 2);
                 if (prc != 0) {
@@ -221,6 +247,7 @@ int main(int argc, char **argv)
             }
             if (prev >= 0) { /* the buffer of the previous push is free again (adsb_push_async's contract) */
                 pthread_mutex_lock(&rg.mu);
+                rg.slot[prev].ready = 0;
                 rg.slot[prev].filled = 0;
                 pthread_cond_broadcast(&rg.cv);
                 pthread_mutex_unlock(&rg.mu);
@@ -238,19 +265,21 @@ int main(int argc, char **argv)
         if (rc != 0) { /* let the reader run out: hand every buffer back */
             pthread_mutex_lock(&rg.mu);
             for (int i = 0; i < rg.nbuf; i++)
-                rg.slot[i].filled = 0;
+                rg.slot[i].ready = rg.slot[i].filled = 0;
             pthread_cond_broadcast(&rg.cv);
             pthread_mutex_unlock(&rg.mu);
             close(rg.fd); /* read() fails from here on */
         }
-        pthread_join(reader, NULL);
-        if (rc == 0)
+        if (rc == 0) { /* (after a failure the threads are left to the process exit) */
+            pthread_join(reader, NULL);
+            pthread_join(locker, NULL);
             close(rg.fd);
+        }
     }
     const double t_done = now_ms();
     if (timing)
-        fprintf(stderr, "timing: runtime init %.1f ms, decode %.1f ms (of which page-locking %.1f ms), total %.1f ms\n",
-                t_init - t_start, t_done - t_init, t_reg, t_done - t_start);
+        fprintf(stderr, "timing: runtime init %.1f ms, decode %.1f ms (page-locking, on its own thread: %.1f ms), total %.1f ms\n",
+                t_init - t_start, t_done - t_init, rg.t_reg, t_done - t_start);
 
     adsb_stats st;
     if (adsb_get_stats(dec, &st) == 0) { /* valid.c:84-100 */

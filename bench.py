@@ -427,8 +427,8 @@ def main():
     # every capture of the rotation, decoded once more and kept for the gate
     per_capture = []
     for j in range(len(ptrs)):
-        step(j)
-        per_capture.append(dec.drain())
+        pj = step(j)
+        per_capture.append(capi._frames_to_dicts(pj[0], pj[1]))
     if frames_key(per_capture[last]) != frames_key(frames):
         raise SystemExit("PARITY FAILURE: the last timed step and a repeat of the same capture differ")
 
@@ -474,8 +474,7 @@ def main():
             if not args.no_cpu_baseline:
                 from oracle import oracle as O
                 wd, _ = O.decode(xd.cpu().numpy().view(np.uint16), df18=True)
-                dstep()
-                gate(dd.drain(), wd, "dense capture vs the oracle")
+                gate(capi._frames_to_dicts(*dstep()), wd, "dense capture vs the oracle")
                 dense["parity_vs_oracle"] = True
             dd.close()
 
@@ -510,7 +509,7 @@ def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fenc
     L = capi.load()
 
     C = ctypes
-    cap = 1 << 16   # records per rank per step the gather is sized for
+    cap = (1 << 16) + me["n_samples"] // 8000   # records per rank per step the gather is sized for (~1 frame per 20 k samples)
     cand_bytes = C.sizeof(capi.Candidate)
     send = torch.zeros((cap + 1) * cand_bytes, dtype=torch.uint8)   # slot 0 carries the count
     send_arr = C.cast(send.data_ptr() + cand_bytes, C.POINTER(capi.Candidate))

@@ -173,7 +173,7 @@ def test_async_pushes_reference_call_size_and_mixed_calls(capi, oracle, dec_fact
     t = _dev(torch_cuda, x)
     d.reset()
     got = []
-    with capi.PinnedBuffers(2, 1 << 20) as bufs:
+    with capi.PinnedBuffers(2, (1 << 20) + 8) as bufs:
         cuts = [0, 1 << 20, (1 << 20) + 4096, 2 << 20, 3 << 20, (3 << 20) + 70_000, 4 << 20, x.size]
         kinds = ["async", "async", "sync", "async", "device", "async", "async"]
         for k, (a, b, kind) in enumerate(zip(cuts, cuts[1:], kinds)):

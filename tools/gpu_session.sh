@@ -29,7 +29,7 @@ x.tofile('/tmp/cap512.u16')
 PY
   for i in 1 2 3; do
     for reg in 1 0; do
-      /usr/bin/env bash -c "cat /tmp/cap512.u16 > /dev/null; s=\$(date +%s.%N); ADSB_CLI_TIMING=1 ADSB_CLI_REGISTER=$reg adsbdec_amd/lib/adsbdec_amd_cli -f /tmp/cap512.u16 > /tmp/cli.out 2> /tmp/cli.err; e=\$(date +%s.%N); echo \"cli register=$reg wall \$(echo \"\$e - \$s\" | bc) s, \$(wc -l < /tmp/cli.out) frames; \$(grep timing /tmp/cli.err)\""
+      cat /tmp/cap512.u16 > /dev/null; s=$(date +%s%N); ADSB_CLI_TIMING=1 ADSB_CLI_REGISTER=$reg adsbdec_amd/lib/adsbdec_amd_cli -f /tmp/cap512.u16 > /tmp/cli.out 2> /tmp/cli.err; e=$(date +%s%N); echo "cli register=$reg wall $(( (e - s) / 1000000 )) ms, $(wc -l < /tmp/cli.out) frames; $(grep timing /tmp/cli.err)"
     done
   done | tee $O/cli_timing.txt
 fi
