@@ -902,9 +902,13 @@ int process_stage(adsb_decoder *d, bool final, bool in_flight = false)
     if (final)
         return 0;
 
-    // keep samples from pair (g_scanned - 8) on; that index is a multiple of 8 samples
+    // Keep samples from pair (g_scanned - 8) on; that index is a multiple of 8 samples.  The
+    // scanned part is only dropped (the tail moved to the other buffer) once the buffer is
+    // half full: until then the next push is appended behind what is there and the next scan
+    // reads [tail | new] where it lies -- small pushes (the reference's 1 Mi-sample calls)
+    // then cost no device-to-device copy at all.
     const uint64_t keep_first = d->g_scanned >= 8 ? 2 * (d->g_scanned - 8) : 0;
-    if (keep_first > d->stage_first) {
+    if (keep_first > d->stage_first && d->stage_fill > (d->stage_cap - kStageSlack) / 2) {
         const uint64_t skip = keep_first - d->stage_first;
         const uint64_t left = d->stage_fill > skip ? d->stage_fill - skip : 0;
         if (left)

@@ -63,7 +63,7 @@ N_SIMD = 256 * 4       # MI355X: 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4        # peak shader clock (MI355X_MICROARCH.md)
 
 
-def _frame_plan(n_samples: int, n_frames: int | None, seed: int, df11_share: float, damage_share: float):
+def _frame_plan(n_samples: int, n_frames: int | None, seed: int, df11_share: float, damage_share: float, amp):
     """Which frames go where; every per-frame detail comes from a generator of its own slot,
     so that a slice of the stream can be synthesised without the rest."""
     rng = np.random.default_rng(seed)
@@ -75,14 +75,14 @@ def _frame_plan(n_samples: int, n_frames: int | None, seed: int, df11_share: flo
     starts = which * FRAME_GAP + rng.integers(0, FRAME_GAP - 2400, size=n_frames)
     is11 = rng.random(n_frames) < df11_share
     damaged = rng.random(n_frames) < damage_share if damage_share else np.zeros(n_frames, bool)
-    amps = rng.uniform(200.0, 1500.0, n_frames)
+    amps = rng.uniform(amp[0], amp[1], n_frames)
     phis = rng.uniform(0, 2 * np.pi, n_frames)
     return which, starts, is11, damaged, amps, phis
 
 
 def make_workload(torch, n_samples: int, n_frames: int | None = None, seed: int = 1,
                   sigma: float = 8.0, df11_share: float = 0.15, device=None, damage_share: float = 0.0,
-                  lo: int = 0, hi: int | None = None):
+                  lo: int = 0, hi: int | None = None, amp=(200.0, 1500.0)):
     """Synthetic capture built ON THE DEVICE: uint16 codes in [0,4095]
     around 2048, fs/4 carrier, PPM frames with valid CRC in ~1 ms slots, Gaussian noise.
     [lo, hi): only that slice of the n_samples-long stream is built (shard mode); the
@@ -92,7 +92,7 @@ def make_workload(torch, n_samples: int, n_frames: int | None = None, seed: int 
 
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     hi = n_samples if hi is None else hi
-    which, starts, is11, damaged, amps, phis = _frame_plan(n_samples, n_frames, seed, df11_share, damage_share)
+    which, starts, is11, damaged, amps, phis = _frame_plan(n_samples, n_frames, seed, df11_share, damage_share, amp)
     sel_all = np.nonzero((starts + 2400 > lo) & (starts < hi))[0]
     waves = np.zeros((sel_all.size, 2400), dtype=np.float32)
     truth = []
@@ -130,9 +130,9 @@ def make_workload(torch, n_samples: int, n_frames: int | None = None, seed: int 
 
 
 def make_dense(torch, n: int, seed: int):
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(seed)
-    return torch.clamp(torch.round(torch.randn(n, generator=gen, device="cuda") * 300.0 + 2048.0), 0, 4095).to(torch.int16)
+    """BASELINE configs[2]: wide-band noise (sigma = 300 around 2048: ~7 % of all offsets pass the
+    preamble test, ~0.65 % the DF gate with -a) with strong 112-bit (DF17) frames on top, one per ms."""
+    return make_workload(torch, n, seed=seed, sigma=300.0, df11_share=0.0, amp=(1200.0, 2000.0))[0]
 
 
 def frames_key(frames, with_g=True):
@@ -340,7 +340,8 @@ def main():
             host_group = dist.group.WORLD
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            host_group = dist.new_group(backend="gloo")  # host-resident candidate records: gathered on the CPU side
+            from adsbdec_amd import sharding
+            host_group = sharding.gloo_group()  # host-resident candidate records: gathered on the CPU side
     if not os.path.exists(capi.LIB_PATH):
         if rank == 0:
             _build.build()
@@ -367,7 +368,8 @@ def main():
     n -= n % 28
     if args.dense:
         xs = [make_dense(torch, n, 100 + 10 * rank + j) for j in range(2)]
-        workload = f"dense noise sigma=300, {n} uint16 samples/GPU, -a (BASELINE configs[2]); the steps rotate over 2 captures"
+        workload = (f"dense noise sigma=300 + one 112-bit frame per ms, {n} uint16 samples/GPU, -a (BASELINE configs[2]); "
+                    "the steps rotate over 2 captures")
     else:
         caps = [make_workload(torch, n, seed=1 + rank + 1000 * j) for j in range(3)]
         xs = [c[0] for c in caps]
@@ -467,7 +469,7 @@ def main():
             q1 = dd.profile()
             droof, _ = roofline_objects(q0, q1, 50, profiles_tag="r2_dense")
             dense = {"workload": f"BASELINE configs[2]: {n} samples of sigma=300 noise (~7 % of offsets pass the preamble "
-                                 "test, ~0.65 % the DF gate), -a", "steps": 50,
+                                 "test, ~0.65 % the DF gate) + one 112-bit frame per ms at amplitude 1200-2000, -a", "steps": 50,
                      "value": round(n * 50 / ddt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ddt / 50 * 1e3, 4),
                      "launch_ms": droof["launch_ms"], "roofline_frac": droof["frac"], "frames": int(draw[1]),
                      "relaunches": int(q1["relaunches"] - q0["relaunches"])}
@@ -500,52 +502,18 @@ def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fenc
     """BASELINE configs[4]: one stream, time-sharded over the ranks (see the module docstring)."""
     total = args.samples or (2 << 30)
     total -= total % 28
-    plan = capi.plan_shards(total, world)
-    me = plan[rank]
-    lo, hi = me["first_sample"], me["first_sample"] + me["n_samples"]
+    from adsbdec_amd import sharding
+    sr = sharding.ShardRank(total, df18=True, device=local_rank, group=host_group, profile=True,
+                            rank=rank if world == 1 else None, world=1 if world == 1 else None)
+    dec = sr.dec
+    lo, hi = sr.first_sample, sr.first_sample + sr.n_samples
     x, _ = make_workload(torch, total, seed=9, lo=lo, hi=hi)
     torch.cuda.synchronize()
-    dec = capi.Decoder(df18=True, device=local_rank, profile=True)
-    L = capi.load()
-
-    C = ctypes
-    cap = (1 << 16) + me["n_samples"] // 8000   # records per rank per step the gather is sized for (~1 frame per 20 k samples)
-    cand_bytes = C.sizeof(capi.Candidate)
-    send = torch.zeros((cap + 1) * cand_bytes, dtype=torch.uint8)   # slot 0 carries the count
-    send_arr = C.cast(send.data_ptr() + cand_bytes, C.POINTER(capi.Candidate))
-    recv = [torch.zeros_like(send) for _ in range(world)] if rank == 0 else None
-    nc, nt = C.c_size_t(0), C.c_size_t(0)
-    state = {"out": (capi.Frame * 1)(), "cap": 1}
-    m_real = 2 * (total // 4)
+    xptr = x.data_ptr()
 
     def step(_i=0):
-        rc = L.adsb_scan_shard(dec._h, x.data_ptr(), me["first_sample"], me["n_samples"], me["g_begin"], me["g_end"],
-                               send_arr, cap, C.byref(nc), None, 0, C.byref(nt))
-        if rc == -2:
-            raise SystemExit(f"shard produced {nc.value} candidates, more than the gather is sized for ({cap})")
-        if rc != 0:
-            raise SystemExit("adsb_scan_shard failed: " + (L.adsb_last_error(dec._h) or b"").decode())
-        C.cast(send.data_ptr(), C.POINTER(C.c_uint64))[0] = nc.value
-        if world > 1:
-            dist.gather(send, recv, dst=0, group=host_group)
-            parts = recv
-        else:
-            parts = [send]
-        if rank != 0:
-            return None
-        r = L.adsb_resolver_create()
-        n_all = 0
-        for t in parts:  # rank order == ascending g: shards are contiguous and ordered
-            k = int(C.cast(t.data_ptr(), C.POINTER(C.c_uint64))[0])
-            L.adsb_resolver_feed(r, C.cast(t.data_ptr() + cand_bytes, C.POINTER(capi.Candidate)), k, None, 0)
-            n_all += k
-        L.adsb_resolver_advance(r, 2 * ((total + 3) // 4), m_real - 1195)
-        if state["cap"] < n_all:
-            state["cap"] = n_all + n_all // 4 + 1
-            state["out"] = (capi.Frame * state["cap"])()
-        got = L.adsb_resolver_drain(r, state["out"], state["cap"])
-        L.adsb_resolver_destroy(r)
-        return state["out"], int(got)
+        got = sr.step(xptr)          # scan my shard -> gather the candidate records -> one resolver on rank 0
+        return None if got is None else (got[0], got[1])
 
     step()
     t_pre = time.perf_counter()
@@ -587,7 +555,7 @@ def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fenc
             "config": {"workload": f"BASELINE configs[4]: ONE stream of {total} uint16 samples time-sharded over {world} "
                                    "rank(s), halo 8 pairs + one 1196-sample window, candidates gathered to one resolver "
                                    "(gloo, host-resident records), -a, 1-bit repair off",
-                       "samples_total": total, "samples_rank0": me["n_samples"], "frames_decoded": len(frames),
+                       "samples_total": total, "samples_rank0": sr.n_samples, "frames_decoded": len(frames),
                        "parity": parity},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
         }

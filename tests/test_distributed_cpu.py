@@ -42,9 +42,31 @@ def _worker(rank, world, port, out_path):
     cands = [(g + off, pw, fr) for g, pw, fr in cands]
     tries = tries + np.uint64(off << 2)
     frames, stats = sharding.gather_and_resolve(cands, tries, x.size, dst=0)
+    # the tensor path of the GPU bench (ShardRank: fixed-layout adsb_candidate arrays, one gather per
+    # step), with the oracle's records standing in for adsb_scan_shard
+    sr = sharding.ShardRank(x.size, df18=True, group=sharding.gloo_group(), collect_stats=True)
+    assert (sr.g_begin, sr.g_end) == (plan["g_begin"], plan["g_end"])
+    tensor_out = None
+    for _ in range(2):                      # buffers are reused from step to step
+        sr.load_records(cands, tries)
+        got = sr.exchange()
+        if rank == 0:
+            arr, n, st = got
+            tensor_out = (capi._frames_to_dicts(arr, n), st)
+        else:
+            assert got is None
+    # error propagation: rank 1 reports a failed scan, rank 0 must raise and name it
+    if rank == 1:
+        sr._hdr[0] = sharding._ERR
+    try:
+        sr.exchange()
+        raised = None
+    except sharding.ShardError as e:
+        raised = str(e)
+    assert (raised is not None and "rank 1" in raised) if rank == 0 else raised is None
     if rank == 0:
         with open(out_path, "wb") as f:
-            pickle.dump((frames, stats), f)
+            pickle.dump((frames, stats, tensor_out), f)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,8 +75,10 @@ def test_two_rank_shard_gather_resolve(tmp_path, oracle, capi):
     from oracle import gen_signal as G
     out = str(tmp_path / "r0.pkl")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    frames, stats = pickle.load(open(out, "rb"))
+    frames, stats, tensor_out = pickle.load(open(out, "rb"))
     x, _ = G.dense_capture(1 << 19, seed=44, sigma=50.0, n_frames=150)
     want, wstats = oracle.decode(x, df18=True)
     assert records(frames) == records(want)
     assert stats == wstats
+    assert records(tensor_out[0]) == records(want)
+    assert tensor_out[1] == wstats

@@ -590,6 +590,31 @@ def test_shard_candidates_equal_oracle_exhaustive(capi, oracle, dec_factory, tor
     assert r.stats() == wstats
 
 
+def test_two_rank_sharded_stream_with_the_hip_kernel():
+    """BASELINE configs[4] plumbing with the HIP kernel in MORE THAN ONE PROCESS: two ranks
+    (both on this GPU: --one-device-test, gloo) each scan their halo'd shard of one stream
+    with adsb_scan_shard, the fixed-layout candidate arrays are gathered to rank 0 and
+    resolved once; bench.py's own gate then compares with the single-GPU decode of the
+    whole stream.  (tests/test_distributed_cpu.py covers the same exchange on CPU.)"""
+    import json
+    import socket
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--mode", "shard", "--one-device-test",
+           "--samples", str(64 << 20), "--steps", "3", "--warmup", "1", "--preroll-ms", "0"]
+    p = subprocess.run(cmd, cwd=root, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["parity"].startswith("equal to the single-GPU decode")
+    assert line["config"]["frames_decoded"] > 3000
+
+
 # ------------------------------------------------------------------ size-independent properties
 def test_round_trip_at_scale(dec_factory, torch_cuda):
     """64 Mi samples generated on the device: every injected, well-separated frame
