@@ -152,9 +152,13 @@ struct adsb_decoder {
     uint64_t prev_frame_g = 0;
     uint32_t prev_frame_span = 0;
     uint32_t launch_gen = 0;   // makes every launch's hand-off tags distinct
-    // adsb_push_async: host-to-device copies run on their own stream, one event per piece
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copy = nullptr;
+    // adsb_push_async: host-to-device copies run on streams of their own, used in turn (measured
+    // with rocprofv3 --memory-copy-trace: two copies queued on ONE stream start ~15 us apart,
+    // whatever their size -- at the reference's 2 MiB per call that is a quarter of the link;
+    // on alternating streams the next copy starts while the previous one is still running)
+    static constexpr int kCopyStreams = 2;
+    hipStream_t copy_stream[kCopyStreams] = {nullptr, nullptr};
+    hipEvent_t ev_copy[kCopyStreams] = {nullptr, nullptr};
     uint64_t piece = 0;        // pieces pushed asynchronously so far
 
     int fail(const char *fmt, ...)
@@ -939,9 +943,10 @@ int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind, bo
         const size_t take = (size_t)std::min<uint64_t>(room, n);
         if (async) {
             d->piece++;
-            HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind, d->copy_stream));
-            HIP_TRY(d, hipEventRecord(d->ev_copy, d->copy_stream));
-            HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_copy, 0));
+            const int cs = (int)(d->piece % adsb_decoder::kCopyStreams);
+            HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind, d->copy_stream[cs]));
+            HIP_TRY(d, hipEventRecord(d->ev_copy[cs], d->copy_stream[cs]));
+            HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_copy[cs], 0));
         } else {
             HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind, d->stream));
         }
@@ -951,6 +956,12 @@ int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind, bo
         n -= take;
         if (process_stage(d, false, async))
             return -1;
+        if (async && d->piece > 1) {
+            // adsb_push_async's contract: the buffer of the PREVIOUS piece is free when this call
+            // returns.  Collecting that piece's scan implies it; a piece too small to launch a
+            // scan leaves only its copy to wait for (already complete in every other case).
+            HIP_TRY(d, hipEventSynchronize(d->ev_copy[(d->piece - 1) % adsb_decoder::kCopyStreams]));
+        }
     }
     return 0;
 }
@@ -1029,9 +1040,10 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipStreamCreate", e);
         d->own_stream = true;
     }
-    if ((e = hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&d->ev_copy, hipEventDisableTiming)) != hipSuccess)
-        return bail("hipStreamCreate(copy)", e);
+    for (int i = 0; i < adsb_decoder::kCopyStreams; i++)
+        if ((e = hipStreamCreateWithFlags(&d->copy_stream[i], hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&d->ev_copy[i], hipEventDisableTiming)) != hipSuccess)
+            return bail("hipStreamCreate(copy)", e);
     for (int i = 0; i < 2; i++)
         if ((e = hipMalloc(&d->stage[i], d->stage_cap * sizeof(uint16_t))) != hipSuccess)
             return bail("hipMalloc(stage)", e);
@@ -1084,12 +1096,15 @@ void adsb_destroy(adsb_decoder *d)
     if (!d)
         return;
     (void)hipSetDevice(d->device);
-    if (d->copy_stream)
-        (void)hipStreamSynchronize(d->copy_stream);
+    for (hipStream_t cs : d->copy_stream)
+        if (cs)
+            (void)hipStreamSynchronize(cs);
     if (d->stream)
         (void)hipStreamSynchronize(d->stream);
-    if (d->ev_copy) (void)hipEventDestroy(d->ev_copy);
-    if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
+    for (int i = 0; i < adsb_decoder::kCopyStreams; i++) {
+        if (d->ev_copy[i]) (void)hipEventDestroy(d->ev_copy[i]);
+        if (d->copy_stream[i]) (void)hipStreamDestroy(d->copy_stream[i]);
+    }
     for (int i = 0; i < 2; i++)
         if (d->stage[i])
             (void)hipFree(d->stage[i]);
@@ -1129,7 +1144,8 @@ int adsb_reset(adsb_decoder *d)
         // launches still in flight (a push failed half-way, or adsb_push_async without adsb_sync):
         // let them end before their slots are reused -- their records are dropped with the stream
         HIP_TRY(d, hipSetDevice(d->device));
-        HIP_TRY(d, hipStreamSynchronize(d->copy_stream));
+        for (hipStream_t cs : d->copy_stream)
+            HIP_TRY(d, hipStreamSynchronize(cs));
         HIP_TRY(d, hipStreamSynchronize(d->stream)); // the report kernel behind each scan has zeroed its counters
         for (ScanSlot &sl : d->slots) {
             sl.busy = false;
@@ -1203,7 +1219,8 @@ int adsb_sync(adsb_decoder *d)
         return -1;
     if (!d->finished)
         d->res.advance(power_samples_produced(d->n_samples), d->g_scanned);
-    HIP_TRY(d, hipStreamSynchronize(d->copy_stream));
+    for (hipStream_t cs : d->copy_stream)
+        HIP_TRY(d, hipStreamSynchronize(cs));
     HIP_TRY(d, hipStreamSynchronize(d->stream)); // tail copies: every borrowed buffer is free
     return 0;
 }
