@@ -93,7 +93,10 @@ _lib = None
 
 
 def load():
-    """dlopen the in-tree library and bind every declared symbol. Raises if absent."""
+    """dlopen the in-tree library and bind every declared symbol. Raises if absent.
+    In a process that also uses PyTorch, import torch BEFORE calling this: torch ships its own
+    libamdhip64, and two HIP runtimes in one process do not share the device (the second one
+    reports "no ROCm-capable device")."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):

@@ -5,6 +5,9 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- BEFORE libadsbdec_amd.so is dlopen'ed: torch bundles its own libamdhip64, and a
+#                process that loads /opt/rocm's runtime first and torch's second ends up with two HIP runtimes,
+#                the second of which finds no device.  Loaded in this order the library binds to torch's copy.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -10,7 +10,7 @@ tag=$1; shift
 R=$PWD; O=$R/gpurun_out; W=/tmp/prof_$tag; mkdir -p $O $W
 export TMPDIR=/tmp
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d $W/trace -o run -- python3 $R/bench.py --no-cpu-baseline --no-extras "$@" > $O/${tag}_bench_under_rocprofv3.json 2> $W/trace.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -o run -- python3 $R/bench.py --no-cpu-baseline --no-extras "$@" > $O/${tag}_bench_under_rocprofv3.json 2> $W/trace.err
 echo "trace run exit $?"; head -c 400 $O/${tag}_bench_under_rocprofv3.json; echo
 i=0
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
@@ -18,7 +18,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
            "FETCH_SIZE GRBM_GUI_ACTIVE" \
            "WRITE_SIZE" $EXTRA_PMC_GROUPS; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $grp -d $W/pmc_g$i -o run -- python3 $R/bench.py --steps 5 --warmup 1 --preroll-ms 0 --no-cpu-baseline --no-extras "$@" > /dev/null 2> $W/pmc_g$i.err
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $W/pmc_g$i -o run -- python3 $R/bench.py --steps 5 --warmup 1 --preroll-ms 0 --no-cpu-baseline --no-extras "$@" > /dev/null 2> $W/pmc_g$i.err
   echo "pmc group $i ($grp) exit $?"
 done
 cd $R
