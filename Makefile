@@ -25,7 +25,7 @@ $(LIB): $(LIBDIR)/scan_kernel.hip.o $(LIBDIR)/decoder.hip.o $(LIBDIR)/format.c.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm
 
 $(CLI): $(CSRC)/cli/adsbdec_amd_cli.c $(LIB) include/adsbdec_amd.h
-	$(CC) -O2 -Wall -o $@ $< -Iinclude -L$(LIBDIR) -ladsbdec_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+	$(CC) -O2 -Wall -o $@ $< -Iinclude -L$(LIBDIR) -ladsbdec_amd -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 # test infrastructure (never linked into the library): the CPU oracle, and the reference
 # objects it is pinned against when /root/reference is present
