@@ -13,6 +13,9 @@ namespace adsb {
 #ifndef ADSB_FIR_GROUP
 #define ADSB_FIR_GROUP 4 // FIR outputs advanced together (independent chains interleaved)
 #endif
+#ifndef ADSB_PREHALO_DPP
+#define ADSB_PREHALO_DPP 0 // experiment: pre-halo pairs from the previous lane by DPP instead of three more loads
+#endif
 #ifndef ADSB_MIN_WAVES
 #define ADSB_MIN_WAVES 4 // __launch_bounds__ second argument (waves per SIMD)
 #endif

@@ -381,6 +381,42 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             rs.z = 64 * kRun * 4 + 64;                                                        // bytes
             rs.w = (int)(4u | 5u << 3 | 6u << 6 | 7u << 9 /* dst_sel xyzw */ | 2u << 12 /* USCALED */ | 12u << 15 /* 16_16_16_16 */);
             const int voff = lane * (kRun * 4);
+#if ADSB_PREHALO_DPP
+            // Experiment: the six pre-halo pairs (slots 0..5) are the previous lane's slots 28..33;
+            // only lane 0 (whose predecessor is another wave) loads them, the others take them by
+            // DPP after the bias step -- 14 loads and 14 x 54 tag look-ups instead of 17 x 54.
+            tl[0] = tl[1] = tl[2] = f32x4{2048.0f, 2048.0f, 2048.0f, 2048.0f};
+            if (lane == 0)
+                asm volatile("buffer_load_format_xyzw %0, %3, %4, 0 offen offset:8\n\t"
+                             "buffer_load_format_xyzw %1, %3, %4, 0 offen offset:16\n\t"
+                             "buffer_load_format_xyzw %2, %3, %4, 0 offen offset:24"
+                             : "=&v"(tl[0]), "=&v"(tl[1]), "=&v"(tl[2])
+                             : "v"(voff), "s"(rs)
+                             : "memory");
+            asm volatile("buffer_load_format_xyzw %0, %14, %15, 0 offen offset:32\n\t"
+                         "buffer_load_format_xyzw %1, %14, %15, 0 offen offset:40\n\t"
+                         "buffer_load_format_xyzw %2, %14, %15, 0 offen offset:48\n\t"
+                         "buffer_load_format_xyzw %3, %14, %15, 0 offen offset:56\n\t"
+                         "buffer_load_format_xyzw %4, %14, %15, 0 offen offset:64\n\t"
+                         "buffer_load_format_xyzw %5, %14, %15, 0 offen offset:72\n\t"
+                         "buffer_load_format_xyzw %6, %14, %15, 0 offen offset:80\n\t"
+                         "buffer_load_format_xyzw %7, %14, %15, 0 offen offset:88\n\t"
+                         "buffer_load_format_xyzw %8, %14, %15, 0 offen offset:96\n\t"
+                         "buffer_load_format_xyzw %9, %14, %15, 0 offen offset:104\n\t"
+                         "buffer_load_format_xyzw %10, %14, %15, 0 offen offset:112\n\t"
+                         "buffer_load_format_xyzw %11, %14, %15, 0 offen offset:120\n\t"
+                         "buffer_load_format_xyzw %12, %14, %15, 0 offen offset:128\n\t"
+                         "buffer_load_format_xyzw %13, %14, %15, 0 offen offset:136\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(tl[3]), "=&v"(tl[4]), "=&v"(tl[5]), "=&v"(tl[6]), "=&v"(tl[7]), "=&v"(tl[8]), "=&v"(tl[9]),
+                           "=&v"(tl[10]), "=&v"(tl[11]), "=&v"(tl[12]), "=&v"(tl[13]), "=&v"(tl[14]), "=&v"(tl[15]),
+                           "=&v"(tl[16])
+                         : "v"(voff), "s"(rs)
+                         : "memory");
+            // lane 0's three loads were issued before the block above, so its vmcnt(0) covers them;
+            // the compiler must not read tl[0..2] before this point
+            asm volatile("" : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]));
+#else
             asm volatile("buffer_load_format_xyzw %0, %17, %18, 0 offen offset:8\n\t"
                          "buffer_load_format_xyzw %1, %17, %18, 0 offen offset:16\n\t"
                          "buffer_load_format_xyzw %2, %17, %18, 0 offen offset:24\n\t"
@@ -404,6 +440,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                            "=&v"(tl[13]), "=&v"(tl[14]), "=&v"(tl[15]), "=&v"(tl[16])
                          : "v"(voff), "s"(rs)
                          : "memory");
+#endif
         } else {
             // Stream start (the ring is zero-initialised, air.c:33: a missing pair is
             // 0x0800,0x0800 -> v = 0) and the ragged end of a buffer: plain loads, converted here
@@ -439,6 +476,15 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             vv[s] = ((s & 1) == 0) ? (f - mid) : (mid - f); // slot s <-> rel pair s-6: same parity
         }
 
+#if ADSB_PREHALO_DPP
+        if (interior) {
+#pragma unroll
+            for (int sl = 0; sl < 6; sl++) { // lane 0 keeps what it loaded (no source lane: `old` stays)
+                vv[sl].x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(vv[sl].x), __float_as_int(vv[sl + 28].x), 0x138, 0xF, 0xF, false));
+                vv[sl].y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(vv[sl].y), __float_as_int(vv[sl + 28].y), 0x138, 0xF, 0xF, false));
+            }
+        }
+#endif
         // a[0..27]: this run; a[28..43]: the first 16 samples of the next run (next lane)
         float a[44];
         power_block<0, 28, ADSB_FIR_GROUP>(vv, a);
