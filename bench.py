@@ -340,8 +340,9 @@ def main():
             host_group = dist.group.WORLD
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            from adsbdec_amd import sharding
-            host_group = sharding.gloo_group()  # host-resident candidate records: gathered on the CPU side
+            if args.mode == "shard":
+                from adsbdec_amd import sharding
+                host_group = sharding.gloo_group()  # host-resident candidate records: gathered on the CPU side
     if not os.path.exists(capi.LIB_PATH):
         if rank == 0:
             _build.build()
