@@ -57,14 +57,19 @@ def run(seconds: float, seed: int = 1, log=print):
     decs = {}
     with_ref = O.ref_available()
 
-    def dec(df18, stats, fix):
-        k = (df18, stats, fix)
+    # a few handles with shrunken record buffers / staged lists (cfg.debug_*): every overflow path --
+    # relaunch with regrown buffers, loose list, partial gather -- runs inside the fuzz as well
+    tight = [dict(), dict(debug_clist_cap=2), dict(debug_cand_cap=24, debug_clist_cap=3),
+             dict(debug_cand_cap=16, debug_try_cap=128), dict(debug_queue_cap=256, debug_clist_cap=1)]
+
+    def dec(df18, stats, fix, caps=0):
+        k = (df18, stats, fix, caps)
         if k not in decs:
             decs[k] = capi.Decoder(df18=df18, collect_stats=stats, fix_1bit=fix,
-                                   stage_samples=int(1 << 17) if len(decs) % 2 else 0)
+                                   stage_samples=int(1 << 17) if len(decs) % 2 else 0, **tight[caps])
         return decs[k]
 
-    t0, it, frames_total, ref_checked = time.time(), 0, 0, 0
+    t0, it, frames_total, ref_checked, tight_runs = time.time(), 0, 0, 0, 0
     modes = [0] * 6
     first_seed = seed
     while time.time() - t0 < seconds:
@@ -78,11 +83,13 @@ def run(seconds: float, seed: int = 1, log=print):
                 f"oracle != real reference chain, seed={seed}"
             assert rstats == {k: wstats[k] for k in ("try", "ok")}, f"oracle stats != real reference chain, seed={seed}"
             ref_checked += 1
-        d = dec(df18, stats, fix)
+        caps = int(rng.integers(1, len(tight))) if rng.random() < 0.2 else 0
+        d = dec(df18, stats, fix, caps)
         mode = int(rng.integers(0, 6))
         modes[mode] += 1
         d.reset()
-        what = f"seed={seed} mode={mode} n={x.size} df18={df18} stats={stats} fix={fix}"
+        what = f"seed={seed} mode={mode} n={x.size} df18={df18} stats={stats} fix={fix} caps={tight[caps]}"
+        tight_runs += 1 if caps else 0
         if mode == 0:      # host pushes, random chunking
             pos = 0
             while pos < x.size:
@@ -133,13 +140,16 @@ def run(seconds: float, seed: int = 1, log=print):
         it += 1
         seed += 1
         frames_total += len(want)
-    for d in decs.values():
-        d.close()
+    decs_all = list(decs.values())
     summary = dict(captures=it, frames=frames_total, first_seed=first_seed, last_seed=seed - 1,
                    seconds=round(time.time() - t0, 1), mismatches=0,
                    captures_by_mode=dict(host_push=modes[0], device_final=modes[1], device_split_aligned=modes[2],
                                          device_split_unaligned=modes[3], shards=modes[4], host_push_async=modes[5]),
-                   also_checked_against_real_reference_chain=ref_checked)
+                   also_checked_against_real_reference_chain=ref_checked,
+                   with_shrunken_record_buffers=tight_runs,
+                   relaunches=sum(int(d.profile()["relaunches"]) for d in decs_all))
+    for d in decs_all:
+        d.close()
     log(f"fuzz ok: {summary}")
     return summary
 
