@@ -13,6 +13,9 @@ namespace adsb {
 #ifndef ADSB_FIR_GROUP
 #define ADSB_FIR_GROUP 4 // FIR outputs advanced together (independent chains interleaved)
 #endif
+#ifndef ADSB_SLEEP_STAGGER
+#define ADSB_SLEEP_STAGGER 90 // s_sleep units (64 cycles) between the starts of a CU's first four workgroups; 0 = off
+#endif
 #ifndef ADSB_PREHALO_DPP
 #define ADSB_PREHALO_DPP 0 // experiment: pre-halo pairs from the previous lane by DPP instead of three more loads
 #endif

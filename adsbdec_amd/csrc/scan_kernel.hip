@@ -291,6 +291,18 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     const int64_t pbuf0 = args.pbuf0, p_lo = args.p_lo, p_hi = args.p_hi;
 
     const int tid = threadIdx.x;
+#if ADSB_SLEEP_STAGGER
+    // The four workgroups that start together on a CU at the head of a large launch (blocks b, b + 256,
+    // b + 512, b + 768 with the observed round-robin placement; nothing depends on it) begin 0, 1, 2, 3 x
+    // ADSB_SLEEP_STAGGER x 64 cycles apart (2.6 us steps), so that their load phases do not coincide from
+    // the first pass on.  Measured in bench.py: -3.2 .. -4.0 % kernel time on one MI355X box, +-0.5 % on
+    // another; steps of 1.2 us did nothing, steps of 3.7 us and more were worse than 2.6.
+    if (gridDim.x >= 1024u && blockIdx.x < 1024u) {
+        const uint32_t slot = blockIdx.x >> 8;
+        for (uint32_t i = 0; i < slot; i++)
+            __builtin_amdgcn_s_sleep(ADSB_SLEEP_STAGGER);
+    }
+#endif
     // cfg.profile: the launch's duration is (latest tile end) - (earliest tile start)
     const uint64_t prof_begin = args.profile ? __builtin_amdgcn_s_memrealtime() : 0;
 #if ADSB_TILE_CLOCK
