@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     // ADSB_SLEEP_STAGGER x 64 cycles apart (2.6 us steps), so that their load phases do not coincide from
     // the first pass on.  Measured in bench.py: -3.2 .. -4.0 % kernel time on one MI355X box, +-0.5 % on
     // another; steps of 1.2 us did nothing, steps of 3.7 us and more were worse than 2.6.
-    if (gridDim.x >= 1024u && blockIdx.x < 1024u) {
+    if (gridDim.x >= 256u * ADSB_MIN_WAVES && blockIdx.x < 256u * ADSB_MIN_WAVES) {
         const uint32_t slot = blockIdx.x >> 8;
         for (uint32_t i = 0; i < slot; i++)
             __builtin_amdgcn_s_sleep(ADSB_SLEEP_STAGGER);
