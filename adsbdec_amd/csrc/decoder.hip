@@ -2,10 +2,12 @@
 // kernel launches, record gather and the C-ABI of include/adsbdec_amd.h.
 //
 // Data layout in HBM
-//   stage[2]   uint16 samples, ping-pong; holds stream samples
-//              [stage_first, stage_first+stage_fill): the unscanned tail plus the
-//              newest push.  stage_first is a multiple of 8 samples so that pair
-//              index/4 alignment and 16-byte loads line up with the stream.
+//   stage[2]   uint16 samples; the current one holds stream samples
+//              [stage_first, stage_first+stage_fill): what has not been dropped yet plus the
+//              newest push (pushes are appended; the scanned part is dropped -- the tail moved to
+//              the other buffer -- when the buffer is half full).  stage_first is a multiple of
+//              8 samples so that pair index/4 alignment and 16-byte loads line up with the stream.
+//              adsb_push_async copies into it on two copy streams of its own (push_copy).
 //   d_tries    one dword per DF-gate pass (collect_stats of a stream: counted on the device)
 //   counters   adsb::kCounterWords dwords per launch slot
 // and in pinned host memory, written by the kernel
