@@ -196,6 +196,27 @@ def test_async_pushes_reference_call_size_and_mixed_calls(capi, oracle, dec_fact
     assert d.stats() == wstats
 
 
+def test_async_pushes_from_pageable_memory(oracle, dec_factory):
+    """adsb_push_async does not require page-locked buffers (the runtime then stages the copy itself and
+    the overlap is lost, not the result): plain numpy arrays, each kept alive until the next call returned."""
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture((3 << 20) + 2, seed=81, sigma=30.0, n_frames=700, amp=(150, 1800))
+    want, wstats = oracle.decode(x, df18=True)
+    d = dec_factory(df18=True, collect_stats=True)
+    d.reset()
+    got, keep = [], []
+    for i in range(0, x.size, 300_001):
+        piece = np.ascontiguousarray(x[i:i + 300_001]).copy()
+        keep.append(piece)                 # borrowed until the NEXT push returns
+        d.push_async(piece)
+        got += d.drain()
+        del keep[:-2]
+    d.finish()
+    got += d.drain()
+    assert records(got) == records(want)
+    assert d.stats() == wstats
+
+
 def test_reset_with_launches_in_flight(oracle, dec_factory, capi):
     """adsb_reset right after adsb_push_async (scans and copies still running): the old
     stream's records are dropped and the next stream decodes cleanly on the same slots."""
