@@ -24,12 +24,16 @@ namespace adsb {
 #endif
 
 constexpr int kRun = 28;        // power samples per thread run (4 x 7: see scan_kernel.hip)
-constexpr int kThreads = 256;   // 4 wavefronts
+#ifndef ADSB_THREADS
+#define ADSB_THREADS 256
+#endif
+constexpr int kThreads = ADSB_THREADS; // 4 wavefronts (experiment: 512 = 8)
+constexpr int kWaves = kThreads / 64;
 constexpr int kWaveRuns = 63;   // distinct runs per wave and pass (lane 63 re-computes the next wave's first run)
-constexpr int kPassRuns = 4 * kWaveRuns;        // 252
+constexpr int kPassRuns = kWaves * kWaveRuns;   // 252
 constexpr int kReachRuns = 44;  // runs of bit planes one long-frame evaluation reaches ahead: ceil((27+1195)/28)
 constexpr int kMaxPasses = 32;
-constexpr int kQueueCap = 1024; // survivors compacted per round
+constexpr int kQueueCap = 4 * kThreads; // survivors compacted per round
 constexpr int kPlanePad = 8;
 constexpr int kClistCap = 192;  // CRC-valid candidates staged per tile for the never-visited filter
 constexpr int ADSB_DECOFFSET_K = 1200; // longest span an accepted frame jumps (adsbdec.h:3)

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     // ADSB_SLEEP_STAGGER x 64 cycles apart (2.6 us steps), so that their load phases do not coincide from
     // the first pass on.  Measured in bench.py: -3.2 .. -4.0 % kernel time on one MI355X box, +-0.5 % on
     // another; steps of 1.2 us did nothing, steps of 3.7 us and more were worse than 2.6.
-    if (gridDim.x >= 256u * ADSB_MIN_WAVES && blockIdx.x < 256u * ADSB_MIN_WAVES) {
+    if (gridDim.x >= 256u * ADSB_MIN_WAVES * 4 / kWaves && blockIdx.x < 256u * ADSB_MIN_WAVES * 4 / kWaves) {
         const uint32_t slot = blockIdx.x >> 8;
         for (uint32_t i = 0; i < slot; i++)
             __builtin_amdgcn_s_sleep(ADSB_SLEEP_STAGGER);
@@ -363,10 +363,10 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     // wave and pass around the wave's own 7 KiB window, so no buffer size limit applies.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * (kWaveRuns * (4 * ps + wave)) - 8; }; // lane 0's
+    auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * (kWaveRuns * (kWaves * ps + wave)) - 8; }; // lane 0's
 #pragma unroll 1
     for (int pass = 0; pass < K; pass++) {
-        const int v0 = kWaveRuns * (4 * pass + wave); // first run of this wave in this pass
+        const int v0 = kWaveRuns * (kWaves * pass + wave); // first run of this wave in this pass
         const int v = v0 + lane;
         const int64_t wlo = pass_first_pair(pass);
         // wave-uniform: every pair this wave loads lies inside the buffer
