@@ -1148,8 +1148,10 @@ int adsb_reset(adsb_decoder *d)
         HIP_TRY(d, hipSetDevice(d->device));
         for (hipStream_t cs : d->copy_stream)
             HIP_TRY(d, hipStreamSynchronize(cs));
-        HIP_TRY(d, hipStreamSynchronize(d->stream)); // the report kernel behind each scan has zeroed its counters
+        HIP_TRY(d, hipStreamSynchronize(d->stream));
         for (ScanSlot &sl : d->slots) {
+            // normally the report kernel behind each scan has left the counters zero; after a failed launch it may not have
+            HIP_TRY(d, hipMemsetAsync(sl.d_counters, 0, adsb::kCounterWords * sizeof(uint32_t), d->stream));
             sl.busy = false;
             sl.prof_pending[0] = sl.prof_pending[1] = false;
         }
