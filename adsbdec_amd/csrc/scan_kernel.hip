@@ -98,11 +98,27 @@ __device__ __forceinline__ void fir_step(const f32x2 (&vv)[34], f32x2 &s)
     constexpr int p = J % 7;
     constexpr int age = (STEP <= p) ? (p - STEP) : (6 - (STEP - p - 1));
     constexpr int slot = J - age + 6;
+#if ADSB_FMA_BIAS
+    // vv holds the RAW sample values f = (float)x here.  The product the reference rounds is
+    // t * v with v = f - 2048 (even pairs) or 2048 - f (odd pairs, fs/4 sign): as a real number that
+    // is t*f - 2048*t, and 2048*t is exact in binary32 (a power-of-two multiple of t), so ONE fused
+    // multiply-add fma(+-t, f, -+2048 t) rounds exactly the same real number once -- the same bits
+    // as sub, then mul -- and the 34 bias subtractions per pass are gone.
+    constexpr float sg = (slot & 1) ? -1.0f : 1.0f;
+    constexpr f32x2 t = {sg * tap<12 - 2 * age>(), sg * tap<13 - 2 * age>()};
+    constexpr f32x2 c = {-sg * 2048.0f * tap<12 - 2 * age>(), -sg * 2048.0f * tap<13 - 2 * age>()};
+    const f32x2 prod = __builtin_elementwise_fma(t, vv[slot], c);
+    if constexpr (STEP == 0)
+        s = prod;
+    else
+        s = s + prod;
+#else
     constexpr f32x2 t = {tap<12 - 2 * age>(), tap<13 - 2 * age>()};
     if constexpr (STEP == 0)
         s = t * vv[slot]; // 0.0f + x == x up to the sign of zero, which the square erases
     else
         s = s + t * vv[slot];
+#endif
 }
 
 // G consecutive outputs advanced together, one FIR step at a time: G independent
@@ -484,8 +500,12 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         for (int s = 0; s < 34; s++) {
             const f32x4 q = tl[s >> 1];
             const f32x2 f = (s & 1) ? f32x2{q.z, q.w} : f32x2{q.x, q.y};
+#if ADSB_FMA_BIAS
+            vv[s] = f; // bias and fs/4 sign are folded into the FIR's products (fir_step)
+#else
             const f32x2 mid = {2048.0f, 2048.0f};
             vv[s] = ((s & 1) == 0) ? (f - mid) : (mid - f); // slot s <-> rel pair s-6: same parity
+#endif
         }
 
 #if ADSB_PREHALO_DPP
