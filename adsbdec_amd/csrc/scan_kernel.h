@@ -19,6 +19,9 @@ namespace adsb {
 #ifndef ADSB_FMA_BIAS
 #define ADSB_FMA_BIAS 0 // fold the -2048 bias and the fs/4 sign into the FIR's products (exact: scan_kernel.hip fir_step)
 #endif
+#ifndef ADSB_STAGEB_PRIO
+#define ADSB_STAGEB_PRIO 0 // s_setprio level of a workgroup's waves from the end of Stage A on (0 = unchanged)
+#endif
 #ifndef ADSB_PREHALO_DPP
 #define ADSB_PREHALO_DPP 0 // experiment: pre-halo pairs from the previous lane by DPP instead of three more loads
 #endif

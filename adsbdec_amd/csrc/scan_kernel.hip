@@ -185,18 +185,30 @@ __device__ __noinline__ uint32_t pw_at(const uint32_t *__restrict__ x, int64_t p
 {
     const int off[4] = {0, 10, 35, 45}; // demod.c:102-105
     uint32_t raw[4][7];
+    if (g - 6 >= p_lo && g + 45 < p_hi) {
+        // the usual case, every pair inside the buffer: one address, 28 loads at immediate offsets
+        const uint32_t *b = x + (g - pbuf0);
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int a = 0; a < 7; a++) {
-            const int64_t pi = g + off[k] - a;
-            raw[k][a] = (pi >= p_lo && pi < p_hi) ? x[pi - pbuf0] : 0x08000800u;
-        }
+            for (int a = 0; a < 7; a++)
+                raw[k][a] = b[off[k] - a];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int a = 0; a < 7; a++) {
+                const int64_t pi = g + off[k] - a;
+                raw[k][a] = (pi >= p_lo && pi < p_hi) ? x[pi - pbuf0] : 0x08000800u;
+            }
+    }
+    // power indices stay below 2^31 (streams of < 2^32 samples): 32-bit arithmetic for phase and parity
+    const uint32_t g32 = (uint32_t)g, g7 = g32 % 7u;
     float pw_s[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int64_t m = g + off[k];
-        const int p = (int)(m % 7);
+        const uint32_t m = g32 + (uint32_t)off[k];
+        const int p = (int)((g7 + (uint32_t)off[k]) % 7u);
         const f32x2 taps[7] = {{tap<12>(), tap<13>()}, {tap<10>(), tap<11>()}, {tap<8>(), tap<9>()},
                                {tap<6>(), tap<7>()},   {tap<4>(), tap<5>()},   {tap<2>(), tap<3>()},
                                {tap<0>(), tap<1>()}};
@@ -324,6 +336,13 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
 #if ADSB_TILE_CLOCK
     // kbench only: when and where each tile ran (100 MHz clock, HW_ID, XCC_ID) -> args.tile_clock[4 * tile ..]
     const uint64_t clk_begin = __builtin_amdgcn_s_memrealtime();
+    const uint64_t cyc_begin = __builtin_amdgcn_s_memtime(); // shader clock: (d cycles) / (d realtime at 100 MHz) = the clock the chip holds
+#endif
+#if ADSB_TILE_CLOCK == 3 // phase stamps of the tile (100 MHz clock), thread 0: see the dump in decoder.hip
+    uint32_t st[8] = {(uint32_t)clk_begin, 0, 0, 0, 0, 0, 0, 0};
+#define ADSB_STAMP(i) do { if (tid == 0) st[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ADSB_STAMP(i) do { } while (0)
 #endif
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -588,6 +607,13 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
 #endif
 
     // ------------------------------ Stage B ------------------------------
+    ADSB_STAMP(1);
+#if ADSB_STAGEB_PRIO
+    // From here on the tile is a chain of short, latency-bound phases between workgroup barriers, often with one
+    // wave working while three wait: at equal priority each of its instructions queues behind the Stage A streams
+    // of the three other workgroups on the SIMD.  Raised priority lets the chain through.
+    __builtin_amdgcn_s_setprio(ADSB_STAGEB_PRIO);
+#endif
     int64_t off_end = (int64_t)args.g_end - t0; // offsets of this tile that exist
     if (off_end > (int64_t)kRun * own)
         off_end = (int64_t)kRun * own;
@@ -734,6 +760,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             emit_loose(g_rel, pw, wds);
         }
 
+        ADSB_STAMP(2);
         if (stage_cands) {
             // Drop candidates the greedy scan (demod.c:89,128,134,141) can never visit.
             // Let c' be the closest candidate before c, with c inside c' (c.g < c'.g +
@@ -744,11 +771,46 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             // list is complete), and none does, c is unreachable.  These are the +-1/2
             // sample shifted copies of every real frame: 3 of 4 records.
             __syncthreads();
+            ADSB_STAMP(3);
             const int ncl = min((int)*cl_n, args.clist_cap); // <= kClistCap <= kThreads: one entry per thread
             const bool complete = *cl_over == 0;
             bool keep = false;
+            uint32_t rank = 0; // kept entries with a smaller offset: the record's place behind the tile's marker
             const uint32_t *ri = cl_rec + tid * kCandWords;
-            if (tid < ncl) {
+            const bool one_wave = ncl <= 64; // workgroup-uniform; the usual case (a tile stages ~20 candidates)
+            if (one_wave) {
+                // Every entry sits in a lane of wave 0 and the all-pairs comparisons run on lane broadcasts
+                // (v_readlane: the loop index is wave-uniform) instead of dependent LDS reads: measured with
+                // per-phase stamps, the LDS loops below took 3.2 us of a 50 us tile, this takes 0.3.
+                if (tid < 64) {
+                    const bool has = tid < ncl;
+                    const int gi = has ? (int)(ri[0] - tile_rel) : 0x3fffffff; // tile-local offset
+                    const int sp = has ? (((ri[1] & 0xFFu) == 0) ? 640 : 1200) : 0;
+                    // pg = the closest candidate before this one (and its span); emax = the latest candidate END that
+                    // is not beyond this one: some frame ends in (pg, gi] <=> emax > pg.  One pass, unrolled so that
+                    // the lane -> scalar -> vector round trips of consecutive entries overlap.
+                    int pg = -1, pspan = 0, emax = -1;
+#pragma unroll 4
+                    for (int j = 0; j < ncl; j++) {
+                        const int gj = __builtin_amdgcn_readlane(gi, j), sj = __builtin_amdgcn_readlane(sp, j);
+                        const int ej = gj + sj;
+                        const bool closer = gj < gi && gj > pg;
+                        pg = closer ? gj : pg;
+                        pspan = closer ? sj : pspan;
+                        emax = (ej <= gi && ej > emax) ? ej : emax;
+                    }
+                    const bool drop = complete && pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan && !(emax > pg);
+                    keep = has && !drop;
+                    const unsigned long long kept = __ballot(keep);
+#pragma unroll 4
+                    for (int j = 0; j < ncl; j++) {
+                        const int gj = __builtin_amdgcn_readlane(gi, j);
+                        rank += (uint32_t)((kept >> j) & 1ull) & (uint32_t)(gj < gi);
+                    }
+                    if (tid == 0)
+                        *tile_n = (uint32_t)__popcll(kept);
+                }
+            } else if (tid < ncl) {
                 const int gi = (int)(ri[0] - tile_rel); // tile-local offset
                 bool drop = false;
                 if (complete) {
@@ -771,23 +833,24 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                     }
                 }
                 keep = !drop;
+                // the tile reserves one marker granule plus two per kept record of the hand-off
+                // stream; the records follow the marker in ascending g (rank = kept entries
+                // with a smaller offset), so that the host can take the range as it is
+                if (keep) {
+                    atomicAdd(tile_n, 1u);
+                    cl_rec[tid * kCandWords + 1] |= 0x10000u; // staged word 1, bit 16: kept
+                }
             }
-            // the tile reserves one marker granule plus two per kept record of the hand-off
-            // stream; the records follow the marker in ascending g (rank = kept entries
-            // with a smaller offset), so that the host can take the range as it is
-            if (keep) {
-                atomicAdd(tile_n, 1u);
-                cl_rec[tid * kCandWords + 1] |= 0x10000u; // staged word 1, bit 16: kept
-            }
+            ADSB_STAMP(4);
             __syncthreads();
+            ADSB_STAMP(5);
             uint32_t res_need = 0, res_base = 0;
             const bool reserves = tid == 0 && args.hand;
             if (reserves) { // the result is not looked at before this thread's own record is finished
                 res_need = stream_granules(*tile_n);
                 res_base = atomicAdd(&args.counters[2], res_need);
             }
-            uint32_t rank = 0;
-            if (keep) {
+            if (keep && !one_wave) {
                 const uint32_t gi = ri[0];
                 for (int j = 0; j < ncl; j++)
                     rank += ((cl_rec[j * kCandWords + 1] >> 16) & 1u) & (uint32_t)(cl_rec[j * kCandWords] < gi);
@@ -808,7 +871,9 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 *tile_fit = (res_base < args.hand_cap && res_need <= args.hand_cap - res_base) ? 1u : 0u;
                 *tile_res = 1;
             }
+            ADSB_STAMP(6);
             __syncthreads(); // tile_base / tile_fit are in, and every staged entry has been read
+            ADSB_STAMP(7);
             const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
             if (keep) {
                 if (to_stream) {
@@ -872,11 +937,22 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     __syncthreads();
     if (tid == 0 && args.tile_clock) {
         const uint64_t clk_end = __builtin_amdgcn_s_memrealtime();
+#if ADSB_TILE_CLOCK == 3
+        uint32_t *o = args.tile_clock + 8 * (size_t)blockIdx.x; // eight stamps per tile
+        for (int i = 0; i < 7; i++)
+            o[i] = st[i];
+        o[7] = (uint32_t)clk_end;
+#else
         uint32_t *o = args.tile_clock + 4 * (size_t)blockIdx.x;
         o[0] = (uint32_t)clk_begin;
         o[1] = (uint32_t)clk_end;
+#if ADSB_TILE_CLOCK == 2
+        o[2] = (uint32_t)(__builtin_amdgcn_s_memtime() - cyc_begin); // shader cycles of this tile
+#else
         o[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
+#endif
         o[3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID[3:0]
+#endif
     }
 #endif
     if (args.hand) {

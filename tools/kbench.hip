@@ -74,6 +74,20 @@ int main(int argc, char **argv)
          CK(adsb::launch_scan(a, false, 0)); CK(hipDeviceSynchronize());
         std::vector<uint32_t> h((size_t)nt * 4); CK(hipMemcpy(h.data(), dclk, h.size() * 4, hipMemcpyDeviceToHost));
         uint32_t t0c = ~0u; for (uint32_t i = 0; i < nt; i++) t0c = std::min(t0c, h[4 * i]);
+#if ADSB_TILE_CLOCK == 2
+        {   // the clock the chip holds while this kernel runs: shader cycles / device real time (100 MHz) per tile
+            std::vector<double> ghz;
+            for (uint32_t i = 0; i < nt; i++) {
+                const double us = (h[4 * i + 1] - h[4 * i]) * 0.01;
+                if (us > 5.0)
+                    ghz.push_back(h[4 * i + 2] / us * 1e-3);
+            }
+            std::sort(ghz.begin(), ghz.end());
+            if (!ghz.empty())
+                printf("in-kernel shader clock over %zu tiles: median %.3f GHz (p5 %.3f, p95 %.3f)\n", ghz.size(), ghz[ghz.size() / 2],
+                       ghz[ghz.size() / 20], ghz[ghz.size() - 1 - ghz.size() / 20]);
+        }
+#endif
         FILE *f = fopen(getenv("ADSB_CLOCK_OUT") ? getenv("ADSB_CLOCK_OUT") : "tile_clock.txt", "w");
         for (uint32_t i = 0; i < nt; i++)
             fprintf(f, "%u %.2f %.2f %u %u %u\n", i, (h[4 * i] - t0c) * 0.01, (h[4 * i + 1] - t0c) * 0.01, h[4 * i + 3] & 15u,
