@@ -25,8 +25,11 @@ C_SOURCES = ["format.c"]
 HEADERS = ["scan_kernel.h", "resolver.hpp", os.path.join(ROOT, "include", "adsbdec_amd.h")]
 # -ffp-contract=off: the reference arithmetic is binary32 multiply THEN add
 # (SURVEY Q3); a fused multiply-add would change rounding.
+# -amdgpu-atomic-optimizer-strategy=None: the compiler otherwise turns the survivor queue's per-lane LDS
+# atomicAdd(qcount, n) into a scalar loop over the active lanes (readlane / writelane prefix sum, one iteration per
+# lane) -- a fine trade for contended global atomics, a bad one for an LDS counter: kernel -3.9 % without it.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
-             "-Wno-unused-function"]
+             "-Wno-unused-function", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def _newer(target: str, deps: list[str]) -> bool:

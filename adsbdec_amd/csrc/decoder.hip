@@ -675,7 +675,30 @@ int slot_collect(adsb_decoder *d)
             return -1;
         partial = rc == 1;
     }
-#if ADSB_TILE_CLOCK
+#if ADSB_TILE_CLOCK == 3
+    if (getenv("ADSB_CLOCK_OUT")) { // tuning builds: mean duration of each phase of a tile (thread 0's stamps, scan_kernel.hip)
+        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        std::vector<uint32_t> h((size_t)s.ntiles * 8);
+        HIP_TRY(d, hipMemcpy(h.data(), s.args.tile_clock, h.size() * 4, hipMemcpyDeviceToHost));
+        double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+        size_t n = 0;
+        for (uint32_t i = 0; i < s.ntiles; i++) {
+            const uint32_t *o = &h[8 * (size_t)i];
+            bool ok = true;
+            for (int k = 1; k < 8; k++)
+                ok &= o[k] != 0 && o[k] >= o[k - 1];
+            if (!ok)
+                continue;
+            for (int k = 0; k < 7; k++)
+                sum[k] += (o[k + 1] - o[k]) * 0.01;
+            n++;
+        }
+        if (n)
+            fprintf(stderr, "tile phases (us, thread 0, mean over %zu of %u tiles): stage A %.2f | gate + slicer %.2f | wait for the other "
+                    "waves %.2f | filter + rank %.2f | barrier %.2f | bytes, pw, reservation back %.2f | wait for the other records %.2f\n",
+                    n, s.ntiles, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n);
+    }
+#elif ADSB_TILE_CLOCK
     if (const char *path = getenv("ADSB_CLOCK_OUT")) {
         HIP_TRY(d, hipStreamSynchronize(d->stream));
         std::vector<uint32_t> h((size_t)s.ntiles * 4);

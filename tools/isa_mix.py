@@ -35,7 +35,7 @@ def main():
     dst, extra = sys.argv[1], sys.argv[2:]
     with tempfile.TemporaryDirectory() as td:
         s = os.path.join(td, "scan.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
                                "-S", "--cuda-device-only", "-o", s] + extra +
                               [os.path.join(ROOT, "adsbdec_amd", "csrc", "scan_kernel.hip")],
                               stderr=subprocess.DEVNULL)
