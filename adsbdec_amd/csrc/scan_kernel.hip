@@ -785,27 +785,39 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 if (tid < 64) {
                     const bool has = tid < ncl;
                     const int gi = has ? (int)(ri[0] - tile_rel) : 0x3fffffff; // tile-local offset
-                    const int sp = has ? (((ri[1] & 0xFFu) == 0) ? 640 : 1200) : 0;
-                    // pg = the closest candidate before this one (and its span); emax = the latest candidate END that
-                    // is not beyond this one: some frame ends in (pg, gi] <=> emax > pg.  One pass, unrolled so that
-                    // the lane -> scalar -> vector round trips of consecutive entries overlap.
-                    int pg = -1, pspan = 0, emax = -1;
-#pragma unroll 4
-                    for (int j = 0; j < ncl; j++) {
-                        const int gj = __builtin_amdgcn_readlane(gi, j), sj = __builtin_amdgcn_readlane(sp, j);
-                        const int ej = gj + sj;
-                        const bool closer = gj < gi && gj > pg;
-                        pg = closer ? gj : pg;
-                        pspan = closer ? sj : pspan;
-                        emax = (ej <= gi && ej > emax) ? ej : emax;
+                    const bool lng = has && (ri[1] & 0xFFu) != 0;
+                    // key = 2 g + (long frame): ordered like g, and the closest predecessor's span comes with its key
+                    const int key = 2 * gi + (lng ? 1 : 0), g2 = 2 * gi;
+                    const int ei = has ? gi + (lng ? 1200 : 640) : 0x7fffffff; // where the candidate's frame ends
+                    // pk = the largest key below this one's = the closest candidate before it (with its length);
+                    // emax = the latest frame END that is not beyond this candidate: some frame ends in (pg, gi] <=> emax > pg.
+                    // Four entries per round, every round's broadcasts and compares independent of each other (lanes
+                    // beyond ncl hold neutral values): the lane -> scalar -> vector round trips overlap.
+                    int pk = -1, emax = -1;
+                    for (int j = 0; j < ncl; j += 4) {
+                        int kj[4], ej[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            kj[u] = __builtin_amdgcn_readlane(key, j + u);
+                            ej[u] = __builtin_amdgcn_readlane(ei, j + u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            kj[u] = kj[u] < g2 ? kj[u] : -1;
+                            ej[u] = ej[u] <= gi ? ej[u] : -1;
+                        }
+                        pk = max(max(pk, kj[0]), max(max(kj[1], kj[2]), kj[3]));
+                        emax = max(max(emax, ej[0]), max(max(ej[1], ej[2]), ej[3]));
                     }
+                    const int pg = pk >> 1, pspan = (pk & 1) ? 1200 : 640; // pk == -1: pg == -1, nothing precedes
                     const bool drop = complete && pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan && !(emax > pg);
                     keep = has && !drop;
                     const unsigned long long kept = __ballot(keep);
-#pragma unroll 4
-                    for (int j = 0; j < ncl; j++) {
-                        const int gj = __builtin_amdgcn_readlane(gi, j);
-                        rank += (uint32_t)((kept >> j) & 1ull) & (uint32_t)(gj < gi);
+                    const int kk = keep ? key : 0x7fffffff; // the entries that stay, as keys; the others never count
+                    for (int j = 0; j < ncl; j += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            rank += (uint32_t)(__builtin_amdgcn_readlane(kk, j + u) < g2);
                     }
                     if (tid == 0)
                         *tile_n = (uint32_t)__popcll(kept);
