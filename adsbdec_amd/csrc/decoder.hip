@@ -131,6 +131,8 @@ struct adsb_decoder {
     adsb::Resolver res;
     std::vector<uint32_t> order, scratch_a, scratch_b, gather, tile_start, tile_count;
     bool no_streaming = false; // ADSB_NO_STREAMING=1: always collect after completion
+    int dbg_async = 0;         // ADSB_DEBUG_ASYNC (diagnosis, tools/async_race.py): 1 = wait for every async copy,
+                               // 2 = copies on the scan stream, 4 = tail copies not ordered before the next copy (the old race)
     // device-side visited-try count (scan_kernel.h TryCountArgs)
     uint64_t *d_carry[2] = {nullptr, nullptr};
     uint32_t *d_carry_n = nullptr; // device: three counts in rotation (in, out, next: TryCountArgs)
@@ -161,6 +163,7 @@ struct adsb_decoder {
     static constexpr int kCopyStreams = 2;
     hipStream_t copy_stream[kCopyStreams] = {nullptr, nullptr};
     hipEvent_t ev_copy[kCopyStreams] = {nullptr, nullptr};
+    hipEvent_t ev_tail = nullptr; // behind a staging compaction's tail copy (process_stage): the copy streams wait for it
     uint64_t piece = 0;        // pieces pushed asynchronously so far
 
     int fail(const char *fmt, ...)
@@ -901,6 +904,18 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
     return 0;
 }
 
+// Where the kept tail of the staging buffer starts: at or below `want` (a multiple of 8 samples), lowered by up
+// to 56 samples so that the tail's END -- where the next push is appended -- falls on a 128-byte line whenever
+// the stream position allows it (n_samples % 8 == 0): pieces of adsb_push_async that start on a line run on
+// alternating copy streams without waiting for each other (push_copy).
+uint64_t line_aligned_keep(uint64_t want, uint64_t n_samples, uint64_t floor_first)
+{
+    if (n_samples % 8 != 0 || want > n_samples)
+        return want;
+    const uint64_t extra = (64 - (n_samples - want) % 64) % 64; // samples; a multiple of 8
+    return want >= floor_first + extra ? want - extra : want;
+}
+
 // Scan what the staged samples allow, resolve, and keep only the unscanned tail.
 // in_flight (adsb_push_async): the launches submitted here are left running; only those
 // of earlier pieces are collected.
@@ -936,13 +951,26 @@ int process_stage(adsb_decoder *d, bool final, bool in_flight = false)
     // half full: until then the next push is appended behind what is there and the next scan
     // reads [tail | new] where it lies -- small pushes (the reference's 1 Mi-sample calls)
     // then cost no device-to-device copy at all.
-    const uint64_t keep_first = d->g_scanned >= 8 ? 2 * (d->g_scanned - 8) : 0;
+    const uint64_t keep_first = line_aligned_keep(d->g_scanned >= 8 ? 2 * (d->g_scanned - 8) : 0, d->n_samples, d->stage_first);
     if (keep_first > d->stage_first && d->stage_fill > (d->stage_cap - kStageSlack) / 2) {
         const uint64_t skip = keep_first - d->stage_first;
         const uint64_t left = d->stage_fill > skip ? d->stage_fill - skip : 0;
-        if (left)
+        if (left) {
             HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur ^ 1], d->stage[d->cur] + skip,
                                       left * sizeof(uint16_t), hipMemcpyDeviceToDevice, d->stream));
+            if (in_flight && d->dbg_async != 4) {
+                // The next asynchronous piece is copied right behind this tail by a copy engine on another
+                // stream, and the two ranges meet inside a cache line (`left` is not line-aligned): unordered,
+                // the tail copy's write-back of that line and the engine's write to it race, and the loser's
+                // bytes are lost (observed: one frame straddling the seam missing in 5-15 % of the runs with a
+                // 64 Ki staging buffer, which compacts at every piece; tools/async_race.py).  So the copy
+                // streams wait for the tail copy.  That serialises the next copy behind this piece's scan -- once
+                // per compaction, i.e. once per ~16 Mi samples with the default staging buffer.
+                HIP_TRY(d, hipEventRecord(d->ev_tail, d->stream));
+                for (hipStream_t cs : d->copy_stream)
+                    HIP_TRY(d, hipStreamWaitEvent(cs, d->ev_tail, 0));
+            }
+        }
         d->cur ^= 1;
         d->stage_first = keep_first;
         d->stage_fill = left;
@@ -969,9 +997,18 @@ int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind, bo
         if (async) {
             d->piece++;
             const int cs = (int)(d->piece % adsb_decoder::kCopyStreams);
-            HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind, d->copy_stream[cs]));
-            HIP_TRY(d, hipEventRecord(d->ev_copy[cs], d->copy_stream[cs]));
-            HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_copy[cs], 0));
+            hipStream_t cstream = d->dbg_async == 2 ? d->stream : d->copy_stream[cs];
+            // Same rule as for the tail copy in process_stage: two writers that are not ordered never share a
+            // cache line.  A piece that starts inside a 128-byte line (pushes of odd sizes) waits for the copy of
+            // the piece before it, which ends in that line.
+            if (d->piece > 1 && (d->stage_fill * sizeof(uint16_t)) % 128 != 0 && d->dbg_async != 2)
+                HIP_TRY(d, hipStreamWaitEvent(cstream, d->ev_copy[cs ^ 1], 0));
+            HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind, cstream));
+            HIP_TRY(d, hipEventRecord(d->ev_copy[cs], cstream));
+            if (d->dbg_async != 2)
+                HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_copy[cs], 0));
+            if (d->dbg_async == 1)
+                HIP_TRY(d, hipStreamSynchronize(cstream));
         } else {
             HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind, d->stream));
         }
@@ -1069,6 +1106,8 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         if ((e = hipStreamCreateWithFlags(&d->copy_stream[i], hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&d->ev_copy[i], hipEventDisableTiming)) != hipSuccess)
             return bail("hipStreamCreate(copy)", e);
+    if ((e = hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming)) != hipSuccess)
+        return bail("hipEventCreate(tail)", e);
     for (int i = 0; i < 2; i++)
         if ((e = hipMalloc(&d->stage[i], d->stage_cap * sizeof(uint16_t))) != hipSuccess)
             return bail("hipMalloc(stage)", e);
@@ -1112,6 +1151,7 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
     }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     d->no_streaming = getenv("ADSB_NO_STREAMING") && atoi(getenv("ADSB_NO_STREAMING")) != 0;
+    d->dbg_async = getenv("ADSB_DEBUG_ASYNC") ? atoi(getenv("ADSB_DEBUG_ASYNC")) : 0;
     d->res.reset();
     return d;
 }
@@ -1130,6 +1170,7 @@ void adsb_destroy(adsb_decoder *d)
         if (d->ev_copy[i]) (void)hipEventDestroy(d->ev_copy[i]);
         if (d->copy_stream[i]) (void)hipStreamDestroy(d->copy_stream[i]);
     }
+    if (d->ev_tail) (void)hipEventDestroy(d->ev_tail);
     for (int i = 0; i < 2; i++)
         if (d->stage[i])
             (void)hipFree(d->stage[i]);
@@ -1351,7 +1392,7 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
     // buffer.  Issued ahead of the scans so that it is finished, in stream order, by
     // the time the last scan is collected (the caller may free the buffer on return).
     const uint64_t g_after = std::max(g_end, d->g_scanned);
-    const uint64_t keep_first = std::max<uint64_t>(g_after >= 8 ? 2 * (g_after - 8) : 0, first);
+    const uint64_t keep_first = line_aligned_keep(std::max<uint64_t>(g_after >= 8 ? 2 * (g_after - 8) : 0, first), total, first);
     const uint64_t left = total - keep_first;
     if (left > d->stage_cap - kStageSlack)
         return d->fail("in-place tail (%llu samples) exceeds the staging buffer", (unsigned long long)left);

@@ -58,6 +58,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "scan_kernel.h"
 
@@ -286,6 +287,21 @@ __device__ __forceinline__ uint32_t push_sign(uint32_t acc, uint32_t v)
 __device__ __forceinline__ float from_next_lane(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
+}
+
+// v_bitop3_b32 (gfx950): EXPR over the words A, B, C; the immediate is EXPR's truth table
+#define ADSB_BITOP3(a, b, c, EXPR) \
+    __builtin_amdgcn_bitop3_b32((a), (b), (c), []() constexpr { constexpr uint32_t A = 0xF0u, B = 0xCCu, C = 0xAAu; return (uint32_t)((EXPR) & 0xFFu); }())
+
+// the same without the final mask: bits 28..31 of the result are not meaningful
+template <int POS>
+__device__ __forceinline__ uint32_t take28u(const uint32_t *w)
+{
+    constexpr int k = POS / 28, s = POS % 28;
+    uint32_t r = w[k] >> s;
+    if constexpr (s != 0)
+        r |= w[k + 1] << (28 - s);
+    return r;
 }
 
 // 28 bits starting at bit `POS` of the stream w[0] | w[1]<<28 | w[2]<<56 | ... (28 valid bits per word)
@@ -614,9 +630,9 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     // of the three other workgroups on the SIMD.  Raised priority lets the chain through.
     __builtin_amdgcn_s_setprio(ADSB_STAGEB_PRIO);
 #endif
-    int64_t off_end = (int64_t)args.g_end - t0; // offsets of this tile that exist
-    if (off_end > (int64_t)kRun * own)
-        off_end = (int64_t)kRun * own;
+    const int64_t off_end64 = (int64_t)args.g_end - t0; // offsets of this tile that exist
+    const int off_end = off_end64 > (int64_t)kRun * own ? kRun * own : off_end64 < 0 ? 0 : (int)off_end64;
+    const uint32_t df18_mask = args.df18 ? ~0u : 0u;
     const int nchunks = (own + kThreads - 1) / kThreads;
     uint32_t *qover = qcount + 1;
     uint32_t *cl_n = qcount + 2;    // CRC-valid candidates staged in LDS this round
@@ -648,31 +664,45 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             // Two steps per batch of chunks.  First every gate word: plane reads and word-wide logic with no
             // dependence between chunks, so the LDS reads of a whole batch are in flight together (one chunk at
             // a time this loop took 3.2 us of a 46 us tile, most of it LDS latency) ...
-            uint32_t gt[kGateBatch], g11[kGateBatch], g17[kGateBatch];
-#pragma unroll
-            for (int u = 0; u < kGateBatch; u++) {
-                const int ch = base + u;
-                const int v = ch * kThreads + tid;
-                gt[u] = g11[u] = g17[u] = 0;
-                if (ch >= ch_hi || v >= own || (int64_t)kRun * v >= off_end)
-                    continue;
+            uint32_t gt[kGateBatch], gb1[kGateBatch], gb4[kGateBatch];
+            // workgroup-uniform: every run of the batch exists and is complete (all but a tile's last batch, and
+            // the last tiles of a launch): no per-lane range logic at all
+            const bool full = grp < 0 && base + kGateBatch <= ch_hi && kRun * kThreads * (base + kGateBatch) <= off_end;
+            auto gate_word = [&](int u, auto is_full) {
+                const int vq = (base + u) * kThreads + tid;
+                const int nvalid = off_end - kRun * vq; // <= 0: the run does not exist (vq >= own included: off_end <= 28 own)
+                const int v = (decltype(is_full)::value || nvalid > 0) ? vq : 0; // planes are only read where they exist
                 const uint32_t e2w[2] = {pl_e2[v + 1], pl_e2[v + 2]};
                 const uint32_t dw[4] = {pl_d[v + 2], pl_d[v + 3], pl_d[v + 4], pl_d[v + 5]};
+                // byte 0, bits 0..4 sit 80, 90, .., 120 samples after g (demod.c:109,46-81).  Bits 28..31 of
+                // these words are whatever the funnel shift left there: the AND with E1 (28 valid bits) clears them.
+                const uint32_t b0 = take28u<80 - 56>(dw), b1 = take28u<90 - 56>(dw), b2 = take28u<100 - 56>(dw),
+                               b3 = take28u<110 - 56>(dw), b4 = take28u<120 - 56>(dw);
+                // v_bitop3_b32: any function of three words in one instruction (the truth table is the immediate)
+                const uint32_t hi = ADSB_BITOP3(b0, b1, b2, A & ~B & ~C);               // 10xxx
+                const uint32_t lo = ADSB_BITOP3(b3, b4, df18_mask, (A ^ B) & (B | C));  // xxx01 (DF17, demod.c:64-67); xxx10 (DF18, :57-62) with -a
+                const uint32_t h11 = ADSB_BITOP3(b0, b1, b2, ~A & B & ~C);              // 010xx
+                const uint32_t m11 = ADSB_BITOP3(h11, b3, b4, A & B & C);               // 01011 (demod.c:70-77)
+                const uint32_t df = ADSB_BITOP3(hi, lo, m11, (A & B) | C);
                 // preamble: p1 > 2 s1 at g, p2 > 2 s2 <=> E2 at g + 30
-                const uint32_t pre = pl_e1[v] & take28<30 - 28>(e2w);
-                // byte 0, bits 0..4 sit 80, 90, .., 120 samples after g (demod.c:109,46-81)
-                const uint32_t b0 = take28<80 - 56>(dw), b1 = take28<90 - 56>(dw), b2 = take28<100 - 56>(dw),
-                               b3 = take28<110 - 56>(dw), b4 = take28<120 - 56>(dw);
-                const uint32_t m17 = b0 & ~b1 & ~b2 & ~b3 & b4;                    // 10001 (demod.c:64-67)
-                const uint32_t m11 = ~b0 & b1 & ~b2 & b3 & b4;                     // 01011 (demod.c:70-77)
-                const uint32_t m18 = args.df18 ? (b0 & ~b1 & ~b2 & b3 & ~b4) : 0u; // 10010 (demod.c:57-62)
-                uint32_t gate = pre & (m17 | m11 | m18);
-                const int64_t nvalid = off_end - (int64_t)kRun * v;
-                if (nvalid < kRun)
-                    gate &= (1u << (int)nvalid) - 1u;
-                if (grp >= 0)
-                    gate &= 1u << grp;
-                gt[u] = gate, g11[u] = m11, g17[u] = m17;
+                uint32_t gate = ADSB_BITOP3(pl_e1[v], take28u<30 - 28>(e2w), df, A & B & C);
+                if constexpr (!decltype(is_full)::value) {
+                    gate &= nvalid >= kRun ? ~0u : nvalid > 0 ? (1u << nvalid) - 1u : 0u;
+                    if (base + u >= ch_hi)
+                        gate = 0;
+                    if (grp >= 0)
+                        gate &= 1u << grp;
+                }
+                gt[u] = gate, gb1[u] = b1, gb4[u] = b4; // of a passing offset: b1 set <=> DF11; else b4 set <=> DF17
+            };
+            if (full) {
+#pragma unroll
+                for (int u = 0; u < kGateBatch; u++)
+                    gate_word(u, std::true_type{});
+            } else {
+#pragma unroll
+                for (int u = 0; u < kGateBatch; u++)
+                    gate_word(u, std::false_type{});
             }
             // ... then the survivors (13 % of the lanes have one) go to the queue
 #pragma unroll
@@ -686,7 +716,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                         while (gate) {
                             const int j = __ffs(gate) - 1;
                             gate &= gate - 1;
-                            const uint32_t code = ((g11[u] >> j) & 1u) ? 0u : ((g17[u] >> j) & 1u) ? 1u : 2u;
+                            const uint32_t code = ((gb1[u] >> j) & 1u) ? 0u : ((gb4[u] >> j) & 1u) ? 1u : 2u;
                             queue[slot++] = ((uint32_t)v << 7) | ((uint32_t)j << 2) | code;
                         }
                     } else {

@@ -196,6 +196,26 @@ def test_async_pushes_reference_call_size_and_mixed_calls(capi, oracle, dec_fact
     assert d.stats() == wstats
 
 
+@pytest.mark.parametrize("stats", [False, True])
+def test_async_small_staging_seam_is_ordered(capi, dec_factory, stats):
+    """Regression for a race found in round 2: with a 64 Ki-sample staging buffer every asynchronous piece
+    compacts the buffer, and the next piece's host-to-device copy (copy engine, own stream) lands right behind the
+    compaction's tail copy (scan stream) -- inside one cache line.  Unordered, one of the two writes was lost in
+    5-35 % of the runs and a frame straddling the seam disappeared (tools/async_race.py reproduces it with
+    ADSB_DEBUG_ASYNC=4).  The copy streams now wait for the tail copy; 150 decodes, odd push sizes included."""
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture((5 << 20) + 6, seed=61, sigma=30.0, n_frames=1200, amp=(150, 1800))
+    ref = dec_factory(df18=True, collect_stats=stats)
+    want = ref.decode(x)
+    wstats = ref.stats() if stats else None
+    d = dec_factory(df18=True, collect_stats=stats, stage_samples=1 << 16)
+    for i in range(150):
+        chunk = (1 << 20) if i % 3 else 65546 + 2 * i
+        assert records(d.decode(x, chunk=chunk, mode="async")) == records(want), f"run {i}, chunk {chunk}"
+        if stats:
+            assert d.stats() == wstats, f"run {i}, chunk {chunk}"
+
+
 def test_async_pushes_from_pageable_memory(oracle, dec_factory):
     """adsb_push_async does not require page-locked buffers (the runtime then stages the copy itself and
     the overlap is lost, not the result): plain numpy arrays, each kept alive until the next call returned."""

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Diagnosis: repeat an asynchronous small-staging decode and count runs whose frames / statistics differ
+from a synchronous decode of the same capture.   python tools/async_race.py [iterations]"""
+import os
+import sys
+
+import numpy as np
+import torch  # noqa: F401  (first: one HIP runtime)
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from adsbdec_amd import capi  # noqa: E402
+from tools import gen_signal as G  # noqa: E402
+
+
+def rec(fs):
+    return [(f["g"], f["ts"], f["pw"], bytes(f["frame"])) for f in fs]
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    x, _ = G.dense_capture((5 << 20) + 6, seed=61, sigma=30.0, n_frames=1200, amp=(150, 1800))
+    ref = capi.Decoder(df18=True, collect_stats=True)
+    want = rec(ref.decode(x))
+    wstats = ref.stats()
+    ref.close()
+    print("frames", len(want), "stats", wstats, flush=True)
+    configs = []
+    for stats in (False, True):
+        for env in ({}, {"ADSB_NO_STREAMING": "1"}, {"ADSB_DEBUG_ASYNC": "4"}):
+            configs.append((f"async stage=64Ki stats={int(stats)} {env}", dict(stage=1 << 16, stats=stats, mode="async", env=env)))
+    configs += [
+        ("sync  stage=64Ki stats=0 chunk 1Mi", dict(stage=1 << 16, stats=False, mode="sync", env={})),
+        ("async stage=default stats=0", dict(stage=0, stats=False, mode="async", env={})),
+        ("async stage=1Mi stats=0", dict(stage=1 << 20, stats=False, mode="async", env={})),
+        ("async stage=64Ki stats=0 chunk 65546", dict(stage=1 << 16, stats=False, mode="async", env={}, chunk=65546)),
+        ("async stage=default stats=1 chunk 65546", dict(stage=0, stats=True, mode="async", env={}, chunk=65546)),
+        ("async stage=default stats=0 chunk 99998", dict(stage=0, stats=False, mode="async", env={}, chunk=99998)),
+    ]
+    only = os.environ.get("RACE_ONLY")
+    for name, c in configs:
+        if only and only not in name:
+            continue
+        for k in ("ADSB_NO_STREAMING", "ADSB_DEBUG_ASYNC"):
+            os.environ.pop(k, None)
+        os.environ.update(c["env"])
+        d = capi.Decoder(df18=True, collect_stats=c["stats"], stage_samples=c["stage"])
+        bad_f = bad_s = 0
+        first = None
+        for i in range(iters):
+            got = rec(d.decode(x, chunk=c.get("chunk", 1 << 20), mode=c["mode"]))
+            if got != want:
+                bad_f += 1
+                if first is None:
+                    a = set(got) ^ set(want)
+                    first = (i, len(got), sorted(a)[:4])
+            elif c["stats"] and d.stats() != wstats:
+                bad_s += 1
+                if first is None:
+                    first = (i, "stats", d.stats()["try"])
+        d.close()
+        print(f"{name}: {bad_f} frame mismatches, {bad_s} stats-only mismatches of {iters}; first: {first}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
