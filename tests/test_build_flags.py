@@ -41,3 +41,13 @@ def test_no_scratch_and_gfx950_only(isa):
     assert ".amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"" in isa
     for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)", isa):
         assert int(m.group(1)) == 0, "kernel spills to scratch"
+
+
+def test_atomic_optimizer_off_and_bitop3_gate(isa):
+    """Two build properties the measured kernel time depends on: the compiler's atomic
+    optimizer is off (it turns the survivor queue's per-lane LDS adds, which 13 % of the lanes execute, into a
+    wave-wide DPP scan: +3.9 % kernel time), and the gate words are formed by gfx950's v_bitop3_b32."""
+    from adsbdec_amd import _build
+    assert "-amdgpu-atomic-optimizer-strategy=None" in _build.HIP_FLAGS
+    assert len(re.findall(r"^\s*v_bitop3_b32", isa, flags=re.M)) >= 24   # 6 per chunk, 4 chunks per batch, two paths, two kernels
+    assert re.search(r"^\s*ds_add_rtn_u32", isa, flags=re.M)
