@@ -66,11 +66,13 @@ def run(seconds: float, seed: int = 1, log=print):
         k = (df18, stats, fix, caps)
         if k not in decs:
             decs[k] = capi.Decoder(df18=df18, collect_stats=stats, fix_1bit=fix,
-                                   stage_samples=int(1 << 17) if len(decs) % 2 else 0, **tight[caps])
+                                   stage_samples=[0, 1 << 17, 1 << 16][len(decs) % 3], **tight[caps])
         return decs[k]
 
     t0, it, frames_total, ref_checked, tight_runs = time.time(), 0, 0, 0, 0
-    modes = [0] * 6
+    modes = [0] * 7
+    pinned = capi.PinnedBuffers(2, 1 << 20)
+    bufs = pinned.__enter__()
     first_seed = seed
     while time.time() - t0 < seconds:
         rng = np.random.default_rng(seed)
@@ -85,7 +87,7 @@ def run(seconds: float, seed: int = 1, log=print):
             ref_checked += 1
         caps = int(rng.integers(1, len(tight))) if rng.random() < 0.2 else 0
         d = dec(df18, stats, fix, caps)
-        mode = int(rng.integers(0, 6))
+        mode = int(rng.integers(0, 7))
         modes[mode] += 1
         d.reset()
         what = f"seed={seed} mode={mode} n={x.size} df18={df18} stats={stats} fix={fix} caps={tight[caps]}"
@@ -98,6 +100,27 @@ def run(seconds: float, seed: int = 1, log=print):
                 pos += c
             d.finish()
             got = d.drain()
+        elif mode == 6:    # one stream through every kind of call in random order: async (two page-locked buffers in
+            got, pos, k = [], 0, 0   # turn), sync, device (staged or in place), adsb_sync now and then, frames drained as they come
+            t = torch.from_numpy(x.view(np.int16)).cuda()
+            while pos < x.size:
+                c = min(x.size - pos, int(rng.choice([4, 1000, 4096, 65536, 65536 + 6, 200_000, 1 << 20])))
+                kind = int(rng.integers(0, 3))
+                if kind == 0:
+                    b = bufs[k % 2][:c]
+                    b[:] = x[pos:pos + c]
+                    d.push_async(b)
+                    k += 1
+                elif kind == 1:
+                    d.push(x[pos:pos + c])
+                else:
+                    d.push_device(t.data_ptr() + 2 * pos, c)
+                pos += c
+                if rng.random() < 0.1:
+                    d.sync()
+                got += d.drain()
+            d.finish()
+            got += d.drain()
         elif mode == 5:    # overlapped host pushes (adsb_push_async), random chunking, frames drained as they come
             got = d.decode(x, chunk=int(rng.choice([1000, 4096, 65536 + 4, 1 << 18, 1 << 20, max(1, x.size)])), mode="async")
         else:
@@ -144,12 +167,14 @@ def run(seconds: float, seed: int = 1, log=print):
     summary = dict(captures=it, frames=frames_total, first_seed=first_seed, last_seed=seed - 1,
                    seconds=round(time.time() - t0, 1), mismatches=0,
                    captures_by_mode=dict(host_push=modes[0], device_final=modes[1], device_split_aligned=modes[2],
-                                         device_split_unaligned=modes[3], shards=modes[4], host_push_async=modes[5]),
+                                         device_split_unaligned=modes[3], shards=modes[4], host_push_async=modes[5],
+                                         mixed_async_sync_device=modes[6]),
                    also_checked_against_real_reference_chain=ref_checked,
                    with_shrunken_record_buffers=tight_runs,
                    relaunches=sum(int(d.profile()["relaunches"]) for d in decs_all))
     for d in decs_all:
         d.close()
+    pinned.__exit__(None, None, None)
     log(f"fuzz ok: {summary}")
     return summary
 
