@@ -63,6 +63,11 @@ struct ScanSlot {
     uint32_t *tries = nullptr;      // pinned, written by the kernel (per-shard scans that return the list)
     uint32_t *d_tries = nullptr;    // device: statistics runs of a stream count tries on the device
     size_t cand_cap = 0, try_cap = 0, d_try_cap = 0;
+    // d_tries = [d_try_tiles regions of adsb::kTryRegion words][launch-wide list of d_try_cap words]; a tile's
+    // whole-tile round writes its region and d_try_counts[tile] (scan_kernel.h), the list takes the rest
+    uint32_t *d_try_counts = nullptr;
+    size_t d_try_tiles = 0;
+    bool try_regions = false;       // the launch in flight uses the regions
     bool tries_on_device = false;   // which of the two the launch in flight uses
     int ev_cur = 0;                  // copy of the launch in flight
     uint64_t ev_offsets[2] = {0, 0}; // offsets of the launch each copy belongs to
@@ -77,6 +82,8 @@ struct ScanSlot {
     bool busy = false;
     uint64_t piece = 0; // adsb_push_async: the launch belongs to this push piece (collected one piece later)
     bool prof_pending[2] = {false, false}; // kernel time of a collected launch not read yet
+    hipEvent_t ev_count = nullptr; // statistics runs: the count pass over d_tries (count stream) has ended;
+    bool count_pending = false;    // the slot's next scan waits for it before it overwrites the list
 };
 
 constexpr int kSlots = 4;
@@ -146,11 +153,12 @@ struct adsb_decoder {
     bool acc_dirty = false;                  // ... since d_try_acc was last zeroed
     adsb::TryFrame *h_frames[2] = {nullptr, nullptr}; // pinned upload buffers, used in turn (a pass is never waited for)
     hipEvent_t ev_frames[2] = {nullptr, nullptr};
+    hipStream_t count_stream = nullptr; // statistics runs: frame uploads + count kernels (count_tries_pass)
     bool frames_pending[2] = {false, false};
     int frames_buf = 0;
     bool final_follows = false;   // adsb_push_device_final: the end-of-stream count pass comes next
-    const uint32_t *deferred_tries = nullptr; // try list of the last launch, left for that pass
     uint32_t deferred_n = 0;
+    ScanSlot *deferred_slot = nullptr;
     uint64_t deferred_base = 0;
     bool have_prev_frame = false; // last accepted frame of earlier passes (its span may cover later tries)
     uint64_t prev_frame_g = 0;
@@ -196,15 +204,23 @@ inline uint64_t power_samples_produced(uint64_t n_samples)
 constexpr size_t kTryStateBytes = 4 * sizeof(unsigned long long) + 4 * sizeof(uint32_t); // d_try_acc + d_carry_n
 constexpr uint32_t kCarryCap = 1u << 20; // undecided tries carried between count passes (a few hundred in practice)
 
-int slot_reserve_device_tries(adsb_decoder *d, ScanSlot &s, size_t want)
+int slot_reserve_device_tries(adsb_decoder *d, ScanSlot &s, size_t want_list, size_t want_tiles)
 {
-    if (want > s.d_try_cap) {
+    if (want_list > s.d_try_cap || want_tiles > s.d_try_tiles) {
+        want_list = std::max(want_list, s.d_try_cap);
+        want_tiles = std::max(want_tiles, s.d_try_tiles);
+        if (d->count_stream) // a count pass may still be reading the old arrays
+            HIP_TRY(d, hipStreamSynchronize(d->count_stream));
         if (s.d_tries)
             HIP_TRY(d, hipFree(s.d_tries));
-        s.d_tries = nullptr;
-        s.d_try_cap = 0;
-        HIP_TRY(d, hipMalloc(&s.d_tries, want * sizeof(uint32_t)));
-        s.d_try_cap = want;
+        if (s.d_try_counts)
+            HIP_TRY(d, hipFree(s.d_try_counts));
+        s.d_tries = s.d_try_counts = nullptr;
+        s.d_try_cap = s.d_try_tiles = 0;
+        HIP_TRY(d, hipMalloc(&s.d_tries, (want_tiles * adsb::kTryRegion + want_list) * sizeof(uint32_t)));
+        HIP_TRY(d, hipMalloc(&s.d_try_counts, std::max<size_t>(want_tiles, 1) * sizeof(uint32_t)));
+        s.d_try_cap = want_list;
+        s.d_try_tiles = want_tiles;
     }
     return 0;
 }
@@ -306,8 +322,18 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.args.counters = s.d_counters;
     s.args.cands = s.cands;
     s.args.cand_cap = (uint32_t)std::min<size_t>(s.cand_cap, 0xFFFFFFFFu);
+    if (s.count_pending) { // the count pass over this slot's previous try list (count stream) must be over
+        HIP_TRY(d, hipStreamWaitEvent(d->stream, s.ev_count, 0));
+        s.count_pending = false;
+    }
+    // debug_try_cap (tests of the relaunch path) wants every try on the launch-wide list
+    s.try_regions = s.tries_on_device && d->cfg.debug_try_cap <= 0;
+    if (s.try_regions && slot_reserve_device_tries(d, s, s.d_try_cap, s.ntiles))
+        return -1;
     s.args.tries = s.tries_on_device ? s.d_tries : s.tries;
     s.args.try_cap = (uint32_t)std::min<size_t>(s.tries_on_device ? s.d_try_cap : s.try_cap, 0xFFFFFFFFu);
+    s.args.try_counts = s.try_regions ? s.d_try_counts : nullptr;
+    s.args.try_list_first = s.try_regions ? (uint32_t)(s.d_try_tiles * adsb::kTryRegion) : 0u;
     // d_counters are zero here: cleared at creation, and the report kernel behind every scan leaves them so
     s.args.profile = d->cfg.profile ? 1 : 0;
     s.args.report = s.hc();
@@ -577,8 +603,14 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
 // decides every try below the resolver's position against the frames it accepted
 // since the previous pass (plus the last one before, whose span may reach further),
 // adds three counters to the statistics and carries the undecided tries.
-int count_tries_pass(adsb_decoder *d, const uint32_t *d_tries, uint32_t n_tries, uint64_t g_base, bool final)
+// Everything here goes to the decoder's COUNT stream: the upload of the accepted frames and the count kernel
+// (~40 us of device time together) run beside the next scan instead of in front of it.  Nothing on the scan
+// stream depends on them except the reuse of the slot's try list, four launches later (ev_count).  No event is
+// needed in the other direction: the host has seen the launch's report, so the scan that wrote the list is over.
+int count_tries_pass(adsb_decoder *d, ScanSlot *slot, uint32_t n_tries, uint64_t g_base, bool final)
 {
+    hipStream_t cs = d->count_stream;
+    const bool regions = slot && slot->try_regions;
     auto &log = d->res.accepted_log();
     const size_t nf = log.size() + (d->have_prev_frame ? 1 : 0);
     auto remember_last = [&] {
@@ -589,12 +621,12 @@ int count_tries_pass(adsb_decoder *d, const uint32_t *d_tries, uint32_t n_tries,
             log.clear();
         }
     };
-    if (n_tries == 0 && !d->carry_maybe) {
+    if (n_tries == 0 && !regions && !d->carry_maybe) {
         remember_last();
         return 0;
     }
     if (nf > d->frames_cap) { // rare: grow the frame arrays (passes in flight use them: drain the stream first)
-        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        HIP_TRY(d, hipStreamSynchronize(cs));
         const size_t cap = std::max<size_t>(nf + nf / 4, 4096);
         if (d->d_frames) HIP_TRY(d, hipFree(d->d_frames));
         d->d_frames = nullptr;
@@ -620,14 +652,19 @@ int count_tries_pass(adsb_decoder *d, const uint32_t *d_tries, uint32_t n_tries,
         d->h_frames[b][k++] = adsb::TryFrame{f.first, f.second, 0};
     remember_last();
     if (nf) {
-        HIP_TRY(d, hipMemcpyAsync(d->d_frames, d->h_frames[b], nf * sizeof(adsb::TryFrame), hipMemcpyHostToDevice, d->stream));
-        HIP_TRY(d, hipEventRecord(d->ev_frames[b], d->stream));
+        HIP_TRY(d, hipMemcpyAsync(d->d_frames, d->h_frames[b], nf * sizeof(adsb::TryFrame), hipMemcpyHostToDevice, cs));
+        HIP_TRY(d, hipEventRecord(d->ev_frames[b], cs));
         d->frames_pending[b] = true;
     }
     const int c_in = d->carry_n_cur, c_out = (c_in + 1) % 3, c_next = (c_in + 2) % 3;
     adsb::TryCountArgs a{};
-    a.tries = d_tries;
+    a.tries = slot ? slot->d_tries + slot->args.try_list_first : nullptr;
     a.n_tries = n_tries;
+    a.regions = regions ? slot->d_tries : nullptr;
+    a.region_counts = regions ? slot->d_try_counts : nullptr;
+    a.n_tiles = regions ? slot->ntiles : 0;
+    a.passes = slot ? slot->args.passes : 0;
+    a.stagger = slot ? slot->args.stagger : 0;
     a.g_base = g_base;
     a.carry_in = d->d_carry[d->carry_cur];
     a.n_carry = d->d_carry_n + c_in;
@@ -640,7 +677,11 @@ int count_tries_pass(adsb_decoder *d, const uint32_t *d_tries, uint32_t n_tries,
     a.n_carry_out = d->d_carry_n + c_out; // zero: cleared at creation / reset, or by the pass before last
     a.n_carry_next = d->d_carry_n + c_next;
     a.acc = d->d_try_acc;
-    HIP_TRY(d, adsb::launch_count_tries(a, d->stream)); // enqueued and forgotten: read_tries() collects
+    HIP_TRY(d, adsb::launch_count_tries(a, cs)); // enqueued and forgotten: read_tries() collects
+    if (slot && (n_tries || regions)) {
+        HIP_TRY(d, hipEventRecord(slot->ev_count, cs));
+        slot->count_pending = true;
+    }
     d->prof.tries += n_tries;
     d->carry_cur ^= 1;
     d->carry_n_cur = c_out;
@@ -656,8 +697,8 @@ int read_tries(adsb_decoder *d)
     if (!d->tries_unread)
         return 0;
     unsigned long long acc[4];
-    HIP_TRY(d, hipMemcpyAsync(acc, d->d_try_acc, sizeof acc, hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    HIP_TRY(d, hipMemcpyAsync(acc, d->d_try_acc, sizeof acc, hipMemcpyDeviceToHost, d->count_stream));
+    HIP_TRY(d, hipStreamSynchronize(d->count_stream));
     d->tries_unread = false;
     if (acc[3])
         return d->fail("undecided tries exceeded the carry buffer (%u entries)", kCarryCap);
@@ -760,7 +801,7 @@ int slot_collect(adsb_decoder *d)
         if (slot_reserve(d, s, std::max(s.cand_cap, nc + nc / 8 + 64),
                          s.tries_on_device ? s.try_cap : std::max(s.try_cap, nt + nt / 8 + 64)))
             return -1;
-        if (s.tries_on_device && slot_reserve_device_tries(d, s, std::max(s.d_try_cap, nt + nt / 8 + 64)))
+        if (s.tries_on_device && slot_reserve_device_tries(d, s, std::max(s.d_try_cap, nt + nt / 8 + 64), s.d_try_tiles))
             return -1;
         if (slot_launch(d, s))
             return -1;
@@ -821,10 +862,10 @@ int slot_collect(adsb_decoder *d)
         if (d->final_follows && d->slot_count == 1) {
             // last launch of the stream: its tries are counted by the end-of-stream pass, which
             // runs right after the final resolver step -- one device round trip instead of two
-            d->deferred_tries = s.d_tries;
+            d->deferred_slot = &s;
             d->deferred_n = (uint32_t)nt;
             d->deferred_base = s.args.g_begin;
-        } else if (count_tries_pass(d, s.d_tries, (uint32_t)nt, s.args.g_begin, false)) {
+        } else if (count_tries_pass(d, &s, (uint32_t)nt, s.args.g_begin, false)) {
             return -1;
         }
     }
@@ -865,7 +906,7 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
         if (slot_reserve(d, s, std::max<size_t>(s.cand_cap, cand_want),
                          host_tries ? std::max<size_t>(s.try_cap, try_want) : s.try_cap))
             return -1;
-        if (stats && !host_tries && slot_reserve_device_tries(d, s, std::max<size_t>(s.d_try_cap, try_want)))
+        if (stats && !host_tries && slot_reserve_device_tries(d, s, std::max<size_t>(s.d_try_cap, try_want), s.d_try_tiles))
             return -1;
         adsb::ScanArgs &a = s.args;
         a = adsb::ScanArgs{};
@@ -1147,6 +1188,13 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             (e = hipEventCreate(&d->ev_frames[0])) != hipSuccess || (e = hipEventCreate(&d->ev_frames[1])) != hipSuccess)
             return bail("hipMalloc(try counters)", e);
         d->d_carry_n = reinterpret_cast<uint32_t *>(d->d_try_acc + 4);
+        int prio_least = 0, prio_greatest = 0; // the count passes give way to the scans they run beside
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if ((e = hipStreamCreateWithPriority(&d->count_stream, hipStreamNonBlocking, prio_least)) != hipSuccess)
+            return bail("hipStreamCreate(count)", e);
+        for (ScanSlot &sl : d->slots)
+            if ((e = hipEventCreateWithFlags(&sl.ev_count, hipEventDisableTiming)) != hipSuccess)
+                return bail("hipEventCreate(count)", e);
         d->res.log_accepted(true);
     }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1166,6 +1214,10 @@ void adsb_destroy(adsb_decoder *d)
             (void)hipStreamSynchronize(cs);
     if (d->stream)
         (void)hipStreamSynchronize(d->stream);
+    if (d->count_stream) {
+        (void)hipStreamSynchronize(d->count_stream);
+        (void)hipStreamDestroy(d->count_stream);
+    }
     for (int i = 0; i < adsb_decoder::kCopyStreams; i++) {
         if (d->ev_copy[i]) (void)hipEventDestroy(d->ev_copy[i]);
         if (d->copy_stream[i]) (void)hipStreamDestroy(d->copy_stream[i]);
@@ -1190,9 +1242,11 @@ void adsb_destroy(adsb_decoder *d)
         if (sl.cands) (void)hipHostFree(sl.cands);
         if (sl.tries) (void)hipHostFree(sl.tries);
         if (sl.d_tries) (void)hipFree(sl.d_tries);
+        if (sl.d_try_counts) (void)hipFree(sl.d_try_counts);
         if (sl.hand) (void)hipHostFree(sl.hand);
         for (hipEvent_t ev : sl.ev_ready)
             if (ev) (void)hipEventDestroy(ev);
+        if (sl.ev_count) (void)hipEventDestroy(sl.ev_count);
     }
     if (d->own_stream && d->stream)
         (void)hipStreamDestroy(d->stream);
@@ -1213,16 +1267,19 @@ int adsb_reset(adsb_decoder *d)
         for (hipStream_t cs : d->copy_stream)
             HIP_TRY(d, hipStreamSynchronize(cs));
         HIP_TRY(d, hipStreamSynchronize(d->stream));
+        if (d->count_stream)
+            HIP_TRY(d, hipStreamSynchronize(d->count_stream));
         for (ScanSlot &sl : d->slots) {
             // normally the report kernel behind each scan has left the counters zero; after a failed launch it may not have
             HIP_TRY(d, hipMemsetAsync(sl.d_counters, 0, adsb::kCounterWords * sizeof(uint32_t), d->stream));
             sl.busy = false;
+            sl.count_pending = false;
             sl.prof_pending[0] = sl.prof_pending[1] = false;
         }
     }
     d->final_follows = false;
-    d->deferred_tries = nullptr;
     d->deferred_n = 0;
+    d->deferred_slot = nullptr;
     d->deferred_base = 0;
     d->sink = ScanSink{};
     d->n_samples = 0;
@@ -1235,13 +1292,17 @@ int adsb_reset(adsb_decoder *d)
     d->res.log_accepted(d->cfg.collect_stats != 0);
     if (d->acc_dirty) { // behind any count pass still queued
         HIP_TRY(d, hipSetDevice(d->device));
-        HIP_TRY(d, hipMemsetAsync(d->d_try_acc, 0, kTryStateBytes, d->stream));
+        HIP_TRY(d, hipMemsetAsync(d->d_try_acc, 0, kTryStateBytes, d->count_stream));
     }
     d->acc_dirty = false;
     d->tries_unread = false;
     d->carry_maybe = false;
     d->have_prev_frame = false;
-    d->slot_head = 0;
+    // In a statistics run slot_head keeps turning: the next stream's first scan then does not have to wait for
+    // the count pass that the last launch of this one left behind on the count stream.  Otherwise a stream of
+    // one launch stays in slot 0 (the other slots' buffers are never allocated).
+    if (!d->cfg.collect_stats)
+        d->slot_head = 0;
     d->slot_count = 0;
     d->err.clear();
     return 0;
@@ -1370,14 +1431,14 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
         }
         const auto t1 = clk::now();
         d->final_follows = true;
-        d->deferred_tries = nullptr, d->deferred_n = 0;
+        d->deferred_n = 0, d->deferred_slot = nullptr;
         const int rc = scan_drain(d);
         d->final_follows = false;
         if (rc)
             return -1;
         const auto t2 = clk::now();
         d->res.advance(2 * ((total + 3) / 4), d->g_scanned); // EOF rule: see process_stage()
-        if (d->cfg.collect_stats && count_tries_pass(d, d->deferred_tries, d->deferred_n, d->deferred_base, true))
+        if (d->cfg.collect_stats && count_tries_pass(d, d->deferred_slot, d->deferred_n, d->deferred_base, true))
             return -1; // tries beyond the final position are never visited
         d->stage_fill = 0;
         d->finished = true;

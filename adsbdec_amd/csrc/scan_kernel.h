@@ -152,9 +152,16 @@ struct ScanArgs {
     int profile;
     uint32_t *cands;     // kCandWords dwords per record
     uint32_t cand_cap;
-    uint32_t *tries;     // (g_rel << 2) | code
+    // Tries (statistics runs): words (g_rel << 2) | code.  With try_counts (device-resident counting of a
+    // stream): tile t's whole-tile round writes try_counts[t] words into tries[t * kTryRegion ..], and only
+    // queue-overflow rounds append to the launch-wide list tries[try_list_first ..] (try_cap words, counted in
+    // counters[1]).  Without (try_counts == null, try_list_first == 0): everything goes to the list.
+    uint32_t *tries;
     uint32_t try_cap;
+    uint32_t *try_counts;
+    uint32_t try_list_first;
 };
+constexpr int kTryRegion = kQueueCap; // a whole-tile round queues at most queue_cap <= kQueueCap survivors
 
 // Second, tiny kernel of statistics runs (valid.c:46,68 count a Try only for VISITED
 // offsets): the try words of a launch stay on the device; once the host has
@@ -168,8 +175,13 @@ struct TryFrame { // an accepted frame as the count kernel needs it (one upload 
     uint32_t span, pad;
 };
 struct TryCountArgs {
-    const uint32_t *tries;     // this launch: (g_rel << 2) | code
+    const uint32_t *tries;     // this launch's launch-wide list: (g_rel << 2) | code
     uint32_t n_tries;
+    const uint32_t *regions;   // ... and its per-tile regions (ScanArgs::try_counts), or null
+    const uint32_t *region_counts;
+    uint32_t n_tiles;
+    int passes;                // the launch's tile geometry (tile_first_run)
+    uint32_t stagger;
     uint64_t g_base;
     const uint64_t *carry_in;  // undecided tries of earlier passes: (g << 2) | code
     const uint32_t *n_carry;   // device: how many (left there by the previous pass)

@@ -728,10 +728,19 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         __syncthreads();
         const bool over = *qover != 0;
         const int qn = over ? 0 : (int)*qcount;
-        if (kStats) { // one reservation of the launch-wide try list per round, not one per try
-            if (tid == 0)
-                *try_base = qn ? atomicAdd(&args.counters[1], (uint32_t)qn) : 0u;
-            __syncthreads();
+        // valid.c:46,68: every DF-gate pass that is visited is a Try -- the queue entries ARE the tries.  A
+        // whole-tile round puts them into the tile's own region of args.tries (kTryRegion words; the count goes
+        // to args.try_counts[tile]): no launch-wide reservation -- one more device-scope atomic per tile, awaited
+        // by the wave that issued it at its next load, cost 22 % of the kernel (0.174 against 0.142 ms).  Fallback
+        // rounds (queue overflow), and launches without regions (per-shard scans hand a dense list to the host),
+        // reserve a range of the launch-wide list behind the regions; that round trip runs under the slicer.
+        const bool try_region = kStats && args.try_counts && grp < 0; // workgroup-uniform
+        uint32_t try_res = 0;
+        if (kStats && tid == 0) {
+            if (try_region)
+                args.try_counts[blockIdx.x] = (uint32_t)qn; // 0 when the queue overflowed: the fallback rounds list them
+            else if (qn)
+                try_res = atomicAdd(&args.counters[1], (uint32_t)qn);
         }
 #pragma unroll 1
         for (int q = tid; q < qn; q += kThreads) {
@@ -739,11 +748,6 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             const int sv = (int)(ent >> 7), sj = (int)((ent >> 2) & 31u);
             const uint32_t code = ent & 3u;
             const uint32_t g_rel = (uint32_t)(t0 - (int64_t)args.g_begin) + (uint32_t)(kRun * sv + sj);
-            if (kStats) { // valid.c:46,68: every DF-gate pass that is visited is a Try
-                const uint32_t ts = *try_base + (uint32_t)q;
-                if (ts < args.try_cap)
-                    args.tries[ts] = (g_rel << 2) | code;
-            }
             // Frame bit k = 14 b + c lies 80 + 10 k samples after g: column c is
             // at stream position sj + 80 + 10 c (+ 140 b = 5 words per b).
             const uint32_t *dcol = pl_d + sv;
@@ -807,6 +811,19 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             emit_loose(g_rel, pw, wds);
         }
 
+        if (kStats && qn) { // (qn is workgroup-uniform)
+            if (tid == 0)
+                *try_base = try_res;
+            __syncthreads(); // (the slicer only reads the queue)
+            const uint32_t tb = *try_base;
+            uint32_t *dst = args.tries + (try_region ? (size_t)blockIdx.x * kTryRegion : (size_t)args.try_list_first + tb);
+            const uint32_t room = try_region ? (uint32_t)kTryRegion : (tb < args.try_cap ? args.try_cap - tb : 0u);
+            for (int q = tid; q < qn; q += kThreads) { // adjacent lanes, adjacent words
+                const uint32_t ent = queue[q];
+                if ((uint32_t)q < room)
+                    dst[q] = ((tile_rel + (uint32_t)kRun * (ent >> 7) + ((ent >> 2) & 31u)) << 2) | (ent & 3u);
+            }
+        }
         ADSB_STAMP(2);
         if (stage_cands) {
             // Drop candidates the greedy scan (demod.c:89,128,134,141) can never visit.
@@ -1064,48 +1081,118 @@ __global__ __launch_bounds__(64) void report_kernel(uint32_t *counters, uint32_t
     store_granule_through(report, 1, u32x4{(uint32_t)nb, (uint32_t)(nb >> 32), (uint32_t)en, (uint32_t)(en >> 32)});
 }
 
-__global__ __launch_bounds__(256) void count_tries_kernel(const TryCountArgs a)
+// Is g inside an accepted frame that starts before it?  (The frame's own offset is a visited Try: strict
+// inequality.)  Binary search over the whole frame array: the list and carry entries, and tiles whose window
+// of frames does not fit a wave.
+__device__ __forceinline__ bool try_shadowed(const TryCountArgs &a, uint64_t g)
+{
+    uint32_t lo = 0, hi = a.n_frames;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.frames[mid].g < g)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo > 0 && g < a.frames[lo - 1].g + a.frames[lo - 1].span;
+}
+
+// Blocks [0, ceil(n_tiles / 4)): one WAVE per tile region.  The accepted frames that can shadow a try of the
+// tile start inside (t0 - 1200, t0 + tile offsets): the wave finds the first of them with a 64-way search (three
+// rounds of one load per lane for 13 k frames, instead of 14 dependent loads per try), keeps the window one
+// frame per lane, and tests every try against it on lane broadcasts.  Measured: the per-try binary search took
+// 34 us per 256 Mi samples with 8 192 resident waves, and slowed the scan kernel running beside it by as much.
+// The remaining blocks: the launch-wide list and the carry of earlier passes, grid-stride.
+constexpr int kCountThreads = 256;
+__global__ __launch_bounds__(kCountThreads) void count_tries_kernel(const TryCountArgs a)
 {
     uint32_t cnt[3] = {0, 0, 0};
-    const uint32_t n_carry = min(*a.n_carry, a.carry_cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        *a.n_carry_next = 0; // three counts in rotation: nobody reads or appends to this one during this pass
-    const uint32_t total = a.n_tries + n_carry;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        uint64_t g;
-        uint32_t code;
-        if (i < a.n_tries) {
-            const uint32_t w = a.tries[i];
-            g = a.g_base + (w >> 2);
-            code = w & 3u;
-        } else {
-            const uint64_t w = a.carry_in[i - a.n_tries];
-            g = w >> 2;
-            code = (uint32_t)w & 3u;
-        }
-        if (g >= a.hi) { // the scan has not got there yet
-            if (!a.final) {
-                const uint32_t slot = atomicAdd(a.n_carry_out, 1u);
-                if (slot < a.carry_cap)
-                    a.carry_out[slot] = (g << 2) | code;
-                else
-                    a.acc[3] = 1; // reported when the statistics are read
+    const uint32_t region_blocks = a.regions ? (a.n_tiles + 3u) / 4u : 0u;
+    auto carry = [&](uint64_t g, uint32_t code) { // the scan has not got there yet
+        if (a.final)
+            return;
+        const uint32_t slot = atomicAdd(a.n_carry_out, 1u);
+        if (slot < a.carry_cap)
+            a.carry_out[slot] = (g << 2) | code;
+        else
+            a.acc[3] = 1; // reported when the statistics are read
+    };
+    if (blockIdx.x < region_blocks) {
+        const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+        const uint32_t n = tile < a.n_tiles ? min(a.region_counts[tile], (uint32_t)kTryRegion) : 0u;
+        if (n) { // wave-uniform
+            const uint64_t t0 = a.g_base + (uint64_t)kRun * tile_first_run(tile, a.stagger, a.passes);
+            const uint64_t t1 = t0 + (uint64_t)kRun * (uint64_t)owned_runs(tile_passes(tile, a.stagger, a.passes));
+            const uint64_t key = t0 >= (uint64_t)(ADSB_DECOFFSET_K - 1) ? t0 - (ADSB_DECOFFSET_K - 1) : 0; // frames below cannot reach t0
+            // first frame with g >= key: the answer lies in [lo, hi]
+            uint32_t lo = 0, hi = a.n_frames;
+            while (lo < hi) {
+                const uint32_t step = (hi - lo + 63u) / 64u, idx = lo + lane * step;
+                const bool below = idx < hi && a.frames[idx].g < key; // true for a prefix of the lanes
+                const uint32_t k = (uint32_t)__popcll(__ballot(below));
+                if (k == 0) {
+                    hi = lo;
+                } else {
+                    const uint32_t nlo = lo + (k - 1u) * step + 1u;
+                    hi = min(lo + k * step, hi);
+                    lo = nlo;
+                }
             }
-            continue;
+            // the window, one frame per lane, relative to key (everything fits 32 bits)
+            const uint32_t fi = lo + lane;
+            const bool have = fi < a.n_frames && a.frames[fi].g < t1;
+            const uint32_t fr = have ? (uint32_t)(a.frames[fi].g - key) : 0xFFFFFFFFu;
+            const uint32_t fe = have ? fr + a.frames[fi].span : 0u;
+            const uint32_t w = (uint32_t)__popcll(__ballot(have));
+            const bool fits = w < 64u || lo + 64u >= a.n_frames || a.frames[lo + 64u].g >= t1; // wave-uniform
+            const uint32_t *reg = a.regions + (size_t)tile * kTryRegion;
+            for (uint32_t i = lane; i < n; i += 64u) {
+                const uint32_t word = reg[i], code = word & 3u;
+                const uint64_t g = a.g_base + (word >> 2);
+                if (g >= a.hi) {
+                    carry(g, code);
+                    continue;
+                }
+                bool shadowed;
+                if (fits) {
+                    const uint32_t rt = (uint32_t)(g - key);
+                    shadowed = false;
+                    for (uint32_t j = 0; j < w; j++) { // (w is wave-uniform; lanes that left the loop above just idle)
+                        const uint32_t fj = __builtin_amdgcn_readlane(fr, j), ej = __builtin_amdgcn_readlane(fe, j);
+                        shadowed |= fj < rt && rt < ej;
+                    }
+                } else {
+                    shadowed = try_shadowed(a, g);
+                }
+                if (!shadowed)
+                    cnt[code < 3 ? code : 2]++;
+            }
         }
-        // last accepted frame that starts before g: is g inside it?  (The frame's own
-        // offset is a visited Try: strict inequality.)
-        uint32_t lo = 0, hi = a.n_frames;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (a.frames[mid].g < g)
-                lo = mid + 1;
-            else
-                hi = mid;
+    } else {
+        const uint32_t n_carry = min(*a.n_carry, a.carry_cap);
+        if (blockIdx.x == region_blocks && threadIdx.x == 0)
+            *a.n_carry_next = 0; // three counts in rotation: nobody reads or appends to this one during this pass
+        const uint32_t total = a.n_tries + n_carry;
+        const uint32_t nb = gridDim.x - region_blocks;
+        for (uint32_t i = (blockIdx.x - region_blocks) * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
+            uint64_t g;
+            uint32_t code;
+            if (i < a.n_tries) {
+                const uint32_t w = a.tries[i];
+                g = a.g_base + (w >> 2);
+                code = w & 3u;
+            } else {
+                const uint64_t w = a.carry_in[i - a.n_tries];
+                g = w >> 2;
+                code = (uint32_t)w & 3u;
+            }
+            if (g >= a.hi) {
+                carry(g, code);
+                continue;
+            }
+            if (!try_shadowed(a, g))
+                cnt[code < 3 ? code : 2]++;
         }
-        const bool shadowed = lo > 0 && g < a.frames[lo - 1].g + a.frames[lo - 1].span;
-        if (!shadowed)
-            cnt[code < 3 ? code : 2]++;
     }
     // one atomic per block and counter: same-address atomics serialise in L2
     __shared__ uint32_t part[3];
@@ -1127,10 +1214,11 @@ __global__ __launch_bounds__(256) void count_tries_kernel(const TryCountArgs a)
 
 hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream)
 {
-    // the carry count lives on the device: a fixed grid, grid-stride over whatever there is
+    // the carry count lives on the device: a fixed number of blocks, grid-stride over whatever there is
+    const uint32_t region_blocks = args.regions ? (args.n_tiles + 3u) / 4u : 0u;
     const uint32_t guess = args.n_tries + 65536u;
-    const unsigned blocks = (unsigned)std::min<uint32_t>((guess + 255u) / 256u, 2048u);
-    hipLaunchKernelGGL(count_tries_kernel, dim3(blocks), dim3(256), 0, stream, args);
+    const unsigned list_blocks = (unsigned)std::min<uint32_t>((guess + kCountThreads - 1u) / kCountThreads, args.regions ? 64u : 2048u);
+    hipLaunchKernelGGL(count_tries_kernel, dim3(region_blocks + list_blocks), dim3(kCountThreads), 0, stream, args);
     return hipGetLastError();
 }
 

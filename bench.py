@@ -240,6 +240,14 @@ def roofline_objects(p0, p1, steps, profiles_tag="r2"):
     return roofline, valu
 
 
+def preroll(step, ms, at_least=40):
+    """Untimed steps for `ms` of wall time (and at least `at_least` of them): the clock governor's ramp, see main()."""
+    t, i = time.perf_counter(), 0
+    while i < at_least or (time.perf_counter() - t) * 1e3 < ms:
+        step(i)
+        i += 1
+
+
 def timed_steps(step, steps, fence):
     fence()
     t0 = time.perf_counter()
@@ -450,8 +458,38 @@ def main():
     # ---- extra legs, after the timed region (rank 0, N == 1): dense sub-record, host-fed rates ----
     dense = None
     e2e = None
+    with_stats = None
     if rank == 0 and world == 1 and not args.no_extras:
         e2e = host_fed_rates(torch, capi, xs[0], args.dense)
+        if not args.stats:
+            # the same step with valid.c's Try/Ok table reproduced too (the reference always keeps it and prints
+            # it at exit): tries counted on the device beside the next scan; the table is read once, after the loop
+            ds = capi.Decoder(df18=args.dense, device=local_rank, profile=True, collect_stats=True)
+
+            def sstep(i=0):
+                p, m = ptrs[i % len(ptrs)]
+                ds.reset()
+                ds.push_device_final(p, m)
+                return ds.take_raw()
+            preroll(sstep, args.preroll_ms)
+            torch.cuda.synchronize()
+            s0 = ds.profile()
+            sdt, _ = timed_steps(sstep, 50, torch.cuda.synchronize)
+            s1 = ds.profile()
+            sroof, _ = roofline_objects(s0, s1, 50, "r2_dense" if args.dense else "r2")
+            with_stats = {"what": "collect_stats=1: the step above + the Try table of valid.c:84-100", "steps": 50, "preroll_ms": args.preroll_ms,
+                          "value": round(n * 50 / sdt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(sdt / 50 * 1e3, 4),
+                          "launch_ms": sroof["launch_ms"]}
+            if not args.no_cpu_baseline:
+                from oracle import oracle as O
+                sstep(0)
+                _, wst = O.decode(xs[0].cpu().numpy().view(np.uint16), df18=args.dense)
+                got = ds.stats()
+                if got["try"] != wst["try"] or got["ok"] != wst["ok"]:
+                    raise SystemExit(f"PARITY FAILURE: Try/Ok table {got} != oracle {wst}")
+                with_stats["table"] = {"try": got["try"], "ok": got["ok"]}
+                with_stats["parity_vs_oracle"] = True
+            ds.close()
         if not args.dense:
             del xs[1:], ptrs[1:]
             torch.cuda.empty_cache()
@@ -462,8 +500,7 @@ def main():
                 dd.reset()
                 dd.push_device_final(xd.data_ptr(), xd.numel())
                 return dd.take_raw()
-            for _ in range(40):
-                dstep()
+            preroll(dstep, args.preroll_ms)
             torch.cuda.synchronize()
             q0 = dd.profile()
             ddt, draw = timed_steps(dstep, 50, torch.cuda.synchronize)
@@ -471,6 +508,7 @@ def main():
             droof, _ = roofline_objects(q0, q1, 50, profiles_tag="r2_dense")
             dense = {"workload": f"BASELINE configs[2]: {n} samples of sigma=300 noise (~7 % of offsets pass the preamble "
                                  "test, ~0.65 % the DF gate) + one 112-bit frame per ms at amplitude 1200-2000, -a", "steps": 50,
+                     "preroll_ms": args.preroll_ms,
                      "value": round(n * 50 / ddt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ddt / 50 * 1e3, 4),
                      "launch_ms": droof["launch_ms"], "roofline_frac": droof["frac"], "frames": int(draw[1]),
                      "relaunches": int(q1["relaunches"] - q0["relaunches"])}
@@ -491,7 +529,7 @@ def main():
             "config": {"workload": workload, "samples_per_gpu": n, "frames_decoded_rank0": len(frames),
                        "parity_vs_cpu": parity},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
-            "value_cold": value_cold, "dense": dense, "e2e_host_fed": e2e,
+            "value_cold": value_cold, "with_stats": with_stats, "dense": dense, "e2e_host_fed": e2e,
         }
         print(json.dumps(line), flush=True)
     dec.close()

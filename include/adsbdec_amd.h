@@ -107,7 +107,8 @@ typedef struct adsb_profile {
     double last_kernel_ms;
     uint64_t last_offsets;
     uint64_t candidates;       /* CRC-valid candidates received from the device     */
-    uint64_t tries;            /* DF-gate passes received (collect_stats=1 only)    */
+    uint64_t tries;            /* DF-gate passes that came through launch-wide lists (collect_stats=1: per-shard scans and
+                                * queue-overflow rounds; tries counted from the tiles' own regions on the device are not in it) */
     double host_ms;            /* host time spent sorting + resolving records       */
     double wait_ms;            /* host time blocked waiting for the device          */
     uint64_t big_offsets;      /* offsets per launch of the largest launch size seen */

@@ -196,6 +196,33 @@ def test_async_pushes_reference_call_size_and_mixed_calls(capi, oracle, dec_fact
     assert d.stats() == wstats
 
 
+@pytest.mark.parametrize("passes", ["7", "10"])
+def test_try_counting_with_more_than_64_frames_per_tile(oracle, dec_factory, monkeypatch, passes):
+    """Statistics runs count the tries on the device, one wave per tile, against the window of accepted frames
+    that can shadow the tile's offsets -- one frame per lane.  Short frames packed back to back (640 offsets
+    apart: the greedy scan lands exactly on the next preamble, demod.c:128) put 75+ accepted frames into the
+    window of a 7-pass tile, more than a wave holds: the per-try binary search takes over.  Tile size forced
+    through ADSB_PASSES (launches this small would take 2..6 passes)."""
+    from oracle import gen_signal as G
+    monkeypatch.setenv("ADSB_PASSES", passes)
+    rng = np.random.default_rng(11)
+    n = 3 << 19
+    frames = [(5_000 + 1_280 * i, G.make_frame(11, rng), float(rng.uniform(600, 1500)), float(rng.uniform(0, 6.28)))
+              for i in range((n - 10_000) // 1_280)]
+    frames = [f for k, f in enumerate(frames) if k % 97 != 50]        # a few gaps, so that noise tries exist between runs
+    x = G.synth(n, frames, 25.0, 5)
+    want, wstats = oracle.decode(x, df18=True)
+    assert len(want) > 1000 and sum(wstats["try"].values()) > len(want)
+    d = dec_factory(df18=True, collect_stats=True)
+    assert records(d.decode(x)) == records(want)
+    assert d.stats() == wstats
+    t = __import__("torch").from_numpy(x.view(np.int16)).cuda()
+    d.reset()
+    d.push_device_final(t.data_ptr(), t.numel())
+    assert records(d.drain()) == records(want)
+    assert d.stats() == wstats
+
+
 @pytest.mark.parametrize("stats", [False, True])
 def test_async_small_staging_seam_is_ordered(capi, dec_factory, stats):
     """Regression for a race found in round 2: with a 64 Ki-sample staging buffer every asynchronous piece
