@@ -55,7 +55,7 @@ inline uint64_t round_down(uint64_t v, uint64_t q) { return v - v % q; }
 // this slot's PINNED HOST buffers (the records are tens of bytes per frame; PCIe writes
 // are free next to the sample traffic) -- no device-to-host copy of records, ever.
 struct ScanSlot {
-    uint32_t *d_counters = nullptr; // device: adsb::kCounterWords (ScanArgs::counters)
+    uint32_t *d_counters = nullptr; // device: adsb::kDevCounterWords (ScanArgs::counters)
     uint32_t *h_counters = nullptr; // pinned, written by the launch's report kernel (ScanArgs::report): two copies
                                     // used in turn (ev_cur), so that a launch's kernel time can be read
                                     // behind the slot's NEXT launch instead of in front of it
@@ -1153,9 +1153,9 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         if ((e = hipMalloc(&d->stage[i], d->stage_cap * sizeof(uint16_t))) != hipSuccess)
             return bail("hipMalloc(stage)", e);
     for (ScanSlot &sl : d->slots) {
-        if ((e = hipMalloc(&sl.d_counters, adsb::kCounterWords * sizeof(uint32_t))) != hipSuccess)
+        if ((e = hipMalloc(&sl.d_counters, adsb::kDevCounterWords * sizeof(uint32_t))) != hipSuccess)
             return bail("hipMalloc(counters)", e);
-        if ((e = hipMemset(sl.d_counters, 0, adsb::kCounterWords * sizeof(uint32_t))) != hipSuccess)
+        if ((e = hipMemset(sl.d_counters, 0, adsb::kDevCounterWords * sizeof(uint32_t))) != hipSuccess)
             return bail("hipMemset(counters)", e);
         if ((e = hipHostMalloc(&sl.h_counters, 2 * adsb::kCounterWords * sizeof(uint32_t), hipHostMallocCoherent)) != hipSuccess)
             return bail("hipHostMalloc(counters)", e);
@@ -1271,7 +1271,7 @@ int adsb_reset(adsb_decoder *d)
             HIP_TRY(d, hipStreamSynchronize(d->count_stream));
         for (ScanSlot &sl : d->slots) {
             // normally the report kernel behind each scan has left the counters zero; after a failed launch it may not have
-            HIP_TRY(d, hipMemsetAsync(sl.d_counters, 0, adsb::kCounterWords * sizeof(uint32_t), d->stream));
+            HIP_TRY(d, hipMemsetAsync(sl.d_counters, 0, adsb::kDevCounterWords * sizeof(uint32_t), d->stream));
             sl.busy = false;
             sl.count_pending = false;
             sl.prof_pending[0] = sl.prof_pending[1] = false;

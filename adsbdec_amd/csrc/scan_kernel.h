@@ -48,7 +48,14 @@ constexpr int kSyndWords = 14 * 256;
 constexpr int kFixSlots = 512;
 // hand-off stream (ScanArgs::hand): 16-byte granules
 constexpr int kGranuleWords = 4;
-constexpr int kCounterWords = 8; // ScanArgs::counters
+constexpr int kCounterWords = 8; // the launch counters as the host sees them (ScanArgs::report)
+// On the device every counter has a 128-byte line of its own (ScanArgs::counters[i * kCounterPad]; the two
+// 64-bit profile maxima are counters 4 and 5).  All of a launch's tiles hit them with device-scope atomics.
+#ifndef ADSB_COUNTER_PAD
+#define ADSB_COUNTER_PAD 32
+#endif
+constexpr int kCounterPad = ADSB_COUNTER_PAD;
+constexpr int kDevCounterWords = 6 * kCounterPad;
 constexpr uint32_t kMarkOver = 0x10000u;  // marker flag: some records of the tile are on the loose list
 constexpr uint32_t kMarkNoFit = 0x20000u; // marker flag: the tile's range ran past the array (records are loose)
 // Granules a tile with n records reserves: marker + 2 n, rounded up to whole 64-byte lines, so

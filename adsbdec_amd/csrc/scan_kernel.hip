@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     auto emit_loose = [&](uint32_t g_rel, uint32_t pw, const uint32_t (&wds)[4]) {
         if (args.hand)
             *tile_over = 1;
-        const uint32_t slot = atomicAdd(&args.counters[0], 1u);
+        const uint32_t slot = atomicAdd(&args.counters[0 * kCounterPad], 1u);
         if (slot < args.cand_cap) {
             uint32_t *rec = args.cands + (size_t)slot * kCandWords;
             rec[0] = g_rel;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     __syncthreads();
 #if ADSB_ABLATE != 0
     if (pl_d[(tid * 29) % (kPassRuns * K)] == 0x12345678u) // kbench: keep Stage A alive, skip the rest
-        atomicAdd(&args.counters[0], 1u);
+        atomicAdd(&args.counters[0 * kCounterPad], 1u);
     return;
 #endif
 
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             if (try_region)
                 args.try_counts[blockIdx.x] = (uint32_t)qn; // 0 when the queue overflowed: the fallback rounds list them
             else if (qn)
-                try_res = atomicAdd(&args.counters[1], (uint32_t)qn);
+                try_res = atomicAdd(&args.counters[1 * kCounterPad], (uint32_t)qn);
         }
 #pragma unroll 1
         for (int q = tid; q < qn; q += kThreads) {
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             const bool reserves = tid == 0 && args.hand;
             if (reserves) { // the result is not looked at before this thread's own record is finished
                 res_need = stream_granules(*tile_n);
-                res_base = atomicAdd(&args.counters[2], res_need);
+                res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
             }
             if (keep && !one_wave) {
                 const uint32_t gi = ri[0];
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         if (tid == 0 && *tile_res != 2) {
             uint32_t b = *tile_base, fit = *tile_fit;
             if (!*tile_res) { // no whole-tile round staged anything (all_candidates, fallback rounds)
-                b = atomicAdd(&args.counters[2], stream_granules(0));
+                b = atomicAdd(&args.counters[2 * kCounterPad], stream_granules(0));
                 fit = b < args.hand_cap;
             }
             if (b < args.hand_cap) {
@@ -1057,8 +1057,8 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         __syncthreads();
         if (tid == 64) { // not wave 0: that one has just issued the tile's write-through stores
             unsigned long long *c64 = reinterpret_cast<unsigned long long *>(args.counters);
-            atomicMax(&c64[2], ~(unsigned long long)prof_begin);
-            atomicMax(&c64[3], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+            atomicMax(&c64[2 * kCounterPad], ~(unsigned long long)prof_begin); // = counters 4 and 5
+            atomicMax(&c64[(5 * kCounterPad) / 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
         }
     }
 }
@@ -1074,9 +1074,10 @@ __global__ __launch_bounds__(64) void report_kernel(uint32_t *counters, uint32_t
     if (threadIdx.x != 0)
         return;
     unsigned long long *c64 = reinterpret_cast<unsigned long long *>(counters);
-    const uint32_t c0 = atomicExch(&counters[0], 0u), c1 = atomicExch(&counters[1], 0u), c2 = atomicExch(&counters[2], 0u);
-    atomicExch(&counters[3], 0u);
-    const unsigned long long nb = atomicExch(&c64[2], 0ull), en = atomicExch(&c64[3], 0ull);
+    const uint32_t c0 = atomicExch(&counters[0], 0u), c1 = atomicExch(&counters[1 * kCounterPad], 0u),
+                   c2 = atomicExch(&counters[2 * kCounterPad], 0u);
+    atomicExch(&counters[3 * kCounterPad], 0u);
+    const unsigned long long nb = atomicExch(&c64[2 * kCounterPad], 0ull), en = atomicExch(&c64[(5 * kCounterPad) / 2], 0ull);
     store_granule_through(report, 0, u32x4{c0, c1, c2, gen});
     store_granule_through(report, 1, u32x4{(uint32_t)nb, (uint32_t)(nb >> 32), (uint32_t)en, (uint32_t)(en >> 32)});
 }

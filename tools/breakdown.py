@@ -7,7 +7,7 @@ torch.cuda.set_device(0)
 n = (256<<20); n -= n % 28
 x, truth = make_workload(torch, n, seed=1)
 torch.cuda.synchronize()
-dec = capi.Decoder(profile=True, collect_stats=bool(os.environ.get("ADSB_STATS")))
+dec = capi.Decoder(profile=True, collect_stats=bool(os.environ.get("ADSB_STATS")), debug_try_cap=int(os.environ.get("ADSB_TRYCAP", "0")))
 for it in range(int(os.environ.get("ADSB_STEPS", "8"))):
     t0=time.perf_counter(); dec.reset()
     t1=time.perf_counter(); dec.push_device_final(x.data_ptr(), x.numel())

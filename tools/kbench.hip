@@ -38,7 +38,7 @@ int main(int argc, char **argv)
     n -= n % 28;
     uint16_t *x; uint32_t *counters, *cands;
     CK(hipMalloc(&x, n * 2));
-    CK(hipMalloc(&counters, 32));
+    CK(hipMalloc(&counters, adsb::kDevCounterWords * 4));
     CK(hipMalloc(&cands, (1u << 20) * 24));
     fill_noise<<<4096, 256>>>(x, n, 12345, argc > 4 ? (float)atof(argv[4]) : 8.0f);
     CK(hipDeviceSynchronize());
@@ -58,7 +58,7 @@ int main(int argc, char **argv)
     a.passes = argc > 3 && atoi(argv[3]) > 0 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256);
     a.stagger = adsb::choose_stagger(a.g_end - a.g_begin, 256, a.passes); // ADSB_STAGGER=0 turns it off
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; i++) { CK(hipMemset(counters, 0, 32)); CK(adsb::launch_scan(a, false, 0)); }
+    for (int i = 0; i < 3; i++) { CK(hipMemset(counters, 0, adsb::kDevCounterWords * 4)); CK(adsb::launch_scan(a, false, 0)); }
     CK(hipDeviceSynchronize());
     std::vector<float> t;
     for (int i = 0; i < iters; i++) {
