@@ -722,7 +722,7 @@ int slot_collect(adsb_decoder *d)
 #if ADSB_TILE_CLOCK == 3
     if (getenv("ADSB_CLOCK_OUT")) { // tuning builds: mean duration of each phase of a tile (thread 0's stamps, scan_kernel.hip)
         HIP_TRY(d, hipStreamSynchronize(d->stream));
-        std::vector<uint32_t> h((size_t)s.ntiles * 8);
+        std::vector<uint32_t> h((size_t)s.ntiles * 9);
         HIP_TRY(d, hipMemcpy(h.data(), s.args.tile_clock, h.size() * 4, hipMemcpyDeviceToHost));
         double sum[7] = {0, 0, 0, 0, 0, 0, 0};
         size_t n = 0;
@@ -737,6 +737,11 @@ int slot_collect(adsb_decoder *d)
                 sum[k] += (o[k + 1] - o[k]) * 0.01;
             n++;
         }
+        double arrive = 0;
+        for (uint32_t i = 0; i < s.ntiles; i++)
+            arrive += h[8 * (size_t)s.ntiles + i] * 0.01 / 4;
+        if (n)
+            fprintf(stderr, "waves reach the barrier behind stage A %.2f us after the tile's begin on average (it opens at the time printed next)\n", arrive / s.ntiles);
         if (n)
             fprintf(stderr, "tile phases (us, thread 0, mean over %zu of %u tiles): stage A %.2f | gate + slicer %.2f | wait for the other "
                     "waves %.2f | filter + rank %.2f | barrier %.2f | bytes, pw, reservation back %.2f | wait for the other records %.2f\n",

@@ -615,7 +615,17 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             pl_e2[v] = e2;
         }
     }
+#if ADSB_TILE_CLOCK == 3
+    if (lane == 0) // when each wave reaches the barrier behind Stage A: how long the four wait for each other
+        tile_chk[wave] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();
+#if ADSB_TILE_CLOCK == 3
+    const uint32_t arrive_sum = tile_chk[0] + tile_chk[1] + tile_chk[2] + tile_chk[3] - 4u * (uint32_t)clk_begin;
+    __syncthreads();
+    if (tid == 0)
+        tile_chk[0] = tile_chk[1] = tile_chk[2] = tile_chk[3] = 0;
+#endif
 #if ADSB_ABLATE != 0
     if (pl_d[(tid * 29) % (kPassRuns * K)] == 0x12345678u) // kbench: keep Stage A alive, skip the rest
         atomicAdd(&args.counters[0 * kCounterPad], 1u);
@@ -1018,6 +1028,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         for (int i = 0; i < 7; i++)
             o[i] = st[i];
         o[7] = (uint32_t)clk_end;
+        args.tile_clock[8 * (size_t)gridDim.x + blockIdx.x] = arrive_sum; // behind the stamps: sum over the waves of (arrival - begin)
 #else
         uint32_t *o = args.tile_clock + 4 * (size_t)blockIdx.x;
         o[0] = (uint32_t)clk_begin;
