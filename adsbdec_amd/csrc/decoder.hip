@@ -1002,19 +1002,25 @@ int process_stage(adsb_decoder *d, bool final, bool in_flight = false)
         const uint64_t skip = keep_first - d->stage_first;
         const uint64_t left = d->stage_fill > skip ? d->stage_fill - skip : 0;
         if (left) {
-            HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur ^ 1], d->stage[d->cur] + skip,
-                                      left * sizeof(uint16_t), hipMemcpyDeviceToDevice, d->stream));
-            if (in_flight && d->dbg_async != 4) {
-                // The next asynchronous piece is copied right behind this tail by a copy engine on another
-                // stream, and the two ranges meet inside a cache line (`left` is not line-aligned): unordered,
-                // the tail copy's write-back of that line and the engine's write to it race, and the loser's
-                // bytes are lost (observed: one frame straddling the seam missing in 5-15 % of the runs with a
-                // 64 Ki staging buffer, which compacts at every piece; tools/async_race.py).  So the copy
-                // streams wait for the tail copy.  That serialises the next copy behind this piece's scan -- once
-                // per compaction, i.e. once per ~16 Mi samples with the default staging buffer.
-                HIP_TRY(d, hipEventRecord(d->ev_tail, d->stream));
+            // The next asynchronous piece is copied right behind this tail by a copy engine on another stream,
+            // and the two ranges meet inside a cache line (when `left` is not line-aligned): unordered, the tail
+            // copy's write-back of that line and the engine's write to it race, and the loser's bytes are lost
+            // (observed: one frame straddling the seam missing in 5-35 % of the runs with a 64 Ki staging buffer,
+            // which compacts at every piece; tools/async_race.py).  So every later copy waits for the tail copy.
+            // The tail copy itself needs this piece's copy and nothing else -- the buffer it writes was last read
+            // by launches that have been collected, and it only reads the current one -- so in asynchronous mode
+            // it follows that copy on ITS stream instead of queueing behind this piece's scan: the bubble per
+            // compaction is the tail copy (a few KB), not a scan.
+            const bool aside = in_flight && d->dbg_async != 4 && d->dbg_async != 2;
+            hipStream_t ts = aside ? d->copy_stream[d->piece % adsb_decoder::kCopyStreams] : d->stream;
+            HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur ^ 1], d->stage[d->cur] + skip, left * sizeof(uint16_t),
+                                      hipMemcpyDeviceToDevice, ts));
+            if (aside) {
+                HIP_TRY(d, hipEventRecord(d->ev_tail, ts));
+                HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_tail, 0));
                 for (hipStream_t cs : d->copy_stream)
-                    HIP_TRY(d, hipStreamWaitEvent(cs, d->ev_tail, 0));
+                    if (cs != ts)
+                        HIP_TRY(d, hipStreamWaitEvent(cs, d->ev_tail, 0));
             }
         }
         d->cur ^= 1;
