@@ -159,6 +159,17 @@ struct adsb_decoder {
     bool final_follows = false;   // adsb_push_device_final: the end-of-stream count pass comes next
     uint32_t deferred_n = 0;
     ScanSlot *deferred_slot = nullptr;
+    // A count pass that has been prepared (frames in h_frames[b], arguments fixed) but not enqueued yet: its HIP
+    // calls (~14 us of host time) are made right BEHIND the next scan launch instead of in front of it
+    // (count_flush), or when the statistics are asked for.  An adsb_reset in between queues its clearing of the
+    // accumulators behind it.
+    struct PendingCount {
+        bool valid = false, clear_after = false;
+        adsb::TryCountArgs a{};
+        size_t nf = 0;
+        int b = 0;
+        ScanSlot *slot = nullptr; // records its ev_count
+    } pending;
     uint64_t deferred_base = 0;
     bool have_prev_frame = false; // last accepted frame of earlier passes (its span may cover later tries)
     uint64_t prev_frame_g = 0;
@@ -204,13 +215,18 @@ inline uint64_t power_samples_produced(uint64_t n_samples)
 constexpr size_t kTryStateBytes = 4 * sizeof(unsigned long long) + 4 * sizeof(uint32_t); // d_try_acc + d_carry_n
 constexpr uint32_t kCarryCap = 1u << 20; // undecided tries carried between count passes (a few hundred in practice)
 
+int count_flush(adsb_decoder *d);
+
 int slot_reserve_device_tries(adsb_decoder *d, ScanSlot &s, size_t want_list, size_t want_tiles)
 {
     if (want_list > s.d_try_cap || want_tiles > s.d_try_tiles) {
         want_list = std::max(want_list, s.d_try_cap);
         want_tiles = std::max(want_tiles, s.d_try_tiles);
-        if (d->count_stream) // a count pass may still be reading the old arrays
+        if (d->count_stream) { // a count pass may still be reading the old arrays
+            if (count_flush(d))
+                return -1;
             HIP_TRY(d, hipStreamSynchronize(d->count_stream));
+        }
         if (s.d_tries)
             HIP_TRY(d, hipFree(s.d_tries));
         if (s.d_try_counts)
@@ -322,6 +338,8 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.args.counters = s.d_counters;
     s.args.cands = s.cands;
     s.args.cand_cap = (uint32_t)std::min<size_t>(s.cand_cap, 0xFFFFFFFFu);
+    if (d->pending.valid && d->pending.slot == &s && count_flush(d)) // (the pass that reads this slot's list is still to come)
+        return -1;
     if (s.count_pending) { // the count pass over this slot's previous try list (count stream) must be over
         HIP_TRY(d, hipStreamWaitEvent(d->stream, s.ev_count, 0));
         s.count_pending = false;
@@ -339,6 +357,8 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.args.report = s.hc();
     HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
     HIP_TRY(d, hipEventRecord(s.ev_ready[s.ev_cur], d->stream));
+    if (stats && count_flush(d)) // the previous pass's calls are made now, while this scan runs
+        return -1;
     for (ScanSlot &o : d->slots) // kernel times of earlier launches: read now, behind this launch
         for (int pair = 0; pair < 2; pair++)
             if (!(&o == &s && pair == s.ev_cur) && slot_settle_profile(d, o, pair))
@@ -607,9 +627,36 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
 // (~40 us of device time together) run beside the next scan instead of in front of it.  Nothing on the scan
 // stream depends on them except the reuse of the slot's try list, four launches later (ev_count).  No event is
 // needed in the other direction: the host has seen the launch's report, so the scan that wrote the list is over.
+// Enqueue the prepared count pass, if any (and the clearing an adsb_reset has queued behind it).
+int count_flush(adsb_decoder *d)
+{
+    auto &p = d->pending;
+    hipStream_t cs = d->count_stream;
+    if (p.valid) {
+        p.valid = false;
+        if (p.nf) {
+            HIP_TRY(d, hipMemcpyAsync(d->d_frames, d->h_frames[p.b], p.nf * sizeof(adsb::TryFrame), hipMemcpyHostToDevice, cs));
+            HIP_TRY(d, hipEventRecord(d->ev_frames[p.b], cs));
+            d->frames_pending[p.b] = true;
+        }
+        HIP_TRY(d, adsb::launch_count_tries(p.a, cs)); // enqueued and forgotten: read_tries() collects
+        if (p.slot) {
+            HIP_TRY(d, hipEventRecord(p.slot->ev_count, cs));
+            p.slot->count_pending = true;
+        }
+    }
+    if (p.clear_after) {
+        p.clear_after = false;
+        HIP_TRY(d, hipMemsetAsync(d->d_try_acc, 0, kTryStateBytes, cs));
+    }
+    return 0;
+}
+
 int count_tries_pass(adsb_decoder *d, ScanSlot *slot, uint32_t n_tries, uint64_t g_base, bool final)
 {
     hipStream_t cs = d->count_stream;
+    if (count_flush(d)) // one pass pending at a time, in order
+        return -1;
     const bool regions = slot && slot->try_regions;
     auto &log = d->res.accepted_log();
     const size_t nf = log.size() + (d->have_prev_frame ? 1 : 0);
@@ -651,11 +698,6 @@ int count_tries_pass(adsb_decoder *d, ScanSlot *slot, uint32_t n_tries, uint64_t
     for (const auto &f : log)
         d->h_frames[b][k++] = adsb::TryFrame{f.first, f.second, 0};
     remember_last();
-    if (nf) {
-        HIP_TRY(d, hipMemcpyAsync(d->d_frames, d->h_frames[b], nf * sizeof(adsb::TryFrame), hipMemcpyHostToDevice, cs));
-        HIP_TRY(d, hipEventRecord(d->ev_frames[b], cs));
-        d->frames_pending[b] = true;
-    }
     const int c_in = d->carry_n_cur, c_out = (c_in + 1) % 3, c_next = (c_in + 2) % 3;
     adsb::TryCountArgs a{};
     a.tries = slot ? slot->d_tries + slot->args.try_list_first : nullptr;
@@ -677,11 +719,11 @@ int count_tries_pass(adsb_decoder *d, ScanSlot *slot, uint32_t n_tries, uint64_t
     a.n_carry_out = d->d_carry_n + c_out; // zero: cleared at creation / reset, or by the pass before last
     a.n_carry_next = d->d_carry_n + c_next;
     a.acc = d->d_try_acc;
-    HIP_TRY(d, adsb::launch_count_tries(a, cs)); // enqueued and forgotten: read_tries() collects
-    if (slot && (n_tries || regions)) {
-        HIP_TRY(d, hipEventRecord(slot->ev_count, cs));
-        slot->count_pending = true;
-    }
+    d->pending.valid = true;
+    d->pending.a = a;
+    d->pending.nf = nf;
+    d->pending.b = b;
+    d->pending.slot = (slot && (n_tries || regions)) ? slot : nullptr;
     d->prof.tries += n_tries;
     d->carry_cur ^= 1;
     d->carry_n_cur = c_out;
@@ -696,6 +738,8 @@ int read_tries(adsb_decoder *d)
 {
     if (!d->tries_unread)
         return 0;
+    if (count_flush(d))
+        return -1;
     unsigned long long acc[4];
     HIP_TRY(d, hipMemcpyAsync(acc, d->d_try_acc, sizeof acc, hipMemcpyDeviceToHost, d->count_stream));
     HIP_TRY(d, hipStreamSynchronize(d->count_stream));
@@ -1278,8 +1322,11 @@ int adsb_reset(adsb_decoder *d)
         for (hipStream_t cs : d->copy_stream)
             HIP_TRY(d, hipStreamSynchronize(cs));
         HIP_TRY(d, hipStreamSynchronize(d->stream));
-        if (d->count_stream)
+        if (d->count_stream) {
+            if (count_flush(d))
+                return -1;
             HIP_TRY(d, hipStreamSynchronize(d->count_stream));
+        }
         for (ScanSlot &sl : d->slots) {
             // normally the report kernel behind each scan has left the counters zero; after a failed launch it may not have
             HIP_TRY(d, hipMemsetAsync(sl.d_counters, 0, adsb::kDevCounterWords * sizeof(uint32_t), d->stream));
@@ -1301,9 +1348,13 @@ int adsb_reset(adsb_decoder *d)
     d->cur = 0;
     d->res.reset();
     d->res.log_accepted(d->cfg.collect_stats != 0);
-    if (d->acc_dirty) { // behind any count pass still queued
-        HIP_TRY(d, hipSetDevice(d->device));
-        HIP_TRY(d, hipMemsetAsync(d->d_try_acc, 0, kTryStateBytes, d->count_stream));
+    if (d->acc_dirty) { // behind any count pass still queued -- or still to be enqueued (count_flush)
+        if (d->pending.valid) {
+            d->pending.clear_after = true;
+        } else {
+            HIP_TRY(d, hipSetDevice(d->device));
+            HIP_TRY(d, hipMemsetAsync(d->d_try_acc, 0, kTryStateBytes, d->count_stream));
+        }
     }
     d->acc_dirty = false;
     d->tries_unread = false;
