@@ -169,6 +169,7 @@ struct adsb_decoder {
         size_t nf = 0;
         int b = 0;
         ScanSlot *slot = nullptr; // records its ev_count
+        hipEvent_t after = nullptr; // the scan (and the report kernel behind it) whose tries the pass reads
     } pending;
     uint64_t deferred_base = 0;
     bool have_prev_frame = false; // last accepted frame of earlier passes (its span may cover later tries)
@@ -625,8 +626,8 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
 // adds three counters to the statistics and carries the undecided tries.
 // Everything here goes to the decoder's COUNT stream: the upload of the accepted frames and the count kernel
 // (~40 us of device time together) run beside the next scan instead of in front of it.  Nothing on the scan
-// stream depends on them except the reuse of the slot's try list, four launches later (ev_count).  No event is
-// needed in the other direction: the host has seen the launch's report, so the scan that wrote the list is over.
+// stream depends on them except the reuse of the slot's try list, four launches later (ev_count); in the other
+// direction the count stream waits for the end of the scan that wrote the list (count_flush).
 // Enqueue the prepared count pass, if any (and the clearing an adsb_reset has queued behind it).
 int count_flush(adsb_decoder *d)
 {
@@ -639,6 +640,11 @@ int count_flush(adsb_decoder *d)
             HIP_TRY(d, hipEventRecord(d->ev_frames[p.b], cs));
             d->frames_pending[p.b] = true;
         }
+        // The host may have taken the launch's last tile before the scan kernel has ended (slot_collect does not
+        // wait for the launch counters when no tile needed them): the try words become visible to other kernels
+        // with the kernel's end, so the count stream waits for it.
+        if (p.after)
+            HIP_TRY(d, hipStreamWaitEvent(cs, p.after, 0));
         HIP_TRY(d, adsb::launch_count_tries(p.a, cs)); // enqueued and forgotten: read_tries() collects
         if (p.slot) {
             HIP_TRY(d, hipEventRecord(p.slot->ev_count, cs));
@@ -724,6 +730,7 @@ int count_tries_pass(adsb_decoder *d, ScanSlot *slot, uint32_t n_tries, uint64_t
     d->pending.nf = nf;
     d->pending.b = b;
     d->pending.slot = (slot && (n_tries || regions)) ? slot : nullptr;
+    d->pending.after = d->pending.slot ? slot->ev_ready[slot->ev_cur] : nullptr;
     d->prof.tries += n_tries;
     d->carry_cur ^= 1;
     d->carry_n_cur = c_out;
@@ -807,14 +814,24 @@ int slot_collect(adsb_decoder *d)
         }
     }
 #endif
-    if (s.streaming && !partial && !s.tries_on_device) {
-        // Every tile has been published and consumed and none used the loose list: the
-        // launch-wide counters have nothing to add, so do not wait for them (nor for the
-        // kernel's end event -- the profile reads that later).
+    if (s.streaming && !partial && (!s.tries_on_device || s.try_regions)) {
+        // Every tile has been published and consumed and none used the loose list -- nor, in a statistics
+        // run, the launch-wide try list: a tile that falls back to overflow rounds flags its marker, and
+        // the tries of all others are in their regions.  The launch-wide counters have nothing to add, so
+        // do not wait for them (nor for the kernel's end event -- the profile reads that later).
         s.prof_pending[s.ev_cur] = d->cfg.profile != 0;
         d->prof.launches++;
         d->prof.offsets += s.args.g_end - s.args.g_begin;
         d->prof.last_offsets = s.args.g_end - s.args.g_begin;
+        if (s.tries_on_device) {
+            if (d->final_follows && d->slot_count == 1) { // (see below)
+                d->deferred_slot = &s;
+                d->deferred_n = 0;
+                d->deferred_base = s.args.g_begin;
+            } else if (count_tries_pass(d, &s, 0, s.args.g_begin, false)) {
+                return -1;
+            }
+        }
         s.busy = false;
         d->slot_head = (d->slot_head + 1) % kSlots;
         d->slot_count--;

@@ -747,6 +747,8 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         const bool try_region = kStats && args.try_counts && grp < 0; // workgroup-uniform
         uint32_t try_res = 0;
         if (kStats && tid == 0) {
+            if (over && args.hand)
+                *tile_over = 1; // the launch-wide try list is in use: the host must wait for the launch's counters
             if (try_region)
                 args.try_counts[blockIdx.x] = (uint32_t)qn; // 0 when the queue overflowed: the fallback rounds list them
             else if (qn)
