@@ -8,8 +8,11 @@
 //              the other buffer -- when the buffer is half full).  stage_first is a multiple of
 //              8 samples so that pair index/4 alignment and 16-byte loads line up with the stream.
 //              adsb_push_async copies into it on two copy streams of its own (push_copy).
-//   d_tries    one dword per DF-gate pass (collect_stats of a stream: counted on the device)
-//   counters   adsb::kCounterWords dwords per launch slot
+//              Ordering rule of the copies into it: two writers that are not ordered never share a
+//              cache line (process_stage, push_copy).
+//   d_tries    one dword per DF-gate pass (collect_stats of a stream: counted on the device, on a
+//              count stream of its own): a region of kTryRegion words per tile + a launch-wide list
+//   counters   adsb::kDevCounterWords dwords per launch slot, every counter on a cache line of its own
 // and in pinned host memory, written by the kernel
 //   hand       the hand-off stream: a marker + the kept records of every tile (scan_kernel.h),
 //              consumed while the kernel runs
