@@ -15,6 +15,8 @@ for k in range(10):
     lo, hi = T * k / 10, T * (k + 1) / 10
     occ = sum(max(0.0, min(e, hi) - max(b, lo)) for b, e, _ in tiles) / (hi - lo) / ncu
     print(f"  {lo:6.1f} .. {hi:6.1f} us: {occ:.2f} tiles resident per CU")
+print("mean life of the tiles that BEGIN in each tenth of the launch (us):",
+      " ".join(f"{(lambda v: sum(v) / len(v) if v else 0.0)([e - b for b, e, _ in tiles if T * k / 10 <= b < T * (k + 1) / 10]):.1f}" for k in range(10)))
 per = collections.defaultdict(list)
 for b, e, c in tiles:
     per[c].append((b, e))
