@@ -221,6 +221,17 @@ constexpr uint32_t kCarryCap = 1u << 20; // undecided tries carried between coun
 
 int count_flush(adsb_decoder *d);
 
+// The reference's ring index `fidx` is a uint32_t that counts input samples (air.c:34): at 2^32 samples it
+// wraps, 2^32 mod 14 = 4, and the ring phase jumps.  No parity is defined beyond that point, so a
+// stream is refused there instead of being decoded differently from the reference.
+bool stream_too_long(adsb_decoder *d, size_t n)
+{
+    if (d->n_samples + (uint64_t)n < (1ull << 32))
+        return false;
+    d->fail("stream would reach 2^32 samples: the reference's sample counter wraps there (air.c:34) and no parity is defined beyond");
+    return true;
+}
+
 int slot_reserve_device_tries(adsb_decoder *d, ScanSlot &s, size_t want_list, size_t want_tiles)
 {
     if (want_list > s.d_try_cap || want_tiles > s.d_try_tiles) {
@@ -1396,6 +1407,8 @@ int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n)
         return -1;
     if (d->finished)
         return d->fail("adsb_push after adsb_finish");
+    if (stream_too_long(d, n))
+        return -1;
     if (n == 0)
         return 0;
     if (!samples)
@@ -1413,6 +1426,8 @@ int adsb_push_async(adsb_decoder *d, const uint16_t *samples, size_t n)
         return -1;
     if (d->finished)
         return d->fail("adsb_push_async after adsb_finish");
+    if (stream_too_long(d, n))
+        return -1;
     if (n == 0)
         return 0;
     if (!samples)
@@ -1473,6 +1488,8 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
         return -1;
     if (d->finished)
         return d->fail("adsb_push_device after adsb_finish");
+    if (stream_too_long(d, n))
+        return -1;
     if (n && !device_samples)
         return d->fail("adsb_push_device: NULL samples");
     HIP_TRY(d, hipSetDevice(d->device));

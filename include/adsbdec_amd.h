@@ -24,7 +24,7 @@
  * and `2*s1` overflow -- undefined behaviour in C that happens to wrap with gcc --
  * while this library compares the un-wrapped values; adsb_push accepts such samples
  * but no parity is claimed for them.  Streams are limited to < 2^32
- * samples (the reference's `fidx` wraps there).
+ * samples (the reference's `fidx` wraps there): a push that would reach 2^32 fails.
  */
 #ifndef ADSBDEC_AMD_H
 #define ADSBDEC_AMD_H

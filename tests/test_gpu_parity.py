@@ -196,6 +196,22 @@ def test_async_pushes_reference_call_size_and_mixed_calls(capi, oracle, dec_fact
     assert d.stats() == wstats
 
 
+def test_stream_of_2_to_32_samples_is_refused(capi, dec_factory, torch_cuda):
+    """The reference's sample counter is a uint32_t (air.c:34): at 2^32 samples its ring phase jumps
+    and no parity is defined, so the library refuses such a stream -- loudly, before it touches the buffer."""
+    d = dec_factory()
+    t = torch_cuda.zeros(1 << 16, dtype=torch_cuda.int16, device="cuda")
+    d.reset()
+    d.push_device(t.data_ptr(), t.numel())
+    with pytest.raises(capi.AdsbError, match="2\\^32"):
+        d.push_device(t.data_ptr(), (1 << 32) - t.numel())
+    h = np.zeros(64, np.uint16)
+    with pytest.raises(capi.AdsbError, match="2\\^32"):
+        d._check(capi.load().adsb_push(d._h, h.ctypes.data, 1 << 32), "adsb_push")
+    d.push_device(t.data_ptr(), t.numel())      # the handle is still usable below the limit
+    d.finish()
+
+
 @pytest.mark.parametrize("passes", ["7", "10"])
 def test_try_counting_with_more_than_64_frames_per_tile(oracle, dec_factory, monkeypatch, passes):
     """Statistics runs count the tries on the device, one wave per tile, against the window of accepted frames
