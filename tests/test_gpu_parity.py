@@ -196,6 +196,50 @@ def test_async_pushes_reference_call_size_and_mixed_calls(capi, oracle, dec_fact
     assert d.stats() == wstats
 
 
+def test_statistics_read_patterns(capi, oracle, dec_factory, torch_cuda):
+    """The count passes of a statistics run are prepared when a launch has been resolved and enqueued later (behind
+    the next scan launch, or when the table is asked for), on a stream of their own, and an adsb_reset queues its
+    clearing behind a pass that is still pending.  Every order of reading, not reading, resetting and destroying
+    must give the table of the stream that was decoded last -- here 60 steps over three captures with the table
+    read never, once or twice per step, between pushes of one stream too, and handles closed with a pass pending."""
+    from oracle import gen_signal as G
+    rng = np.random.default_rng(77)
+    caps = []
+    for k in range(3):
+        x, _ = G.dense_capture((1 << 20) + 8 * k, seed=500 + k, sigma=[30.0, 120.0, 300.0][k], n_frames=200, amp=(200, 1800))
+        want, wstats = oracle.decode(x, df18=True)
+        caps.append((x, _dev(torch_cuda, x), records(want), wstats))
+    d = dec_factory(df18=True, collect_stats=True)
+    for step in range(60):
+        x, t, want, wstats = caps[int(rng.integers(0, 3))]
+        d.reset()
+        mode = int(rng.integers(0, 3))
+        if mode == 0:
+            d.push_device_final(t.data_ptr(), t.numel())
+        elif mode == 1:                                   # two pushes, the table asked for in between (a partial one)
+            sp = 8 * int(rng.integers(20_000, x.size // 8 - 20_000))
+            d.push_device(t.data_ptr(), sp)
+            if rng.random() < 0.5:
+                mid = d.stats()
+                assert sum(mid["try"].values()) <= sum(wstats["try"].values())
+            d.push_device_final(t.data_ptr() + 2 * sp, x.size - sp)
+        else:
+            d.push(x)
+            d.finish()
+        assert records(d.drain()) == want
+        for _ in range(int(rng.integers(0, 3))):
+            assert d.stats() == wstats, f"step {step} mode {mode}"
+    x, t, want, wstats = caps[0]
+    for _ in range(3):                                    # destroyed with a pass pending
+        e = capi.Decoder(df18=True, collect_stats=True)
+        e.reset()
+        e.push_device_final(t.data_ptr(), t.numel())
+        e.close()
+    d.reset()
+    d.push_device_final(t.data_ptr(), t.numel())
+    assert d.stats() == wstats and d.stats() == wstats
+
+
 def test_stream_of_2_to_32_samples_is_refused(capi, dec_factory, torch_cuda):
     """The reference's sample counter is a uint32_t (air.c:34): at 2^32 samples its ring phase jumps
     and no parity is defined, so the library refuses such a stream -- loudly, before it touches the buffer."""
