@@ -128,6 +128,8 @@ struct adsb_decoder {
     uint64_t stage_cap = 0;   // samples per staging buffer
     uint64_t stage_first = 0; // stream index of stage[cur][0]
     uint64_t stage_fill = 0;  // samples held
+    bool copy_unconfirmed = false; // a copy of caller's samples has been enqueued on the scan stream and no scan
+                                   // launched behind it has been collected yet (the caller's buffer is still in use)
 
     uint32_t *d_synd = nullptr; // 14 x 256 CRC-24 syndrome table (scan_kernel.h)
     uint32_t *d_fix = nullptr;  // single-bit syndrome hash (extension, cfg.fix_1bit)
@@ -1046,17 +1048,22 @@ int process_stage(adsb_decoder *d, bool final, bool in_flight = false)
     uint64_t g_end = m_real >= ADSB_WINDOW ? m_real - ADSB_WINDOW + 1 : 0;
     if (!final)
         g_end = round_down(g_end, 28);
+    bool launched = false;
     if (g_end > d->g_scanned) {
         if (scan_submit(d, d->stage[d->cur], d->stage_first, d->stage_fill, d->g_scanned, g_end))
             return -1;
         d->g_scanned = g_end;
+        launched = true;
     }
     if (in_flight) {
         while (d->slot_count && d->slots[d->slot_head].piece < d->piece)
             if (slot_collect(d))
                 return -1;
-    } else if (scan_drain(d)) { // frames become drainable within the call that supplied their samples
-        return -1;
+    } else {
+        if (scan_drain(d)) // frames become drainable within the call that supplied their samples
+            return -1;
+        if (launched) // its tiles have all been taken: the scan, and with it every copy queued in front of it, is over
+            d->copy_unconfirmed = false;
     }
     // At EOF a trailing partial quad still makes the reference produce two (garbage)
     // power samples (air.c:59 loop bound); they can never be read by a visited
@@ -1138,6 +1145,7 @@ int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind, bo
                 HIP_TRY(d, hipStreamSynchronize(cstream));
         } else {
             HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind, d->stream));
+            d->copy_unconfirmed = true;
         }
         d->stage_fill += take;
         d->n_samples += take;
@@ -1416,7 +1424,10 @@ int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n)
     HIP_TRY(d, hipSetDevice(d->device));
     if (push_copy(d, samples, n, hipMemcpyHostToDevice))
         return -1;
-    HIP_TRY(d, hipStreamSynchronize(d->stream)); // `samples` is only borrowed for the call
+    if (d->copy_unconfirmed) { // `samples` is only borrowed for the call: no scan behind the last copy has confirmed it
+        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        d->copy_unconfirmed = false;
+    }
     return 0;
 }
 
@@ -1502,7 +1513,10 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
             return adsb_finish(d);
         // the staging copy may still be queued when no scan was launched behind it (and
         // collected): the caller is free to reuse or free the buffer on return
-        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        if (d->copy_unconfirmed) {
+            HIP_TRY(d, hipStreamSynchronize(d->stream));
+            d->copy_unconfirmed = false;
+        }
         return 0;
     }
 
