@@ -999,8 +999,9 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
         a.g_begin = g_begin;
         a.g_end = g_stop;
         a.df18 = d->cfg.df18 ? 1 : 0;
-        a.passes = adsb::choose_passes(n_off, d->n_cus);
-        a.stagger = adsb::choose_stagger(n_off, d->n_cus, a.passes);
+        a.pipe = adsb::choose_pipe(n_off) ? 1 : 0;
+        a.passes = adsb::choose_passes(n_off, d->n_cus, a.pipe != 0);
+        a.stagger = a.pipe ? 0u : adsb::choose_stagger(n_off, d->n_cus, a.passes);
 #if ADSB_TILE_CLOCK
         {   // tuning builds: per-tile device timestamps of the LAST launch, dumped at collect
             static uint32_t *dclk = nullptr;

@@ -69,6 +69,19 @@ constexpr size_t lds_bytes(int passes)
 {
     return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6);
 }
+// the pipelined kernel (ScanArgs::pipe): two sets of planes, queue, 32 control words, 64 staged candidates
+#ifndef ADSB_PIPE_WAVES
+#define ADSB_PIPE_WAVES 5 // waves per SIMD its register budget is set for: 5 = 96 VGPRs, four workgroups per CU; 4 = 128, three
+#endif
+constexpr int kPipeMaxPasses = ADSB_PIPE_WAVES >= 5 ? 5 : 7; // 36 KiB x 4 workgroups, or 48 KiB x 3, of a CU's 160 KiB
+#ifndef ADSB_PIPE_MIN_OFFSETS
+#define ADSB_PIPE_MIN_OFFSETS (~0ull) // launches of at least this many offsets use the pipelined kernel (choose_pipe)
+#endif
+constexpr uint64_t kPipeMinOffsets = ADSB_PIPE_MIN_OFFSETS;
+constexpr size_t lds_bytes_pipe(int passes)
+{
+    return sizeof(uint32_t) * (size_t)(6 * (kPassRuns * passes + kPlanePad) + kQueueCap + 32 + 64 * 6);
+}
 
 // Tile geometry of a launch.  Every tile takes K = `passes` passes, except that the first
 // `stagger` tiles (a multiple of 4, K >= 5; 0 = off, the default) cycle through K-3, K-2,
@@ -127,6 +140,9 @@ struct ScanArgs {
     uint64_t g_end;      // one past the last offset
     int df18;            // demod.c:26
     int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
+    int pipe;            // 1: the pipelined kernel (persistent five-wave workgroups, Stage B on a wave of its own;
+                         // passes <= kPipeMaxPasses, stagger == 0); 0: the classic one-workgroup-per-tile kernel
+    uint32_t n_tiles;    // tile_count() of the launch (launch_scan fills it in)
     uint32_t *tile_clock; // ADSB_TILE_CLOCK builds only: 4 dwords per tile {begin, end (100 MHz), HW_ID, XCC_ID}
     uint32_t stagger;    // the first `stagger` tiles take K-3..K passes in turn (tile_passes)
     int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
@@ -150,7 +166,7 @@ struct ScanArgs {
     uint32_t fix_mul;
     const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
     // Device counters, zero at launch: [0] loose candidates, [1] tries (may exceed the
-    // capacities), [2] hand-off granules, [3] spare; with `profile` [4..5] max over tiles of
+    // capacities), [2] hand-off granules, [3] the pipelined kernel's tile counter; with `profile` [4..5] max over tiles of
     // ~(start) and [6..7] max of end on the device's 100 MHz clock (64-bit).  launch_scan
     // puts one wave behind the scan (report_kernel) that writes them to `report` (pinned
     // host, same layout, word [3] = gen; null: no report) and zeroes them.
@@ -212,7 +228,9 @@ void make_syndrome_table(uint32_t *out /* kSyndWords */);
 uint32_t make_fix_table(uint32_t *tab /* kFixSlots */);
 // Host: choose the passes-per-tile for a launch of n_offsets on a device with
 // `slots` resident workgroups (balances halo overhead against tail quantisation).
-int choose_passes(uint64_t n_offsets, int cus);
+int choose_passes(uint64_t n_offsets, int cus, bool pipe = false);
+// Host: which kernel scans a launch of n_offsets (ScanArgs::pipe).  ADSB_PIPE=0/1 forces one (read per launch).
+bool choose_pipe(uint64_t n_offsets);
 // Host: how many leading tiles to stagger (tile_passes): 0 unless ADSB_STAGGER is set
 // (measured: no gain, see choose_stagger).
 uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes);

@@ -317,96 +317,13 @@ __device__ __forceinline__ uint32_t take28(const uint32_t *w)
 
 } // namespace
 
-template <bool kStats>
-__global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const ScanArgs args)
+// ------------------------------ Stage A ------------------------------
+// One tile's arithmetic for one of the tile's four Stage A waves: K passes, a run of 28 power samples per lane and
+// pass, three plane words per run into LDS.  No barrier, no divergence.
+__device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const int64_t pbuf0, const int64_t p_lo,
+                                        const int64_t p_hi, const int64_t t0, const int K, const int wave, const int lane,
+                                        uint32_t *pl_d, uint32_t *pl_e1, uint32_t *pl_e2)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int K = tile_passes(blockIdx.x, args.stagger, args.passes);
-    const int nplane = kPassRuns * K + kPlanePad;
-    uint32_t *pl_d = smem;
-    uint32_t *pl_e1 = smem + nplane;
-    uint32_t *pl_e2 = smem + 2 * nplane;
-    uint32_t *queue = smem + 3 * nplane;
-    uint32_t *qcount = queue + kQueueCap;
-
-    // kernel arguments are only ever used by value (taking their address would
-    // demote the sample pointer to a flat/scratch access)
-    const uint32_t *__restrict__ xin = args.x;
-    const int64_t pbuf0 = args.pbuf0, p_lo = args.p_lo, p_hi = args.p_hi;
-
-    const int tid = threadIdx.x;
-#if ADSB_SLEEP_STAGGER
-    // The four workgroups that start together on a CU at the head of a large launch (blocks b, b + 256,
-    // b + 512, b + 768 with the observed round-robin placement; nothing depends on it) begin 0, 1, 2, 3 x
-    // ADSB_SLEEP_STAGGER x 64 cycles apart (2.6 us steps), so that their load phases do not coincide from
-    // the first pass on.  Measured in bench.py: -3.2 .. -4.0 % kernel time on one MI355X box, +-0.5 % on
-    // another; steps of 1.2 us did nothing, steps of 3.7 us and more were worse than 2.6.
-    if (gridDim.x >= 256u * ADSB_MIN_WAVES * 4 / kWaves && blockIdx.x < 256u * ADSB_MIN_WAVES * 4 / kWaves) {
-        const uint32_t slot = blockIdx.x >> 8;
-        for (uint32_t i = 0; i < slot; i++)
-            __builtin_amdgcn_s_sleep(ADSB_SLEEP_STAGGER);
-    }
-#endif
-    // cfg.profile: the launch's duration is (latest tile end) - (earliest tile start)
-    const uint64_t prof_begin = args.profile ? __builtin_amdgcn_s_memrealtime() : 0;
-#if ADSB_TILE_CLOCK
-    // kbench only: when and where each tile ran (100 MHz clock, HW_ID, XCC_ID) -> args.tile_clock[4 * tile ..]
-    const uint64_t clk_begin = __builtin_amdgcn_s_memrealtime();
-    const uint64_t cyc_begin = __builtin_amdgcn_s_memtime(); // shader clock: (d cycles) / (d realtime at 100 MHz) = the clock the chip holds
-#endif
-#if ADSB_TILE_CLOCK == 3 // phase stamps of the tile (100 MHz clock), thread 0: see the dump in decoder.hip
-    uint32_t st[8] = {(uint32_t)clk_begin, 0, 0, 0, 0, 0, 0, 0};
-#define ADSB_STAMP(i) do { if (tid == 0) st[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define ADSB_STAMP(i) do { } while (0)
-#endif
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int own = kPassRuns * K - kReachRuns;
-    const int64_t t0 = // first owned offset
-        (int64_t)args.g_begin + (int64_t)kRun * (int64_t)tile_first_run(blockIdx.x, args.stagger, args.passes);
-
-    uint32_t *tile_n = qcount + 4;    // records this tile keeps (ranked into its hand-off range)
-    uint32_t *tile_over = qcount + 5; // some records had to go to the loose list
-    uint32_t *tile_base = qcount + 6; // granule index of the tile's marker in args.hand
-    uint32_t *try_base = qcount + 7;  // first index of the round's range in args.tries (kStats)
-    uint32_t *tile_res = qcount + 8;  // the tile has reserved its range of args.hand
-    uint32_t *tile_fit = qcount + 9;  // ... and the whole range lies inside the array
-    uint32_t *tile_chk = qcount + 10; // [4]: XOR of the granules the tile wrote there, word by word
-    if (tid == 0) {
-        *tile_n = 0;
-        *tile_over = 0;
-        *tile_base = 0;
-        *tile_res = 0;
-        *tile_fit = 0;
-        tile_chk[0] = tile_chk[1] = tile_chk[2] = tile_chk[3] = 0;
-    }
-    // A finished record that cannot go through the hand-off stream (hand-off disabled,
-    // record emitted outside the whole-tile round, stream full) goes to the launch-wide
-    // loose list; the tile's marker then tells the host to collect after completion.
-    auto emit_loose = [&](uint32_t g_rel, uint32_t pw, const uint32_t (&wds)[4]) {
-        if (args.hand)
-            *tile_over = 1;
-        const uint32_t slot = atomicAdd(&args.counters[0 * kCounterPad], 1u);
-        if (slot < args.cand_cap) {
-            uint32_t *rec = args.cands + (size_t)slot * kCandWords;
-            rec[0] = g_rel;
-            rec[1] = pw;
-            rec[2] = wds[0];
-            rec[3] = wds[1];
-            rec[4] = wds[2];
-            rec[5] = wds[3];
-        }
-    };
-
-    // plane words past the last computed run are read (never used) by Stage B
-    if (tid < kPlanePad) {
-        pl_d[kPassRuns * K + tid] = 0;
-        pl_e1[kPassRuns * K + tid] = 0;
-        pl_e2[kPassRuns * K + tid] = 0;
-    }
-
-    // ------------------------------ Stage A ------------------------------
     // Input: the 34 pairs (6 of pre-halo + 28) a run needs are 17 TYPED buffer loads of 8
     // bytes per lane (buffer_load_format_xyzw, data format 16_16_16_16, number format
     // USCALED): the load path itself converts the four uint16 to four floats -- exactly, and
@@ -615,24 +532,77 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             pl_e2[v] = e2;
         }
     }
-#if ADSB_TILE_CLOCK == 3
-    if (lane == 0) // when each wave reaches the barrier behind Stage A: how long the four wait for each other
-        tile_chk[wave] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
-    __syncthreads();
-#if ADSB_TILE_CLOCK == 3
-    const uint32_t arrive_sum = tile_chk[0] + tile_chk[1] + tile_chk[2] + tile_chk[3] - 4u * (uint32_t)clk_begin;
-    __syncthreads();
-    if (tid == 0)
-        tile_chk[0] = tile_chk[1] = tile_chk[2] = tile_chk[3] = 0;
-#endif
-#if ADSB_ABLATE != 0
-    if (pl_d[(tid * 29) % (kPassRuns * K)] == 0x12345678u) // kbench: keep Stage A alive, skip the rest
-        atomicAdd(&args.counters[0 * kCounterPad], 1u);
-    return;
+}
+
+// ------------------------------ Stage B ------------------------------
+// Everything behind a tile's planes: gate, survivor queue, slicer + CRC, never-visited filter, ranking, finishing and
+// the hand-off.  NT threads work on it: the tile's four waves between workgroup barriers (scan_kernel, NT = 256), or ONE
+// wave on its own while the other four already compute the next tile's planes (scan_pipe_kernel, NT = 64: every
+// "barrier" is then only a fence inside the wave, whose LDS operations execute in order).
+template <int NT>
+__device__ __forceinline__ void tile_sync()
+{
+    if constexpr (NT == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+struct StageStamps {
+    uint32_t st[8];
+};
+#if ADSB_TILE_CLOCK == 3 // phase stamps of the tile (100 MHz clock), thread 0: see the dump in decoder.hip
+#define ADSB_STAMP(i) do { if (tid == 0) stamps.st[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ADSB_STAMP(i) do { } while (0)
 #endif
 
-    // ------------------------------ Stage B ------------------------------
+// LDS of Stage B: queue[queue_cap], ctl[32] (qcount, qover, cl_n, cl_over, tile_n, tile_over, tile_base, try_base,
+// tile_res, tile_fit, tile_chk[4]; the rest is the kernel's), cl_rec[clist_cap * kCandWords].
+template <bool kStats, int NT>
+__device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t tile, const int K, const int64_t t0, const int tid,
+                                        const uint32_t *pl_d, const uint32_t *pl_e1, const uint32_t *pl_e2, uint32_t *queue,
+                                        uint32_t *qcount, uint32_t *cl_rec, const int clist_cap, StageStamps &stamps)
+{
+    constexpr int kFallbackChunks = 256 / NT; // a fallback round takes one bit position of 256 runs: <= 256 entries
+    const uint32_t *__restrict__ xin = args.x;
+    const int64_t pbuf0 = args.pbuf0, p_lo = args.p_lo, p_hi = args.p_hi;
+    const int own = kPassRuns * K - kReachRuns;
+    uint32_t *tile_n = qcount + 4;    // records this tile keeps (ranked into its hand-off range)
+    uint32_t *tile_over = qcount + 5; // some records had to go to the loose list
+    uint32_t *tile_base = qcount + 6; // granule index of the tile's marker in args.hand
+    uint32_t *try_base = qcount + 7;  // first index of the round's range in args.tries (kStats)
+    uint32_t *tile_res = qcount + 8;  // the tile has reserved its range of args.hand
+    uint32_t *tile_fit = qcount + 9;  // ... and the whole range lies inside the array
+    uint32_t *tile_chk = qcount + 10; // [4]: XOR of the granules the tile wrote there, word by word
+    if (tid == 0) { // (the first barrier of the round loop below orders these)
+        *tile_n = 0;
+        *tile_over = 0;
+        *tile_base = 0;
+        *tile_res = 0;
+        *tile_fit = 0;
+        tile_chk[0] = tile_chk[1] = tile_chk[2] = tile_chk[3] = 0;
+    }
+    // A finished record that cannot go through the hand-off stream (hand-off disabled,
+    // record emitted outside the whole-tile round, stream full) goes to the launch-wide
+    // loose list; the tile's marker then tells the host to collect after completion.
+    auto emit_loose = [&](uint32_t g_rel, uint32_t pw, const uint32_t (&wds)[4]) {
+        if (args.hand)
+            *tile_over = 1;
+        const uint32_t slot = atomicAdd(&args.counters[0 * kCounterPad], 1u);
+        if (slot < args.cand_cap) {
+            uint32_t *rec = args.cands + (size_t)slot * kCandWords;
+            rec[0] = g_rel;
+            rec[1] = pw;
+            rec[2] = wds[0];
+            rec[3] = wds[1];
+            rec[4] = wds[2];
+            rec[5] = wds[3];
+        }
+    };
     ADSB_STAMP(1);
 #if ADSB_STAGEB_PRIO
     // From here on the tile is a chain of short, latency-bound phases between workgroup barriers, often with one
@@ -643,11 +613,10 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     const int64_t off_end64 = (int64_t)args.g_end - t0; // offsets of this tile that exist
     const int off_end = off_end64 > (int64_t)kRun * own ? kRun * own : off_end64 < 0 ? 0 : (int)off_end64;
     const uint32_t df18_mask = args.df18 ? ~0u : 0u;
-    const int nchunks = (own + kThreads - 1) / kThreads;
+    const int nchunks = (own + NT - 1) / NT;
     uint32_t *qover = qcount + 1;
     uint32_t *cl_n = qcount + 2;    // CRC-valid candidates staged in LDS this round
     uint32_t *cl_over = qcount + 3; // some were emitted directly: the staged list is incomplete
-    uint32_t *cl_rec = qcount + 16; // kClistCap records of kCandWords
     const uint32_t qcap = (uint32_t)args.queue_cap;
     const uint32_t tile_rel = (uint32_t)(t0 - (int64_t)args.g_begin);
 
@@ -664,7 +633,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             *cl_n = 0;
             *cl_over = 0;
         }
-        __syncthreads();
+        tile_sync<NT>();
         // Whole-tile rounds see every CRC-valid candidate of the tile, which is what
         // the never-visited filter below needs; fallback rounds emit directly.
         const bool stage_cands = (grp < 0) && !args.all_candidates;
@@ -677,9 +646,9 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             uint32_t gt[kGateBatch], gb1[kGateBatch], gb4[kGateBatch];
             // workgroup-uniform: every run of the batch exists and is complete (all but a tile's last batch, and
             // the last tiles of a launch): no per-lane range logic at all
-            const bool full = grp < 0 && base + kGateBatch <= ch_hi && kRun * kThreads * (base + kGateBatch) <= off_end;
+            const bool full = grp < 0 && base + kGateBatch <= ch_hi && kRun * NT * (base + kGateBatch) <= off_end;
             auto gate_word = [&](int u, auto is_full) {
-                const int vq = (base + u) * kThreads + tid;
+                const int vq = (base + u) * NT + tid;
                 const int nvalid = off_end - kRun * vq; // <= 0: the run does not exist (vq >= own included: off_end <= 28 own)
                 const int v = (decltype(is_full)::value || nvalid > 0) ? vq : 0; // planes are only read where they exist
                 const uint32_t e2w[2] = {pl_e2[v + 1], pl_e2[v + 2]};
@@ -720,7 +689,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 uint32_t gate = gt[u];
                 const int n = __popc(gate);
                 if (n) {
-                    const int v = (base + u) * kThreads + tid;
+                    const int v = (base + u) * NT + tid;
                     uint32_t slot = atomicAdd(qcount, (uint32_t)n);
                     if (slot + n <= qcap) {
                         while (gate) {
@@ -735,7 +704,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 }
             }
         }
-        __syncthreads();
+        tile_sync<NT>();
         const bool over = *qover != 0;
         const int qn = over ? 0 : (int)*qcount;
         // valid.c:46,68: every DF-gate pass that is visited is a Try -- the queue entries ARE the tries.  A
@@ -750,12 +719,12 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             if (over && args.hand)
                 *tile_over = 1; // the launch-wide try list is in use: the host must wait for the launch's counters
             if (try_region)
-                args.try_counts[blockIdx.x] = (uint32_t)qn; // 0 when the queue overflowed: the fallback rounds list them
+                args.try_counts[tile] = (uint32_t)qn; // 0 when the queue overflowed: the fallback rounds list them
             else if (qn)
                 try_res = atomicAdd(&args.counters[1 * kCounterPad], (uint32_t)qn);
         }
 #pragma unroll 1
-        for (int q = tid; q < qn; q += kThreads) {
+        for (int q = tid; q < qn; q += NT) {
             const uint32_t ent = queue[q];
             const int sv = (int)(ent >> 7), sj = (int)((ent >> 2) & 31u);
             const uint32_t code = ent & 3u;
@@ -804,7 +773,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             // {g_rel, code, columns} -- and finished below with dense lanes.
             if (stage_cands) {
                 const uint32_t ci = atomicAdd(cl_n, 1u);
-                if (ci < (uint32_t)args.clist_cap) {
+                if (ci < (uint32_t)clist_cap) {
                     uint32_t *rec = cl_rec + ci * kCandWords;
                     rec[0] = g_rel;
                     rec[1] = code | (fixed << 8);
@@ -826,11 +795,11 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
         if (kStats && qn) { // (qn is workgroup-uniform)
             if (tid == 0)
                 *try_base = try_res;
-            __syncthreads(); // (the slicer only reads the queue)
+            tile_sync<NT>(); // (the slicer only reads the queue)
             const uint32_t tb = *try_base;
-            uint32_t *dst = args.tries + (try_region ? (size_t)blockIdx.x * kTryRegion : (size_t)args.try_list_first + tb);
+            uint32_t *dst = args.tries + (try_region ? (size_t)tile * kTryRegion : (size_t)args.try_list_first + tb);
             const uint32_t room = try_region ? (uint32_t)kTryRegion : (tb < args.try_cap ? args.try_cap - tb : 0u);
-            for (int q = tid; q < qn; q += kThreads) { // adjacent lanes, adjacent words
+            for (int q = tid; q < qn; q += NT) { // adjacent lanes, adjacent words
                 const uint32_t ent = queue[q];
                 if ((uint32_t)q < room)
                     dst[q] = ((tile_rel + (uint32_t)kRun * (ent >> 7) + ((ent >> 2) & 31u)) << 2) | (ent & 3u);
@@ -846,9 +815,9 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             // could (they start at >= c'.g - 1199, i.e. inside this tile, and the staged
             // list is complete), and none does, c is unreachable.  These are the +-1/2
             // sample shifted copies of every real frame: 3 of 4 records.
-            __syncthreads();
+            tile_sync<NT>();
             ADSB_STAMP(3);
-            const int ncl = min((int)*cl_n, args.clist_cap); // <= kClistCap <= kThreads: one entry per thread
+            const int ncl = min((int)*cl_n, clist_cap); // <= kClistCap <= NT: one entry per thread
             const bool complete = *cl_over == 0;
             bool keep = false;
             uint32_t rank = 0; // kept entries with a smaller offset: the record's place behind the tile's marker
@@ -930,7 +899,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 }
             }
             ADSB_STAMP(4);
-            __syncthreads();
+            tile_sync<NT>();
             ADSB_STAMP(5);
             uint32_t res_need = 0, res_base = 0;
             const bool reserves = tid == 0 && args.hand;
@@ -960,7 +929,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                 *tile_res = 1;
             }
             ADSB_STAMP(6);
-            __syncthreads(); // tile_base / tile_fit are in, and every staged entry has been read
+            tile_sync<NT>(); // tile_base / tile_fit are in, and every staged entry has been read
             ADSB_STAMP(7);
             const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
             if (keep) {
@@ -981,19 +950,19 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             }
             if (to_stream) {
                 // the tile's range {marker, records} leaves as one store of adjacent lanes
-                __syncthreads();
+                tile_sync<NT>();
                 const uint32_t nk = *tile_n;
                 // no fallback rounds will follow (they emit loose records): the marker is final
                 const bool marker_now = !over;
-                for (uint32_t L = tid; L < 1u + 2u * nk; L += kThreads) {
+                for (uint32_t L = tid; L < 1u + 2u * nk; L += NT) {
                     u32x4 gv;
                     if (L == 0) {
                         if (!marker_now)
                             continue;
                         const uint32_t nf = nk | (*tile_over ? kMarkOver : 0u);
                         uint32_t lo, hi;
-                        marker_check(blockIdx.x, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
-                        gv = u32x4{blockIdx.x, nf, lo, hi};
+                        marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
+                        gv = u32x4{tile, nf, lo, hi};
                         *tile_res = 2; // marker written
                     } else {
                         const uint32_t *r = cl_rec + ((L - 1u) >> 1) * kCandWords;
@@ -1009,17 +978,118 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             if (!over)
                 break;
             ch_lo = 0;
-            ch_hi = 1;
+            ch_hi = kFallbackChunks;
             grp = 0;
         } else if (++grp == kRun) {
             grp = 0;
-            ch_lo++;
-            ch_hi++;
+            ch_lo += kFallbackChunks;
+            ch_hi += kFallbackChunks;
             if (ch_lo >= nchunks)
                 break;
         }
-        __syncthreads(); // queue is rewritten
+        tile_sync<NT>(); // queue is rewritten
     }
+
+
+    if (args.hand) {
+        // Publish the tile: its marker granule {tile, count | flags, checksum} in front of
+        // its records.  No fence: a system-scope release in every thread writes back the
+        // L2 per tile (measured: 4.5x slower kernel), and without one nothing orders these
+        // stores on their way to host memory (measured: a flag does overtake the records)
+        // -- which is why the marker carries a checksum of the records (scan_kernel.h).
+        tile_sync<NT>();
+        if (tid == 0 && *tile_res != 2) {
+            uint32_t b = *tile_base, fit = *tile_fit;
+            if (!*tile_res) { // no whole-tile round staged anything (all_candidates, fallback rounds)
+                b = atomicAdd(&args.counters[2 * kCounterPad], stream_granules(0));
+                fit = b < args.hand_cap;
+            }
+            if (b < args.hand_cap) {
+                const uint32_t nf = *tile_n | (*tile_over ? kMarkOver : 0u) | (fit ? 0u : kMarkNoFit);
+                uint32_t lo, hi;
+                marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
+                store_granule_through(args.hand, b, u32x4{tile, nf, lo, hi});
+            }
+        }
+    }
+
+}
+
+// The classic kernel: one workgroup of four waves per tile; Stage A, a barrier, Stage B between barriers.
+template <bool kStats>
+__global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const ScanArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int K = tile_passes(blockIdx.x, args.stagger, args.passes);
+    const int nplane = kPassRuns * K + kPlanePad;
+    uint32_t *pl_d = smem;
+    uint32_t *pl_e1 = smem + nplane;
+    uint32_t *pl_e2 = smem + 2 * nplane;
+    uint32_t *queue = smem + 3 * nplane;
+    uint32_t *qcount = queue + kQueueCap;
+    uint32_t *cl_rec = qcount + 16; // kClistCap records of kCandWords
+
+    const int tid = threadIdx.x;
+#if ADSB_SLEEP_STAGGER
+    // The four workgroups that start together on a CU at the head of a large launch (blocks b, b + 256,
+    // b + 512, b + 768 with the observed round-robin placement; nothing depends on it) begin 0, 1, 2, 3 x
+    // ADSB_SLEEP_STAGGER x 64 cycles apart (2.6 us steps), so that their load phases do not coincide from
+    // the first pass on.  Measured in bench.py: -3.2 .. -4.0 % kernel time on one MI355X box, +-0.5 % on
+    // another; steps of 1.2 us did nothing, steps of 3.7 us and more were worse than 2.6.
+    if (gridDim.x >= 256u * ADSB_MIN_WAVES * 4 / kWaves && blockIdx.x < 256u * ADSB_MIN_WAVES * 4 / kWaves) {
+        const uint32_t slot = blockIdx.x >> 8;
+        for (uint32_t i = 0; i < slot; i++)
+            __builtin_amdgcn_s_sleep(ADSB_SLEEP_STAGGER);
+    }
+#endif
+    // cfg.profile: the launch's duration is (latest tile end) - (earliest tile start)
+    const uint64_t prof_begin = args.profile ? __builtin_amdgcn_s_memrealtime() : 0;
+#if ADSB_TILE_CLOCK
+    // kbench only: when and where each tile ran (100 MHz clock, HW_ID, XCC_ID) -> args.tile_clock[4 * tile ..]
+    const uint64_t clk_begin = __builtin_amdgcn_s_memrealtime();
+    const uint64_t cyc_begin = __builtin_amdgcn_s_memtime(); // shader clock: (d cycles) / (d realtime at 100 MHz) = the clock the chip holds
+#endif
+    StageStamps stamps{};
+#if ADSB_TILE_CLOCK == 3
+    stamps.st[0] = (uint32_t)clk_begin;
+#endif
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t t0 = // first owned offset
+        (int64_t)args.g_begin + (int64_t)kRun * (int64_t)tile_first_run(blockIdx.x, args.stagger, args.passes);
+
+    // plane words past the last computed run are read (never used) by Stage B
+    if (tid < kPlanePad) {
+        pl_d[kPassRuns * K + tid] = 0;
+        pl_e1[kPassRuns * K + tid] = 0;
+        pl_e2[kPassRuns * K + tid] = 0;
+    }
+
+    // kernel arguments are only ever used by value (taking their address would
+    // demote the sample pointer to a flat/scratch access)
+    stage_a(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl_d, pl_e1, pl_e2);
+#if ADSB_TILE_CLOCK == 3
+    uint32_t *tile_chk = qcount + 10;
+    if (lane == 0) // when each wave reaches the barrier behind Stage A: how long the four wait for each other
+        tile_chk[wave] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+    __syncthreads();
+#if ADSB_TILE_CLOCK == 3
+    const uint32_t arrive_sum = tile_chk[0] + tile_chk[1] + tile_chk[2] + tile_chk[3] - 4u * (uint32_t)clk_begin;
+    __syncthreads();
+#endif
+#if ADSB_ABLATE != 0
+    if (pl_d[(tid * 29) % (kPassRuns * K)] == 0x12345678u) // kbench: keep Stage A alive, skip the rest
+        atomicAdd(&args.counters[0 * kCounterPad], 1u);
+    return;
+#endif
+#if ADSB_STAGEB_PRIO
+    // From here on the tile is a chain of short, latency-bound phases between workgroup barriers, often with one
+    // wave working while three wait: at equal priority each of its instructions queues behind the Stage A streams
+    // of the three other workgroups on the SIMD.  Raised priority lets the chain through.
+    __builtin_amdgcn_s_setprio(ADSB_STAGEB_PRIO);
+#endif
+    stage_b<kStats, kThreads>(args, blockIdx.x, K, t0, tid, pl_d, pl_e1, pl_e2, queue, qcount, cl_rec, args.clist_cap, stamps);
 
 #if ADSB_TILE_CLOCK
     __syncthreads();
@@ -1028,7 +1098,7 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
 #if ADSB_TILE_CLOCK == 3
         uint32_t *o = args.tile_clock + 8 * (size_t)blockIdx.x; // eight stamps per tile
         for (int i = 0; i < 7; i++)
-            o[i] = st[i];
+            o[i] = stamps.st[i];
         o[7] = (uint32_t)clk_end;
         args.tile_clock[8 * (size_t)gridDim.x + blockIdx.x] = arrive_sum; // behind the stamps: sum over the waves of (arrival - begin)
 #else
@@ -1044,28 +1114,6 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
 #endif
     }
 #endif
-    if (args.hand) {
-        // Publish the tile: its marker granule {tile, count | flags, checksum} in front of
-        // its records.  No fence: a system-scope release in every thread writes back the
-        // L2 per tile (measured: 4.5x slower kernel), and without one nothing orders these
-        // stores on their way to host memory (measured: a flag does overtake the records)
-        // -- which is why the marker carries a checksum of the records (scan_kernel.h).
-        __syncthreads();
-        if (tid == 0 && *tile_res != 2) {
-            uint32_t b = *tile_base, fit = *tile_fit;
-            if (!*tile_res) { // no whole-tile round staged anything (all_candidates, fallback rounds)
-                b = atomicAdd(&args.counters[2 * kCounterPad], stream_granules(0));
-                fit = b < args.hand_cap;
-            }
-            if (b < args.hand_cap) {
-                const uint32_t nf = *tile_n | (*tile_over ? kMarkOver : 0u) | (fit ? 0u : kMarkNoFit);
-                uint32_t lo, hi;
-                marker_check(blockIdx.x, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
-                store_granule_through(args.hand, b, u32x4{blockIdx.x, nf, lo, hi});
-            }
-        }
-    }
-
     if (args.profile) { // the launch's duration is (latest tile end) - (earliest tile start)
         __syncthreads();
         if (tid == 64) { // not wave 0: that one has just issued the tile's write-through stores
@@ -1073,6 +1121,87 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             atomicMax(&c64[2 * kCounterPad], ~(unsigned long long)prof_begin); // = counters 4 and 5
             atomicMax(&c64[(5 * kCounterPad) / 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
         }
+    }
+}
+
+// The pipelined kernel (ScanArgs::pipe): PERSISTENT workgroups of FIVE waves.  Waves 0..3 run Stage A of tile i + 1
+// into one set of planes while wave 4 runs the whole of Stage B for tile i from the other set -- gate, slicer,
+// filter, finishing, hand-off, as one sequential wave with no workgroup barrier inside -- and the five meet at ONE
+// barrier per tile.  Why: in the classic kernel a tile spends a quarter of its life (11.7 of 45.6 us) in Stage B,
+// a chain of short latency-bound phases during which its four waves issue next to nothing while still holding
+// their slots; here the four arithmetic waves of a workgroup never leave Stage A.  Tiles come from a device counter
+// (counters[3]), fetched one tile ahead, so the dispatcher's gap between two tiles of a slot is gone as well, and a
+// workgroup's first tile is its block index.  LDS: two sets of planes + queue + staged list = 36 KiB at five
+// passes per tile, four workgroups (twenty waves, 96 VGPRs each) per CU.
+constexpr int kPipeThreads = 320;
+constexpr int kPipeWave = 4;    // the wave that runs Stage B
+constexpr int kPipeClist = 64;  // staged candidates per tile: one per lane of the Stage B wave
+template <bool kStats>
+__global__ __attribute__((amdgpu_flat_work_group_size(kPipeThreads, kPipeThreads), amdgpu_waves_per_eu(ADSB_PIPE_WAVES, ADSB_PIPE_WAVES)))
+void scan_pipe_kernel(const ScanArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int K = args.passes;
+    const int nplane = kPassRuns * K + kPlanePad;
+    uint32_t *queue = smem + 6 * nplane;
+    uint32_t *ctl = queue + kQueueCap; // [0..13] Stage B's, [14..15] the next tile of the workgroup (two in rotation)
+    uint32_t *cl_rec = ctl + 32;
+    const int tid = threadIdx.x;
+    const int lane_id = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int own = kPassRuns * K - kReachRuns;
+    const int ntiles = (int)args.n_tiles;
+#if ADSB_SLEEP_STAGGER
+    // the workgroups that begin together on a CU start 0, 1, 2, 3 x 2.6 us apart (see scan_kernel)
+    if (gridDim.x >= 1024u) {
+        const uint32_t slot = (blockIdx.x >> 8) & 3u;
+        for (uint32_t i = 0; i < slot; i++)
+            __builtin_amdgcn_s_sleep(ADSB_SLEEP_STAGGER);
+    }
+#endif
+    const uint64_t prof_begin = args.profile ? __builtin_amdgcn_s_memrealtime() : 0;
+    if (tid < 2 * kPlanePad) { // plane words past the last computed run are read (never used) by Stage B
+        uint32_t *b = smem + (tid >= kPlanePad ? 3 * nplane : 0) + kPassRuns * K + (tid & (kPlanePad - 1));
+        b[0] = 0;
+        b[nplane] = 0;
+        b[2 * nplane] = 0;
+    }
+    StageStamps stamps{};
+    int tile_a = (int)blockIdx.x < ntiles ? (int)blockIdx.x : -1, tile_b = -1;
+    for (int it = 0; tile_a >= 0 || tile_b >= 0; it++) {
+        // (opaque to the optimiser: lane-dependent addresses are then recomputed per tile -- a few instructions --
+        // instead of being hoisted out of this loop, kept alive across both stages and spilled for it)
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        if (wave != kPipeWave) {
+            if (tile_a >= 0) {
+                uint32_t *pl = smem + (it & 1) * 3 * nplane;
+                const int64_t t0 = (int64_t)args.g_begin + (int64_t)kRun * own * (int64_t)tile_a;
+                stage_a(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl, pl + nplane, pl + 2 * nplane);
+            }
+        } else {
+            int next = -1;
+            if (tile_a >= 0 && lane_id == 0) { // this workgroup's tile after tile_a; the answer is needed at the barrier
+                const uint32_t k = gridDim.x + atomicAdd(&args.counters[3 * kCounterPad], 1u);
+                next = k < (uint32_t)ntiles ? (int)k : -1;
+            }
+            if (tile_b >= 0) {
+                const uint32_t *pl = smem + ((it & 1) ^ 1) * 3 * nplane;
+                const int64_t t0 = (int64_t)args.g_begin + (int64_t)kRun * own * (int64_t)tile_b;
+                const int clcap = args.clist_cap < kPipeClist ? args.clist_cap : kPipeClist;
+                stage_b<kStats, 64>(args, (uint32_t)tile_b, K, t0, lane, pl, pl + nplane, pl + 2 * nplane, queue, ctl, cl_rec, clcap, stamps);
+            }
+            if (lane_id == 0)
+                ctl[14 + (it & 1)] = (uint32_t)next;
+        }
+        __syncthreads();
+        tile_b = tile_a;
+        tile_a = __builtin_amdgcn_readfirstlane((int)ctl[14 + (it & 1)]);
+    }
+    if (args.profile && tid == 0) { // the launch's duration is (latest workgroup end) - (earliest workgroup start)
+        unsigned long long *c64 = reinterpret_cast<unsigned long long *>(args.counters);
+        atomicMax(&c64[2 * kCounterPad], ~(unsigned long long)prof_begin); // = counters 4 and 5
+        atomicMax(&c64[(5 * kCounterPad) / 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 
@@ -1282,16 +1411,34 @@ uint32_t make_fix_table(uint32_t *tab)
     }
 }
 
-int choose_passes(uint64_t n_offsets, int cus)
+bool choose_pipe(uint64_t n_offsets)
+{
+    if (const char *e = getenv("ADSB_PIPE")) // tuning, tests, A/B runs
+        return atoi(e) != 0;
+    return n_offsets >= kPipeMinOffsets;
+}
+
+int choose_passes(uint64_t n_offsets, int cus, bool pipe)
 {
     // Estimated time = rounds x passes, rounds = ceil(tiles / resident workgroups);
     // long tiles amortise the 44-run halo, short ones fill the last round better.
     if (cus <= 0)
         cus = 256;
+    const int k_max = pipe ? kPipeMaxPasses : kMaxPasses;
     if (const char *e = getenv("ADSB_PASSES")) { // tuning and tests
         const int k = atoi(e);
         if (k >= 2 && k <= kMaxPasses)
-            return k;
+            return std::min(k, k_max);
+    }
+    if (pipe) {
+        // Persistent workgroups take tiles from a counter: no rounds to quantise.  Five passes (the most that
+        // fits four workgroups' double-buffered planes into a CU's LDS) once every workgroup gets a few tiles;
+        // below that, the longest tile that still gives every resident workgroup one.
+        const uint64_t groups = (uint64_t)cus * 4;
+        for (int k = kPipeMaxPasses; k > 2; k--)
+            if (n_offsets / (uint64_t)tile_offsets(k) >= groups)
+                return k;
+        return 2;
     }
     // Large launches: tiles retire at a steady rate in index order (each CU favours its older
     // workgroups, so there are no "rounds" to quantise), and a longer tile only amortises its
@@ -1340,22 +1487,55 @@ uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes)
     return tiles >= 2ull * st ? st : 0u;
 }
 
-hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream)
+// Workgroups of the pipelined kernel that are resident at once (they are persistent: that is the grid).
+static int pipe_resident_groups(bool stats, int passes)
 {
+    static int cache[2][kMaxPasses + 1];
+    int &c = cache[stats ? 1 : 0][passes];
+    if (c == 0) {
+        int dev = 0, cus = 256, per_cu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const hipError_t e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_pipe_kernel<true>, kPipeThreads, lds_bytes_pipe(passes))
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_pipe_kernel<false>, kPipeThreads, lds_bytes_pipe(passes));
+        if (e != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        if (const char *f = getenv("ADSB_PIPE_GROUPS_PER_CU")) // tuning
+            per_cu = std::max(1, atoi(f));
+        c = std::max(1, cus) * per_cu;
+    }
+    return c;
+}
+
+hipError_t launch_scan(const ScanArgs &args_in, bool stats, hipStream_t stream)
+{
+    ScanArgs args = args_in;
     if (args.g_end <= args.g_begin)
         return hipSuccess;
     const uint64_t n = args.g_end - args.g_begin;
     const uint64_t per = (uint64_t)tile_offsets(args.passes);
     const uint64_t blocks = tile_count(n, args.stagger, args.passes);
-    const size_t lds = lds_bytes(args.passes);
+    args.n_tiles = (uint32_t)blocks;
+    const size_t lds = args.pipe ? lds_bytes_pipe(args.passes) : lds_bytes(args.passes);
     if (getenv("ADSB_DEBUG_LAUNCH"))
-        fprintf(stderr, "launch_scan: n=%llu passes=%d per=%llu blocks=%llu lds=%zu prior_err=%d\n",
-                (unsigned long long)n, args.passes, (unsigned long long)per, (unsigned long long)blocks, lds,
+        fprintf(stderr, "launch_scan: n=%llu passes=%d per=%llu blocks=%llu lds=%zu pipe=%d prior_err=%d\n",
+                (unsigned long long)n, args.passes, (unsigned long long)per, (unsigned long long)blocks, lds, args.pipe,
                 (int)hipPeekAtLastError());
-    if (stats)
+    if (args.pipe) {
+        if (args.stagger != 0 || args.passes > kPipeMaxPasses)
+            return hipErrorInvalidValue;
+        const unsigned grid = (unsigned)std::min<uint64_t>(blocks, (uint64_t)pipe_resident_groups(stats, args.passes));
+        if (getenv("ADSB_DEBUG_LAUNCH"))
+            fprintf(stderr, "launch_scan: pipelined kernel, %u persistent workgroups for %llu tiles\n", grid, (unsigned long long)blocks);
+        if (stats)
+            hipLaunchKernelGGL(scan_pipe_kernel<true>, dim3(grid), dim3(kPipeThreads), lds, stream, args);
+        else
+            hipLaunchKernelGGL(scan_pipe_kernel<false>, dim3(grid), dim3(kPipeThreads), lds, stream, args);
+    } else if (stats) {
         hipLaunchKernelGGL(scan_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args);
-    else
+    } else {
         hipLaunchKernelGGL(scan_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args);
+    }
     if (args.report)
         hipLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, stream, args.counters, args.report, args.gen);
     return hipGetLastError();

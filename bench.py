@@ -248,14 +248,36 @@ def preroll(step, ms, at_least=40):
         i += 1
 
 
-def timed_steps(step, steps, fence):
+def timed_steps(step, steps, fence, sync=None):
+    """K steps bracketed by barrier + synchronize on both sides.  The time is this rank's own: from the common
+    start (behind the opening barrier) to the completion of its K-th step (device idle); the caller takes the
+    max over ranks.  The closing barrier's own latency (gloo: a few hundred microseconds) is not part of it."""
     fence()
     t0 = time.perf_counter()
     raw = None
     for i in range(steps):
         raw = step(i)
+    if sync is not None:
+        sync()
+    dt = time.perf_counter() - t0
     fence()
-    return time.perf_counter() - t0, raw
+    return dt, raw
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a plain shell: run the same command line under torch.distributed.run."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def host_fed_rates(torch, capi, x_dev, df18):
@@ -326,14 +348,19 @@ def main():
                     help="plumbing test only: every rank uses GPU 0 and gloo (numbers are meaningless)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) and relay rank 0's
+        # line.  This parent has not touched the GPU and never does: the workers are children, not an exec.
+        return self_launch(args.gpus)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
     import torch
     from adsbdec_amd import _build, capi
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     if args.one_device_test:
@@ -342,15 +369,14 @@ def main():
     dist = None
     host_group = None
     if world > 1:
+        # No data-path collective exists in either mode: the ranks only meet at the barriers around
+        # the timed region, for the max of their times, the parity flags, and -- shard mode -- the exchange of
+        # host-resident records.  All of that is CPU-side, so the one process group is gloo; RCCL is not
+        # initialised at all (it would move nothing).
+        import datetime
         import torch.distributed as dist
-        if args.one_device_test:
-            dist.init_process_group("gloo")
-            host_group = dist.group.WORLD
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            if args.mode == "shard":
-                from adsbdec_amd import sharding
-                host_group = sharding.gloo_group()  # host-resident candidate records: gathered on the CPU side
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+        host_group = dist.group.WORLD
     if not os.path.exists(capi.LIB_PATH):
         if rank == 0:
             _build.build()
@@ -361,17 +387,23 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
 
     def max_over_ranks(dt):
         if world == 1:
             return dt
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.one_device_test else "cuda")
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_ranks_ok(ok):
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     if args.mode == "shard":
-        return run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fence, max_over_ranks)
+        return run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fence, max_over_ranks, all_ranks_ok)
 
     n = (args.samples or (256 << 20))
     n -= n % 28
@@ -426,7 +458,7 @@ def main():
 
     fence()
     p0 = dec.profile()  # counters accumulate over the handle's life: take differences
-    dt, raw = timed_steps(step, args.steps, fence)
+    dt, raw = timed_steps(step, args.steps, fence, torch.cuda.synchronize)
     dt = max_over_ranks(dt)
     last = (args.steps - 1) % len(ptrs)
 
@@ -443,16 +475,26 @@ def main():
     if frames_key(per_capture[last]) != frames_key(frames):
         raise SystemExit("PARITY FAILURE: the last timed step and a repeat of the same capture differ")
 
-    # ---- CPU baseline + correctness gate (rank 0 only, N == 1 only) ----
+    # ---- correctness gate on EVERY rank (each decodes its own stream: demod.c:86,99,125-141 and air.c:94-99 are
+    # sequential rules that nothing else would check at N > 1) + the CPU baseline, timed on rank 0 only ----
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         from oracle import oracle as O
-        cpu, want = cpu_reference(xs[0].cpu().numpy().view(np.uint16), args.dense)
-        gate(per_capture[0], want, "capture 0 vs the CPU path")
-        for j in range(1, len(xs)):  # the other captures of the rotation: against the oracle
-            wj, _ = O.decode(xs[j].cpu().numpy().view(np.uint16), df18=args.dense)
-            gate(per_capture[j], wj, f"capture {j} vs the oracle")
+        ok, why = True, ""
+        try:
+            first = 0
+            if rank == 0:
+                cpu, want = cpu_reference(xs[0].cpu().numpy().view(np.uint16), args.dense)
+                gate(per_capture[0], want, "capture 0 vs the CPU path")
+                first = 1
+            for j in range(first, len(xs)):  # the other captures of the rotation: against the oracle
+                wj, _ = O.decode(xs[j].cpu().numpy().view(np.uint16), df18=args.dense)
+                gate(per_capture[j], wj, f"rank {rank}, capture {j} vs the oracle")
+        except SystemExit as e:  # a mismatch on one rank must fail the job, not hang the others in the all-reduce
+            ok, why = False, str(e)
+        if not all_ranks_ok(ok):
+            raise SystemExit(why or "PARITY FAILURE on another rank")
         parity = True
 
     # ---- extra legs, after the timed region (rank 0, N == 1): dense sub-record, host-fed rates ----
@@ -527,7 +569,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "samples_per_gpu": n, "frames_decoded_rank0": len(frames),
-                       "parity_vs_cpu": parity},
+                       "parity_vs_cpu": parity, "ranks_gated": world if parity else 0},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
             "value_cold": value_cold, "with_stats": with_stats, "dense": dense, "e2e_host_fed": e2e,
         }
@@ -537,7 +579,7 @@ def main():
         dist.destroy_process_group()
 
 
-def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fence, max_over_ranks):
+def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fence, max_over_ranks, all_ranks_ok):
     """BASELINE configs[4]: one stream, time-sharded over the ranks (see the module docstring)."""
     total = args.samples or (2 << 30)
     total -= total % 28
@@ -562,7 +604,7 @@ def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fenc
         step()
     fence()
     p0 = dec.profile()
-    dt, raw = timed_steps(step, args.steps, fence)
+    dt, raw = timed_steps(step, args.steps, fence, torch.cuda.synchronize)
     dt = max_over_ranks(dt)
     p1 = dec.profile()
     roofline, roofline_valu = roofline_objects(p0, p1, args.steps)

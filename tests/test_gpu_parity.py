@@ -13,6 +13,14 @@ from conftest import golden_cases, golden_records, load_golden, records, shard_p
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["classic", "pipe"])
+def kernel_variant(request, monkeypatch):
+    """Every test runs with both scan kernels (scan_kernel.hip): the classic one-workgroup-per-tile kernel and the
+    pipelined one (persistent five-wave workgroups, Stage B on a wave of its own).  ADSB_PIPE is read per launch."""
+    monkeypatch.setenv("ADSB_PIPE", "1" if request.param == "pipe" else "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def torch_cuda():
     import torch
@@ -718,29 +726,40 @@ def test_shard_candidates_equal_oracle_exhaustive(capi, oracle, dec_factory, tor
     assert r.stats() == wstats
 
 
-def test_two_rank_sharded_stream_with_the_hip_kernel():
-    """BASELINE configs[4] plumbing with the HIP kernel in MORE THAN ONE PROCESS: two ranks
-    (both on this GPU: --one-device-test, gloo) each scan their halo'd shard of one stream
-    with adsb_scan_shard, the fixed-layout candidate arrays are gathered to rank 0 and
-    resolved once; bench.py's own gate then compares with the single-GPU decode of the
-    whole stream.  (tests/test_distributed_cpu.py covers the same exchange on CPU.)"""
+def _bench_line(extra, timeout=900):
+    """`python bench.py ...` from a plain shell -- the driver's command shape: with --gpus N > 1 and no WORLD_SIZE
+    the script starts its N ranks itself (before any GPU call) and relays rank 0's JSON line."""
     import json
-    import socket
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--mode", "shard", "--one-device-test",
-           "--samples", str(64 << 20), "--steps", "3", "--warmup", "1", "--preroll-ms", "0"]
-    p = subprocess.run(cmd, cwd=root, capture_output=True, timeout=900)
-    assert p.returncode == 0, p.stderr.decode()[-2000:]
-    line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "bench.py"] + extra, cwd=root, capture_output=True, timeout=timeout, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    return json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+
+
+def test_two_rank_sharded_stream_with_the_hip_kernel():
+    """BASELINE configs[4] plumbing with the HIP kernel in MORE THAN ONE PROCESS: two ranks
+    (both on this GPU: --one-device-test, gloo) each scan their halo'd shard of one stream,
+    resolve it speculatively, and rank 0 stitches the seams; bench.py's own gate then compares
+    with the single-GPU decode of the whole stream.  (tests/test_distributed_cpu.py covers the
+    same exchange on CPU.)"""
+    line = _bench_line(["--gpus", "2", "--mode", "shard", "--one-device-test", "--samples", str(64 << 20), "--steps", "3",
+                        "--warmup", "1", "--preroll-ms", "0"])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert line["config"]["parity"].startswith("equal to the single-GPU decode")
     assert line["config"]["frames_decoded"] > 3000
+
+
+def test_two_rank_independent_streams_are_gated_on_every_rank():
+    """BASELINE configs[3] plumbing: `python bench.py --gpus 2` (stream mode), two ranks on this one GPU, each
+    with its own stream and handle; EVERY rank compares its frames with the oracle after the timed region."""
+    line = _bench_line(["--gpus", "2", "--one-device-test", "--samples", str(16 << 20), "--steps", "3", "--warmup", "1",
+                        "--preroll-ms", "0", "--no-extras"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["parity_vs_cpu"] is True and line["config"]["ranks_gated"] == 2
+    assert line["config"]["frames_decoded_rank0"] > 500
+    assert line["cpu_baseline"]["value"] > 0
 
 
 # ------------------------------------------------------------------ size-independent properties
