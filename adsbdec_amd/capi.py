@@ -35,12 +35,26 @@ class Stats(C.Structure):
     _fields_ = [("try_", C.c_uint64 * 3), ("ok", C.c_uint64 * 3), ("fixed", C.c_uint64)]
 
 
+class ShardHead(C.Structure):
+    _fields_ = [("g_begin", C.c_uint64), ("g_end", C.c_uint64), ("n_frames", C.c_uint64), ("n_head", C.c_uint64),
+                ("head_end", C.c_uint64), ("skipped", C.c_uint64), ("status", C.c_uint64), ("reserved", C.c_uint64)]
+
+
+class ShardPart(C.Structure):
+    _fields_ = [("head", C.POINTER(ShardHead)), ("frames", C.POINTER(Frame)), ("head_cands", C.POINTER(Candidate))]
+
+
+class ShardFix(C.Structure):
+    _fields_ = [("new_first", C.c_uint64), ("n_new", C.c_uint64), ("drop_front", C.c_uint64), ("keep", C.c_uint64),
+                ("ts_sub", C.c_int64)]
+
+
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("df18", C.c_int32), ("device", C.c_int32),
                 ("collect_stats", C.c_int32), ("profile", C.c_int32), ("debug_queue_cap", C.c_int32),
                 ("stage_samples", C.c_uint64), ("stream", C.c_void_p), ("all_candidates", C.c_int32),
                 ("fix_1bit", C.c_int32), ("debug_cand_cap", C.c_int32), ("debug_try_cap", C.c_int32),
-                ("debug_clist_cap", C.c_int32), ("reserved0", C.c_int32)]
+                ("debug_clist_cap", C.c_int32), ("push_overlap", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -81,6 +95,15 @@ SYMBOLS = {
     "adsb_resolver_advance": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "adsb_resolver_drain": (C.c_long, [C.c_void_p, C.POINTER(Frame), C.c_size_t]),
     "adsb_resolver_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "adsb_scan_shard_resolved": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64, C.c_uint64,
+                                           C.POINTER(ShardHead), C.POINTER(Frame), C.c_size_t, C.POINTER(Candidate),
+                                           C.c_size_t]),
+    "adsb_stitch_shards": (C.c_int, [C.POINTER(ShardPart), C.c_int, C.c_uint64, C.POINTER(ShardFix), C.POINTER(Frame),
+                                     C.c_size_t, C.POINTER(C.c_size_t)]),
+    "adsb_shard_apply_fix": (None, [C.POINTER(Frame), C.c_size_t, C.c_int64]),
+    "adsb_resolver_start_chain": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "adsb_resolver_head": (C.c_long, [C.c_void_p, C.POINTER(Candidate), C.c_size_t]),
+    "adsb_resolver_skipped": (C.c_uint64, [C.c_void_p]),
     "adsb_plan_shards": (C.c_int, [C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "adsb_scan_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64,
@@ -139,7 +162,7 @@ class Decoder:
     def __init__(self, df18: bool = False, device: int = -1, collect_stats: bool = False,
                  profile: bool = False, stage_samples: int = 0, stream: int | None = None,
                  debug_queue_cap: int = 0, all_candidates: bool = False, fix_1bit: bool = False,
-                 debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0):
+                 debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0, push_overlap: bool = False):
         L = load()
         cfg = Config()
         L.adsb_config_default(C.byref(cfg))
@@ -155,6 +178,7 @@ class Decoder:
         cfg.debug_cand_cap = debug_cand_cap
         cfg.debug_try_cap = debug_try_cap
         cfg.debug_clist_cap = debug_clist_cap
+        cfg.push_overlap = int(push_overlap)
         self._L = L
         self._fix = bool(fix_1bit)
         self._h = L.adsb_create(C.byref(cfg))
@@ -271,6 +295,8 @@ class Decoder:
         self.reset()
         if mode == "async":
             return self._decode_async(x, chunk or x.size)
+        if mode == "overlap":
+            return self._decode_overlap(x, chunk or x.size)
         if chunk is None:
             self.push(x)
         else:
@@ -288,6 +314,23 @@ class Decoder:
                 b[:] = piece                # the previous push from this buffer was two calls ago: free again
                 self.push_async(b)
                 out += self.drain()         # frames of the previous piece
+            self.finish()
+            out += self.drain()
+        return out
+
+
+    def _decode_overlap(self, x: np.ndarray, chunk: int):
+        """cfg.push_overlap: adsb_push from ONE page-locked buffer (fileInput's single iqbuff, air.c:230-239) that is
+        overwritten the moment the call returns -- the copy must be complete by then; frames follow one call later."""
+        out = []
+        with PinnedBuffers(1, max(1, min(chunk, max(1, x.size)))) as bufs:
+            for i in range(0, x.size, chunk):
+                piece = x[i:i + chunk]
+                b = bufs[0][: piece.size]
+                b[:] = piece
+                self._check(self._L.adsb_push(self._h, b.ctypes.data, b.size), "adsb_push")
+                b[:] = 0xFFFF               # the buffer is the caller's again
+                out += self.drain()
             self.finish()
             out += self.drain()
         return out

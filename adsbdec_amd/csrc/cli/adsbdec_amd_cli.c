@@ -236,8 +236,9 @@ int main(int argc, char **argv)
             pthread_mutex_lock(&rg.mu);
             while (!s->ready)
                 pthread_cond_wait(&rg.cv, &rg.mu);
+            const int reader_failed = rg.failed; /* (written under the mutex by the reader) */
             pthread_mutex_unlock(&rg.mu);
-            if (rg.failed) {
+            if (reader_failed) {
                 fprintf(stderr, "out of memory for the read buffers\n");
                 rc = 255;
                 break;
@@ -251,8 +252,10 @@ int main(int argc, char **argv)
                     rc = 255;
                     break;
                 }
-                if (flush_frames(dec, outformat) != 0)
+                if (flush_frames(dec, outformat) != 0) { /* stdout is gone (EPIPE, disk full): stop, and say so */
+                    rc = 1;
                     break;
+                }
             }
             if (prev >= 0) { /* the buffer of the previous push is free again (adsb_push_async's contract) */
                 pthread_mutex_lock(&rg.mu);

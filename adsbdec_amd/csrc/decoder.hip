@@ -40,6 +40,7 @@
 #include "../../include/adsbdec_amd.h"
 #include "resolver.hpp"
 #include "scan_kernel.h"
+#include "stitch.hpp"
 
 namespace {
 
@@ -222,6 +223,16 @@ constexpr size_t kTryStateBytes = 4 * sizeof(unsigned long long) + 4 * sizeof(ui
 constexpr uint32_t kCarryCap = 1u << 20; // undecided tries carried between count passes (a few hundred in practice)
 
 int count_flush(adsb_decoder *d);
+
+// adsb_push_async: wait for the copy of the last piece (a no-op when a collected scan has implied it).
+int wait_last_copy(adsb_decoder *d)
+{
+    if (d->piece == 0 || d->dbg_async == 2)
+        return 0;
+    HIP_TRY(d, hipSetDevice(d->device));
+    HIP_TRY(d, hipEventSynchronize(d->ev_copy[d->piece % adsb_decoder::kCopyStreams]));
+    return 0;
+}
 
 // The reference's ring index `fidx` is a uint32_t that counts input samples (air.c:34): at 2^32 samples it
 // wraps, 2^32 mod 14 = 4, and the ring phase jumps.  No parity is defined beyond that point, so a
@@ -461,6 +472,7 @@ void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uin
         for (size_t i = 0; i < nt; i++)
             d->sink.tries->push_back((((uint64_t)(tries[i] >> 2) + s.args.g_begin) << 2) | (tries[i] & 3u));
     } else if (nt == 0) {
+        d->res.capture_head(recs, order, nc, words, off, s.args.g_begin);
         d->res.advance_device(recs, order, nc, words, off, s.args.g_begin, power_samples_produced(d->n_samples),
                               g_complete);
     } else {
@@ -554,6 +566,8 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
             for (uint32_t u = delivered; u < upto; u++)
                 nc += t_count[u];
             d->prof.candidates += nc;
+            if (d->res.head_wanted(s.args.g_begin + adsb::kRun * adsb::tile_first_run(delivered, s.args.stagger, s.args.passes)))
+                d->res.capture_head_tiles(s.hand, t_start.data(), t_count.data(), delivered, upto, s.args.g_begin);
             d->res.advance_tiles(s.hand, t_start.data(), t_count.data(), delivered, upto, 0, s.args.g_begin,
                                  power_samples_produced(d->n_samples), g_complete);
         }
@@ -1096,11 +1110,19 @@ int process_stage(adsb_decoder *d, bool final, bool in_flight = false)
             // compaction is the tail copy (a few KB), not a scan.
             const bool aside = in_flight && d->dbg_async != 4 && d->dbg_async != 2;
             hipStream_t ts = aside ? d->copy_stream[d->piece % adsb_decoder::kCopyStreams] : d->stream;
+            // The tail also holds the end of the PREVIOUS piece whenever this piece is shorter than the tail
+            // (~2.5 K samples), and that piece was copied on the other copy stream: order behind it too (an event
+            // that has already completed costs nothing).
+            if (aside && d->piece > 1)
+                HIP_TRY(d, hipStreamWaitEvent(ts, d->ev_copy[(d->piece - 1) % adsb_decoder::kCopyStreams], 0));
             HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur ^ 1], d->stage[d->cur] + skip, left * sizeof(uint16_t),
                                       hipMemcpyDeviceToDevice, ts));
-            if (aside) {
+            // Behind EVERY tail copy, the one of a synchronous push on the scan stream included: a following
+            // adsb_push_async copies right behind this tail on a copy stream that nothing else orders against it.
+            if (d->dbg_async != 4) {
                 HIP_TRY(d, hipEventRecord(d->ev_tail, ts));
-                HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_tail, 0));
+                if (ts != d->stream)
+                    HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_tail, 0));
                 for (hipStream_t cs : d->copy_stream)
                     if (cs != ts)
                         HIP_TRY(d, hipStreamWaitEvent(cs, d->ev_tail, 0));
@@ -1375,6 +1397,9 @@ int adsb_reset(adsb_decoder *d)
             sl.prof_pending[0] = sl.prof_pending[1] = false;
         }
     }
+    else if (wait_last_copy(d)) // a late asynchronous copy must not land in stage[0] beside the next stream's
+        return -1;
+    d->piece = 0;
     d->final_follows = false;
     d->deferred_n = 0;
     d->deferred_slot = nullptr;
@@ -1423,6 +1448,16 @@ int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n)
     if (!samples)
         return d->fail("adsb_push: NULL samples");
     HIP_TRY(d, hipSetDevice(d->device));
+    if (d->cfg.push_overlap) {
+        // The caller's ONE buffer (fileInput's iqbuff, air.c:230-239; the callback's transfer, air.c:173-177) is
+        // only borrowed until its bytes are on the device: return when the COPY has completed and leave the scan
+        // in flight -- the host is back in read() while the device scans, and this call has meanwhile collected
+        // the frames of the previous one (frames arrive one call late, never reordered; adsb_finish / adsb_sync
+        // deliver the rest).  That is adsb_push_async plus the wait for this piece's own copy.
+        if (push_copy(d, samples, n, hipMemcpyHostToDevice, true))
+            return -1;
+        return wait_last_copy(d);
+    }
     if (push_copy(d, samples, n, hipMemcpyHostToDevice))
         return -1;
     if (d->copy_unconfirmed) { // `samples` is only borrowed for the call: no scan behind the last copy has confirmed it
@@ -1616,6 +1651,8 @@ int adsb_finish(adsb_decoder *d)
         return -1;
     if (d->cfg.collect_stats && count_tries_pass(d, nullptr, 0, 0, true))
         return -1; // tries beyond the final position are never visited
+    if (wait_last_copy(d)) // the contract of adsb_push_async: every borrowed buffer is free when adsb_finish returns,
+        return -1;         // also when the last piece launched no scan that would have implied it
     d->finished = true;
     return 0;
 }
@@ -1709,6 +1746,78 @@ int adsb_scan_shard(adsb_decoder *d, const void *device_samples, uint64_t first_
     return 0;
 }
 
+// The same scan, resolved on the fly by this handle's own resolver in chain mode (resolver.hpp): the streaming
+// hand-off feeds it while the kernel runs, exactly like a stream's scan; the frames come out with shard-local ts.
+int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n, uint64_t g_begin,
+                             uint64_t g_end, adsb_shard_head *head, adsb_frame *frames, size_t frame_cap,
+                             adsb_candidate *head_cands, size_t head_cap)
+{
+    if (!d || !device_samples || !head || (frame_cap && !frames) || (head_cap && !head_cands))
+        return -1;
+    std::memset(head, 0, sizeof *head);
+    head->status = 1;
+    if (d->cfg.collect_stats)
+        return d->fail("adsb_scan_shard_resolved: statistics of a sharded stream go through adsb_scan_shard");
+    if (first_sample % 8 || (uintptr_t)device_samples % 16)
+        return d->fail("adsb_scan_shard_resolved: buffer must start at a multiple of 8 samples, 16-byte aligned");
+    if (g_begin % 28)
+        return d->fail("adsb_scan_shard_resolved: g_begin must be a multiple of 28");
+    if (g_end > g_begin) {
+        const uint64_t need_lo = g_begin >= 6 ? 2 * (g_begin - 6) : 0;
+        const uint64_t need_hi = 2 * (g_end - 1 + ADSB_WINDOW);
+        if (first_sample > need_lo || first_sample + n < need_hi)
+            return d->fail("adsb_scan_shard_resolved: buffer does not cover the window of the owned offsets");
+    }
+    HIP_TRY(d, hipSetDevice(d->device));
+    if (scan_drain(d))
+        return -1;
+    static const uint64_t head_span = [] {
+        const char *e = getenv("ADSB_SHARD_HEAD"); // tests shrink it to reach the stitcher's fallback
+        const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
+        return v ? v : (uint64_t)16384;
+    }();
+    std::vector<adsb_candidate> hv;
+    const uint64_t head_end = std::min<uint64_t>(g_end, g_begin + head_span);
+    d->sink = ScanSink{};
+    d->res.start_chain(g_begin, head_end, &hv);
+    int rc = scan_submit(d, static_cast<const uint16_t *>(device_samples), first_sample, n, g_begin, g_end);
+    if (rc == 0)
+        rc = scan_drain(d);
+    if (rc == 0)
+        d->res.advance(0, g_end);
+    const adsb_frame *fp = nullptr;
+    const size_t nf = rc == 0 ? d->res.take(&fp) : 0;
+    head->g_begin = g_begin;
+    head->g_end = g_end;
+    head->n_frames = nf;
+    head->n_head = hv.size();
+    head->head_end = head_end;
+    head->skipped = d->res.skipped();
+    if (rc == 0 && nf <= frame_cap && hv.size() <= head_cap) {
+        if (nf)
+            std::memcpy(frames, fp, nf * sizeof(adsb_frame));
+        if (!hv.empty())
+            std::memcpy(head_cands, hv.data(), hv.size() * sizeof(adsb_candidate));
+        head->status = 0;
+    }
+    d->res.reset(); // (the head vector dies with this call)
+    if (rc)
+        return -1;
+    return head->status == 0 ? 0 : -2;
+}
+
+int adsb_stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
+                       adsb_frame *new_frames, size_t new_cap, size_t *n_new_total)
+{
+    return adsb::stitch_shards(parts, n_parts, total_samples, fix, new_frames, new_cap, n_new_total);
+}
+
+void adsb_shard_apply_fix(adsb_frame *frames, size_t n, int64_t ts_sub)
+{
+    for (size_t i = 0; i < n; i++)
+        frames[i].ts = (uint64_t)((int64_t)frames[i].ts - ts_sub);
+}
+
 int adsb_plan_shards(uint64_t total_samples, int n_shards, uint64_t *g_begin, uint64_t *g_end,
                      uint64_t *first_sample, uint64_t *n_samples)
 {
@@ -1737,6 +1846,7 @@ int adsb_plan_shards(uint64_t total_samples, int n_shards, uint64_t *g_begin, ui
 // ---- resolver handle ----------------------------------------------------------
 struct adsb_resolver {
     adsb::Resolver r;
+    std::vector<adsb_candidate> head;
 };
 
 adsb_resolver *adsb_resolver_create(void)
@@ -1772,6 +1882,27 @@ long adsb_resolver_drain(adsb_resolver *r, adsb_frame *out, size_t cap)
         return -1;
     return (long)r->r.drain(out, cap);
 }
+
+int adsb_resolver_start_chain(adsb_resolver *r, uint64_t g_begin, uint64_t head_end)
+{
+    if (!r)
+        return -1;
+    r->head.clear();
+    r->r.start_chain(g_begin, head_end, &r->head);
+    return 0;
+}
+
+long adsb_resolver_head(adsb_resolver *r, adsb_candidate *out, size_t cap)
+{
+    if (!r || (!out && cap))
+        return -1;
+    const size_t n = std::min(cap, r->head.size());
+    if (n)
+        std::memcpy(out, r->head.data(), n * sizeof(adsb_candidate));
+    return (long)r->head.size();
+}
+
+uint64_t adsb_resolver_skipped(const adsb_resolver *r) { return r ? r->r.skipped() : 0; }
 
 int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out)
 {

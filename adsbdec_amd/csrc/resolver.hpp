@@ -29,6 +29,9 @@ public:
     void reset()
     {
         base_ = 0;
+        chain_ = false;
+        head_end_ = 0;
+        head_ = nullptr;
         skipped_ = 0;
         cands_.clear();
         chead_ = 0;
@@ -44,6 +47,9 @@ public:
     void feed(const adsb_candidate *c, size_t n, const uint64_t *tries, size_t nt)
     {
         compact();
+        if (head_)
+            for (size_t i = 0; i < n && c[i].g < head_end_; i++)
+                head_->push_back(c[i]);
         if (n)
             cands_.insert(cands_.end(), c, c + n);
         if (nt)
@@ -111,11 +117,59 @@ public:
         keep_leftovers();
     }
 
+    // CHAIN mode (time-sharded streams, one resolver per shard): only the greedy rule itself (demod.c:89,128,134,
+    // 141), started at offset g_begin as if no earlier frame reached into the shard.  The deqframe call pattern
+    // (air.c:94-99) does not change which frames the chain accepts -- a call ends at an offset, the next one starts at
+    // that offset -- only where the stream's LAST call ends (the end-of-file horizon), and the stitcher replays that
+    // on the accepted frames (stitch.hpp).  ts comes out local: g + 1 - (offsets jumped inside this shard).
+    // Every candidate with g < head_end is also copied to `head`: what the stitcher needs to re-run the chain
+    // across the seam when a frame of the previous shard does reach in.
+    void start_chain(uint64_t g_begin, uint64_t head_end, std::vector<adsb_candidate> *head)
+    {
+        reset();
+        base_ = g_begin;
+        chain_ = true;
+        head_end_ = head_end;
+        head_ = head;
+    }
+    uint64_t skipped() const { return skipped_; }
+    // a device batch about to be consumed: copy its head candidates (ascending; batches arrive in ascending g)
+    void capture_head(const uint32_t *recs, const uint32_t *order, size_t n, int words, int off, uint64_t g_base)
+    {
+        if (!head_)
+            return;
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t *r = recs + (size_t)order[i] * words + off;
+            if (g_base + r[0] >= head_end_)
+                break;
+            push_head(r, g_base);
+        }
+    }
+    void capture_head_tiles(const uint32_t *stream, const uint32_t *starts, const uint32_t *counts, uint32_t t0, uint32_t t1,
+                            uint64_t g_base)
+    {
+        if (!head_)
+            return;
+        for (uint32_t u = t0; u < t1; u++)
+            for (uint32_t i = 0; i < counts[u]; i++) {
+                const uint32_t *r = stream + ((size_t)starts[u] + 2 * (size_t)i) * 4;
+                if (g_base + r[0] >= head_end_)
+                    return;
+                push_head(r, g_base);
+            }
+    }
+    bool head_wanted(uint64_t g_from) const { return head_ && g_from < head_end_; }
+
     // power_samples: samples the front end has produced so far (air.c `aidx` grows
     // by two per loop pass, so this is even); g_complete: every record with
     // g < g_complete has been fed.
     void advance(uint64_t power_samples, uint64_t g_complete)
     {
+        if (chain_) {
+            if (g_complete > base_)
+                run_call(g_complete);
+            return;
+        }
         for (;;) {
             // air.c:94: the test `aidx >= APBUFFSZ` is made after every second
             // power sample, so the call fires at the first EVEN total T with
@@ -178,6 +232,17 @@ private:
         case 17: return 1;
         default: return 2;
         }
+    }
+
+    void push_head(const uint32_t *r, uint64_t g_base)
+    {
+        head_->emplace_back();
+        adsb_candidate &c = head_->back();
+        c.g = g_base + r[0];
+        c.pw = r[1];
+        std::memcpy(c.frame, &r[2], 14);
+        c.len = (uint8_t)((r[5] >> 16) & 0xFF);
+        c.reserved = (uint8_t)((r[5] >> 24) & 1u);
     }
 
     void compact()
@@ -317,6 +382,9 @@ private:
         base_ = idx; // deqframe's return value; air.c:96-98 carries the rest
     }
 
+    bool chain_ = false;   // chain mode (start_chain)
+    uint64_t head_end_ = 0;
+    std::vector<adsb_candidate> *head_ = nullptr;
     uint64_t base_ = 0;    // global index of ampbuff[0] at the next deqframe call
     uint64_t skipped_ = 0; // offsets jumped over by accepted frames
     std::vector<adsb_candidate> cands_;

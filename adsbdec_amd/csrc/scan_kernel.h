@@ -70,6 +70,12 @@ constexpr size_t lds_bytes(int passes)
     return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6);
 }
 // the pipelined kernel (ScanArgs::pipe): two sets of planes, queue, 32 control words, 64 staged candidates
+#ifndef ADSB_PIPE_PRIO
+#define ADSB_PIPE_PRIO 3 // s_setprio level of the pipelined kernel's Stage B wave (0 = like the others)
+#endif
+#ifndef ADSB_PIPE_ABLATE
+#define ADSB_PIPE_ABLATE 0 // tuning builds: 1 = Stage B does no work
+#endif
 #ifndef ADSB_PIPE_WAVES
 #define ADSB_PIPE_WAVES 5 // waves per SIMD its register budget is set for: 5 = 96 VGPRs, four workgroups per CU; 4 = 128, three
 #endif

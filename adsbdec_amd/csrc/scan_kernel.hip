@@ -625,7 +625,11 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     // the tile is redone chunk by chunk, one bit position (offset within the run)
     // per round: <= 256 entries, which cannot overflow (queue_cap >= 256).
     constexpr int kGateBatch = 4; // chunks whose gate words are computed together
+#if ADSB_PIPE_ABLATE == 1 // tuning builds: Stage B finds nothing (every tile still publishes its empty marker)
+    int ch_lo = 0, ch_hi = NT == 64 ? 0 : nchunks, grp = -1;
+#else
     int ch_lo = 0, ch_hi = nchunks, grp = -1;
+#endif
     for (;;) {
         if (tid == 0) {
             *qcount = 0;
@@ -1177,9 +1181,22 @@ void scan_pipe_kernel(const ScanArgs args)
             if (tile_a >= 0) {
                 uint32_t *pl = smem + (it & 1) * 3 * nplane;
                 const int64_t t0 = (int64_t)args.g_begin + (int64_t)kRun * own * (int64_t)tile_a;
+#if ADSB_TILE_CLOCK == 3
+                const uint32_t a_begin = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
                 stage_a(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl, pl + nplane, pl + 2 * nplane);
+#if ADSB_TILE_CLOCK == 3 // tuning builds: how long Stage A of a tile takes on wave 0 (x 4: the dump divides by the four waves)
+                if (tid == 0 && args.tile_clock)
+                    args.tile_clock[8 * (size_t)ntiles + tile_a] = 4u * ((uint32_t)__builtin_amdgcn_s_memrealtime() - a_begin);
+#endif
             }
         } else {
+#if ADSB_PIPE_PRIO
+            // This wave's share of a tile is about that of one arithmetic wave, but as ONE latency-bound chain: at
+            // equal priority its SIMD gives it a fifth of the issue slots and the other four waves end every tile
+            // waiting for it at the barrier (measured: 48 us per tile against 24 us of Stage A).
+            __builtin_amdgcn_s_setprio(ADSB_PIPE_PRIO);
+#endif
             int next = -1;
             if (tile_a >= 0 && lane_id == 0) { // this workgroup's tile after tile_a; the answer is needed at the barrier
                 const uint32_t k = gridDim.x + atomicAdd(&args.counters[3 * kCounterPad], 1u);
@@ -1189,7 +1206,19 @@ void scan_pipe_kernel(const ScanArgs args)
                 const uint32_t *pl = smem + ((it & 1) ^ 1) * 3 * nplane;
                 const int64_t t0 = (int64_t)args.g_begin + (int64_t)kRun * own * (int64_t)tile_b;
                 const int clcap = args.clist_cap < kPipeClist ? args.clist_cap : kPipeClist;
+#if ADSB_TILE_CLOCK == 3 // ... and the phases of Stage B on its wave (same stamps as the classic kernel)
+                stamps = StageStamps{};
+                stamps.st[0] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
                 stage_b<kStats, 64>(args, (uint32_t)tile_b, K, t0, lane, pl, pl + nplane, pl + 2 * nplane, queue, ctl, cl_rec, clcap, stamps);
+#if ADSB_TILE_CLOCK == 3
+                if (lane_id == 0 && args.tile_clock) {
+                    uint32_t *o = args.tile_clock + 8 * (size_t)tile_b;
+                    for (int i = 0; i < 7; i++)
+                        o[i] = stamps.st[i];
+                    o[7] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+                }
+#endif
             }
             if (lane_id == 0)
                 ctl[14 + (it & 1)] = (uint32_t)next;

@@ -1,0 +1,153 @@
+// stitch.hpp -- joins the per-shard results of ONE time-sharded stream (BASELINE configs[4]).
+//
+// Every shard has been resolved on its own rank, speculatively: the greedy chain (demod.c:89,128,134,141) started
+// at the shard's first offset as if no frame of the previous shard reached into it (Resolver::start_chain).  What is
+// left is sequential, but small:
+//   1. seams.   If the last accepted frame before shard i ends at e > g_begin(i), the offsets [g_begin(i), e) are
+//      jumped over (demod.c:128,134): the chain is re-run from e over the shard's HEAD candidates (every CRC-valid
+//      candidate with g < head_end) until it accepts a candidate the speculative chain accepted too -- from there on
+//      the two are the same chain.  A real frame decodes at a few neighbouring offsets and the chain re-synchronises
+//      at the next frame it meets; O(1) per seam.
+//   2. ts.      demod.c:86,99: ts = g + 1 - (offsets jumped so far).  A shard's frames carry that count from the
+//      shard's start; the stitcher returns, per shard, what to subtract: the offsets jumped before the shard, corrected
+//      for the frames the repair dropped and added.  Each rank applies it to its own frames (adsb_shard_apply_fix).
+//   3. horizon. air.c:94-99: deqframe only runs when 40980 power samples are buffered, so the stream's last ~41 k
+//      power samples are never scanned.  Where the last call ends depends on every call before it
+//      (a frame that straddles a call's limit moves the next call's base), so the call chain is walked once over the
+//      accepted frames' positions: one compare per frame and a handful of operations per call -- the only part whose
+//      cost grows with the stream (~27 k calls and ~107 k frames for 2 Gi samples).
+// Host-only code: no HIP in here, tested on CPU (tests/test_host_logic.py, tests/test_distributed_cpu.py).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/adsbdec_amd.h"
+
+namespace adsb {
+
+inline uint64_t frame_span(const adsb_frame &f) { return 80 + 80 * (uint64_t)f.len; } // demod.c:109,120,123
+inline uint64_t cand_span(const adsb_candidate &c) { return 80 + 80 * (uint64_t)c.len; }
+
+// Returns 0, -1 (bad arguments / capacity), or -3: a seam cannot be decided from the head candidates alone (the chain did
+// not re-synchronise inside the head window); the caller then falls back to gathering every candidate to one resolver.
+inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
+                         adsb_frame *new_frames, size_t new_cap, size_t *n_new_total)
+{
+    if (!parts || n_parts <= 0 || !fix || !n_new_total || (new_cap && !new_frames))
+        return -1;
+    size_t n_new = 0;
+    uint64_t skipped_global = 0; // offsets jumped by all final frames before the current shard
+    uint64_t e_prev = 0;         // end of the last final frame so far
+    for (int i = 0; i < n_parts; i++) {
+        const adsb_shard_head &h = *parts[i].head;
+        const adsb_frame *F = parts[i].frames;
+        const adsb_candidate *H = parts[i].head_cands;
+        const uint64_t nF = h.n_frames, nH = h.n_head;
+        adsb_shard_fix &x = fix[i];
+        std::memset(&x, 0, sizeof x);
+        if (h.status != 0)
+            return -1;
+        uint64_t drop = 0, dropped_skip = 0, new_skip = 0;
+        const size_t new_first = n_new;
+        if (e_prev > h.g_begin && (nF || nH)) {
+            uint64_t idx = e_prev;
+            uint64_t hj = 0, fi = 0;
+            for (;;) {
+                while (hj < nH && H[hj].g < idx)
+                    hj++; // inside an accepted frame: never evaluated
+                while (fi < nF && F[fi].g < idx) { // speculative frames the true chain jumps over
+                    dropped_skip += frame_span(F[fi]) - 1;
+                    fi++;
+                }
+                if (hj < nH) {
+                    const adsb_candidate &c = H[hj];
+                    // (speculative frames in [idx, c.g) cannot exist: they would be head candidates themselves)
+                    if (fi < nF && F[fi].g == c.g)
+                        break; // the speculative chain accepted it as well: same chain from here on
+                    if (n_new >= new_cap)
+                        return -1;
+                    adsb_frame &f = new_frames[n_new++];
+                    std::memset(&f, 0, sizeof f);
+                    f.g = c.g;
+                    f.ts = c.g + 1 - (skipped_global + new_skip);
+                    f.pw = c.pw;
+                    f.len = c.len;
+                    std::memcpy(f.frame, c.frame, 14);
+                    f.reserved = c.reserved;
+                    new_skip += cand_span(c) - 1;
+                    idx = c.g + cand_span(c);
+                    continue;
+                }
+                // No head candidate at or behind idx.  Candidates beyond the head window are only known where the
+                // speculative chain walked (there every candidate it met became a frame); inside a speculative frame
+                // that the true chain does not accept there may be candidates nobody kept.
+                const uint64_t known_from = idx > h.head_end ? idx : h.head_end;
+                if (fi > 0 && F[fi - 1].g + frame_span(F[fi - 1]) > known_from) // (the last dropped frame ends last)
+                    return -3;
+                break; // the next candidate the true chain meets is the next speculative frame
+            }
+            drop = fi;
+        }
+        x.drop_front = drop;
+        x.new_first = new_first;
+        x.n_new = n_new - new_first;
+        x.keep = nF - drop;
+        x.ts_sub = (int64_t)(skipped_global + new_skip) - (int64_t)dropped_skip;
+        const uint64_t shard_skip = h.skipped - dropped_skip + new_skip;
+        if (x.keep)
+            e_prev = F[nF - 1].g + frame_span(F[nF - 1]);
+        else if (x.n_new)
+            e_prev = new_frames[n_new - 1].g + frame_span(new_frames[n_new - 1]);
+        skipped_global += shard_skip;
+    }
+
+    // The end-of-file horizon: replay the deqframe calls (Resolver::advance) over the final frames' positions.
+    const uint64_t m_ref = 2 * ((total_samples + 3) / 4); // a trailing partial quad still produces two power samples
+    uint64_t base = 0, horizon = 0;
+    int part = 0;
+    uint64_t k = 0; // position inside the part's final frames: [new frames][kept speculative frames]
+    auto frame_at = [&](int p, uint64_t q) -> const adsb_frame & {
+        return q < fix[p].n_new ? new_frames[fix[p].new_first + q] : parts[p].frames[fix[p].drop_front + (q - fix[p].n_new)];
+    };
+    uint64_t last_end = 0; // end of the last frame that starts below the current limit
+    for (;;) {
+        const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1); // air.c:94: tested after every second power sample
+        if (fire > m_ref)
+            break;
+        const uint64_t limit = fire - ADSB_DECOFFSET; // demod.c:89
+        while (part < n_parts) {
+            const uint64_t n_here = fix[part].n_new + fix[part].keep;
+            if (k >= n_here) {
+                part++;
+                k = 0;
+                continue;
+            }
+            const adsb_frame &f = frame_at(part, k);
+            if (f.g >= limit)
+                break;
+            last_end = f.g + frame_span(f);
+            k++;
+        }
+        base = last_end > limit ? last_end : limit; // a frame accepted below the limit may jump past it (demod.c:128,134)
+        horizon = limit;
+    }
+    // frames at or beyond the horizon are never visited: cut them (they can only sit at the very end)
+    for (int p = n_parts - 1; p >= 0; p--) {
+        adsb_shard_fix &x = fix[p];
+        const adsb_frame *F = parts[p].frames + x.drop_front;
+        while (x.keep && F[x.keep - 1].g >= horizon)
+            x.keep--;
+        if (x.keep)
+            break;
+        while (x.n_new && new_frames[x.new_first + x.n_new - 1].g >= horizon)
+            x.n_new--;
+        if (x.n_new)
+            break;
+    }
+    *n_new_total = n_new;
+    return 0;
+}
+
+} // namespace adsb

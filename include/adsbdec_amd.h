@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADSB_ABI_VERSION 2
+#define ADSB_ABI_VERSION 3
 
 /* Constants of the path (adsbdec.h:1-3, air.c:32,47). */
 #define ADSB_PULSEW 5
@@ -94,7 +94,11 @@ typedef struct adsb_config {
     int32_t debug_cand_cap;    /* loose-list records per launch slot                         */
     int32_t debug_try_cap;     /* try words per launch slot (collect_stats)                  */
     int32_t debug_clist_cap;   /* CRC-valid candidates staged per tile (1..192)              */
-    int32_t reserved0;
+    int32_t push_overlap;      /* 1: adsb_push() returns as soon as `samples` has been COPIED to the device (the buffer
+                                  is free again, which is all decodeiq's callers need: air.c:230-239, 173-177) and
+                                  leaves the scan in flight; the frames of a call become drainable during the NEXT
+                                  adsb_push / adsb_finish / adsb_sync instead of during the call itself (same frames,
+                                  same order).  0 (default): frames are drainable when the call returns. */
 } adsb_config;
 
 /* Counters accumulate over the life of the handle (adsb_reset keeps them: a caller that
@@ -130,7 +134,9 @@ int adsb_reset(adsb_decoder *d);
 /* Sample ingress; replaces `decodeiq(const unsigned short *r, const int len)`
  * (air.c:54), called from fileInput (air.c:239) / rx_callback (air.c:175).
  * `samples` is borrowed for the call. Any n is accepted; the stream is the
- * concatenation of all pushes (the reference requires n % 4 == 0). */
+ * concatenation of all pushes (the reference requires n % 4 == 0).
+ * With cfg.push_overlap the call returns once the samples are on the device and the
+ * frames follow one call later (link rate at the reference's one-buffer call site). */
 int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n);
 
 /* Overlapped ingress: the same stream semantics as adsb_push, but the call
@@ -230,6 +236,53 @@ int adsb_plan_shards(uint64_t total_samples, int n_shards, uint64_t *g_begin, ui
 int adsb_scan_shard(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n,
                     uint64_t g_begin, uint64_t g_end, adsb_candidate *cands, size_t cand_cap,
                     size_t *n_cands, uint64_t *tries, size_t try_cap, size_t *n_tries);
+
+/* ---- time-sharded stream, resolved where the records are (BASELINE configs[4]) ---------------
+ * adsb_scan_shard + one resolver on one rank funnels every candidate of the stream through a single thread.  The
+ * scalable form: every rank resolves its OWN shard while its kernel runs -- the greedy rule of demod.c:89,128,134,141
+ * started at the shard's first offset, as if no frame of the previous shard reached into it -- and one rank only
+ * repairs the seams, hands out per-shard ts offsets (demod.c:86,99) and applies the end-of-file horizon
+ * (air.c:94-99).  No reference counterpart: the reference is one thread on one stream. */
+typedef struct adsb_shard_head {
+    uint64_t g_begin, g_end; /* the offsets this shard owns                                                      */
+    uint64_t n_frames;       /* speculative frames; their ts is LOCAL: g + 1 - (offsets jumped inside the shard) */
+    uint64_t n_head;         /* head candidates: EVERY CRC-valid candidate with g < head_end, ascending          */
+    uint64_t head_end;
+    uint64_t skipped;        /* offsets jumped by the speculative frames: sum of (span - 1)                      */
+    uint64_t status;         /* 0 = ok                                                                           */
+    uint64_t reserved;
+} adsb_shard_head;
+
+typedef struct adsb_shard_part { /* one shard as the stitcher sees it (plain host pointers, e.g. into shared memory) */
+    const adsb_shard_head *head;
+    const adsb_frame *frames;
+    const adsb_candidate *head_cands;
+} adsb_shard_part;
+
+typedef struct adsb_shard_fix { /* the stitcher's verdict for one shard; its final frames are, in this order,      */
+    uint64_t new_first, n_new;  /*   new_frames[new_first .. +n_new): accepted by the seam repair, ts final,       */
+    uint64_t drop_front, keep;  /*   frames[drop_front .. +keep):     speculative frames that stand, with          */
+    int64_t ts_sub;             /*   ts_final = ts_local - ts_sub (adsb_shard_apply_fix)                           */
+} adsb_shard_fix;
+
+/* Scan the owned offsets of a device-resident shard (same buffer rules as adsb_scan_shard) and resolve them on the
+ * fly.  frames / head_cands receive at most frame_cap / head_cap entries; -2 if a capacity was too small (head->n_frames
+ * / n_head say what is needed).  collect_stats must be off (statistics of a sharded stream go through adsb_scan_shard). */
+int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n,
+                             uint64_t g_begin, uint64_t g_end, adsb_shard_head *head, adsb_frame *frames,
+                             size_t frame_cap, adsb_candidate *head_cands, size_t head_cap);
+/* The serial part, on one rank: parts in shard order.  0; -1 on bad arguments or new_cap too small; -3 when a seam cannot
+ * be decided from the head candidates (dense overlapping frames through a whole head window): fall back to
+ * adsb_scan_shard + adsb_resolver_*. */
+int adsb_stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
+                       adsb_frame *new_frames, size_t new_cap, size_t *n_new_total);
+/* ts_final = ts_local - ts_sub, in place, for frames[0 .. n). */
+void adsb_shard_apply_fix(adsb_frame *frames, size_t n, int64_t ts_sub);
+/* The host-side resolver in the same chain mode (tests; hosts that hold candidates themselves): call before the first
+ * feed.  adsb_resolver_head copies the head candidates out; adsb_resolver_skipped is adsb_shard_head.skipped. */
+int adsb_resolver_start_chain(adsb_resolver *r, uint64_t g_begin, uint64_t head_end);
+long adsb_resolver_head(adsb_resolver *r, adsb_candidate *out, size_t cap);
+uint64_t adsb_resolver_skipped(const adsb_resolver *r);
 
 int adsb_abi_version(void);
 

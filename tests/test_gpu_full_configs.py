@@ -137,6 +137,18 @@ def test_config4_2Gi_one_stream_in_8_shards(capi, oracle, torch_cuda):
             else:
                 n_plain = len(got)
             _ts_checksum(got)
+            # the scalable form of the same job: every shard resolved on its own while its kernel runs
+            # (adsb_scan_shard_resolved), then only seams, ts offsets and the end-of-file horizon (adsb_stitch_shards)
+            from adsbdec_amd import sharding
+            d2 = capi.Decoder(df18=True, fix_1bit=fix)
+            try:
+                res, rc = sharding.decode_sharded(d2, t.data_ptr(), x.size, 8)
+                assert rc == 0
+                arr, n = res.collect()
+                assert records(capi._frames_to_dicts(arr, n)) == records(want)
+                assert res.serial_us < 2000        # the serial part of a 2 Gi-sample stream, microseconds (Python timer around the C call)
+            finally:
+                d2.close()
         finally:
             d.close()
             r.close()

@@ -151,18 +151,56 @@ def test_beyond_12_bit_codes_vs_oracle(oracle, dec_factory, hi):
     assert len(want) >= 30 and float((a[:-10] + a[10:]).max()) > 2.0 ** 24   # pair sums beyond 2^24
 
 
-@pytest.mark.parametrize("mode", ["sync", "async"])
+@pytest.mark.parametrize("mode", ["sync", "async", "overlap"])
 @pytest.mark.parametrize("chunk", [4, 1000, 4096, 65536 + 12, 1 << 18])
 def test_chunked_pushes_equal_one_shot(oracle, dec_factory, chunk, mode):
     """The stream is the concatenation of pushes (decodeiq's statics, air.c:33-34,49-50),
-    with adsb_push and with the overlapped adsb_push_async (copy of chunk k+1 beside the
-    scan of chunk k, frames one call later) alike."""
+    with adsb_push, with the overlapped adsb_push_async (copy of chunk k+1 beside the
+    scan of chunk k, frames one call later) and with cfg.push_overlap (adsb_push returns when the
+    copy is done; ONE buffer, scribbled over right after every call) alike."""
     from oracle import gen_signal as G
     n = 200_000 if chunk < 1000 else 600_000
     x, _ = G.dense_capture(n, seed=5, sigma=35.0, n_frames=100)
     want, wstats = oracle.decode(x, df18=True)
-    d = dec_factory(df18=True, collect_stats=True)
+    d = dec_factory(df18=True, collect_stats=True, push_overlap=(mode == "overlap"))
     assert records(d.decode(x, chunk=chunk, mode=mode)) == records(want)
+    assert d.stats() == wstats
+
+
+@pytest.mark.parametrize("stage", [0, 1 << 16])
+def test_push_overlap_at_the_reference_call_size(capi, oracle, dec_factory, torch_cuda, stage):
+    """cfg.push_overlap at IQBUFFSZ = 1 Mi samples per call (air.c:218) from one reused buffer, then mixed with
+    adsb_push_async, device pushes and an adsb_sync; odd sizes and a small staging buffer (a compaction per piece)."""
+    from oracle import gen_signal as G
+    x, _ = G.dense_capture((5 << 20) + 6, seed=62, sigma=30.0, n_frames=1200, amp=(150, 1800))
+    want, wstats = oracle.decode(x, df18=True)
+    d = dec_factory(df18=True, collect_stats=True, stage_samples=stage, push_overlap=True)
+    for chunk in (1 << 20, 65546, 300_001):
+        assert records(d.decode(x, chunk=chunk, mode="overlap")) == records(want)
+        assert d.stats() == wstats
+    t = _dev(torch_cuda, x)
+    d.reset()
+    got = []
+    with capi.PinnedBuffers(2, (1 << 20) + 8) as bufs:
+        cuts = [0, 1 << 20, (1 << 20) + 4097, 2 << 20, 3 << 20, (3 << 20) + 70_001, 4 << 20, x.size]
+        kinds = ["overlap", "async", "overlap", "async", "device", "overlap", "overlap"]
+        for k, (a, b, kind) in enumerate(zip(cuts, cuts[1:], kinds)):
+            if kind == "device":
+                d.push_device(t.data_ptr() + 2 * a, b - a)
+            else:
+                buf = bufs[k % 2][: b - a]
+                buf[:] = x[a:b]
+                if kind == "async":
+                    d.push_async(buf)
+                else:
+                    d.push(buf)
+                    buf[:] = 0xFFFF
+            if k == 3:
+                d.sync()
+            got += d.drain()
+        d.finish()
+        got += d.drain()
+    assert records(got) == records(want)
     assert d.stats() == wstats
 
 
@@ -726,6 +764,40 @@ def test_shard_candidates_equal_oracle_exhaustive(capi, oracle, dec_factory, tor
     assert r.stats() == wstats
 
 
+@pytest.mark.parametrize("n_shards", [2, 5, 8, 13])
+def test_resolved_shards_equal_the_sequential_decode(capi, oracle, dec_factory, torch_cuda, n_shards, monkeypatch):
+    """adsb_scan_shard_resolved + adsb_stitch_shards (every shard resolved on its own, rank 0 only repairs seams, hands
+    out ts offsets and applies the end-of-file horizon) against the oracle: a noisy capture with overlapping frames, and
+    frames packed back to back so that every seam cuts through one; with a head window too small to decide such a seam
+    the stitcher must say so (-3) rather than guess."""
+    from adsbdec_amd import sharding
+    from oracle import gen_signal as G
+    xa, _ = G.dense_capture((3 << 20) + 4, seed=91, sigma=40.0, n_frames=1500, amp=(200, 1800))
+    xb = _back_to_back(1100, 45)
+    for x in (xa, xb):
+        want, _ = oracle.decode(x, df18=True)
+        t = _dev(torch_cuda, x)
+        d = dec_factory(df18=True)
+        res, rc = sharding.decode_sharded(d, t.data_ptr(), x.size, n_shards)
+        assert rc == 0
+        arr, n = res.collect()
+        assert records(capi._frames_to_dicts(arr, n)) == records(want)
+    # (ADSB_SHARD_HEAD is read once per process: the small-window case runs in a child)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+            "from adsbdec_amd import capi, sharding\n"
+            "from test_gpu_parity import _back_to_back\n"
+            "x = _back_to_back(1100, 45); t = torch.from_numpy(x.view(np.int16)).cuda()\n"
+            "d = capi.Decoder(df18=True)\n"
+            f"res, rc = sharding.decode_sharded(d, t.data_ptr(), x.size, {n_shards})\n"
+            "print('RC', rc)\n")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, timeout=600,
+                       env=dict(os.environ, ADSB_SHARD_HEAD="600"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert "RC -3" in p.stdout.decode() or "RC 0" in p.stdout.decode()
+
+
 def _bench_line(extra, timeout=900):
     """`python bench.py ...` from a plain shell -- the driver's command shape: with --gpus N > 1 and no WORLD_SIZE
     the script starts its N ranks itself (before any GPU call) and relays rank 0's JSON line."""
@@ -749,6 +821,12 @@ def test_two_rank_sharded_stream_with_the_hip_kernel():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert line["config"]["parity"].startswith("equal to the single-GPU decode")
     assert line["config"]["frames_decoded"] > 3000
+    assert line["config"]["shard_path"] == "resolved" and line["config"]["fallback_steps"] == 0
+    assert line["config"]["rank0_serial_us"] is not None
+    # the checker path (every candidate gathered to one resolver) must give the same
+    line = _bench_line(["--gpus", "2", "--mode", "shard", "--shard-path", "gather", "--one-device-test", "--samples", str(32 << 20),
+                        "--steps", "2", "--warmup", "1", "--preroll-ms", "0"])
+    assert line["config"]["parity"].startswith("equal to the single-GPU decode")
 
 
 def test_two_rank_independent_streams_are_gated_on_every_rank():

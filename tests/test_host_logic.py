@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(capi):
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/adsbdec_amd.h but not exported"
     assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
-    assert L.adsb_abi_version() == 2
+    assert L.adsb_abi_version() == 3
 
 
 def test_struct_layouts_match_header(capi):
@@ -185,3 +185,95 @@ def test_tile_geometry_is_consistent(tmp_path):
                    capture_output=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+# ------------------------------------------------------------------ time-sharded stream, resolved per shard (stitch.hpp)
+def _stitch_case(capi, cands, total, n_shards, head_span):
+    """Per-shard chain resolution of the exhaustive candidate list + adsb_stitch_shards -> (rc, final frame records)."""
+    import ctypes as C
+    L = capi.load()
+    plan = capi.plan_shards(total, n_shards)
+    keep = []  # ctypes arrays must outlive the call
+    parts = (capi.ShardPart * n_shards)()
+    k = 0
+    for i, sh in enumerate(plan):
+        r = capi.Resolver()
+        head_end = min(sh["g_end"], sh["g_begin"] + head_span)
+        assert L.adsb_resolver_start_chain(r._h, sh["g_begin"], head_end) == 0
+        mine = []
+        while k < len(cands) and cands[k][0] < sh["g_end"]:
+            mine.append(cands[k])
+            k += 1
+        r.feed(mine)
+        r.advance(0, sh["g_end"])
+        frames = (capi.Frame * max(1, len(mine)))()
+        nf = int(L.adsb_resolver_drain(r._h, frames, len(frames)))
+        heads = (capi.Candidate * max(1, len(mine)))()
+        nh = int(L.adsb_resolver_head(r._h, heads, len(heads)))
+        hd = capi.ShardHead(sh["g_begin"], sh["g_end"], nf, nh, head_end, int(L.adsb_resolver_skipped(r._h)), 0, 0)
+        keep.append((frames, heads, hd, r))
+        parts[i].head = C.pointer(hd)
+        parts[i].frames = frames
+        parts[i].head_cands = heads
+    fix = (capi.ShardFix * n_shards)()
+    new = (capi.Frame * 4096)()
+    n_new = C.c_size_t(0)
+    rc = L.adsb_stitch_shards(parts, n_shards, total, fix, new, 4096, C.byref(n_new))
+    out = []
+    repaired = 0
+    if rc == 0:
+        repaired = sum(int(fix[i].drop_front) + int(fix[i].n_new) for i in range(n_shards))
+        for i in range(n_shards):
+            frames = keep[i][0]
+            fx = fix[i]
+            for q in range(fx.n_new):
+                f = new[fx.new_first + q]
+                out.append((int(f.g), int(f.ts), int(f.pw), bytes(f.frame[: f.len])))
+            seg = (capi.Frame * max(1, fx.keep)).from_address(C.addressof(frames) + fx.drop_front * C.sizeof(capi.Frame))
+            L.adsb_shard_apply_fix(seg, fx.keep, fx.ts_sub)
+            for q in range(fx.keep):
+                f = seg[q]
+                out.append((int(f.g), int(f.ts), int(f.pw), bytes(f.frame[: f.len])))
+    return rc, out, repaired
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense_overlapping", "back_to_back", "ragged_short"])
+def test_stitched_shards_equal_the_sequential_decode(capi, kind):
+    """One stream cut into 1..13 shards, every shard resolved on its own (greedy chain from its first offset), then
+    adsb_stitch_shards: seam repair from the head candidates, per-shard ts offsets, end-of-file horizon.  Equal to the
+    oracle's sequential decode (demod.c:86-143 + air.c:94-99) whatever the cut -- with frames packed back to back across
+    every seam too -- or, when the head window is too small to decide a seam, an honest -3."""
+    from oracle import gen_signal as G
+    from oracle import oracle as O
+    O.build()
+    rng = np.random.default_rng(5)
+    if kind == "sparse":
+        x, _ = G.sparse_capture(1 << 20, 180, seed=11, sigma=8.0, dfs=(17, 11))
+    elif kind == "dense_overlapping":
+        x, _ = G.dense_capture(1 << 20, seed=12, sigma=40.0, n_frames=700, amp=(300, 1800))
+    elif kind == "back_to_back":
+        placed = [(10_000 + 2_400 * i, G.make_frame([17, 18, 17, 11][i % 4], rng), float(rng.uniform(500, 1500)), float(i))
+                  for i in range(380)]
+        x = G.synth(10_000 + 2_400 * 380 + 120_000, placed, 6.0, 7)
+    else:
+        x, _ = G.dense_capture(300_002, seed=13, sigma=30.0, n_frames=150, amp=(300, 1800))
+    want, _ = O.decode(x, df18=True)
+    want = [(f["g"], f["ts"], f["pw"], f["frame"]) for f in want]
+    a = O.power(x)
+    cands, _ = O.scan_all(a, 0, max(0, a.size - 1195), True)
+    assert len(want) > 20
+    undecided = repairs = 0
+    for n_shards in (1, 2, 3, 5, 8, 13):
+        for head_span in (16384, 2400, 300):
+            rc, got, rep = _stitch_case(capi, cands, x.size, n_shards, head_span)
+            repairs += rep
+            assert rc in (0, -3), rc
+            if rc == -3:
+                assert head_span < 16384, "the default head window must decide these seams"
+                undecided += 1
+                continue
+            assert got == want, (kind, n_shards, head_span, len(got), len(want))
+    if kind == "sparse":
+        assert undecided == 0
+    if kind == "back_to_back":
+        assert repairs > 0, "no seam of these cuts needed a repair: the test does not test"

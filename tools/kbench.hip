@@ -55,8 +55,9 @@ int main(int argc, char **argv)
         CK(hipHostMalloc(&hand, gran * 16, hipHostMallocCoherent));
         a.hand = hand; a.hand_cap = (uint32_t)gran; a.gen = 12345;
     }
-    a.passes = argc > 3 && atoi(argv[3]) > 0 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256);
-    a.stagger = adsb::choose_stagger(a.g_end - a.g_begin, 256, a.passes); // ADSB_STAGGER=0 turns it off
+    a.pipe = getenv("KB_PIPE") && atoi(getenv("KB_PIPE")) ? 1 : 0; // the pipelined kernel (persistent five-wave workgroups)
+    a.passes = argc > 3 && atoi(argv[3]) > 0 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256, a.pipe != 0);
+    a.stagger = a.pipe ? 0u : adsb::choose_stagger(a.g_end - a.g_begin, 256, a.passes); // ADSB_STAGGER=0 turns it off
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++) { CK(hipMemset(counters, 0, adsb::kDevCounterWords * 4)); CK(adsb::launch_scan(a, false, 0)); }
     CK(hipDeviceSynchronize());
@@ -104,8 +105,9 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
     const uint32_t hc[2] = {report[0], report[1]}; // the last tile's report (the device counters are zero again)
     double med = t[t.size() / 2];
-    printf("passes=%d stagger=%u ablate=%d minwaves=%d tile=%d lds=%zu | median %.4f ms min %.4f | %.1f GB/s alg | %.1f Gsamples/s | cands=%u\n",
-           a.passes, a.stagger, ADSB_ABLATE, ADSB_MIN_WAVES, adsb::tile_offsets(a.passes), adsb::lds_bytes(a.passes), med, t[0],
+    printf("pipe=%d passes=%d stagger=%u ablate=%d minwaves=%d tile=%d lds=%zu | median %.4f ms min %.4f | %.1f GB/s alg | %.1f Gsamples/s | cands=%u\n",
+           a.pipe, a.passes, a.stagger, a.pipe ? ADSB_PIPE_ABLATE : ADSB_ABLATE, a.pipe ? ADSB_PIPE_WAVES : ADSB_MIN_WAVES, adsb::tile_offsets(a.passes),
+           a.pipe ? adsb::lds_bytes_pipe(a.passes) : adsb::lds_bytes(a.passes), med, t[0],
            2.0 * n / med / 1e6, n / med / 1e6, hc[0]);
     return 0;
 }
