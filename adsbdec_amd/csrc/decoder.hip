@@ -85,6 +85,7 @@ struct ScanSlot {
     adsb::ScanArgs args{};
     bool busy = false;
     uint64_t piece = 0; // adsb_push_async: the launch belongs to this push piece (collected one piece later)
+    hipStream_t launch_stream = nullptr; // where the launch in flight (or the slot's last one) was enqueued
     bool prof_pending[2] = {false, false}; // kernel time of a collected launch not read yet
     hipEvent_t ev_count = nullptr; // statistics runs: the count pass over d_tries (count stream) has ended;
     bool count_pending = false;    // the slot's next scan waits for it before it overwrites the list
@@ -116,6 +117,13 @@ struct adsb_decoder {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // A second compute stream: the launches of a multi-launch IN-PLACE scan (adsb_push_device*, adsb_scan_shard*)
+    // alternate between the two, so that launch k+1's first tiles fill the slots launch k's last tiles leave empty
+    // (a launch drains for about one tile life, ~40 us of falling occupancy; on one stream the next launch cannot
+    // start before the previous one -- and the report kernel behind it -- has ended).  Staged scans stay on `stream`,
+    // behind their copies.  ADSB_ALT_STREAMS=0 turns it off; a caller-supplied cfg.stream does too.
+    hipStream_t stream2 = nullptr;
+    bool alt_next = false; // scan_submit: the launches being submitted may alternate
     std::string err;
 
     // stream position
@@ -368,8 +376,13 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     s.args.cand_cap = (uint32_t)std::min<size_t>(s.cand_cap, 0xFFFFFFFFu);
     if (d->pending.valid && d->pending.slot == &s && count_flush(d)) // (the pass that reads this slot's list is still to come)
         return -1;
+    const int slot_index = (int)(&s - d->slots);
+    hipStream_t ls = (d->alt_next && d->stream2 && (slot_index & 1)) ? d->stream2 : d->stream;
+    if (s.launch_stream && s.launch_stream != ls) // the slot's previous launch (its report kernel zeroes the counters) ran on the other stream
+        HIP_TRY(d, hipStreamWaitEvent(ls, s.ev_ready[s.ev_cur ^ 1], 0));
+    s.launch_stream = ls;
     if (s.count_pending) { // the count pass over this slot's previous try list (count stream) must be over
-        HIP_TRY(d, hipStreamWaitEvent(d->stream, s.ev_count, 0));
+        HIP_TRY(d, hipStreamWaitEvent(ls, s.ev_count, 0));
         s.count_pending = false;
     }
     // debug_try_cap (tests of the relaunch path) wants every try on the launch-wide list
@@ -383,8 +396,8 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     // d_counters are zero here: cleared at creation, and the report kernel behind every scan leaves them so
     s.args.profile = d->cfg.profile ? 1 : 0;
     s.args.report = s.hc();
-    HIP_TRY(d, adsb::launch_scan(s.args, stats, d->stream));
-    HIP_TRY(d, hipEventRecord(s.ev_ready[s.ev_cur], d->stream));
+    HIP_TRY(d, adsb::launch_scan(s.args, stats, ls));
+    HIP_TRY(d, hipEventRecord(s.ev_ready[s.ev_cur], ls));
     if (stats && count_flush(d)) // the previous pass's calls are made now, while this scan runs
         return -1;
     for (ScanSlot &o : d->slots) // kernel times of earlier launches: read now, behind this launch
@@ -893,7 +906,7 @@ int slot_collect(adsb_decoder *d)
         if (attempt >= 2)
             return d->fail("record buffers overflowed repeatedly (%zu candidates, %zu tries)", nc, nt);
         d->prof.relaunches++;
-        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        HIP_TRY(d, hipStreamSynchronize(s.launch_stream ? s.launch_stream : d->stream));
         if (slot_reserve(d, s, std::max(s.cand_cap, nc + nc / 8 + 64),
                          s.tries_on_device ? s.try_cap : std::max(s.try_cap, nt + nt / 8 + 64)))
             return -1;
@@ -1260,6 +1273,9 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipStreamCreate", e);
         d->own_stream = true;
     }
+    if (d->own_stream && !(getenv("ADSB_ALT_STREAMS") && atoi(getenv("ADSB_ALT_STREAMS")) == 0) &&
+        (e = hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate(second scan stream)", e);
     for (int i = 0; i < adsb_decoder::kCopyStreams; i++)
         if ((e = hipStreamCreateWithFlags(&d->copy_stream[i], hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&d->ev_copy[i], hipEventDisableTiming)) != hipSuccess)
@@ -1331,6 +1347,10 @@ void adsb_destroy(adsb_decoder *d)
             (void)hipStreamSynchronize(cs);
     if (d->stream)
         (void)hipStreamSynchronize(d->stream);
+    if (d->stream2) {
+        (void)hipStreamSynchronize(d->stream2);
+        (void)hipStreamDestroy(d->stream2);
+    }
     if (d->count_stream) {
         (void)hipStreamSynchronize(d->count_stream);
         (void)hipStreamDestroy(d->count_stream);
@@ -1384,6 +1404,8 @@ int adsb_reset(adsb_decoder *d)
         for (hipStream_t cs : d->copy_stream)
             HIP_TRY(d, hipStreamSynchronize(cs));
         HIP_TRY(d, hipStreamSynchronize(d->stream));
+        if (d->stream2)
+            HIP_TRY(d, hipStreamSynchronize(d->stream2));
         if (d->count_stream) {
             if (count_flush(d))
                 return -1;
@@ -1495,6 +1517,8 @@ int adsb_sync(adsb_decoder *d)
     for (hipStream_t cs : d->copy_stream)
         HIP_TRY(d, hipStreamSynchronize(cs));
     HIP_TRY(d, hipStreamSynchronize(d->stream)); // tail copies: every borrowed buffer is free
+    if (d->stream2)
+        HIP_TRY(d, hipStreamSynchronize(d->stream2));
     return 0;
 }
 
@@ -1574,7 +1598,10 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
         const bool dbg_on = getenv("ADSB_DEBUG_HOST") != nullptr;
         const auto t0 = clk::now();
         if (g_end > d->g_scanned) {
-            if (scan_submit(d, p, first, n, d->g_scanned, g_end))
+            d->alt_next = true; // in place: nothing on d->stream has to precede these launches
+            const int rc_submit = scan_submit(d, p, first, n, d->g_scanned, g_end);
+            d->alt_next = false;
+            if (rc_submit)
                 return -1;
             d->g_scanned = g_end;
         }
@@ -1612,7 +1639,10 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
     d->stage_first = keep_first;
     d->stage_fill = left;
     if (g_end > d->g_scanned) {
-        if (scan_submit(d, p, first, n, d->g_scanned, g_end))
+        d->alt_next = true;
+        const int rc_submit = scan_submit(d, p, first, n, d->g_scanned, g_end);
+        d->alt_next = false;
+        if (rc_submit)
             return -1;
         d->g_scanned = g_end;
     } else {
@@ -1620,6 +1650,8 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
     }
     if (scan_drain(d))
         return -1;
+    if (d->stream2) // the launches may all have gone to the second stream: the tail copy is not implied by their end
+        HIP_TRY(d, hipStreamSynchronize(d->stream));
     d->res.advance(m_real, d->g_scanned);
     return 0;
 }
@@ -1729,7 +1761,9 @@ int adsb_scan_shard(adsb_decoder *d, const void *device_samples, uint64_t first_
         return -1;
     d->sink.cands = &cv;
     d->sink.tries = &tv;
+    d->alt_next = true;
     int rc = scan_submit(d, static_cast<const uint16_t *>(device_samples), first_sample, n, g_begin, g_end);
+    d->alt_next = false;
     if (rc == 0)
         rc = scan_drain(d);
     d->sink = ScanSink{};
@@ -1780,7 +1814,9 @@ int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64
     const uint64_t head_end = std::min<uint64_t>(g_end, g_begin + head_span);
     d->sink = ScanSink{};
     d->res.start_chain(g_begin, head_end, &hv);
+    d->alt_next = true;
     int rc = scan_submit(d, static_cast<const uint16_t *>(device_samples), first_sample, n, g_begin, g_end);
+    d->alt_next = false;
     if (rc == 0)
         rc = scan_drain(d);
     if (rc == 0)

@@ -424,7 +424,8 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
         } else {
             // Stream start (the ring is zero-initialised, air.c:33: a missing pair is
             // 0x0800,0x0800 -> v = 0) and the ragged end of a buffer: plain loads, converted here
-            const int64_t pr0 = wlo + (int64_t)kRun * lane;
+            int64_t pr0 = wlo + (int64_t)kRun * lane;
+            asm volatile("" : "+v"(pr0)); // (opaque: keeps the 34 pair indices of this rare path from being precomputed per tile and spilled)
 #pragma unroll
             for (int k = 0; k < 17; k++) {
                 const int64_t pa = pr0 + 2 * k + 2, pb = pa + 1;
@@ -1152,9 +1153,27 @@ void scan_pipe_kernel(const ScanArgs args)
     uint32_t *cl_rec = ctl + 32;
     const int tid = threadIdx.x;
     const int lane_id = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int own = kPassRuns * K - kReachRuns;
     const int ntiles = (int)args.n_tiles;
+    // Roles by SIMD.  The workgroup's five waves sit on the CU's four SIMDs, so two of them share one: the LATER of such
+    // a pair runs Stage B, and the four arithmetic waves are spread as evenly over the SIMDs as the placement allows --
+    // with a fixed role (wave 4 = Stage B) a SIMD can end up holding five arithmetic waves of different workgroups and
+    // another three, and every workgroup then waits for its wave on the crowded one at every tile's barrier.
+    int wave = wave_id, b_wave = kPipeWave;
+#if ADSB_PIPE_ROLES
+    {
+        const uint32_t simd = (__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u; // HW_REG_HW_ID.SIMD_ID
+        if (lane_id == 0)
+            ctl[16 + wave_id] = simd;
+        __syncthreads();
+        const uint32_t s0 = __builtin_amdgcn_readfirstlane((int)ctl[16]), s1 = __builtin_amdgcn_readfirstlane((int)ctl[17]),
+                       s2 = __builtin_amdgcn_readfirstlane((int)ctl[18]), s3 = __builtin_amdgcn_readfirstlane((int)ctl[19]),
+                       s4 = __builtin_amdgcn_readfirstlane((int)ctl[20]);
+        b_wave = (s4 == s0 || s4 == s1 || s4 == s2 || s4 == s3) ? 4 : (s3 == s0 || s3 == s1 || s3 == s2) ? 3 : (s2 == s0 || s2 == s1) ? 2 : 1;
+        wave = (wave_id > b_wave ? wave_id - 1 : wave_id) & 3; // (meaningless for the Stage B wave itself)
+    }
+#endif
 #if ADSB_SLEEP_STAGGER
     // the workgroups that begin together on a CU start 0, 1, 2, 3 x 2.6 us apart (see scan_kernel)
     if (gridDim.x >= 1024u) {
@@ -1177,7 +1196,7 @@ void scan_pipe_kernel(const ScanArgs args)
         // instead of being hoisted out of this loop, kept alive across both stages and spilled for it)
         int lane = lane_id;
         asm volatile("" : "+v"(lane));
-        if (wave != kPipeWave) {
+        if (wave_id != b_wave) {
             if (tile_a >= 0) {
                 uint32_t *pl = smem + (it & 1) * 3 * nplane;
                 const int64_t t0 = (int64_t)args.g_begin + (int64_t)kRun * own * (int64_t)tile_a;

@@ -187,7 +187,7 @@ def gate(got, want, what):
         raise SystemExit(f"PARITY FAILURE ({what}): GPU path returned {len(a)} frames, expected {len(b)}; first difference at index {i}")
 
 
-def roofline_objects(p0, p1, steps, profiles_tag="r2"):
+def roofline_objects(p0, p1, steps, profiles_tag="r3", clock=None):
     """HBM roofline of the dominant launch + the VALU-issue roofline that actually binds it."""
     kernel_ms = p1["kernel_ms"] - p0["kernel_ms"]
     big_off = p1["big_offsets"]
@@ -197,8 +197,8 @@ def roofline_objects(p0, p1, steps, profiles_tag="r2"):
         n_big, ms_big = p1["big_launches"], p1["big_ms"]
     avg_ms = ms_big / n_big if n_big else 0.0
     achieved = 4.0 * big_off / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, valu = None, None
-    for name in (f"{profiles_tag}_pmc.json", "r1_v12_pmc.json"):
+    traffic, traffic_source, valu = None, None, None
+    for name in (f"{profiles_tag}_pmc.json", f"{profiles_tag.replace('r3', 'r2')}_pmc.json", "r1_v12_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -208,6 +208,9 @@ def roofline_objects(p0, p1, steps, profiles_tag="r2"):
             continue
         if "hbm_bytes_per_launch" in pmc:
             traffic = int(pmc["hbm_bytes_per_launch"])
+            traffic_source = (f"profiles/{name}: rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE per dispatch of this kernel, "
+                              "MI355X_MICROARCH.md's gfx950 correction) recorded by tools/profile_session.sh on a launch of the same "
+                              "size; a committed figure, NOT collected in this run (counters cannot share a run with timing)")
         c = pmc["counters"]
         if "SQ_INSTS_VALU" in c and avg_ms > 0:
             # Floor of the launch if the VALU did nothing but issue: wave-instructions (PMC) x
@@ -224,14 +227,23 @@ def roofline_objects(p0, p1, steps, profiles_tag="r2"):
                 cyc = float(mix["cycles_per_valu_instruction"])
                 mix_src = f"profiles/{os.path.basename(mix_path)}"
             insts = float(c["SQ_INSTS_VALU"]["mean"])
-            floor_ms = insts * cyc / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
+            floor_peak_ms = insts * cyc / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
+            # the chip does not hold its 2.4 GHz under this load (it runs at its power limit): price the floor at the
+            # clock it did hold -- sampled from sysfs while the timed steps ran, else the figure of profiles/r2_power_trace.txt
+            ghz, ghz_src = (clock[0], f"sysfs freq1_input, median of {clock[1]} samples taken every 2 ms during the timed steps") \
+                if clock and clock[0] else (2.33, "profiles/r2_power_trace.txt (rocm-smi beside a 15 s bench run; sysfs was not readable in this run)")
+            floor_ms = insts * cyc / N_SIMD / (ghz * 1e9) * 1e3
             valu = {"bound": "valu_issue", "valu_wave_instructions": int(insts), "cycles_per_instruction": round(cyc, 3),
-                    "mix_source": mix_src, "simds": N_SIMD, "clock_ghz": CLOCK_GHZ, "floor_ms": round(floor_ms, 5),
-                    "launch_ms": round(avg_ms, 5), "frac": round(floor_ms / avg_ms, 4),
-                    "pmc_source": f"profiles/{name}"}
+                    "mix_source": mix_src, "simds": N_SIMD, "clock_ghz": round(ghz, 3), "clock_source": ghz_src,
+                    "floor_ms": round(floor_ms, 5), "launch_ms": round(avg_ms, 5), "frac": round(floor_ms / avg_ms, 4),
+                    "floor_ms_at_peak_clock": round(floor_peak_ms, 5), "peak_clock_ghz": CLOCK_GHZ,
+                    "frac_at_peak_clock": round(floor_peak_ms / avg_ms, 4),
+                    "pmc_source": f"profiles/{name} (a committed count for a launch of this size, not collected in this run)"}
         break
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                "launch_ms_source": "the kernel's own clock (latest tile end - earliest tile start on the device's 100 MHz counter), "
+                                    "averaged over the launches of the timed steps: live, this run",
                 "kernel": "adsb::scan_kernel", "launch_offsets": big_off, "launch_bytes": 4 * big_off,
                 "launch_ms": round(avg_ms, 5), "launches_per_step": round(n_big / steps, 2),
                 "kernel_ms_per_step": round(kernel_ms / steps, 4),
@@ -280,6 +292,139 @@ def self_launch(n):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+class ClockSampler:
+    """Shader clock of GPU `index` while the timed steps run: sysfs freq1_input (Hz) read every 2 ms on a thread."""
+
+    def __init__(self, index=0):
+        import glob
+        import threading
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        self.path = cards[index] if index < len(cards) else None
+        self.samples, self._stop, self._t = [], False, None
+        if self.path:
+            self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop:
+            try:
+                with open(self.path) as f:
+                    self.samples.append(int(f.read()))
+            except (OSError, ValueError):
+                return
+            time.sleep(0.002)
+
+    def __enter__(self):
+        if self._t:
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._t:
+            self._t.join(timeout=1)
+
+    def ghz(self):
+        v = [x for x in self.samples if x > 0]
+        return (float(np.median(v)) / 1e9, len(v)) if v else (None, 0)
+
+
+def preamble_pass_fraction(x_host: np.ndarray, n=4 << 20):
+    """Share of the preamble offsets of a prefix that pass demod.c:102-107 (p1 > 2 s1 && p2 > 2 s2), from the oracle's
+    power samples: the density figure BASELINE configs[2] quotes ("~10 % of offsets above preamble threshold")."""
+    from oracle import oracle as O
+    a = O.power(np.ascontiguousarray(x_host[:n]))
+    m = a.size - 1196
+    c = np.trunc(a[:-10] + a[10:]).astype(np.int64)   # c[k] = (int)(a[k] + a[k+10]): all four sums have this form
+    p1, s1, s2, p2 = c[0:m], c[5:m + 5], c[30:m + 30], c[35:m + 35]
+    return float(np.mean((p1 > 2 * s1) & (p2 > 2 * s2)))
+
+
+def cli_whole_process(x_host: np.ndarray, capi, df18: bool):
+    """The C host program (the actual drop-in: reader thread, async pushes, AVR to stdout, Try/Ok table) on the
+    capture as a file: wall time of the whole process, exec to exit, and its own clock's split."""
+    import subprocess
+    if not os.path.exists(capi.CLI_PATH):
+        return None
+    path = ("/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp") + f"/adsb_bench_cli_{os.getpid()}.u16"
+    x_host.tofile(path)
+    try:
+        walls, inits, decodes, frames = [], [], [], None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            p = subprocess.run([capi.CLI_PATH] + (["-a"] if df18 else []) + ["-f", path], capture_output=True,
+                               env=dict(os.environ, ADSB_CLI_TIMING="1"))
+            walls.append(time.perf_counter() - t0)
+            if p.returncode != 0:
+                return {"error": p.stderr.decode()[-300:]}
+            frames = p.stdout.count(b"\n")
+            for ln in p.stderr.decode().splitlines():
+                if ln.startswith("timing:"):
+                    f = ln.replace(",", " ").split()
+                    inits.append(float(f[3]))
+                    decodes.append(float(f[6]))
+        wall = sorted(walls)[1]
+        return {"what": "adsbdec_amd_cli -f <capture as a tmpfs file>: whole process, exec to exit, median of 3 (AVR lines to a "
+                        "pipe, Try/Ok table on stderr)", "samples": int(x_host.size), "frames": frames,
+                "wall_ms": round(wall * 1e3, 1), "value": round(x_host.size / wall / 1e6, 1), "unit": "Msamples/s",
+                "runtime_init_ms": round(sorted(inits)[len(inits) // 2], 1) if inits else None,
+                "decode_ms": round(sorted(decodes)[len(decodes) // 2], 1) if decodes else None,
+                "init_share": "the dynamic loader + the GPU runtime's start (runtime_init_ms, measured from main(); the loader "
+                              "adds ~0.1 s in front of it) are most of the wall time; decode_ms is reading, copying, scanning "
+                              "and writing the whole capture once the runtime is up"}
+    finally:
+        os.unlink(path)
+
+
+def multi_stream_host_fed(torch, capi, x_dev, df18, counts=(1, 2, 4)):
+    """configs[3]'s host side on ONE GPU: K handles driven by K host threads, each pushing its own stream from
+    page-locked memory with adsb_push_async at the reference's call size (1 Mi samples).  What it shows: whether
+    anything in the library or the runtime serialises the streams before the links do."""
+    import threading
+    n = min(x_dev.numel(), 64 << 20)
+    n -= n % (1 << 20)
+    L = capi.load()
+    p = L.adsb_host_alloc(2 * n)
+    if not p:
+        return None
+    out = {"samples_per_stream": n, "unit": "Msamples/s", "call": "adsb_push_async, 1 Mi samples per call, frames taken after "
+           "every call; one host thread per handle; every handle reads the same page-locked capture; best of 3"}
+    try:
+        host = np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(p))
+        host[:] = x_dev[:n].cpu().numpy().view(np.uint16)
+        chunk = 1 << 20
+        for k in counts:
+            decs = [capi.Decoder(df18=df18) for _ in range(k)]
+            got = [0] * k
+
+            def run(i):
+                d = decs[i]
+                d.reset()
+                c = 0
+                for off in range(0, n, chunk):
+                    d.push_async((p + 2 * off, min(chunk, n - off)))
+                    c += d.take_raw()[1]
+                d.finish()
+                got[i] = c + d.take_raw()[1]
+
+            best = 1e9
+            for _ in range(3):
+                ths = [threading.Thread(target=run, args=(i,)) for i in range(k)]
+                t0 = time.perf_counter()
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                best = min(best, time.perf_counter() - t0)
+            if len(set(got)) != 1:
+                raise SystemExit(f"PARITY FAILURE (multi-stream host-fed, {k} handles): {got}")
+            out[f"streams_{k}"] = {"aggregate": round(k * n / best / 1e6, 1), "host_threads": k, "frames_per_stream": got[0]}
+            for d in decs:
+                d.close()
+    finally:
+        L.adsb_host_free(p)
+    return out
+
+
 def host_fed_rates(torch, capi, x_dev, df18):
     """PCIe-inclusive decode rates from page-locked host memory (128 Mi samples)."""
     n = min(x_dev.numel(), 128 << 20)
@@ -294,10 +439,10 @@ def host_fed_rates(torch, capi, x_dev, df18):
     try:
         host = np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(p))
         host[:] = x_dev[:n].cpu().numpy().view(np.uint16)
-        dec = capi.Decoder(df18=df18)
+        dec_plain, dec_overlap = capi.Decoder(df18=df18), capi.Decoder(df18=df18, push_overlap=True)
         ref_frames = None
 
-        def run(chunk, asyn):
+        def run(dec, chunk, asyn):
             dec.reset()
             got = 0
             for i in range(0, n, chunk):
@@ -310,12 +455,15 @@ def host_fed_rates(torch, capi, x_dev, df18):
             dec.finish()
             return got + dec.take_raw()[1]
 
-        for label, chunk, asyn in (("push_1Mi_sync", 1 << 20, False), ("push_1Mi_async", 1 << 20, True),
-                                   ("push_16Mi_sync", 16 << 20, False), ("push_16Mi_async", 16 << 20, True)):
+        # push_*_overlap: adsb_push with cfg.push_overlap (ONE buffer, the call returns when the copy is done, the scan
+        # stays in flight): the three-line drop-in of INTEGRATION.md at the reference's own call site (air.c:230-239)
+        for label, chunk, asyn, dec in (("push_1Mi_sync", 1 << 20, False, dec_plain), ("push_1Mi_overlap", 1 << 20, False, dec_overlap),
+                                        ("push_1Mi_async", 1 << 20, True, dec_plain), ("push_16Mi_sync", 16 << 20, False, dec_plain),
+                                        ("push_16Mi_overlap", 16 << 20, False, dec_overlap), ("push_16Mi_async", 16 << 20, True, dec_plain)):
             best, frames = 1e9, None
             for _ in range(3):
                 t0 = time.perf_counter()
-                frames = run(chunk, asyn)
+                frames = run(dec, chunk, asyn)
                 best = min(best, time.perf_counter() - t0)
             if ref_frames is None:
                 ref_frames = frames
@@ -323,7 +471,8 @@ def host_fed_rates(torch, capi, x_dev, df18):
                 raise SystemExit(f"PARITY FAILURE (host-fed {label}): {frames} frames vs {ref_frames}")
             out[label] = round(n / best / 1e6, 1)
         out["frames"] = ref_frames
-        dec.close()
+        dec_plain.close()
+        dec_overlap.close()
     finally:
         L.adsb_host_free(p)
     return out
@@ -446,7 +595,8 @@ def main():
         cold_dt = max_over_ranks(time.perf_counter() - tc0)
         value_cold = {"value": round(world * n * cold_steps / cold_dt / 1e6, 1), "unit": "Msamples/s", "steps": cold_steps,
                       "ms_per_step": round(cold_dt / cold_steps * 1e3, 4),
-                      "what": "the same step right after 0.5 s of idle: no pre-roll, no warm-up"}
+                      "what": "the same step right after 0.5 s of idle: no pre-roll, no warm-up (the clock governor needs ~20 ms "
+                              "of load to leave its low state: tools/kernel_time_course.py, DESIGN.md 5)"}
 
     # Clock pre-roll (disclosed in the JSON line): on MI355X the first ~40 steps after an idle
     # period run 15 % slower than the steady state while the clock governor settles -- 185 us
@@ -461,14 +611,16 @@ def main():
 
     fence()
     p0 = dec.profile()  # counters accumulate over the handle's life: take differences
-    dt, raw = timed_steps(step, args.steps, fence, torch.cuda.synchronize)
+    with ClockSampler(local_rank) as sampler:
+        dt, raw = timed_steps(step, args.steps, fence, torch.cuda.synchronize)
+    clock = sampler.ghz()
     dt = max_over_ranks(dt)
     last = (args.steps - 1) % len(ptrs)
 
     value = world * n * args.steps / dt / 1e6  # Msamples/s, whole job
     frames = capi._frames_to_dicts(raw[0], raw[1])
     p1 = dec.profile()
-    roofline, roofline_valu = roofline_objects(p0, p1, args.steps, "r2_dense" if args.dense else "r2")
+    roofline, roofline_valu = roofline_objects(p0, p1, args.steps, "r3_dense" if args.dense else "r3", clock)
 
     # every capture of the rotation, decoded once more and kept for the gate
     per_capture = []
@@ -504,8 +656,12 @@ def main():
     dense = None
     e2e = None
     with_stats = None
+    multi = None
+    cli = None
     if rank == 0 and world == 1 and not args.no_extras:
         e2e = host_fed_rates(torch, capi, xs[0], args.dense)
+        multi = multi_stream_host_fed(torch, capi, xs[0], args.dense)
+        cli = cli_whole_process(xs[0].cpu().numpy().view(np.uint16), capi, args.dense)
         if not args.stats:
             # the same step with valid.c's Try/Ok table reproduced too (the reference always keeps it and prints
             # it at exit): tries counted on the device beside the next scan; the table is read once, after the loop
@@ -521,7 +677,7 @@ def main():
             s0 = ds.profile()
             sdt, _ = timed_steps(sstep, 50, torch.cuda.synchronize)
             s1 = ds.profile()
-            sroof, _ = roofline_objects(s0, s1, 50, "r2_dense" if args.dense else "r2")
+            sroof, _ = roofline_objects(s0, s1, 50, "r3_dense" if args.dense else "r3")
             with_stats = {"what": "collect_stats=1: the step above + the Try table of valid.c:84-100", "steps": 50, "preroll_ms": args.preroll_ms,
                           "value": round(n * 50 / sdt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(sdt / 50 * 1e3, 4),
                           "launch_ms": sroof["launch_ms"]}
@@ -550,7 +706,7 @@ def main():
             q0 = dd.profile()
             ddt, draw = timed_steps(dstep, 50, torch.cuda.synchronize)
             q1 = dd.profile()
-            droof, _ = roofline_objects(q0, q1, 50, profiles_tag="r2_dense")
+            droof, _ = roofline_objects(q0, q1, 50, profiles_tag="r3_dense")
             dense = {"workload": f"BASELINE configs[2]: {n} samples of sigma=300 noise (~7 % of offsets pass the preamble "
                                  "test, ~0.65 % the DF gate) + one 112-bit frame per ms at amplitude 1200-2000, -a", "steps": 50,
                      "preroll_ms": args.preroll_ms,
@@ -559,9 +715,16 @@ def main():
                      "relaunches": int(q1["relaunches"] - q0["relaunches"])}
             if not args.no_cpu_baseline:
                 from oracle import oracle as O
-                wd, _ = O.decode(xd.cpu().numpy().view(np.uint16), df18=True)
+                xdh = xd.cpu().numpy().view(np.uint16)
+                wd, wds = O.decode(xdh, df18=True)
                 gate(capi._frames_to_dicts(*dstep()), wd, "dense capture vs the oracle")
                 dense["parity_vs_oracle"] = True
+                # the density BASELINE configs[2] is about, measured on this capture (not assumed)
+                dense["preamble_pass_fraction"] = round(preamble_pass_fraction(xdh), 5)
+                dense["df_gate_pass_fraction_of_visited"] = round(sum(wds["try"].values()) / max(1, n // 2), 6)
+                dense["density_what"] = ("preamble_pass_fraction: share of the first 2 Mi offsets with p1 > 2 s1 && p2 > 2 s2 "
+                                         "(demod.c:102-107), from the oracle's power samples; df_gate_pass_fraction_of_visited: "
+                                         "the oracle's Try total (valid.c:46,68) over all offsets of the capture")
             dd.close()
 
     if rank == 0:
@@ -574,7 +737,13 @@ def main():
             "config": {"workload": workload, "samples_per_gpu": n, "frames_decoded_rank0": len(frames),
                        "parity_vs_cpu": parity, "ranks_gated": world if parity else 0},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
+            "value_dropin": None if with_stats is None else {
+                "value": with_stats["value"], "unit": "Msamples/s", "ms_per_step": with_stats["ms_per_step"],
+                "what": "the like-for-like figure of the drop-in: the same step with collect_stats=1, which is what the C host "
+                        "program and the INTEGRATION.md patch run (the reference always keeps and prints valid.c's Try/Ok table); "
+                        "`value` is the step without that table"},
             "value_cold": value_cold, "with_stats": with_stats, "dense": dense, "e2e_host_fed": e2e,
+            "multi_stream_host_fed": multi, "cli_whole_process": cli,
         }
         print(json.dumps(line), flush=True)
     dec.close()

@@ -15,6 +15,7 @@ for rep in 1 2; do
   for cfg in "${cfgs[@]}"; do
     read -r name pipe k g flags <<< "$cfg"
     [ "$g" = "-" ] && unset ADSB_PIPE_GROUPS_PER_CU || export ADSB_PIPE_GROUPS_PER_CU=$g
-    echo "$name (pipe=$pipe K=$k groups=$g $flags): $(KB_HAND=1 KB_PIPE=$pipe timeout 120 /tmp/kb/$name 256 400 $k 2>&1 | tail -1)"
+    hand=1; [[ $name == *_nohand ]] && hand=   # (names ending in _nohand: no hand-off stream, no reservation, no marker stores)
+    echo "$name (pipe=$pipe K=$k groups=$g $flags): $(KB_HAND=$hand KB_PIPE=$pipe timeout 120 /tmp/kb/$name 256 400 $k 2>&1 | tail -1)"
   done
 done | tee -a $O/kb_runs.txt

@@ -50,7 +50,7 @@ int main(int argc, char **argv)
     std::vector<uint32_t> synd(adsb::kSyndWords); adsb::make_syndrome_table(synd.data());
     uint32_t *dsynd; CK(hipMalloc(&dsynd, synd.size() * 4)); CK(hipMemcpy(dsynd, synd.data(), synd.size() * 4, hipMemcpyHostToDevice));
     a.synd = dsynd; a.queue_cap = adsb::kQueueCap; a.all_candidates = 0; a.clist_cap = adsb::kClistCap; a.fix_tab = nullptr; a.fix_mul = 0; a.hand = nullptr; a.hand_cap = 0; a.gen = 0;
-    if (getenv("KB_HAND")) { // hand-off stream into pinned host memory, nobody reading it
+    if (getenv("KB_HAND") && atoi(getenv("KB_HAND"))) { // hand-off stream into pinned host memory, nobody reading it
         uint32_t *hand; const size_t gran = 4u << 20;
         CK(hipHostMalloc(&hand, gran * 16, hipHostMallocCoherent));
         a.hand = hand; a.hand_cap = (uint32_t)gran; a.gen = 12345;
