@@ -37,11 +37,13 @@ class Stats(C.Structure):
 
 class ShardHead(C.Structure):
     _fields_ = [("g_begin", C.c_uint64), ("g_end", C.c_uint64), ("n_frames", C.c_uint64), ("n_head", C.c_uint64),
-                ("head_end", C.c_uint64), ("skipped", C.c_uint64), ("status", C.c_uint64), ("reserved", C.c_uint64)]
+                ("head_end", C.c_uint64), ("skipped", C.c_uint64), ("status", C.c_uint64), ("n_bases", C.c_uint64),
+                ("walk_final", C.c_uint64), ("reserved", C.c_uint64)]
 
 
 class ShardPart(C.Structure):
-    _fields_ = [("head", C.POINTER(ShardHead)), ("frames", C.POINTER(Frame)), ("head_cands", C.POINTER(Candidate))]
+    _fields_ = [("head", C.POINTER(ShardHead)), ("frames", C.POINTER(Frame)), ("head_cands", C.POINTER(Candidate)),
+                ("bases", C.POINTER(C.c_uint64))]
 
 
 class ShardFix(C.Structure):
@@ -100,6 +102,9 @@ SYMBOLS = {
                                            C.c_size_t]),
     "adsb_stitch_shards": (C.c_int, [C.POINTER(ShardPart), C.c_int, C.c_uint64, C.POINTER(ShardFix), C.POINTER(Frame),
                                      C.c_size_t, C.POINTER(C.c_size_t)]),
+    "adsb_stitch_shards_ex": (C.c_int, [C.POINTER(ShardPart), C.c_int, C.c_uint64, C.POINTER(ShardFix), C.POINTER(Frame),
+                                        C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+    "adsb_shard_walk": (C.c_size_t, [C.POINTER(ShardHead), C.POINTER(Frame), C.c_uint64, C.POINTER(C.c_uint64), C.c_size_t]),
     "adsb_shard_apply_fix": (None, [C.POINTER(Frame), C.c_size_t, C.c_int64]),
     "adsb_resolver_start_chain": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "adsb_resolver_head": (C.c_long, [C.c_void_p, C.POINTER(Candidate), C.c_size_t]),

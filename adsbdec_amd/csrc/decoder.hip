@@ -1848,6 +1848,23 @@ int adsb_stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total
     return adsb::stitch_shards(parts, n_parts, total_samples, fix, new_frames, new_cap, n_new_total);
 }
 
+int adsb_stitch_shards_ex(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
+                          adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t walk_stats[2])
+{
+    return adsb::stitch_shards(parts, n_parts, total_samples, fix, new_frames, new_cap, n_new_total, walk_stats);
+}
+
+size_t adsb_shard_walk(adsb_shard_head *head, const adsb_frame *frames, uint64_t total_samples, uint64_t *bases, size_t cap)
+{
+    if (!head || (head->n_frames && !frames) || (cap && !bases))
+        return 0;
+    int final = 0;
+    const size_t n = adsb::walk_shard_calls(frames, head->n_frames, head->g_begin, head->g_end, total_samples, bases, cap, &final);
+    head->n_bases = n <= cap ? n : 0;
+    head->walk_final = final;
+    return n;
+}
+
 void adsb_shard_apply_fix(adsb_frame *frames, size_t n, int64_t ts_sub)
 {
     for (size_t i = 0; i < n; i++)

@@ -74,7 +74,7 @@ constexpr size_t lds_bytes(int passes)
 #define ADSB_PIPE_PRIO 3 // s_setprio level of the pipelined kernel's Stage B wave (0 = like the others)
 #endif
 #ifndef ADSB_PIPE_ROLES
-#define ADSB_PIPE_ROLES 1 // the Stage B wave is one that shares its SIMD with another wave of the workgroup (0: always wave 4)
+#define ADSB_PIPE_ROLES 0 // 1: the Stage B wave is one that shares its SIMD with another wave of the workgroup (measured: slower); 0: always wave 4
 #endif
 #ifndef ADSB_PIPE_ABLATE
 #define ADSB_PIPE_ABLATE 0 // tuning builds: 1 = Stage B does no work

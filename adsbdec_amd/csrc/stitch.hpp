@@ -30,10 +30,42 @@ namespace adsb {
 inline uint64_t frame_span(const adsb_frame &f) { return 80 + 80 * (uint64_t)f.len; } // demod.c:109,120,123
 inline uint64_t cand_span(const adsb_candidate &c) { return 80 + 80 * (uint64_t)c.len; }
 
+// One shard's own walk of the deqframe call chain (air.c:94-99, demod.c:89) over its speculative frames, from the guessed
+// entry base g_begin: bases[0] = g_begin, then the base of every later call, the last one being the base whose call is not
+// the shard's any more (its limit lies beyond g_end) or does not fire at all (*final = 1: the stream ends first).  Returns
+// how many bases there are (more than cap: the caller's array was too small and holds the first cap).
+inline size_t walk_shard_calls(const adsb_frame *F, uint64_t nF, uint64_t g_begin, uint64_t g_end, uint64_t total_samples,
+                               uint64_t *bases, size_t cap, int *final)
+{
+    const uint64_t m_ref = 2 * ((total_samples + 3) / 4);
+    uint64_t base = g_begin, k = 0, last_end = 0;
+    size_t n = 0;
+    *final = 0;
+    for (;;) {
+        if (n < cap)
+            bases[n] = base;
+        n++;
+        const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1);
+        if (fire > m_ref) {
+            *final = 1;
+            break;
+        }
+        const uint64_t limit = fire - ADSB_DECOFFSET;
+        if (limit > g_end)
+            break;
+        while (k < nF && F[k].g < limit) {
+            last_end = F[k].g + frame_span(F[k]);
+            k++;
+        }
+        base = last_end > limit ? last_end : limit;
+    }
+    return n;
+}
+
 // Returns 0, -1 (bad arguments / capacity), or -3: a seam cannot be decided from the head candidates alone (the chain did
 // not re-synchronise inside the head window); the caller then falls back to gathering every candidate to one resolver.
 inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
-                         adsb_frame *new_frames, size_t new_cap, size_t *n_new_total)
+                         adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t *walk_stats = nullptr)
 {
     if (!parts || n_parts <= 0 || !fix || !n_new_total || (new_cap && !new_frames))
         return -1;
@@ -103,7 +135,13 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
         skipped_global += shard_skip;
     }
 
-    // The end-of-file horizon: replay the deqframe calls (Resolver::advance) over the final frames' positions.
+    // The end-of-file horizon: replay the deqframe calls (Resolver::advance) over the final frames' positions.  The chain
+    // is sequential -- a frame that straddles a call's limit moves every later call -- but it FORGETS: two chains
+    // that reach the same base continue identically, and a chain is re-anchored at a frame's end by every straddle
+    // (about one call in eight at 1 k frames/s).  Every rank has therefore walked the calls of its own shard from a
+    // guessed entry base (walk_shard_calls: in parallel, ~3 400 calls for an eighth of 2 Gi samples) and left the bases
+    // it went through; the true chain is walked here only until it meets one of them, then jumps to that shard's
+    // exit.  What is left for this rank is the walk to the first common base of each shard, not the stream.
     const uint64_t m_ref = 2 * ((total_samples + 3) / 4); // a trailing partial quad still produces two power samples
     uint64_t base = 0, horizon = 0;
     int part = 0;
@@ -111,12 +149,51 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
     auto frame_at = [&](int p, uint64_t q) -> const adsb_frame & {
         return q < fix[p].n_new ? new_frames[fix[p].new_first + q] : parts[p].frames[fix[p].drop_front + (q - fix[p].n_new)];
     };
+    auto next_limit = [](uint64_t b) { return b + ADSB_APBUFFSZ + (b & 1) - ADSB_DECOFFSET; };
     uint64_t last_end = 0; // end of the last frame that starts below the current limit
+    int js = 0;            // shard whose recorded bases the chain is currently compared with
+    uint64_t jb = 0;
+    uint64_t walked = 0, jumped = 0;
     for (;;) {
         const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1); // air.c:94: tested after every second power sample
         if (fire > m_ref)
             break;
         const uint64_t limit = fire - ADSB_DECOFFSET; // demod.c:89
+        while (js < n_parts && limit > parts[js].head->g_end) {
+            js++;
+            jb = 0;
+        }
+        if (js < n_parts && parts[js].bases && parts[js].head->n_bases > 1) {
+            const adsb_shard_head &h = *parts[js].head;
+            // the recorded walk only knew the shard's own speculative frames: it stands for calls whose limit lies where no
+            // frame of the previous shard can reach (g_begin + 1200) and behind the part of the shard a seam repair rewrote
+            const uint64_t valid_from = fix[js].keep ? parts[js].frames[fix[js].drop_front].g : ~0ull;
+            const bool repaired = fix[js].drop_front || fix[js].n_new;
+            if (limit >= h.g_begin + ADSB_DECOFFSET && (!repaired || limit > valid_from)) {
+                const uint64_t *B = parts[js].bases;
+                while (jb + 1 < h.n_bases && B[jb] < base)
+                    jb++;
+                if (jb + 1 < h.n_bases && B[jb] == base) { // same base: same chain from here to the shard's end
+                    jumped += h.n_bases - 1 - jb;
+                    horizon = next_limit(B[h.n_bases - 2]);
+                    base = B[h.n_bases - 1];
+                    // frames that can still straddle a later limit start at or behind base - 1200: re-seat the cursor there
+                    part = js;
+                    uint64_t lo = 0, hi = fix[js].n_new + fix[js].keep;
+                    const uint64_t from = base >= ADSB_DECOFFSET ? base - ADSB_DECOFFSET : 0;
+                    while (lo < hi) {
+                        const uint64_t mid = (lo + hi) / 2;
+                        if (frame_at(js, mid).g < from)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    k = lo;
+                    last_end = 0;
+                    continue;
+                }
+            }
+        }
         while (part < n_parts) {
             const uint64_t n_here = fix[part].n_new + fix[part].keep;
             if (k >= n_here) {
@@ -132,6 +209,11 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
         }
         base = last_end > limit ? last_end : limit; // a frame accepted below the limit may jump past it (demod.c:128,134)
         horizon = limit;
+        walked++;
+    }
+    if (walk_stats) {
+        walk_stats[0] = walked;
+        walk_stats[1] = jumped;
     }
     // frames at or beyond the horizon are never visited: cut them (they can only sit at the very end)
     for (int p = n_parts - 1; p >= 0; p--) {

@@ -254,14 +254,15 @@ _LINE = 64
 
 class ShardBoard:
     """The exchange area of one time-sharded stream: per shard {adsb_shard_head | seq, done | frames | head
-    candidates}, then what rank 0 hands back {status, fix_seq | adsb_shard_fix per shard | frames accepted by seam
-    repairs}.  Lives in any writable buffer: a bytearray (one process driving every shard) or an mmap of a
-    /dev/shm file (one process per GPU)."""
+    candidates | call bases}, then what rank 0 hands back {status, fix_seq | adsb_shard_fix per shard | frames
+    accepted by seam repairs}.  Lives in any writable buffer: a bytearray (one process driving every shard) or an
+    mmap of a /dev/shm file (one process per GPU)."""
 
-    def __init__(self, buf, world: int, frame_cap: int, head_cap: int, new_cap: int = 1024):
+    def __init__(self, buf, world: int, frame_cap: int, head_cap: int, new_cap: int = 1024, bases_cap: int = 0):
         self.buf, self.world, self.frame_cap, self.head_cap, self.new_cap = buf, world, frame_cap, head_cap, new_cap
-        self.region_bytes = self.region_size(frame_cap, head_cap)
-        need = self.size(world, frame_cap, head_cap, new_cap)
+        self.bases_cap = bases_cap
+        self.region_bytes = self.region_size(frame_cap, head_cap, bases_cap)
+        need = self.size(world, frame_cap, head_cap, new_cap, bases_cap)
         assert len(buf) >= need
         self._base = C.addressof(C.c_char.from_buffer(buf))
         ctl = self._base + world * self.region_bytes
@@ -271,34 +272,53 @@ class ShardBoard:
         self.new_frames = (capi.Frame * new_cap).from_address(ctl + _LINE + fix_bytes)
 
     @staticmethod
-    def region_size(frame_cap, head_cap):
-        return 2 * _LINE + FRAME_BYTES * frame_cap + CAND_BYTES * head_cap
+    def region_size(frame_cap, head_cap, bases_cap=0):
+        return 3 * _LINE + FRAME_BYTES * frame_cap + CAND_BYTES * head_cap + -(-8 * bases_cap // _LINE) * _LINE
 
     @classmethod
-    def size(cls, world, frame_cap, head_cap, new_cap=1024):
+    def size(cls, world, frame_cap, head_cap, new_cap=1024, bases_cap=0):
         fix_bytes = -(-C.sizeof(capi.ShardFix) * world // _LINE) * _LINE
-        return world * cls.region_size(frame_cap, head_cap) + _LINE + fix_bytes + FRAME_BYTES * new_cap
+        return world * cls.region_size(frame_cap, head_cap, bases_cap) + _LINE + fix_bytes + FRAME_BYTES * new_cap
 
     def head(self, i):
         return capi.ShardHead.from_address(self._base + i * self.region_bytes)
 
     def flags(self, i):  # [0] seq: the shard's result of step `seq` is in; [1] done: its ts offset has been applied
-        return np.frombuffer(self.buf, dtype=np.uint64, count=8, offset=i * self.region_bytes + _LINE)
+        return np.frombuffer(self.buf, dtype=np.uint64, count=8, offset=i * self.region_bytes + 2 * _LINE)
 
     def frames(self, i):
-        return (capi.Frame * self.frame_cap).from_address(self._base + i * self.region_bytes + 2 * _LINE)
+        return (capi.Frame * self.frame_cap).from_address(self._base + i * self.region_bytes + 3 * _LINE)
 
     def heads(self, i):
         return (capi.Candidate * self.head_cap).from_address(
-            self._base + i * self.region_bytes + 2 * _LINE + FRAME_BYTES * self.frame_cap)
+            self._base + i * self.region_bytes + 3 * _LINE + FRAME_BYTES * self.frame_cap)
+
+    def bases(self, i):
+        return (C.c_uint64 * max(1, self.bases_cap)).from_address(
+            self._base + i * self.region_bytes + 3 * _LINE + FRAME_BYTES * self.frame_cap + CAND_BYTES * self.head_cap)
+
+    def parts(self):
+        parts = (capi.ShardPart * self.world)()
+        for i in range(self.world):
+            parts[i].head = C.pointer(self.head(i))
+            parts[i].frames = self.frames(i)
+            parts[i].head_cands = self.heads(i)
+            parts[i].bases = self.bases(i) if self.bases_cap else None
+        return parts
+
+
+def bases_capacity(plan):
+    """Calls of the deqframe chain a shard can see: one per 39 780 offsets, and a few."""
+    return max((p["g_end"] - p["g_begin"]) // 39780 for p in plan) + 8
 
 
 class ShardResult:
     """The stream's frames as they lie on the board: per shard, the seam repair's frames, then the kept
     speculative ones (ts final).  collect() copies them into one array (reference order)."""
 
-    def __init__(self, board: ShardBoard, serial_us: float):
+    def __init__(self, board: ShardBoard, serial_us: float, walk=(0, 0)):
         self.board, self.serial_us = board, serial_us
+        self.calls_walked, self.calls_jumped = walk   # of the deqframe call chain: walked by the stitcher / skipped
         self.count = sum(int(f.n_new) + int(f.keep) for f in board.fix)
 
     def segments(self):
@@ -345,17 +365,20 @@ class ResolvedShard:
         self.head_cap = head_cap
         self._map = self._path = None
         if board is None:
-            nbytes = ShardBoard.size(world, self.frame_cap, head_cap)
+            bc = bases_capacity(self.plan)
+            nbytes = ShardBoard.size(world, self.frame_cap, head_cap, bases_cap=bc)
             if self._dist is not None and world > 1:
                 buf = self._shared_buffer(nbytes)
             else:
                 buf = bytearray(nbytes)
-            board = ShardBoard(buf, world, self.frame_cap, head_cap)
+            board = ShardBoard(buf, world, self.frame_cap, head_cap, bases_cap=bc)
         self.board = board
         self._step = 0
         self._fallback = None
         self.fallbacks = 0
         self.serial_us = 0.0
+        self.walk = (0, 0)
+        self._parts = None
 
     # -- setup: one file in /dev/shm, created by rank dst, mapped by everyone, unlinked once everyone has it
     def _shared_buffer(self, nbytes):
@@ -407,6 +430,13 @@ class ResolvedShard:
         if rc != 0:
             hd.status = 1
             raise ShardError(f"rank {self.rank}: adsb_scan_shard_resolved failed: {why}")
+        self._walk_calls()
+
+    def _walk_calls(self):
+        """This shard's own walk of the deqframe call chain (the stitcher jumps onto it): in parallel on every rank."""
+        b, i = self.board, self.rank
+        if b.bases_cap:
+            self._L.adsb_shard_walk(C.byref(b.head(i)), b.frames(i), self.total, b.bases(i), b.bases_cap)
 
     def load_candidates(self, cands):
         """The same through the HOST resolver in chain mode, from a list [(g, pw, frame)] of this shard's candidates:
@@ -422,23 +452,24 @@ class ResolvedShard:
         hd = b.head(i)
         hd.g_begin, hd.g_end, hd.n_frames, hd.n_head = self.g_begin, self.g_end, nf, min(nh, b.head_cap)
         hd.head_end, hd.skipped, hd.status = head_end, int(self._L.adsb_resolver_skipped(r._h)), 0 if nh <= b.head_cap else 1
+        hd.n_bases = hd.walk_final = 0
         r.close()
+        self._walk_calls()
 
     def stitch(self):
         """Rank dst: the serial part.  Returns the stitcher's code (0, or -3: undecidable seam)."""
         b = self.board
         t0 = time.perf_counter()
-        parts = (capi.ShardPart * b.world)()
         for i in range(b.world):
-            hd = b.head(i)
-            if hd.status != 0:
+            if b.head(i).status != 0:
                 b.ctl[0] = 1
                 raise ShardError(f"rank {i} reported a failed scan")
-            parts[i].head = C.pointer(hd)
-            parts[i].frames = b.frames(i)
-            parts[i].head_cands = b.heads(i)
+        if self._parts is None:
+            self._parts = b.parts()
         n_new = C.c_size_t(0)
-        rc = self._L.adsb_stitch_shards(parts, b.world, self.total, b.fix, b.new_frames, b.new_cap, C.byref(n_new))
+        ws = (C.c_uint64 * 2)()
+        rc = self._L.adsb_stitch_shards_ex(self._parts, b.world, self.total, b.fix, b.new_frames, b.new_cap, C.byref(n_new), ws)
+        self.walk = (int(ws[0]), int(ws[1]))
         self.serial_us = (time.perf_counter() - t0) * 1e6
         if rc not in (0, -3):
             b.ctl[0] = 1
@@ -489,7 +520,7 @@ class ResolvedShard:
         if self.rank != self.dst:
             return None
         self._wait(lambda: all(int(b.flags(i)[1]) == k for i in range(b.world)), "the other ranks' ts offsets")
-        return ShardResult(b, self.serial_us)
+        return ShardResult(b, self.serial_us, self.walk)
 
     def _step_fallback(self, device_ptr, cands=None):
         """A seam the head candidates cannot decide: this step goes through every-candidate-to-one-resolver."""
@@ -524,21 +555,20 @@ def decode_sharded(dec, device_ptr: int, total_samples: int, n_shards: int, fram
     L = capi.load()
     plan = capi.plan_shards(total_samples, n_shards)
     fc = frame_cap or 65536 + max(p["n_samples"] for p in plan) // 8000
-    board = ShardBoard(bytearray(ShardBoard.size(n_shards, fc, head_cap)), n_shards, fc, head_cap)
+    bc = bases_capacity(plan)
+    board = ShardBoard(bytearray(ShardBoard.size(n_shards, fc, head_cap, bases_cap=bc)), n_shards, fc, head_cap, bases_cap=bc)
     for i, p in enumerate(plan):
         hd = board.head(i)
         rc = L.adsb_scan_shard_resolved(dec._h, device_ptr + 2 * p["first_sample"], p["first_sample"], p["n_samples"], p["g_begin"],
                                         p["g_end"], C.byref(hd), board.frames(i), fc, board.heads(i), head_cap)
         if rc != 0:
             raise ShardError(f"shard {i}: adsb_scan_shard_resolved failed ({rc}): " + (L.adsb_last_error(dec._h) or b"").decode())
-    parts = (capi.ShardPart * n_shards)()
-    for i in range(n_shards):
-        parts[i].head = C.pointer(board.head(i))
-        parts[i].frames = board.frames(i)
-        parts[i].head_cands = board.heads(i)
+        L.adsb_shard_walk(C.byref(hd), board.frames(i), total_samples, board.bases(i), bc)
+    parts = board.parts()
     n_new = C.c_size_t(0)
+    ws = (C.c_uint64 * 2)()
     t0 = time.perf_counter()
-    rc = L.adsb_stitch_shards(parts, n_shards, total_samples, board.fix, board.new_frames, board.new_cap, C.byref(n_new))
+    rc = L.adsb_stitch_shards_ex(parts, n_shards, total_samples, board.fix, board.new_frames, board.new_cap, C.byref(n_new), ws)
     us = (time.perf_counter() - t0) * 1e6
     if rc != 0:
         return None, rc
@@ -547,4 +577,4 @@ def decode_sharded(dec, device_ptr: int, total_samples: int, n_shards: int, fram
         if fx.keep and fx.ts_sub:
             seg = (capi.Frame * int(fx.keep)).from_address(C.addressof(board.frames(i)) + int(fx.drop_front) * FRAME_BYTES)
             L.adsb_shard_apply_fix(seg, int(fx.keep), int(fx.ts_sub))
-    return ShardResult(board, us), 0
+    return ShardResult(board, us, (int(ws[0]), int(ws[1]))), 0

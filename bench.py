@@ -790,7 +790,7 @@ def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fenc
         step()
     fence()
     p0 = dec.profile()
-    serial = []
+    serial, walk = [], None
     t_all = time.perf_counter()
     fence()
     t0 = time.perf_counter()
@@ -799,6 +799,7 @@ def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fenc
         raw = step()
         if isinstance(raw, sharding.ShardResult):
             serial.append(raw.serial_us)
+            walk = (raw.calls_walked, raw.calls_jumped)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fence()
@@ -844,6 +845,8 @@ def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fenc
                        "rank0_serial_what": "adsb_stitch_shards on rank 0 per step (median): seam repair O(ranks) + the walk of "
                                             "the deqframe call chain over the accepted frames for the end-of-file horizon "
                                             "O(calls + frames)" if serial else None,
+                       "deqframe_calls_walked_by_rank0": None if walk is None else walk[0],
+                       "deqframe_calls_jumped": None if walk is None else walk[1],
                        "fallback_steps": getattr(sr, "fallbacks", None)},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
         }

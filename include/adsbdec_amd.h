@@ -250,6 +250,8 @@ typedef struct adsb_shard_head {
     uint64_t head_end;
     uint64_t skipped;        /* offsets jumped by the speculative frames: sum of (span - 1)                      */
     uint64_t status;         /* 0 = ok                                                                           */
+    uint64_t n_bases;        /* the shard's own walk of the deqframe call chain (adsb_shard_part.bases); 0 = none */
+    uint64_t walk_final;     /* 1: that walk ended because the stream does (air.c:94: no further call fires)      */
     uint64_t reserved;
 } adsb_shard_head;
 
@@ -257,6 +259,8 @@ typedef struct adsb_shard_part { /* one shard as the stitcher sees it (plain hos
     const adsb_shard_head *head;
     const adsb_frame *frames;
     const adsb_candidate *head_cands;
+    const uint64_t *bases;       /* head->n_bases call bases from the guessed entry base g_begin on, or NULL: lets the
+                                    stitcher's end-of-file walk jump over the shard once it meets one of them */
 } adsb_shard_part;
 
 typedef struct adsb_shard_fix { /* the stitcher's verdict for one shard; its final frames are, in this order,      */
@@ -271,11 +275,17 @@ typedef struct adsb_shard_fix { /* the stitcher's verdict for one shard; its fin
 int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n,
                              uint64_t g_begin, uint64_t g_end, adsb_shard_head *head, adsb_frame *frames,
                              size_t frame_cap, adsb_candidate *head_cands, size_t head_cap);
+/* A shard's own walk of the deqframe call chain over its speculative frames (each rank, in parallel, after its scan):
+ * fills bases[0 .. min(cap, n)) and head->n_bases / walk_final; returns n (> cap: too small, n_bases is left 0). */
+size_t adsb_shard_walk(adsb_shard_head *head, const adsb_frame *frames, uint64_t total_samples, uint64_t *bases, size_t cap);
 /* The serial part, on one rank: parts in shard order.  0; -1 on bad arguments or new_cap too small; -3 when a seam cannot
  * be decided from the head candidates (dense overlapping frames through a whole head window): fall back to
  * adsb_scan_shard + adsb_resolver_*. */
 int adsb_stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
                        adsb_frame *new_frames, size_t new_cap, size_t *n_new_total);
+/* The same; walk_stats[0] = calls of the deqframe chain walked here, [1] = calls skipped by jumping onto shards' own walks. */
+int adsb_stitch_shards_ex(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
+                          adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t walk_stats[2]);
 /* ts_final = ts_local - ts_sub, in place, for frames[0 .. n). */
 void adsb_shard_apply_fix(adsb_frame *frames, size_t n, int64_t ts_sub);
 /* The host-side resolver in the same chain mode (tests; hosts that hold candidates themselves): call before the first

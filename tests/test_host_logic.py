@@ -277,3 +277,82 @@ def test_stitched_shards_equal_the_sequential_decode(capi, kind):
         assert undecided == 0
     if kind == "back_to_back":
         assert repairs > 0, "no seam of these cuts needed a repair: the test does not test"
+
+
+def _synthetic_candidates(rng, n_offsets, mean_gap, frame=bytes([0x8D]) + bytes(13)):
+    """Candidate records as a sparse stream would produce them, without any signal: one 'frame' per ~mean_gap offsets
+    (long and short mixed), each decoding at 1-3 neighbouring offsets, now and then two frames overlapping."""
+    out, g = [], int(rng.integers(0, mean_gap))
+    while g < n_offsets:
+        fr = frame if rng.random() < 0.8 else bytes([0x5D]) + bytes(6)
+        for d in range(int(rng.integers(1, 4))):
+            if g + d < n_offsets:
+                out.append((g + d, 100 + d, fr))
+        g += int(rng.integers(3, 2 * mean_gap)) if rng.random() < 0.9 else int(rng.integers(3, 1300))
+    return out
+
+
+@pytest.mark.parametrize("seed,total,n_shards", [(1, 64 << 20, 8), (2, 64 << 20, 3), (3, (96 << 20) + 1234, 13), (4, 32 << 20, 2),
+                                                 (5, (16 << 20) + 40990 * 4 + 6, 5)])
+def test_stitcher_horizon_walk_jumps_onto_the_shards_own_walks(capi, seed, total, n_shards):
+    """The end-of-file horizon needs the whole deqframe call chain (air.c:94-99: a frame that straddles a call's limit moves
+    every later call).  Every shard walks its own calls from a guessed entry base; the stitcher walks the true chain only
+    until it meets one of a shard's bases and jumps to that shard's exit.  Checked against the ONE sequential resolver
+    (resolver.hpp, itself pinned by the oracle) on synthetic candidate streams of up to 48 Mi offsets (~1 200 calls): same
+    frames, same ts, same cut at the horizon.  (Two chains only meet when both straddle the same frame, so how much is
+    jumped depends on the traffic: the test asks that jumps happen and that every call is accounted for, not for a share.)"""
+    import ctypes as C
+    from adsbdec_amd import sharding
+    L = capi.load()
+    rng = np.random.default_rng(seed)
+    m = 2 * (total // 4)
+    n_off = m - 1195
+    cands = _synthetic_candidates(rng, n_off, 9000)
+    one = capi.Resolver()
+    one.feed(cands)
+    one.advance(2 * ((total + 3) // 4), n_off)
+    want = [(f["g"], f["ts"], f["pw"], f["frame"]) for f in one.drain()]
+    assert len(want) > 800
+    plan = capi.plan_shards(total, n_shards)
+    fc = len(cands) + 16
+    bc = sharding.bases_capacity(plan)
+    board = sharding.ShardBoard(bytearray(sharding.ShardBoard.size(n_shards, fc, 4096, bases_cap=bc)), n_shards, fc, 4096, bases_cap=bc)
+    k = 0
+    for i, sh in enumerate(plan):
+        rs = sharding.ResolvedShard(total, rank=i, world=n_shards, board=board, frame_cap=fc)
+        mine = []
+        while k < len(cands) and cands[k][0] < sh["g_end"]:
+            mine.append(cands[k])
+            k += 1
+        rs.load_candidates(mine)
+        assert board.head(i).status == 0 and board.head(i).n_bases >= 1
+    n_new = C.c_size_t(0)
+    ws = (C.c_uint64 * 2)()
+    rc = L.adsb_stitch_shards_ex(board.parts(), n_shards, total, board.fix, board.new_frames, board.new_cap, C.byref(n_new), ws)
+    assert rc == 0
+    for i in range(n_shards):
+        fx = board.fix[i]
+        if fx.keep and fx.ts_sub:
+            seg = (capi.Frame * int(fx.keep)).from_address(C.addressof(board.frames(i)) + int(fx.drop_front) * C.sizeof(capi.Frame))
+            L.adsb_shard_apply_fix(seg, int(fx.keep), int(fx.ts_sub))
+    arr, n = sharding.ShardResult(board, 0.0).collect()
+    got = [(int(f.g), int(f.ts), int(f.pw), bytes(f.frame[: f.len])) for f in arr[:n]]
+    assert got == want
+    walked, jumped = int(ws[0]), int(ws[1])
+    # every call of the chain is either walked by the stitcher or covered by a jump: count them with the plain walk
+    plain_parts = board.parts()
+    for i in range(n_shards):
+        plain_parts[i].bases = None
+    ws2 = (C.c_uint64 * 2)()
+    fix2 = (capi.ShardFix * n_shards)()
+    assert L.adsb_stitch_shards_ex(plain_parts, n_shards, total, fix2, board.new_frames, board.new_cap, C.byref(n_new), ws2) == 0
+    assert int(ws2[1]) == 0 and walked + jumped == int(ws2[0]) > 150
+    assert [(int(f.keep), int(f.n_new), int(f.drop_front)) for f in fix2] == [(int(f.keep), int(f.n_new), int(f.drop_front)) for f in board.fix]
+    _JUMPS.append(jumped)
+
+
+_JUMPS = []
+
+
+def test_stitcher_jumps_happened():
+    assert sum(_JUMPS) > 0, "no run of the previous test ever met a shard's own walk: the jump path is untested"
