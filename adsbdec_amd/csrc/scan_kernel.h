@@ -73,6 +73,9 @@ constexpr size_t lds_bytes(int passes)
 #ifndef ADSB_PIPE_PRIO
 #define ADSB_PIPE_PRIO 3 // s_setprio level of the pipelined kernel's Stage B wave (0 = like the others)
 #endif
+#ifndef ADSB_GATE_IN_LOOP
+#define ADSB_GATE_IN_LOOP 0 // experiment (classic kernel): preamble test + DF gate of a wave's previous pass inside the pass loop
+#endif
 #ifndef ADSB_PIPE_ROLES
 #define ADSB_PIPE_ROLES 0 // 1: the Stage B wave is one that shares its SIMD with another wave of the workgroup (measured: slower); 0: always wave 4
 #endif

@@ -317,13 +317,58 @@ __device__ __forceinline__ uint32_t take28(const uint32_t *w)
 
 } // namespace
 
+// Experiment (-DADSB_GATE_IN_LOOP=1, classic kernel only): the preamble test + DF gate of a run, and the enqueue of its
+// survivors, as one call -- so that a wave can gate the 63 runs of its previous pass inside the pass loop (the planes they
+// need are its own: waves then own CONTIGUOUS runs of the tile) instead of after the workgroup barrier.  Same logic as
+// the gate loop of stage_b.
+struct GateCtx {
+    uint32_t *queue, *qcount, *qover;
+    uint32_t qcap, df18_mask;
+    int off_end;
+};
+__device__ __forceinline__ void gate_and_enqueue(const GateCtx &gc, const uint32_t *pl_d, const uint32_t *pl_e1, const uint32_t *pl_e2,
+                                                 const int vq, const bool active)
+{
+    const int nvalid = active ? gc.off_end - kRun * vq : 0;
+    const int v = nvalid > 0 ? vq : 0;
+    const uint32_t e2w[2] = {pl_e2[v + 1], pl_e2[v + 2]};
+    const uint32_t dw[4] = {pl_d[v + 2], pl_d[v + 3], pl_d[v + 4], pl_d[v + 5]};
+    const uint32_t b0 = take28u<80 - 56>(dw), b1 = take28u<90 - 56>(dw), b2 = take28u<100 - 56>(dw), b3 = take28u<110 - 56>(dw),
+                   b4 = take28u<120 - 56>(dw);
+    const uint32_t hi = ADSB_BITOP3(b0, b1, b2, A & ~B & ~C);
+    const uint32_t lo = ADSB_BITOP3(b3, b4, gc.df18_mask, (A ^ B) & (B | C));
+    const uint32_t h11 = ADSB_BITOP3(b0, b1, b2, ~A & B & ~C);
+    const uint32_t m11 = ADSB_BITOP3(h11, b3, b4, A & B & C);
+    const uint32_t df = ADSB_BITOP3(hi, lo, m11, (A & B) | C);
+    uint32_t gate = ADSB_BITOP3(pl_e1[v], take28u<30 - 28>(e2w), df, A & B & C);
+    gate &= nvalid >= kRun ? 0x0FFFFFFFu : nvalid > 0 ? (1u << nvalid) - 1u : 0u;
+    const int n = __popc(gate);
+    if (n) {
+        uint32_t slot = atomicAdd(gc.qcount, (uint32_t)n);
+        if (slot + n <= gc.qcap) {
+            while (gate) {
+                const int j = __ffs(gate) - 1;
+                gate &= gate - 1;
+                const uint32_t code = ((b1 >> j) & 1u) ? 0u : ((b4 >> j) & 1u) ? 1u : 2u;
+                gc.queue[slot++] = ((uint32_t)vq << 7) | ((uint32_t)j << 2) | code;
+            }
+        } else {
+            *gc.qover = 1;
+        }
+    }
+}
+
 // ------------------------------ Stage A ------------------------------
 // One tile's arithmetic for one of the tile's four Stage A waves: K passes, a run of 28 power samples per lane and
 // pass, three plane words per run into LDS.  No barrier, no divergence.
+template <bool kGateInLoop = false>
 __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const int64_t pbuf0, const int64_t p_lo,
                                         const int64_t p_hi, const int64_t t0, const int K, const int wave, const int lane,
-                                        uint32_t *pl_d, uint32_t *pl_e1, uint32_t *pl_e2)
+                                        uint32_t *pl_d, uint32_t *pl_e1, uint32_t *pl_e2, const GateCtx *gc = nullptr)
 {
+    // first run of wave w in pass ps: interleaved (a pass of the four waves is 252 consecutive runs), or -- gate in the
+    // loop -- contiguous per wave (wave w owns runs [63 K w, 63 K (w + 1)))
+    auto first_run = [&](int ps) { return kGateInLoop ? kWaveRuns * (K * wave + ps) : kWaveRuns * (kWaves * ps + wave); };
     // Input: the 34 pairs (6 of pre-halo + 28) a run needs are 17 TYPED buffer loads of 8
     // bytes per lane (buffer_load_format_xyzw, data format 16_16_16_16, number format
     // USCALED): the load path itself converts the four uint16 to four floats -- exactly, and
@@ -331,10 +376,10 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
     // wave and pass around the wave's own 7 KiB window, so no buffer size limit applies.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * (kWaveRuns * (kWaves * ps + wave)) - 8; }; // lane 0's
+    auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * first_run(ps) - 8; }; // lane 0's
 #pragma unroll 1
     for (int pass = 0; pass < K; pass++) {
-        const int v0 = kWaveRuns * (kWaves * pass + wave); // first run of this wave in this pass
+        const int v0 = first_run(pass); // first run of this wave in this pass
         const int v = v0 + lane;
         const int64_t wlo = pass_first_pair(pass);
         // wave-uniform: every pair this wave loads lies inside the buffer
@@ -532,6 +577,16 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
             pl_e1[v] = e1;
             pl_e2[v] = e2;
         }
+        if constexpr (kGateInLoop) {
+            // the 63 runs of this wave's PREVIOUS pass: the planes they reach into (up to five runs further) are the ones
+            // just stored, by this wave -- its LDS operations execute in order, no barrier needed
+            if (pass > 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                gate_and_enqueue(*gc, pl_d, pl_e1, pl_e2, v - kWaveRuns, lane < kWaveRuns);
+            }
+        }
     }
 }
 
@@ -632,6 +687,14 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     int ch_lo = 0, ch_hi = nchunks, grp = -1;
 #endif
     for (;;) {
+#if ADSB_GATE_IN_LOOP
+        if (NT == kThreads && grp < 0) { // (the queue has been filling since the pass loop: the kernel cleared its counters)
+            if (tid == 0) {
+                *cl_n = 0;
+                *cl_over = 0;
+            }
+        } else
+#endif
         if (tid == 0) {
             *qcount = 0;
             *qover = 0;
@@ -643,6 +706,14 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         // the never-visited filter below needs; fallback rounds emit directly.
         const bool stage_cands = (grp < 0) && !args.all_candidates;
 
+#if ADSB_GATE_IN_LOOP
+        if (NT == kThreads && grp < 0) {
+            // the pass loop has gated everything but each wave's LAST pass (its reach is the next wave's first): 4 x 63 runs
+            GateCtx gc{queue, qcount, qover, qcap, df18_mask, off_end};
+            const int w = tid >> 6, l = tid & 63;
+            gate_and_enqueue(gc, pl_d, pl_e1, pl_e2, kWaveRuns * (K * w + K - 1) + l, l < kWaveRuns);
+        } else
+#endif
 #pragma unroll 1
         for (int base = ch_lo; base < ch_hi; base += kGateBatch) {
             // Two steps per batch of chunks.  First every gate word: plane reads and word-wide logic with no
@@ -1072,7 +1143,20 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
 
     // kernel arguments are only ever used by value (taking their address would
     // demote the sample pointer to a flat/scratch access)
+#if ADSB_GATE_IN_LOOP
+    if (tid == 0) {
+        qcount[0] = 0; // survivors queued
+        qcount[1] = 0; // queue overflow
+    }
+    __syncthreads();
+    const int64_t off_end64 = (int64_t)args.g_end - t0;
+    const int own_runs = kPassRuns * K - kReachRuns;
+    const GateCtx gc{queue, qcount, qcount + 1, (uint32_t)args.queue_cap, args.df18 ? ~0u : 0u,
+                     off_end64 > (int64_t)kRun * own_runs ? kRun * own_runs : off_end64 < 0 ? 0 : (int)off_end64};
+    stage_a<true>(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl_d, pl_e1, pl_e2, &gc);
+#else
     stage_a(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl_d, pl_e1, pl_e2);
+#endif
 #if ADSB_TILE_CLOCK == 3
     uint32_t *tile_chk = qcount + 10;
     if (lane == 0) // when each wave reaches the barrier behind Stage A: how long the four wait for each other

@@ -252,6 +252,19 @@ def roofline_objects(p0, p1, steps, profiles_tag="r3", clock=None):
     return roofline, valu
 
 
+_REAL_STDOUT = None
+
+
+def emit_line(line: dict):
+    """Rank 0's ONE JSON line, on the process's real stdout (see main(): with N > 1 fd 1 is parked on stderr)."""
+    text = json.dumps(line) + "\n"
+    if _REAL_STDOUT is None:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, text.encode())
+
+
 def preroll(step, ms, at_least=40):
     """Untimed steps for `ms` of wall time (and at least `at_least` of them): the clock governor's ramp, see main()."""
     t, i = time.perf_counter(), 0
@@ -508,6 +521,15 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    global _REAL_STDOUT
+    if world > 1:
+        # Only rank 0's JSON line may reach stdout: gloo announces its connections on std::cout ("[Gloo] Rank 0 is
+        # connected to 1 peer ranks ..."), from every rank.  Everything this process prints from here on goes to stderr;
+        # emit_line() writes the one line to the real stdout.
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
     import torch
     from adsbdec_amd import _build, capi
 
@@ -751,7 +773,7 @@ def main():
             "value_cold": value_cold, "with_stats": with_stats, "dense": dense, "e2e_host_fed": e2e,
             "multi_stream_host_fed": multi, "cli_whole_process": cli,
         }
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     dec.close()
     if world > 1:
         dist.destroy_process_group()
@@ -850,7 +872,7 @@ def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fenc
                        "fallback_steps": getattr(sr, "fallbacks", None)},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     sr.close()
     if world > 1:
         dist.barrier()

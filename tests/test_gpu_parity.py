@@ -807,7 +807,9 @@ def _bench_line(extra, timeout=900):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, "bench.py"] + extra, cwd=root, capture_output=True, timeout=timeout, env=env)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
-    return json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry rank 0's JSON line and nothing else, got {len(lines)} lines: {lines[:3]}"
+    return json.loads(lines[0])
 
 
 def test_two_rank_sharded_stream_with_the_hip_kernel():

@@ -62,15 +62,18 @@ def run(seconds: float, seed: int = 1, log=print):
     tight = [dict(), dict(debug_clist_cap=2), dict(debug_cand_cap=24, debug_clist_cap=3),
              dict(debug_cand_cap=16, debug_try_cap=128), dict(debug_queue_cap=256, debug_clist_cap=1)]
 
-    def dec(df18, stats, fix, caps=0):
-        k = (df18, stats, fix, caps)
+    def dec(df18, stats, fix, caps=0, overlap=False):
+        k = (df18, stats, fix, caps, overlap)
         if k not in decs:
-            decs[k] = capi.Decoder(df18=df18, collect_stats=stats, fix_1bit=fix,
+            decs[k] = capi.Decoder(df18=df18, collect_stats=stats, fix_1bit=fix, push_overlap=overlap,
                                    stage_samples=[0, 1 << 17, 1 << 16][len(decs) % 3], **tight[caps])
         return decs[k]
 
     t0, it, frames_total, ref_checked, tight_runs = time.time(), 0, 0, 0, 0
-    modes = [0] * 7
+    modes = [0] * 9
+    pipe_runs = 0
+    stitch_fallbacks = [0]
+    pipe_before = os.environ.get("ADSB_PIPE")
     pinned = capi.PinnedBuffers(2, 1 << 20)
     bufs = pinned.__enter__()
     first_seed = seed
@@ -86,11 +89,17 @@ def run(seconds: float, seed: int = 1, log=print):
             assert rstats == {k: wstats[k] for k in ("try", "ok")}, f"oracle stats != real reference chain, seed={seed}"
             ref_checked += 1
         caps = int(rng.integers(1, len(tight))) if rng.random() < 0.2 else 0
-        d = dec(df18, stats, fix, caps)
-        mode = int(rng.integers(0, 7))
+        mode = int(rng.integers(0, 9))
+        if mode == 7 and stats:
+            mode = 4               # statistics of a sharded stream go through the every-candidate path
+        d = dec(df18, stats, fix, caps, overlap=(mode == 8))
         modes[mode] += 1
+        # either scan kernel (scan_kernel.hip; ADSB_PIPE is read per launch): the classic one, or the pipelined one
+        pipe = bool(rng.integers(0, 3) == 0)
+        os.environ["ADSB_PIPE"] = "1" if pipe else "0"
+        pipe_runs += int(pipe)
         d.reset()
-        what = f"seed={seed} mode={mode} n={x.size} df18={df18} stats={stats} fix={fix} caps={tight[caps]}"
+        what = f"seed={seed} mode={mode} pipe={int(pipe)} n={x.size} df18={df18} stats={stats} fix={fix} caps={tight[caps]}"
         tight_runs += 1 if caps else 0
         if mode == 0:      # host pushes, random chunking
             pos = 0
@@ -121,6 +130,22 @@ def run(seconds: float, seed: int = 1, log=print):
                 got += d.drain()
             d.finish()
             got += d.drain()
+        elif mode == 8:    # cfg.push_overlap: adsb_push from ONE page-locked buffer that is scribbled over after every call
+            got = d.decode(x, chunk=int(rng.choice([1000, 4096, 65536 + 4, 1 << 18, 1 << 20, max(1, x.size)])), mode="overlap")
+        elif mode == 7:    # every shard resolved on its own (adsb_scan_shard_resolved) + the stitcher; -3 = honest fallback
+            from adsbdec_amd import sharding
+            t = torch.from_numpy(x.view(np.int16)).cuda()
+            res, rc = sharding.decode_sharded(d, t.data_ptr(), x.size, int(rng.integers(1, 7)))
+            assert rc in (0, -3), f"stitcher failed ({rc}) " + what
+            if rc == 0:
+                arr, n = res.collect()
+                assert key(capi._frames_to_dicts(arr, n)) == key(want), "MISMATCH (resolved shards) " + what
+            else:
+                stitch_fallbacks[0] += 1
+            it += 1
+            seed += 1
+            frames_total += len(want)
+            continue
         elif mode == 5:    # overlapped host pushes (adsb_push_async), random chunking, frames drained as they come
             got = d.decode(x, chunk=int(rng.choice([1000, 4096, 65536 + 4, 1 << 18, 1 << 20, max(1, x.size)])), mode="async")
         else:
@@ -168,13 +193,18 @@ def run(seconds: float, seed: int = 1, log=print):
                    seconds=round(time.time() - t0, 1), mismatches=0,
                    captures_by_mode=dict(host_push=modes[0], device_final=modes[1], device_split_aligned=modes[2],
                                          device_split_unaligned=modes[3], shards=modes[4], host_push_async=modes[5],
-                                         mixed_async_sync_device=modes[6]),
+                                         mixed_async_sync_device=modes[6], resolved_shards=modes[7], push_overlap=modes[8]),
+                   with_the_pipelined_kernel=pipe_runs, stitcher_fallbacks=stitch_fallbacks[0],
                    also_checked_against_real_reference_chain=ref_checked,
                    with_shrunken_record_buffers=tight_runs,
                    relaunches=sum(int(d.profile()["relaunches"]) for d in decs_all))
     for d in decs_all:
         d.close()
     pinned.__exit__(None, None, None)
+    if pipe_before is None:
+        os.environ.pop("ADSB_PIPE", None)
+    else:
+        os.environ["ADSB_PIPE"] = pipe_before
     log(f"fuzz ok: {summary}")
     return summary
 
