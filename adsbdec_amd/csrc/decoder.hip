@@ -165,11 +165,15 @@ struct adsb_decoder {
     unsigned long long *d_try_acc = nullptr; // device: visited tries per DF code since reset + overflow flag
     bool tries_unread = false;               // passes have been enqueued since the statistics were last read
     bool acc_dirty = false;                  // ... since d_try_acc was last zeroed
-    adsb::TryFrame *h_frames[2] = {nullptr, nullptr}; // pinned upload buffers, used in turn (a pass is never waited for)
-    hipEvent_t ev_frames[2] = {nullptr, nullptr};
+    // pinned upload buffers, three in rotation: the resolver logs the frames it accepts straight into one ([0] is kept
+    // for the last frame of the pass before), the pass being prepared uploads from the second, the third may still be
+    // in flight -- so preparing a pass copies nothing and never waits for an upload
+    static constexpr int kFrameBufs = 3;
+    adsb::TryFrame *h_frames[kFrameBufs] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_frames[kFrameBufs] = {nullptr, nullptr, nullptr};
+    int log_buf = 0; // the buffer the resolver is logging into
     hipStream_t count_stream = nullptr; // statistics runs: frame uploads + count kernels (count_tries_pass)
-    bool frames_pending[2] = {false, false};
-    int frames_buf = 0;
+    bool frames_pending[kFrameBufs] = {false, false, false};
     bool final_follows = false;   // adsb_push_device_final: the end-of-stream count pass comes next
     uint32_t deferred_n = 0;
     ScanSlot *deferred_slot = nullptr;
@@ -182,6 +186,7 @@ struct adsb_decoder {
         adsb::TryCountArgs a{};
         size_t nf = 0;
         int b = 0;
+        const adsb::TryFrame *src = nullptr; // first frame to upload (h_frames[b], or one further without a previous frame)
         ScanSlot *slot = nullptr; // records its ev_count
         hipEvent_t after = nullptr; // the scan (and the report kernel behind it) whose tries the pass reads
     } pending;
@@ -679,7 +684,7 @@ int count_flush(adsb_decoder *d)
     if (p.valid) {
         p.valid = false;
         if (p.nf) {
-            HIP_TRY(d, hipMemcpyAsync(d->d_frames, d->h_frames[p.b], p.nf * sizeof(adsb::TryFrame), hipMemcpyHostToDevice, cs));
+            HIP_TRY(d, hipMemcpyAsync(d->d_frames, p.src, p.nf * sizeof(adsb::TryFrame), hipMemcpyHostToDevice, cs));
             HIP_TRY(d, hipEventRecord(d->ev_frames[p.b], cs));
             d->frames_pending[p.b] = true;
         }
@@ -707,46 +712,63 @@ int count_tries_pass(adsb_decoder *d, ScanSlot *slot, uint32_t n_tries, uint64_t
     if (count_flush(d)) // one pass pending at a time, in order
         return -1;
     const bool regions = slot && slot->try_regions;
-    auto &log = d->res.accepted_log();
-    const size_t nf = log.size() + (d->have_prev_frame ? 1 : 0);
-    auto remember_last = [&] {
-        if (!log.empty()) {
-            d->have_prev_frame = true;
-            d->prev_frame_g = log.back().first;
-            d->prev_frame_span = log.back().second;
-            log.clear();
+    static_assert(sizeof(adsb::Resolver::LogEntry) == sizeof(adsb::TryFrame), "the resolver logs TryFrame records in place");
+    auto &over = d->res.accepted_log(); // entries that did not fit the pinned buffer (normally none)
+    const size_t n_ext = d->res.logged_ext(), n_log = n_ext + over.size();
+    const size_t nf = n_log + (d->have_prev_frame ? 1 : 0);
+    int b = d->log_buf;
+    const bool had_prev = d->have_prev_frame;
+    const uint64_t prev_g = d->prev_frame_g;
+    const uint32_t prev_span = d->prev_frame_span;
+    if (n_log) { // the last accepted frame: its span may cover tries of the next pass
+        d->have_prev_frame = true;
+        if (!over.empty()) {
+            d->prev_frame_g = over.back().first;
+            d->prev_frame_span = over.back().second;
+        } else {
+            d->prev_frame_g = d->h_frames[b][n_ext].g; // entries sit at [1 .. n_ext]
+            d->prev_frame_span = d->h_frames[b][n_ext].span;
         }
-    };
+    }
     if (n_tries == 0 && !regions && !d->carry_maybe) {
-        remember_last();
+        d->res.log_clear();
         return 0;
     }
-    if (nf > d->frames_cap) { // rare: grow the frame arrays (passes in flight use them: drain the stream first)
+    if (!over.empty() || nf > d->frames_cap) { // rare: grow the frame arrays (passes in flight use them: drain the stream first)
         HIP_TRY(d, hipStreamSynchronize(cs));
-        const size_t cap = std::max<size_t>(nf + nf / 4, 4096);
+        const size_t cap = std::max<size_t>(nf + nf / 4 + 1, 2 * d->frames_cap);
+        adsb::TryFrame *nh[adsb_decoder::kFrameBufs] = {nullptr, nullptr, nullptr};
+        for (int i = 0; i < adsb_decoder::kFrameBufs; i++)
+            HIP_TRY(d, hipHostMalloc(&nh[i], cap * sizeof(adsb::TryFrame), hipHostMallocDefault));
+        if (n_ext)
+            std::memcpy(nh[b] + 1, d->h_frames[b] + 1, n_ext * sizeof(adsb::TryFrame));
+        size_t k = 1 + n_ext;
+        for (const auto &f : over)
+            nh[b][k++] = adsb::TryFrame{f.first, f.second, 0};
+        for (int i = 0; i < adsb_decoder::kFrameBufs; i++) {
+            if (d->h_frames[i]) HIP_TRY(d, hipHostFree(d->h_frames[i]));
+            d->h_frames[i] = nh[i];
+            d->frames_pending[i] = false;
+        }
         if (d->d_frames) HIP_TRY(d, hipFree(d->d_frames));
         d->d_frames = nullptr;
-        d->frames_cap = 0;
-        for (int b = 0; b < 2; b++) {
-            if (d->h_frames[b]) HIP_TRY(d, hipHostFree(d->h_frames[b]));
-            d->h_frames[b] = nullptr;
-            d->frames_pending[b] = false;
-            HIP_TRY(d, hipHostMalloc(&d->h_frames[b], cap * sizeof(adsb::TryFrame), hipHostMallocDefault));
-        }
         HIP_TRY(d, hipMalloc(&d->d_frames, cap * sizeof(adsb::TryFrame)));
         d->frames_cap = cap;
     }
-    const int b = d->frames_buf ^= 1;
-    if (d->frames_pending[b]) { // the pass before last has long copied this buffer
-        HIP_TRY(d, hipEventSynchronize(d->ev_frames[b]));
-        d->frames_pending[b] = false;
+    const adsb::TryFrame *src = d->h_frames[b] + 1;
+    if (had_prev) {
+        d->h_frames[b][0] = adsb::TryFrame{prev_g, prev_span, 0};
+        src = d->h_frames[b];
     }
-    size_t k = 0;
-    if (d->have_prev_frame)
-        d->h_frames[b][k++] = adsb::TryFrame{d->prev_frame_g, d->prev_frame_span, 0};
-    for (const auto &f : log)
-        d->h_frames[b][k++] = adsb::TryFrame{f.first, f.second, 0};
-    remember_last();
+    {   // the resolver goes on logging into the buffer of the pass before last
+        const int nb = (b + 1) % adsb_decoder::kFrameBufs;
+        if (d->frames_pending[nb]) {
+            HIP_TRY(d, hipEventSynchronize(d->ev_frames[nb]));
+            d->frames_pending[nb] = false;
+        }
+        d->log_buf = nb;
+        d->res.log_into(reinterpret_cast<adsb::Resolver::LogEntry *>(d->h_frames[nb] + 1), d->frames_cap - 1);
+    }
     const int c_in = d->carry_n_cur, c_out = (c_in + 1) % 3, c_next = (c_in + 2) % 3;
     adsb::TryCountArgs a{};
     a.tries = slot ? slot->d_tries + slot->args.try_list_first : nullptr;
@@ -772,6 +794,7 @@ int count_tries_pass(adsb_decoder *d, ScanSlot *slot, uint32_t n_tries, uint64_t
     d->pending.a = a;
     d->pending.nf = nf;
     d->pending.b = b;
+    d->pending.src = src;
     d->pending.slot = (slot && (n_tries || regions)) ? slot : nullptr;
     d->pending.after = d->pending.slot ? slot->ev_ready[slot->ev_cur] : nullptr;
     d->prof.tries += n_tries;
@@ -1317,10 +1340,18 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
                 return bail("hipMalloc(try carry)", e);
         // one allocation, so that adsb_reset clears both with one fill: 4 accumulators + 3 (4) carry counts
         if ((e = hipMalloc(&d->d_try_acc, kTryStateBytes)) != hipSuccess ||
-            (e = hipMemset(d->d_try_acc, 0, kTryStateBytes)) != hipSuccess ||
-            (e = hipEventCreate(&d->ev_frames[0])) != hipSuccess || (e = hipEventCreate(&d->ev_frames[1])) != hipSuccess)
+            (e = hipMemset(d->d_try_acc, 0, kTryStateBytes)) != hipSuccess)
             return bail("hipMalloc(try counters)", e);
         d->d_carry_n = reinterpret_cast<uint32_t *>(d->d_try_acc + 4);
+        d->frames_cap = 1u << 16; // accepted frames between two count passes (a 128 Mi-offset launch at 1 k frames/s: 13 k)
+        if (const char *fc = getenv("ADSB_DEBUG_FRAMES_CAP")) // tests: start small, so that the regrow path runs
+            d->frames_cap = std::max<size_t>(8, strtoull(fc, nullptr, 10));
+        for (int i = 0; i < adsb_decoder::kFrameBufs; i++)
+            if ((e = hipHostMalloc(&d->h_frames[i], d->frames_cap * sizeof(adsb::TryFrame), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipEventCreate(&d->ev_frames[i])) != hipSuccess)
+                return bail("hipHostMalloc(accepted frames)", e);
+        if ((e = hipMalloc(&d->d_frames, d->frames_cap * sizeof(adsb::TryFrame))) != hipSuccess)
+            return bail("hipMalloc(accepted frames)", e);
         int prio_least = 0, prio_greatest = 0; // the count passes give way to the scans they run beside
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
         if ((e = hipStreamCreateWithPriority(&d->count_stream, hipStreamNonBlocking, prio_least)) != hipSuccess)
@@ -1329,6 +1360,7 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             if ((e = hipEventCreateWithFlags(&sl.ev_count, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate(count)", e);
         d->res.log_accepted(true);
+        d->res.log_into(reinterpret_cast<adsb::Resolver::LogEntry *>(d->h_frames[0] + 1), d->frames_cap - 1);
     }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     d->no_streaming = getenv("ADSB_NO_STREAMING") && atoi(getenv("ADSB_NO_STREAMING")) != 0;
@@ -1368,7 +1400,7 @@ void adsb_destroy(adsb_decoder *d)
     for (int i = 0; i < 2; i++)
         if (d->d_carry[i]) (void)hipFree(d->d_carry[i]);
     if (d->d_frames) (void)hipFree(d->d_frames);
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < adsb_decoder::kFrameBufs; b++) {
         if (d->h_frames[b]) (void)hipHostFree(d->h_frames[b]);
         if (d->ev_frames[b]) (void)hipEventDestroy(d->ev_frames[b]);
     }

@@ -40,6 +40,7 @@ public:
         out_.clear();
         ohead_ = 0;
         log_.clear();
+        ext_n_ = 0;
         std::memset(&stats_, 0, sizeof stats_);
     }
 
@@ -190,6 +191,25 @@ public:
     // accepted frame for the device-side visited-try count, and take the counts back.
     void log_accepted(bool on) { log_on_ = on; }
     std::vector<std::pair<uint64_t, uint32_t>> &accepted_log() { return log_; }
+    // ... straight into a buffer of the caller's (the pinned array the count pass uploads from: no copy when the pass is
+    // prepared); what does not fit goes on to the vector above, behind the buffer's entries
+    struct LogEntry {
+        uint64_t g;
+        uint32_t span, pad;
+    };
+    void log_into(LogEntry *buf, size_t cap)
+    {
+        ext_ = buf;
+        ext_cap_ = cap;
+        ext_n_ = 0;
+        log_.clear();
+    }
+    size_t logged_ext() const { return ext_n_; }
+    void log_clear()
+    {
+        ext_n_ = 0;
+        log_.clear();
+    }
     void set_tries(uint64_t df11, uint64_t df17, uint64_t df18)
     {
         stats_.try_[0] = df11;
@@ -375,8 +395,12 @@ private:
             stats_.ok[df_slot(f.frame[0])]++;
             stats_.fixed += f.reserved & 1u;
             skipped_ += span - 1;
-            if (log_on_)
-                log_.emplace_back(g, (uint32_t)span);
+            if (log_on_) {
+                if (ext_n_ < ext_cap_ && log_.empty())
+                    ext_[ext_n_++] = LogEntry{g, (uint32_t)span, 0};
+                else
+                    log_.emplace_back(g, (uint32_t)span);
+            }
             idx = g + span; // demod.c:128,134
         }
         base_ = idx; // deqframe's return value; air.c:96-98 carries the rest
@@ -392,6 +416,8 @@ private:
     Batch batch_;
     bool log_on_ = false;
     std::vector<std::pair<uint64_t, uint32_t>> log_;
+    LogEntry *ext_ = nullptr;
+    size_t ext_cap_ = 0, ext_n_ = 0;
     std::vector<uint64_t> tries_;
     size_t thead_ = 0;
     std::vector<adsb_frame> out_;

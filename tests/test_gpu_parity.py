@@ -286,6 +286,27 @@ def test_statistics_read_patterns(capi, oracle, dec_factory, torch_cuda):
     assert d.stats() == wstats and d.stats() == wstats
 
 
+def test_accepted_frame_log_regrows(capi, oracle, torch_cuda, monkeypatch):
+    """Statistics runs: the resolver logs the frames it accepts straight into the page-locked array the count pass uploads
+    from; when a pass has more frames than the array holds, the rest goes to a vector and the arrays are regrown.  Start
+    with room for 8 frames (ADSB_DEBUG_FRAMES_CAP, read at adsb_create) and decode streams with hundreds of frames per
+    launch, several streams on one handle, chunked and in one piece: the Try/Ok table must equal the oracle's every time."""
+    from oracle import gen_signal as G
+    monkeypatch.setenv("ADSB_DEBUG_FRAMES_CAP", "8")
+    d = capi.Decoder(df18=True, collect_stats=True)
+    try:
+        for seed, n, nfr in ((41, 3 << 20, 900), (42, 1 << 20, 300), (43, (2 << 20) + 6, 1500)):
+            x, _ = G.dense_capture(n, seed=seed, sigma=30.0, n_frames=nfr, amp=(200, 1800))
+            want, wstats = oracle.decode(x, df18=True)
+            t = _dev(torch_cuda, x)
+            d.reset()
+            d.push_device_final(t.data_ptr(), t.numel())
+            assert records(d.drain()) == records(want) and d.stats() == wstats
+            assert records(d.decode(x, chunk=300_000)) == records(want) and d.stats() == wstats
+    finally:
+        d.close()
+
+
 def test_stream_of_2_to_32_samples_is_refused(capi, dec_factory, torch_cuda):
     """The reference's sample counter is a uint32_t (air.c:34): at 2^32 samples its ring phase jumps
     and no parity is defined, so the library refuses such a stream -- loudly, before it touches the buffer."""
