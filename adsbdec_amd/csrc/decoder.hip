@@ -645,7 +645,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
         }
         t_start[tile] = pos + 1;
         t_count[tile] = n;
-        pos += adsb::stream_granules(n);
+        pos += std::max(adsb::marker_granules(nf), adsb::stream_granules(n)); // what the tile reserved (it may have kept fewer records than it reserved for)
         while (frontier < s.ntiles && t_count[frontier] != ~0u)
             frontier++;
         // the tiles of the last resident round finish in a burst at the kernel's end: take
@@ -973,7 +973,7 @@ int slot_collect(adsb_decoder *d)
                     const uint32_t *w = m + (size_t)(1 + 2 * i) * adsb::kGranuleWords;
                     d->gather.insert(d->gather.end(), w, w + 6); // {g_rel, pw, w0..w3}
                 }
-            pos += adsb::stream_granules(n);
+            pos += std::max(adsb::marker_granules(nf), adsb::stream_granules(n));
         }
         // The loose list may also hold records of tiles the streamed part has already
         // delivered: after a relaunch (record buffers regrown) every tile runs again, and

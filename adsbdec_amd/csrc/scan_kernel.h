@@ -58,6 +58,9 @@ constexpr int kCounterPad = ADSB_COUNTER_PAD;
 constexpr int kDevCounterWords = 6 * kCounterPad;
 constexpr uint32_t kMarkOver = 0x10000u;  // marker flag: some records of the tile are on the loose list
 constexpr uint32_t kMarkNoFit = 0x20000u; // marker flag: the tile's range ran past the array (records are loose)
+constexpr int kMarkLinesShift = 18;       // marker word 1, bits 18..31: 64-byte lines the tile reserved (it may keep fewer records
+                                          // than it reserved for: the host skips to the next tile's marker by this)
+__host__ __device__ constexpr uint32_t marker_granules(uint32_t nf) { return (nf >> kMarkLinesShift) * 4u; }
 // Granules a tile with n records reserves: marker + 2 n, rounded up to whole 64-byte lines, so
 // that the host never reads (and caches) a line the device has yet to write another tile into
 // -- every later device write to such a line has to pull it out of the CPU's cache first.
@@ -72,6 +75,10 @@ constexpr size_t lds_bytes(int passes)
 // the pipelined kernel (ScanArgs::pipe): two sets of planes, queue, 32 control words, 64 staged candidates
 #ifndef ADSB_PIPE_PRIO
 #define ADSB_PIPE_PRIO 3 // s_setprio level of the pipelined kernel's Stage B wave (0 = like the others)
+#endif
+#ifndef ADSB_EARLY_RESERVE
+#define ADSB_EARLY_RESERVE 0 // 1: the tile reserves its hand-off range before the never-visited filter, for the staged count (kernel -2 %, but the
+                             // stream gets four times sparser and the host, which chases it marker by marker, takes twice as long: off)
 #endif
 #ifndef ADSB_GATE_IN_LOOP
 #define ADSB_GATE_IN_LOOP 0 // experiment (classic kernel): preamble test + DF gate of a wave's previous pass inside the pass loop

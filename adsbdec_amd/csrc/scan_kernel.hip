@@ -181,11 +181,12 @@ __device__ __forceinline__ float power_ordered(const f32x2 (&pr)[7])
     return sq.x + sq.y;
 }
 
-__device__ __noinline__ uint32_t pw_at(const uint32_t *__restrict__ x, int64_t pbuf0, int64_t p_lo, int64_t p_hi,
-                                       int64_t g)
+// The 28 pairs behind the four power samples of demod.c:102-105 at offset g (0, +10, +35, +45; seven pairs each): the
+// loads on their own, so that a caller can issue them early and do other work while they are in flight.
+__device__ __forceinline__ void pw_load(const uint32_t *__restrict__ x, int64_t pbuf0, int64_t p_lo, int64_t p_hi, int64_t g,
+                                        uint32_t (&raw)[4][7])
 {
     const int off[4] = {0, 10, 35, 45}; // demod.c:102-105
-    uint32_t raw[4][7];
     if (g - 6 >= p_lo && g + 45 < p_hi) {
         // the usual case, every pair inside the buffer: one address, 28 loads at immediate offsets
         const uint32_t *b = x + (g - pbuf0);
@@ -203,6 +204,11 @@ __device__ __noinline__ uint32_t pw_at(const uint32_t *__restrict__ x, int64_t p
                 raw[k][a] = (pi >= p_lo && pi < p_hi) ? x[pi - pbuf0] : 0x08000800u;
             }
     }
+}
+
+__device__ __forceinline__ uint32_t pw_compute(const uint32_t (&raw)[4][7], int64_t g)
+{
+    const int off[4] = {0, 10, 35, 45};
     // power indices stay below 2^31 (streams of < 2^32 samples): 32-bit arithmetic for phase and parity
     const uint32_t g32 = (uint32_t)g, g7 = g32 % 7u;
     float pw_s[4];
@@ -237,6 +243,13 @@ __device__ __noinline__ uint32_t pw_at(const uint32_t *__restrict__ x, int64_t p
     const int p1 = __float2int_rz(pw_s[0] + pw_s[1]);
     const int p2 = __float2int_rz(pw_s[2] + pw_s[3]);
     return (uint32_t)((p1 + p2) / 4); // demod.c:127,133
+}
+
+__device__ __noinline__ uint32_t pw_at(const uint32_t *__restrict__ x, int64_t pbuf0, int64_t p_lo, int64_t p_hi, int64_t g)
+{
+    uint32_t raw[4][7];
+    pw_load(x, pbuf0, p_lo, p_hi, g, raw);
+    return pw_compute(raw, g);
 }
 
 // The slicer gathers the frame as 14 column bytes (frame bit k = 14 b + c is bit b
@@ -634,12 +647,14 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     uint32_t *tile_res = qcount + 8;  // the tile has reserved its range of args.hand
     uint32_t *tile_fit = qcount + 9;  // ... and the whole range lies inside the array
     uint32_t *tile_chk = qcount + 10; // [4]: XOR of the granules the tile wrote there, word by word
+    uint32_t *tile_lines = qcount + 14; // 64-byte lines of args.hand the tile has reserved (its marker says so: kMarkLinesShift)
     if (tid == 0) { // (the first barrier of the round loop below orders these)
         *tile_n = 0;
         *tile_over = 0;
         *tile_base = 0;
         *tile_res = 0;
         *tile_fit = 0;
+        *tile_lines = 0;
         tile_chk[0] = tile_chk[1] = tile_chk[2] = tile_chk[3] = 0;
     }
     // A finished record that cannot go through the hand-off stream (hand-off disabled,
@@ -895,6 +910,19 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             ADSB_STAMP(3);
             const int ncl = min((int)*cl_n, clist_cap); // <= kClistCap <= NT: one entry per thread
             const bool complete = *cl_over == 0;
+            // The tile reserves its range of the hand-off stream -- one marker granule plus two per record, in whole
+            // 64-byte lines -- with one device-scope atomic whose answer takes ~2 us under the scan's traffic.  How many
+            // records it KEEPS is only known behind the filter below; it reserves for the staged ones now (an upper
+            // bound, ~4x: the marker tells the host how many lines to skip), so that the round trip runs beside the
+            // filter and the finishing instead of behind the filter.
+            uint32_t res_need = 0, res_base = 0;
+            const bool reserves = tid == 0 && args.hand;
+#if ADSB_EARLY_RESERVE
+            if (reserves) {
+                res_need = stream_granules((uint32_t)ncl);
+                res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
+            }
+#endif
             bool keep = false;
             uint32_t rank = 0; // kept entries with a smaller offset: the record's place behind the tile's marker
             const uint32_t *ri = cl_rec + tid * kCandWords;
@@ -977,12 +1005,12 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             ADSB_STAMP(4);
             tile_sync<NT>();
             ADSB_STAMP(5);
-            uint32_t res_need = 0, res_base = 0;
-            const bool reserves = tid == 0 && args.hand;
+#if !ADSB_EARLY_RESERVE
             if (reserves) { // the result is not looked at before this thread's own record is finished
                 res_need = stream_granules(*tile_n);
                 res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
             }
+#endif
             if (keep && !one_wave) {
                 const uint32_t gi = ri[0];
                 for (int j = 0; j < ncl; j++)
@@ -1002,6 +1030,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             if (reserves) {
                 *tile_base = res_base;
                 *tile_fit = (res_base < args.hand_cap && res_need <= args.hand_cap - res_base) ? 1u : 0u;
+                *tile_lines = res_need >> 2;
                 *tile_res = 1;
             }
             ADSB_STAMP(6);
@@ -1035,7 +1064,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                     if (L == 0) {
                         if (!marker_now)
                             continue;
-                        const uint32_t nf = nk | (*tile_over ? kMarkOver : 0u);
+                        const uint32_t nf = nk | (*tile_over ? kMarkOver : 0u) | (*tile_lines << kMarkLinesShift);
                         uint32_t lo, hi;
                         marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
                         gv = u32x4{tile, nf, lo, hi};
@@ -1076,12 +1105,14 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         tile_sync<NT>();
         if (tid == 0 && *tile_res != 2) {
             uint32_t b = *tile_base, fit = *tile_fit;
+            uint32_t lines = *tile_lines;
             if (!*tile_res) { // no whole-tile round staged anything (all_candidates, fallback rounds)
                 b = atomicAdd(&args.counters[2 * kCounterPad], stream_granules(0));
                 fit = b < args.hand_cap;
+                lines = stream_granules(0) >> 2;
             }
             if (b < args.hand_cap) {
-                const uint32_t nf = *tile_n | (*tile_over ? kMarkOver : 0u) | (fit ? 0u : kMarkNoFit);
+                const uint32_t nf = *tile_n | (*tile_over ? kMarkOver : 0u) | (fit ? 0u : kMarkNoFit) | (lines << kMarkLinesShift);
                 uint32_t lo, hi;
                 marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
                 store_granule_through(args.hand, b, u32x4{tile, nf, lo, hi});
@@ -1233,7 +1264,7 @@ void scan_pipe_kernel(const ScanArgs args)
     const int K = args.passes;
     const int nplane = kPassRuns * K + kPlanePad;
     uint32_t *queue = smem + 6 * nplane;
-    uint32_t *ctl = queue + kQueueCap; // [0..13] Stage B's, [14..15] the next tile of the workgroup (two in rotation)
+    uint32_t *ctl = queue + kQueueCap; // [0..14] Stage B's, [16..20] the waves' SIMDs, [22..23] the next tile of the workgroup (two in rotation)
     uint32_t *cl_rec = ctl + 32;
     const int tid = threadIdx.x;
     const int lane_id = tid & 63;
@@ -1324,11 +1355,11 @@ void scan_pipe_kernel(const ScanArgs args)
 #endif
             }
             if (lane_id == 0)
-                ctl[14 + (it & 1)] = (uint32_t)next;
+                ctl[22 + (it & 1)] = (uint32_t)next;
         }
         __syncthreads();
         tile_b = tile_a;
-        tile_a = __builtin_amdgcn_readfirstlane((int)ctl[14 + (it & 1)]);
+        tile_a = __builtin_amdgcn_readfirstlane((int)ctl[22 + (it & 1)]);
     }
     if (args.profile && tid == 0) { // the launch's duration is (latest workgroup end) - (earliest workgroup start)
         unsigned long long *c64 = reinterpret_cast<unsigned long long *>(args.counters);

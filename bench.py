@@ -613,8 +613,11 @@ def main():
         pk0 = dec.profile()
         with ClockSampler(local_rank) as cold_clock:
             tc0 = time.perf_counter()
+            cold_each = []
             for i in range(cold_steps):
+                ts0 = time.perf_counter()
                 step(i)
+                cold_each.append(round((time.perf_counter() - ts0) * 1e3, 4))
             torch.cuda.synchronize()
             cold_dt = time.perf_counter() - tc0
         cold_dt = max_over_ranks(cold_dt)
@@ -622,6 +625,7 @@ def main():
         value_cold = {"value": round(world * n * cold_steps / cold_dt / 1e6, 1), "unit": "Msamples/s", "steps": cold_steps,
                       "ms_per_step": round(cold_dt / cold_steps * 1e3, 4),
                       "kernel_ms_per_step": round((pk1["kernel_ms"] - pk0["kernel_ms"]) / cold_steps, 4),
+                      "ms_each_step": cold_each,
                       "sclk_ghz_samples": [round(v / 1e9, 2) for v in cold_clock.samples[:8]],
                       "what": "the same step right after 0.5 s of idle: no pre-roll, no warm-up (the clock governor needs ~20 ms "
                               "of load to leave its low state: tools/kernel_time_course.py, DESIGN.md 5)"}
