@@ -337,8 +337,13 @@ class ClockSampler:
             self._t.join(timeout=1)
 
     def ghz(self):
+        """(median GHz, samples) -- or (None, n) when the figure cannot be the shader clock under load: too few samples, or a
+        value outside 1.2 .. 2.6 GHz (under rocprofv3 the file reads 0.1-2.0: the profiler serialises the dispatches)."""
         v = [x for x in self.samples if x > 0]
-        return (float(np.median(v)) / 1e9, len(v)) if v else (None, 0)
+        if len(v) < 5:
+            return (None, len(v))
+        g = float(np.median(v)) / 1e9
+        return (g, len(v)) if 1.2 <= g <= 2.6 else (None, len(v))
 
 
 def preamble_pass_fraction(x_host: np.ndarray, n=4 << 20):

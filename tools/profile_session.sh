@@ -10,7 +10,9 @@ tag=$1; shift
 R=$PWD; O=$R/gpurun_out; W=/tmp/prof_$tag; mkdir -p $O $W
 export TMPDIR=/tmp
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -o run -- python3 $R/bench.py --no-cpu-baseline --no-extras "$@" > $O/${tag}_bench_under_rocprofv3.json 2> $W/trace.err
+# 1000 timed steps: the pre-roll and warm-up launches (the clock governor's ramp) are then < 30 % of the dispatches the
+# --stats average is taken over, and <tag>_dispatches.csv keeps every one of them for a steady-state average
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -o run -- python3 $R/bench.py --steps ${PROF_STEPS:-1000} --no-cpu-baseline --no-extras "$@" > $O/${tag}_bench_under_rocprofv3.json 2> $W/trace.err
 echo "trace run exit $?"; head -c 400 $O/${tag}_bench_under_rocprofv3.json; echo
 i=0
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
