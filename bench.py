@@ -187,7 +187,7 @@ def gate(got, want, what):
         raise SystemExit(f"PARITY FAILURE ({what}): GPU path returned {len(a)} frames, expected {len(b)}; first difference at index {i}")
 
 
-def roofline_objects(p0, p1, steps, profiles_tag="r3", clock=None):
+def roofline_objects(p0, p1, steps, profiles_tag="r3", clock=None, step_ms=None):
     """HBM roofline of the dominant launch + the VALU-issue roofline that actually binds it."""
     kernel_ms = p1["kernel_ms"] - p0["kernel_ms"]
     big_off = p1["big_offsets"]
@@ -230,7 +230,9 @@ def roofline_objects(p0, p1, steps, profiles_tag="r3", clock=None):
             floor_peak_ms = insts * cyc / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
             # the chip does not hold its 2.4 GHz under this load (it runs at its power limit): price the floor at the
             # clock it did hold -- sampled from sysfs while the timed steps ran, else the figure of profiles/r2_power_trace.txt
-            ghz, ghz_src = (clock[0], f"sysfs freq1_input, median of {clock[1]} samples taken every 2 ms during the timed steps") \
+            ghz, ghz_src = (clock[0], f"sysfs freq1_input, median of {clock[1]} samples taken every 2 ms during the timed steps "
+                                      "(instantaneous DVFS readings: different boxes have read 2.0 and 2.4 GHz for the same kernel time, "
+                                      "so frac_at_peak_clock is the conservative figure)") \
                 if clock and clock[0] else (2.33, "profiles/r2_power_trace.txt (rocm-smi beside a 15 s bench run; sysfs was not readable in this run)")
             floor_ms = insts * cyc / N_SIMD / (ghz * 1e9) * 1e3
             valu = {"bound": "valu_issue", "valu_wave_instructions": int(insts), "cycles_per_instruction": round(cyc, 3),
@@ -249,6 +251,14 @@ def roofline_objects(p0, p1, steps, profiles_tag="r3", clock=None):
                 "kernel_ms_per_step": round(kernel_ms / steps, 4),
                 "limited_by": "VALU issue (every product and sum of the 14-tap FIR is rounded separately: "
                               "784 flops per 28 outputs), not HBM: see roofline_valu and DESIGN.md section 4"}
+    if step_ms and n_big / steps > 1.5 and os.environ.get("ADSB_ALT_STREAMS", "1") != "0":
+        # a multi-launch stream: consecutive launches run on two alternating streams and overlap, so a launch's own duration
+        # (two resident) says nothing about the rate -- price the whole step instead (a lower bound: it includes the host's share)
+        total_bytes = 4.0 * (p1["offsets"] - p0["offsets"]) / steps
+        ach = total_bytes / (step_ms * 1e-3) / 1e9
+        roofline.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "launches_overlap": True,
+                         "achieved_what": "algorithmic bytes of ALL launches of a step / the step's wall time: consecutive launches "
+                                          "overlap on two compute streams, launch_ms is the duration of one launch with two resident"})
     return roofline, valu
 
 
@@ -657,7 +667,7 @@ def main():
     value = world * n * args.steps / dt / 1e6  # Msamples/s, whole job
     frames = capi._frames_to_dicts(raw[0], raw[1])
     p1 = dec.profile()
-    roofline, roofline_valu = roofline_objects(p0, p1, args.steps, "r3_dense" if args.dense else "r3", clock)
+    roofline, roofline_valu = roofline_objects(p0, p1, args.steps, "r3_dense" if args.dense else "r3", clock, dt / args.steps * 1e3)
 
     # every capture of the rotation, decoded once more and kept for the gate
     per_capture = []
@@ -836,7 +846,7 @@ def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fenc
     fence()
     dt = max_over_ranks(dt)
     p1 = dec.profile()
-    roofline, roofline_valu = roofline_objects(p0, p1, args.steps)
+    roofline, roofline_valu = roofline_objects(p0, p1, args.steps, step_ms=dt / args.steps * 1e3)
     value = total * args.steps / dt / 1e6
     del t_all
 
