@@ -80,6 +80,7 @@ SYMBOLS = {
     "adsb_host_unregister": (C.c_int, [C.c_void_p]),
     "adsb_push_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_push_device_final": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "adsb_decode_device": (C.c_long, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(Frame))]),
     "adsb_finish": (C.c_int, [C.c_void_p]),
     "adsb_host_alloc": (C.c_void_p, [C.c_size_t]),
     "adsb_host_free": (None, [C.c_void_p]),
@@ -230,6 +231,14 @@ class Decoder:
 
     def push_device_final(self, ptr: int, n: int):
         self._check(self._L.adsb_push_device_final(self._h, ptr, n), "adsb_push_device_final")
+
+    def decode_device_raw(self, ptr: int, n: int):
+        """adsb_decode_device: reset + push_device_final + take in one call -> (Frame pointer, count)."""
+        p = C.POINTER(Frame)()
+        k = self._L.adsb_decode_device(self._h, ptr, n, C.byref(p))
+        if k < 0:
+            self._check(-1, "adsb_decode_device")
+        return p, int(k)
 
     def finish(self):
         self._check(self._L.adsb_finish(self._h), "adsb_finish")

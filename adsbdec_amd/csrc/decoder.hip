@@ -1704,6 +1704,15 @@ int adsb_push_device_final(adsb_decoder *d, const void *device_samples, size_t n
     return push_device_impl(d, device_samples, n, true);
 }
 
+long adsb_decode_device(adsb_decoder *d, const void *device_samples, size_t n, const adsb_frame **frames)
+{
+    if (!d || !frames)
+        return -1;
+    if (adsb_reset(d) != 0 || push_device_impl(d, device_samples, n, true) != 0)
+        return -1;
+    return (long)d->res.take(frames);
+}
+
 int adsb_finish(adsb_decoder *d)
 {
     if (!d)
@@ -1824,6 +1833,8 @@ int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64
     head->status = 1;
     if (d->cfg.collect_stats)
         return d->fail("adsb_scan_shard_resolved: statistics of a sharded stream go through adsb_scan_shard");
+    if (d->n_samples != 0 || d->res.pending() != 0) // (it runs this handle's own resolver: a stream in progress would be lost)
+        return d->fail("adsb_scan_shard_resolved: the handle holds a stream (adsb_reset it, or use a handle of its own)");
     if (first_sample % 8 || (uintptr_t)device_samples % 16)
         return d->fail("adsb_scan_shard_resolved: buffer must start at a multiple of 8 samples, 16-byte aligned");
     if (g_begin % 28)

@@ -6,7 +6,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 --mode stream (default).  A "step" is one full pass of the hot path over one synthetic
-capture that is already resident in HBM: adsb_reset -> adsb_push_device_final (fused scan
+capture that is already resident in HBM: adsb_decode_device = adsb_reset -> adsb_push_device_final (fused scan
 kernel over every preamble offset, record gather, greedy resolution, end-of-file rule)
 -> adsb_take (frames in reference order, in place).  Workload = BASELINE.json configs[1]:
 256 Mi uint16 samples @ 20 MS/s, sparse frames (~1 k frames/s, DF17 with some DF11),
@@ -614,9 +614,8 @@ def main():
 
     def step(i=0):
         p, m = ptrs[i % len(ptrs)]
-        dec.reset()
-        dec.push_device_final(p, m)  # == push_device + finish, in one pass
-        return dec.take_raw()  # adsb_take: the frames where the library queued them; converted after timing
+        return dec.decode_device_raw(p, m)  # adsb_decode_device == adsb_reset + adsb_push_device_final + adsb_take, one call;
+        #                                     the frames stay where the library queued them and are converted after timing
 
     # ---- cold figure: the first steps after an idle period, no pre-roll (a one-shot `adsbdec -f` user lives here)
     value_cold = None
@@ -683,6 +682,10 @@ def main():
     parity = None
     if not args.no_cpu_baseline:
         from oracle import oracle as O
+        if world > 1:        # one rank (re)builds the checker's shared object, the others load it afterwards
+            if rank == 0:
+                O.build()
+            dist.barrier()
         ok, why = True, ""
         try:
             first = 0
@@ -716,9 +719,7 @@ def main():
 
             def sstep(i=0):
                 p, m = ptrs[i % len(ptrs)]
-                ds.reset()
-                ds.push_device_final(p, m)
-                return ds.take_raw()
+                return ds.decode_device_raw(p, m)
             preroll(sstep, args.preroll_ms)
             torch.cuda.synchronize()
             s0 = ds.profile()
@@ -745,9 +746,7 @@ def main():
             dd = capi.Decoder(df18=True, device=local_rank, profile=True)
 
             def dstep(_i=0):
-                dd.reset()
-                dd.push_device_final(xd.data_ptr(), xd.numel())
-                return dd.take_raw()
+                return dd.decode_device_raw(xd.data_ptr(), xd.numel())
             preroll(dstep, args.preroll_ms)
             torch.cuda.synchronize()
             q0 = dd.profile()

@@ -165,6 +165,10 @@ int adsb_push_device(adsb_decoder *d, const void *device_samples, size_t n);
  * resident in HBM. */
 int adsb_push_device_final(adsb_decoder *d, const void *device_samples, size_t n);
 
+/* The whole of `adsbdec -f` for ONE capture that is resident in HBM, in one call: adsb_reset + adsb_push_device_final +
+ * adsb_take.  Returns the number of frames (*frames as adsb_take), or -1. */
+long adsb_decode_device(adsb_decoder *d, const void *device_samples, size_t n, const adsb_frame **frames);
+
 /* Page-locked host buffers for adsb_push(): the counterpart of fileInput's
  * malloc'd iqbuff (air.c:230).  read() straight into one and the push is a single
  * DMA; ordinary malloc'd memory works too, through the driver's bounce buffers. */
@@ -271,7 +275,8 @@ typedef struct adsb_shard_fix { /* the stitcher's verdict for one shard; its fin
 
 /* Scan the owned offsets of a device-resident shard (same buffer rules as adsb_scan_shard) and resolve them on the
  * fly.  frames / head_cands receive at most frame_cap / head_cap entries; -2 if a capacity was too small (head->n_frames
- * / n_head say what is needed).  collect_stats must be off (statistics of a sharded stream go through adsb_scan_shard). */
+ * / n_head say what is needed).  collect_stats must be off (statistics of a sharded stream go through adsb_scan_shard), and
+ * the handle must not hold a stream of its own (fresh or adsb_reset): the call runs the handle's resolver. */
 int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n,
                              uint64_t g_begin, uint64_t g_end, adsb_shard_head *head, adsb_frame *frames,
                              size_t frame_cap, adsb_candidate *head_cands, size_t head_cap);

@@ -307,6 +307,19 @@ def test_accepted_frame_log_regrows(capi, oracle, torch_cuda, monkeypatch):
         d.close()
 
 
+def test_decode_device_is_reset_push_final_take(capi, oracle, dec_factory, torch_cuda):
+    """adsb_decode_device: one call per device-resident capture, several captures on one handle (statistics too)."""
+    from oracle import gen_signal as G
+    d = dec_factory(df18=True, collect_stats=True)
+    for seed, n in ((11, 1 << 21), (12, (1 << 20) + 6), (13, 90_000), (14, 3 << 20)):
+        x, _ = G.dense_capture(n, seed=seed, sigma=30.0, n_frames=n // 5000, amp=(200, 1800))
+        want, wstats = oracle.decode(x, df18=True)
+        t = _dev(torch_cuda, x)
+        p, k = d.decode_device_raw(t.data_ptr(), t.numel())
+        assert records(capi._frames_to_dicts(p, k)) == records(want)
+        assert d.stats() == wstats and d.drain() == []
+
+
 def test_stream_of_2_to_32_samples_is_refused(capi, dec_factory, torch_cuda):
     """The reference's sample counter is a uint32_t (air.c:34): at 2^32 samples its ring phase jumps
     and no parity is defined, so the library refuses such a stream -- loudly, before it touches the buffer."""
