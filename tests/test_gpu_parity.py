@@ -846,19 +846,22 @@ def _bench_line(extra, timeout=900):
     return json.loads(lines[0])
 
 
-def test_two_rank_sharded_stream_with_the_hip_kernel():
-    """BASELINE configs[4] plumbing with the HIP kernel in MORE THAN ONE PROCESS: two ranks
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_two_rank_sharded_stream_with_the_hip_kernel(ranks):
+    """BASELINE configs[4] plumbing with the HIP kernel in MORE THAN ONE PROCESS: two (three) ranks
     (both on this GPU: --one-device-test, gloo) each scan their halo'd shard of one stream,
     resolve it speculatively, and rank 0 stitches the seams; bench.py's own gate then compares
     with the single-GPU decode of the whole stream.  (tests/test_distributed_cpu.py covers the
     same exchange on CPU.)"""
-    line = _bench_line(["--gpus", "2", "--mode", "shard", "--one-device-test", "--samples", str(64 << 20), "--steps", "3",
+    line = _bench_line(["--gpus", str(ranks), "--mode", "shard", "--one-device-test", "--samples", str(64 << 20), "--steps", "3",
                         "--warmup", "1", "--preroll-ms", "0"])
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["n_gpus"] == ranks and line["scaling"] == "strong"
     assert line["config"]["parity"].startswith("equal to the single-GPU decode")
     assert line["config"]["frames_decoded"] > 3000
     assert line["config"]["shard_path"] == "resolved" and line["config"]["fallback_steps"] == 0
     assert line["config"]["rank0_serial_us"] is not None
+    if ranks != 2:
+        return
     # the checker path (every candidate gathered to one resolver) must give the same
     line = _bench_line(["--gpus", "2", "--mode", "shard", "--shard-path", "gather", "--one-device-test", "--samples", str(32 << 20),
                         "--steps", "2", "--warmup", "1", "--preroll-ms", "0"])
