@@ -45,6 +45,12 @@
 //  as one write-through store of adjacent lanes into the host's hand-off stream
 //  (scan_kernel.h), or -- fallbacks -- through the launch-wide loose list.
 //
+//  Two kernels share stage_a() and stage_b<>(): scan_kernel, the one that ships -- a workgroup of four waves per tile, Stage A,
+//  a barrier, Stage B between barriers -- and scan_pipe_kernel (ScanArgs::pipe, ADSB_PIPE=1), round 3's experiment:
+//  persistent five-wave workgroups in which a wave of its own runs Stage B of tile t while the other four run Stage A of
+//  tile t + 1.  It is bit-identical and 45 % slower (Stage B is a latency chain that one wave cannot run as fast as Stage A
+//  feeds it: DESIGN.md section 4, profiles/r3_ab_runs.txt); every -m gpu test runs with both.
+//
 //  A workgroup owns owned_runs(K) = 252 K - 44 runs and computes 252 K (+1): the halo
 //  (the 1196-sample reach of a long frame) costs 44 runs of planes per tile (2 % at
 //  K = 8) instead of 1204 float samples of LDS.
