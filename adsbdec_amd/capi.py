@@ -101,6 +101,9 @@ SYMBOLS = {
     "adsb_scan_shard_resolved": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64, C.c_uint64,
                                            C.POINTER(ShardHead), C.POINTER(Frame), C.c_size_t, C.POINTER(Candidate),
                                            C.c_size_t]),
+    "adsb_scan_shard_resolved_walk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64,
+                                                C.POINTER(ShardHead), C.POINTER(Frame), C.c_size_t, C.POINTER(Candidate),
+                                                C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t]),
     "adsb_stitch_shards": (C.c_int, [C.POINTER(ShardPart), C.c_int, C.c_uint64, C.POINTER(ShardFix), C.POINTER(Frame),
                                      C.c_size_t, C.POINTER(C.c_size_t)]),
     "adsb_stitch_shards_ex": (C.c_int, [C.POINTER(ShardPart), C.c_int, C.c_uint64, C.POINTER(ShardFix), C.POINTER(Frame),
@@ -108,6 +111,8 @@ SYMBOLS = {
     "adsb_shard_walk": (C.c_size_t, [C.POINTER(ShardHead), C.POINTER(Frame), C.c_uint64, C.POINTER(C.c_uint64), C.c_size_t]),
     "adsb_shard_apply_fix": (None, [C.POINTER(Frame), C.c_size_t, C.c_int64]),
     "adsb_resolver_start_chain": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "adsb_resolver_start_walk": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_size_t]),
+    "adsb_resolver_walk_result": (C.c_size_t, [C.c_void_p, C.POINTER(C.c_int)]),
     "adsb_resolver_head": (C.c_long, [C.c_void_p, C.POINTER(Candidate), C.c_size_t]),
     "adsb_resolver_skipped": (C.c_uint64, [C.c_void_p]),
     "adsb_plan_shards": (C.c_int, [C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),

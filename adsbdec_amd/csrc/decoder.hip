@@ -1827,6 +1827,15 @@ int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64
                              uint64_t g_end, adsb_shard_head *head, adsb_frame *frames, size_t frame_cap,
                              adsb_candidate *head_cands, size_t head_cap)
 {
+    return adsb_scan_shard_resolved_walk(d, device_samples, first_sample, n, g_begin, g_end, 0, head, frames, frame_cap, head_cands,
+                                         head_cap, nullptr, 0);
+}
+
+int adsb_scan_shard_resolved_walk(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n, uint64_t g_begin,
+                                  uint64_t g_end, uint64_t total_samples, adsb_shard_head *head, adsb_frame *frames,
+                                  size_t frame_cap, adsb_candidate *head_cands, size_t head_cap, uint64_t *bases,
+                                  size_t bases_cap)
+{
     if (!d || !device_samples || !head || (frame_cap && !frames) || (head_cap && !head_cands))
         return -1;
     std::memset(head, 0, sizeof *head);
@@ -1857,6 +1866,8 @@ int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64
     const uint64_t head_end = std::min<uint64_t>(g_end, g_begin + head_span);
     d->sink = ScanSink{};
     d->res.start_chain(g_begin, head_end, &hv);
+    if (bases && bases_cap) // the shard's own walk of the deqframe calls, advanced beside the chain while the kernel runs
+        d->res.start_walk(g_begin, g_end, total_samples, bases, bases_cap);
     d->alt_next = true;
     int rc = scan_submit(d, static_cast<const uint16_t *>(device_samples), first_sample, n, g_begin, g_end);
     d->alt_next = false;
@@ -1872,6 +1883,10 @@ int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64
     head->n_head = hv.size();
     head->head_end = head_end;
     head->skipped = d->res.skipped();
+    if (bases && bases_cap && rc == 0) {
+        head->n_bases = d->res.walk_bases() <= bases_cap ? d->res.walk_bases() : 0;
+        head->walk_final = d->res.walk_final() ? 1 : 0;
+    }
     if (rc == 0 && nf <= frame_cap && hv.size() <= head_cap) {
         if (nf)
             std::memcpy(frames, fp, nf * sizeof(adsb_frame));
@@ -1986,6 +2001,23 @@ int adsb_resolver_start_chain(adsb_resolver *r, uint64_t g_begin, uint64_t head_
     r->head.clear();
     r->r.start_chain(g_begin, head_end, &r->head);
     return 0;
+}
+
+int adsb_resolver_start_walk(adsb_resolver *r, uint64_t g_begin, uint64_t g_end, uint64_t total_samples, uint64_t *bases, size_t cap)
+{
+    if (!r || (cap && !bases))
+        return -1;
+    r->r.start_walk(g_begin, g_end, total_samples, bases, cap);
+    return 0;
+}
+
+size_t adsb_resolver_walk_result(const adsb_resolver *r, int *final)
+{
+    if (!r)
+        return 0;
+    if (final)
+        *final = r->r.walk_final() ? 1 : 0;
+    return r->r.walk_bases();
 }
 
 long adsb_resolver_head(adsb_resolver *r, adsb_candidate *out, size_t cap)

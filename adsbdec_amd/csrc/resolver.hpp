@@ -30,6 +30,7 @@ public:
     {
         base_ = 0;
         chain_ = false;
+        w_on_ = false;
         head_end_ = 0;
         head_ = nullptr;
         skipped_ = 0;
@@ -134,6 +135,25 @@ public:
         head_ = head;
     }
     uint64_t skipped() const { return skipped_; }
+    // ... and, beside the chain, the shard's own walk of the deqframe CALLS (air.c:94-99; stitch.hpp walk_shard_calls) from
+    // the guessed entry base g_begin, advanced as the frames come in -- a call can be replayed once the chain has passed its
+    // limit -- so that it costs the rank nothing behind its scan.  bases[0 .. min(n, cap)) as walk_shard_calls leaves them.
+    void start_walk(uint64_t g_begin, uint64_t g_end, uint64_t total_samples, uint64_t *bases, size_t cap)
+    {
+        w_on_ = true;
+        w_base_ = g_begin;
+        w_end_ = g_end;
+        w_mref_ = 2 * ((total_samples + 3) / 4);
+        w_bases_ = bases;
+        w_cap_ = cap;
+        w_n_ = w_k_ = 0;
+        w_last_end_ = 0;
+        w_final_ = w_stop_ = false;
+        walk_record();
+    }
+    size_t walk_bases() const { return w_n_; }
+    bool walk_final() const { return w_final_; }
+    bool walk_complete() const { return w_stop_; }
     // a device batch about to be consumed: copy its head candidates (ascending; batches arrive in ascending g)
     void capture_head(const uint32_t *recs, const uint32_t *order, size_t n, int words, int off, uint64_t g_base)
     {
@@ -169,6 +189,8 @@ public:
         if (chain_) {
             if (g_complete > base_)
                 run_call(g_complete);
+            if (w_on_)
+                walk_advance();
             return;
         }
         for (;;) {
@@ -251,6 +273,36 @@ private:
         case 11: return 0;
         case 17: return 1;
         default: return 2;
+        }
+    }
+
+    void walk_record()
+    {
+        if (w_n_ < w_cap_)
+            w_bases_[w_n_] = w_base_;
+        w_n_++;
+    }
+    void walk_advance()
+    {
+        while (!w_stop_) {
+            const uint64_t fire = w_base_ + ADSB_APBUFFSZ + (w_base_ & 1); // air.c:94
+            if (fire > w_mref_) {
+                w_final_ = w_stop_ = true; // the stream ends before this call fires
+                break;
+            }
+            const uint64_t limit = fire - ADSB_DECOFFSET; // demod.c:89
+            if (limit > w_end_) {
+                w_stop_ = true; // the next shard's call
+                break;
+            }
+            if (limit > base_)
+                break; // the chain has not passed the limit yet: a frame below it may still be accepted
+            while (w_k_ < out_.size() && out_[w_k_].g < limit) {
+                w_last_end_ = out_[w_k_].g + 80 + 80 * (uint64_t)out_[w_k_].len;
+                w_k_++;
+            }
+            w_base_ = w_last_end_ > limit ? w_last_end_ : limit;
+            walk_record();
         }
     }
 
@@ -406,6 +458,10 @@ private:
         base_ = idx; // deqframe's return value; air.c:96-98 carries the rest
     }
 
+    bool w_on_ = false, w_final_ = false, w_stop_ = false; // the call walk beside the chain (start_walk)
+    uint64_t w_base_ = 0, w_end_ = 0, w_mref_ = 0, w_last_end_ = 0;
+    uint64_t *w_bases_ = nullptr;
+    size_t w_cap_ = 0, w_n_ = 0, w_k_ = 0;
     bool chain_ = false;   // chain mode (start_chain)
     uint64_t head_end_ = 0;
     std::vector<adsb_candidate> *head_ = nullptr;

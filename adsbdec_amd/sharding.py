@@ -420,8 +420,9 @@ class ResolvedShard:
         b, i = self.board, self.rank
         hd = b.head(i)
         try:
-            rc = self._L.adsb_scan_shard_resolved(self.dec._h, device_ptr, self.first_sample, self.n_samples, self.g_begin,
-                                                  self.g_end, C.byref(hd), b.frames(i), b.frame_cap, b.heads(i), b.head_cap)
+            rc = self._L.adsb_scan_shard_resolved_walk(self.dec._h, device_ptr, self.first_sample, self.n_samples, self.g_begin,
+                                                       self.g_end, self.total, C.byref(hd), b.frames(i), b.frame_cap, b.heads(i),
+                                                       b.head_cap, b.bases(i) if b.bases_cap else None, b.bases_cap)
             why = "" if rc == 0 else (
                 f"{hd.n_frames} frames / {hd.n_head} head candidates exceed the board's capacity ({b.frame_cap} / {b.head_cap})"
                 if rc == -2 else (self._L.adsb_last_error(self.dec._h) or b"").decode())
@@ -430,7 +431,6 @@ class ResolvedShard:
         if rc != 0:
             hd.status = 1
             raise ShardError(f"rank {self.rank}: adsb_scan_shard_resolved failed: {why}")
-        self._walk_calls()
 
     def _walk_calls(self):
         """This shard's own walk of the deqframe call chain (the stitcher jumps onto it): in parallel on every rank."""
@@ -559,11 +559,11 @@ def decode_sharded(dec, device_ptr: int, total_samples: int, n_shards: int, fram
     board = ShardBoard(bytearray(ShardBoard.size(n_shards, fc, head_cap, bases_cap=bc)), n_shards, fc, head_cap, bases_cap=bc)
     for i, p in enumerate(plan):
         hd = board.head(i)
-        rc = L.adsb_scan_shard_resolved(dec._h, device_ptr + 2 * p["first_sample"], p["first_sample"], p["n_samples"], p["g_begin"],
-                                        p["g_end"], C.byref(hd), board.frames(i), fc, board.heads(i), head_cap)
+        rc = L.adsb_scan_shard_resolved_walk(dec._h, device_ptr + 2 * p["first_sample"], p["first_sample"], p["n_samples"], p["g_begin"],
+                                             p["g_end"], total_samples, C.byref(hd), board.frames(i), fc, board.heads(i), head_cap,
+                                             board.bases(i), bc)
         if rc != 0:
             raise ShardError(f"shard {i}: adsb_scan_shard_resolved failed ({rc}): " + (L.adsb_last_error(dec._h) or b"").decode())
-        L.adsb_shard_walk(C.byref(hd), board.frames(i), total_samples, board.bases(i), bc)
     parts = board.parts()
     n_new = C.c_size_t(0)
     ws = (C.c_uint64 * 2)()

@@ -280,6 +280,12 @@ typedef struct adsb_shard_fix { /* the stitcher's verdict for one shard; its fin
 int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n,
                              uint64_t g_begin, uint64_t g_end, adsb_shard_head *head, adsb_frame *frames,
                              size_t frame_cap, adsb_candidate *head_cands, size_t head_cap);
+/* The same, and the shard's walk of the deqframe call chain (adsb_shard_walk) done on the way, while the kernel runs:
+ * total_samples is the whole stream's length; bases / bases_cap as adsb_shard_walk. */
+int adsb_scan_shard_resolved_walk(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n,
+                                  uint64_t g_begin, uint64_t g_end, uint64_t total_samples, adsb_shard_head *head,
+                                  adsb_frame *frames, size_t frame_cap, adsb_candidate *head_cands, size_t head_cap,
+                                  uint64_t *bases, size_t bases_cap);
 /* A shard's own walk of the deqframe call chain over its speculative frames (each rank, in parallel, after its scan):
  * fills bases[0 .. min(cap, n)) and head->n_bases / walk_final; returns n (> cap: too small, n_bases is left 0). */
 size_t adsb_shard_walk(adsb_shard_head *head, const adsb_frame *frames, uint64_t total_samples, uint64_t *bases, size_t cap);
@@ -296,6 +302,11 @@ void adsb_shard_apply_fix(adsb_frame *frames, size_t n, int64_t ts_sub);
 /* The host-side resolver in the same chain mode (tests; hosts that hold candidates themselves): call before the first
  * feed.  adsb_resolver_head copies the head candidates out; adsb_resolver_skipped is adsb_shard_head.skipped. */
 int adsb_resolver_start_chain(adsb_resolver *r, uint64_t g_begin, uint64_t head_end);
+/* ... with the shard's walk of the deqframe calls advanced beside it (what adsb_scan_shard_resolved_walk does): call right
+ * after adsb_resolver_start_chain; bases must stay valid until the last adsb_resolver_advance.  adsb_resolver_walk_result:
+ * the number of bases (as adsb_shard_walk returns it) and *final. */
+int adsb_resolver_start_walk(adsb_resolver *r, uint64_t g_begin, uint64_t g_end, uint64_t total_samples, uint64_t *bases, size_t cap);
+size_t adsb_resolver_walk_result(const adsb_resolver *r, int *final);
 long adsb_resolver_head(adsb_resolver *r, adsb_candidate *out, size_t cap);
 uint64_t adsb_resolver_skipped(const adsb_resolver *r);
 

@@ -356,3 +356,42 @@ _JUMPS = []
 
 def test_stitcher_jumps_happened():
     assert sum(_JUMPS) > 0, "no run of the previous test ever met a shard's own walk: the jump path is untested"
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_incremental_call_walk_equals_the_walk_over_the_finished_shard(capi, seed):
+    """adsb_scan_shard_resolved_walk advances the shard's walk of the deqframe calls beside the greedy chain, as the frames come
+    in (a call is replayed once the chain has passed its limit).  Whatever the batching of the records, the bases must be the
+    ones adsb_shard_walk finds on the finished shard."""
+    import ctypes as C
+    L = capi.load()
+    rng = np.random.default_rng(seed)
+    total = (24 << 20) + 4 * int(rng.integers(0, 50_000))
+    n_off = 2 * (total // 4) - 1195
+    cands = _synthetic_candidates(rng, n_off, 7000)
+    for g_begin, g_end in ((0, n_off), (28 * 100_000, 28 * 300_000), (28 * 200_001, n_off)):
+        mine = [c for c in cands if g_begin <= c[0] < g_end]
+        cap = (g_end - g_begin) // 39780 + 8
+        inc = (C.c_uint64 * cap)()
+        r = capi.Resolver()
+        assert L.adsb_resolver_start_chain(r._h, g_begin, min(g_end, g_begin + 16384)) == 0
+        assert L.adsb_resolver_start_walk(r._h, g_begin, g_end, total, inc, cap) == 0
+        k = 0
+        while k < len(mine):       # records arrive in batches, each followed by an advance to somewhere behind the batch
+            step = int(rng.integers(1, 400))
+            batch = mine[k:k + step]
+            k += step
+            r.feed(batch)
+            # everything below g_complete must have been fed: anywhere up to the next record still to come
+            r.advance(0, max(g_begin, mine[k][0] - int(rng.integers(0, 3)) * int(rng.integers(0, 20_000))) if k < len(mine) else g_end)
+        r.advance(0, g_end)
+        fin = C.c_int(0)
+        n_inc = int(L.adsb_resolver_walk_result(r._h, C.byref(fin)))
+        frames = (capi.Frame * max(1, len(mine)))()
+        nf = int(L.adsb_resolver_drain(r._h, frames, len(frames)))
+        hd = capi.ShardHead(g_begin, g_end, nf, 0, 0, 0, 0, 0, 0, 0)
+        ref = (C.c_uint64 * cap)()
+        n_ref = int(L.adsb_shard_walk(C.byref(hd), frames, total, ref, cap))
+        assert n_inc == n_ref > 100 and list(inc[:n_inc]) == list(ref[:n_ref])
+        assert fin.value == int(hd.walk_final) and (fin.value == 1) == (g_end == n_off)
+        r.close()
