@@ -54,7 +54,7 @@ def shards():
     sh2, st2, s2g = J("r3_bench_shard_N2_one_device_plumbing.json"), J("r3_bench_stream_N2_one_device_plumbing.json"), J("r3_bench_stream_2Gi.json")
     return f"""| run | ms per step | Msamples/s | rank-0 serial part | note |
 |---|---|---|---|---|
-| N = 1, 2 Gi samples, resolved path | {sh['ms_per_step']:.3f} | {sh['value']:.0f} | {sh['config']['rank0_serial_us']} µs | {sh['config']['frames_decoded']} frames equal to the real reference chain's; the shard's own walk starts at the stream's true first base, so the stitcher jumps over all {sh['config']['deqframe_calls_jumped']} calls; the walk itself (≈ 0.19 ms for 27 k calls and 107 k frames) is in the rank's parallel part |
+| N = 1, 2 Gi samples, resolved path | {sh['ms_per_step']:.3f} | {sh['value']:.0f} | {sh['config']['rank0_serial_us']} µs | {sh['config']['frames_decoded']} frames equal to the real reference chain's; the shard's own walk starts at the stream's true first base, so the stitcher jumps over all {sh['config']['deqframe_calls_jumped']} calls; the walk itself (27 k calls over 107 k frames, ≈ 0.19 ms if done afterwards) is advanced beside the greedy chain while the kernel runs (`Resolver::start_walk`) |
 | N = 1, 2 Gi samples, checker path (every candidate to one resolver) | {shg['ms_per_step']:.3f} | {shg['value']:.0f} | the whole resolve | round 2's path: 2.40 ms |
 | N = 1, 2 Gi samples, plain stream path (`bench.py --samples 2 Gi`) | {s2g['ms_per_step']:.3f} | {s2g['value']:.0f} | — | eight launches on alternating streams |
 | N = 2 on ONE GPU, 512 Mi samples, resolved path | {sh2['ms_per_step']:.3f} | {sh2['value']:.0f} | {sh2['config']['rank0_serial_us']} µs | shard 0 jumped, shard 1's {sh2['config']['deqframe_calls_walked_by_rank0']} calls walked by rank 0 (9 ns per call): the two chains never met |

@@ -77,7 +77,9 @@ def run(seconds: float, seed: int = 1, log=print):
     pinned = capi.PinnedBuffers(2, 1 << 20)
     bufs = pinned.__enter__()
     first_seed = seed
+    verbose = os.environ.get("FUZZ_VERBOSE") is not None
     while time.time() - t0 < seconds:
+        t_cap = time.time()
         rng = np.random.default_rng(seed)
         x = make_capture(rng)
         df18, stats, fix = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
@@ -188,6 +190,8 @@ def run(seconds: float, seed: int = 1, log=print):
         it += 1
         seed += 1
         frames_total += len(want)
+        if verbose:
+            log(f"  {time.time() - t_cap:7.2f} s  {what}")
     decs_all = list(decs.values())
     summary = dict(captures=it, frames=frames_total, first_seed=first_seed, last_seed=seed - 1,
                    seconds=round(time.time() - t0, 1), mismatches=0,
