@@ -10,7 +10,7 @@ CSRC     := adsbdec_amd/csrc
 LIBDIR   := adsbdec_amd/lib
 LIB      := $(LIBDIR)/libadsbdec_amd.so
 CLI      := $(LIBDIR)/adsbdec_amd_cli
-HDRS     := $(CSRC)/scan_kernel.h $(CSRC)/resolver.hpp include/adsbdec_amd.h
+HDRS     := $(CSRC)/scan_kernel.h $(CSRC)/resolver.hpp $(CSRC)/stitch.hpp include/adsbdec_amd.h
 
 all: $(LIB) $(CLI)
 

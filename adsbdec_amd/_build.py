@@ -22,7 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 HIP_SOURCES = ["scan_kernel.hip", "decoder.hip"]
 C_SOURCES = ["format.c"]
-HEADERS = ["scan_kernel.h", "resolver.hpp", os.path.join(ROOT, "include", "adsbdec_amd.h")]
+HEADERS = ["scan_kernel.h", "resolver.hpp", "stitch.hpp", os.path.join(ROOT, "include", "adsbdec_amd.h")]
 # -ffp-contract=off: the reference arithmetic is binary32 multiply THEN add
 # (SURVEY Q3); a fused multiply-add would change rounding.
 # -amdgpu-atomic-optimizer-strategy=None: the compiler otherwise turns the survivor queue's per-lane LDS
