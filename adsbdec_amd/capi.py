@@ -56,7 +56,8 @@ class Config(C.Structure):
                 ("collect_stats", C.c_int32), ("profile", C.c_int32), ("debug_queue_cap", C.c_int32),
                 ("stage_samples", C.c_uint64), ("stream", C.c_void_p), ("all_candidates", C.c_int32),
                 ("fix_1bit", C.c_int32), ("debug_cand_cap", C.c_int32), ("debug_try_cap", C.c_int32),
-                ("debug_clist_cap", C.c_int32), ("push_overlap", C.c_int32)]
+                ("debug_clist_cap", C.c_int32), ("push_overlap", C.c_int32),
+                ("host_threads", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -173,7 +174,8 @@ class Decoder:
     def __init__(self, df18: bool = False, device: int = -1, collect_stats: bool = False,
                  profile: bool = False, stage_samples: int = 0, stream: int | None = None,
                  debug_queue_cap: int = 0, all_candidates: bool = False, fix_1bit: bool = False,
-                 debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0, push_overlap: bool = False):
+                 debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0, push_overlap: bool = False,
+                 host_threads: int = 0):
         L = load()
         cfg = Config()
         L.adsb_config_default(C.byref(cfg))
@@ -190,6 +192,7 @@ class Decoder:
         cfg.debug_try_cap = debug_try_cap
         cfg.debug_clist_cap = debug_clist_cap
         cfg.push_overlap = int(push_overlap)
+        cfg.host_threads = int(host_threads)
         self._L = L
         self._fix = bool(fix_1bit)
         self._h = L.adsb_create(C.byref(cfg))

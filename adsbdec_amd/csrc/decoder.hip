@@ -27,15 +27,20 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <emmintrin.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include "../../include/adsbdec_amd.h"
 #include "resolver.hpp"
@@ -112,6 +117,10 @@ struct ScanSink { // where collected records go: a caller's vectors, or (null) t
     std::vector<uint64_t> *tries = nullptr;
 };
 
+namespace {
+struct StreamReader;
+}
+
 struct adsb_decoder {
     adsb_config cfg{};
     int device = 0;
@@ -151,6 +160,8 @@ struct adsb_decoder {
     adsb_profile prof{};
     adsb::Resolver res;
     std::vector<uint32_t> order, scratch_a, scratch_b, gather, tile_start, tile_count;
+    StreamReader *reader = nullptr;    // cfg.host_threads = 2: the thread that reads the hand-off stream (slot_collect_streaming)
+    uint32_t reader_min_tiles = 1024; // launches below this many tiles are collected by the calling thread alone
     bool no_streaming = false; // ADSB_NO_STREAMING=1: always collect after completion
     int dbg_async = 0;         // ADSB_DEBUG_ASYNC (diagnosis, tools/async_race.py): 1 = wait for every async copy,
                                // 2 = copies on the scan stream, 4 = tail copies not ordered before the next copy (the old race)
@@ -510,28 +521,60 @@ void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uin
 // Returns 1 if a tile reported records on the loose list (or the stream is full): the
 // caller then finishes the launch through the collect-after-completion path, from tile
 // *resume_tile on.
-int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
-{
+// The reading side of the streaming collect: where the host stands in a launch's hand-off stream.
+struct HandCursor {
     using clk = std::chrono::steady_clock;
-    const uint32_t gen = s.args.gen;
-    const uint32_t cap = s.args.hand_cap;
+    const ScanSlot &s;
+    uint32_t *t_start, *t_count; // per tile: granule index of its first record, and its record count (~0u: not in yet)
+    const uint32_t gen, cap;
+    uint32_t pos = 0;      // granules of the stream consumed
+    uint32_t frontier = 0; // every tile below is in
+    uint32_t tile = 0, nf = 0; // the marker tile_in() accepted last
     double wait_ms = 0;
-    const auto t_begin = clk::now();
-    auto t_last_wait = t_begin;
-    // spin until `ready()`; gives up (with an error) once the kernel has long finished
-    static const int kPollPause = [] {
-        const char *e = getenv("ADSB_POLL_PAUSE");
-        const int v = e ? atoi(e) : -1;
-        return v >= 0 ? v : 4; // measured: 0..256 make no difference to the kernel or the step
-    }();
-    auto wait_for = [&](auto &&ready) -> bool {
-        if (ready())
+    clk::time_point t_last_wait;
+
+    HandCursor(const ScanSlot &slot, uint32_t *ts, uint32_t *tc)
+        : s(slot), t_start(ts), t_count(tc), gen(slot.args.gen), cap(slot.args.hand_cap), t_last_wait(clk::now())
+    {
+    }
+    // marker {tile, n | flags, check}: valid once it and the XOR of the 2n granules
+    // behind it agree (16-byte loads; the bytes are re-read on every poll)
+    bool tile_in()
+    {
+        const __m128i *gp = reinterpret_cast<const __m128i *>(s.hand) + pos;
+        std::atomic_signal_fence(std::memory_order_seq_cst); // compiler: re-read the bytes on every poll
+        const __m128i mk = _mm_load_si128(gp);
+        alignas(16) uint32_t mw[4], a[4];
+        _mm_store_si128(reinterpret_cast<__m128i *>(mw), mk);
+        tile = mw[0], nf = mw[1];
+        const uint32_t n = nf & 0xFFFFu;
+        const bool fits = !(nf & adsb::kMarkNoFit);
+        if (tile >= s.ntiles || (fits && (uint64_t)pos + 1 + 2ull * n > cap))
+            return false; // not a marker of this launch (yet)
+        __m128i acc = _mm_setzero_si128();
+        if (fits)
+            for (uint32_t k = 1; k <= 2 * n; k++)
+                acc = _mm_xor_si128(acc, _mm_load_si128(gp + k));
+        _mm_store_si128(reinterpret_cast<__m128i *>(a), acc);
+        uint32_t lo, hi;
+        adsb::marker_check(tile, nf, gen, a[0], a[1], a[2], a[3], lo, hi);
+        return mw[2] == lo && mw[3] == hi;
+    }
+    // spin until tile_in(); gives up (false) once the kernel has long finished
+    bool wait_tile()
+    {
+        static const int kPollPause = [] {
+            const char *e = getenv("ADSB_POLL_PAUSE");
+            const int v = e ? atoi(e) : -1;
+            return v >= 0 ? v : 4; // measured: 0..256 make no difference to the kernel or the step
+        }();
+        if (tile_in())
             return true;
         const auto t_w = clk::now();
         bool ok = false;
         uint64_t after_done = 0;
         for (uint64_t spins = 1;; spins++) {
-            if (ready()) {
+            if (tile_in()) {
                 ok = true;
                 break;
             }
@@ -548,7 +591,191 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
         t_last_wait = clk::now();
         wait_ms += std::chrono::duration<double, std::milli>(t_last_wait - t_w).count();
         return ok;
+    }
+    // Take the tile whose marker tile_in() just accepted.  0: taken; 1: it (or the stream) says "finish after
+    // completion"; -1: the stream is corrupt.
+    int take()
+    {
+        const uint32_t n = nf & 0xFFFFu;
+        if (t_count[tile] != ~0u)
+            return -1;
+        if (nf & (adsb::kMarkOver | adsb::kMarkNoFit))
+            return 1;
+        t_start[tile] = pos + 1;
+        t_count[tile] = n;
+        pos += std::max(adsb::marker_granules(nf), adsb::stream_granules(n)); // what the tile reserved (it may have kept fewer records than it reserved for)
+        while (frontier < s.ntiles && t_count[frontier] != ~0u)
+            frontier++;
+        return 0;
+    }
+};
+
+// A decoder's second host thread (cfg.host_threads = 2): it reads and checks the hand-off stream of the launch being
+// collected and publishes how far the stream is complete, while the calling thread resolves behind it.  One thread
+// doing both has ~125 us of work per 256 Mi-sample launch inside the ~105 us between the first tile's end and the
+// last one's, and ends 15-20 us behind the kernel; split, neither side is the bottleneck.  The thread spins for a
+// short while after a job (so that back-to-back launches find it awake), then sleeps.
+struct StreamReader {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<bool> sleeping{false}, quit{false};
+    std::atomic<uint32_t> job_seq{0};
+    int device = 0;
+    // the job (written by the caller before job_seq)
+    const ScanSlot *slot = nullptr;
+    uint32_t *t_start = nullptr, *t_count = nullptr;
+    // progress and result (written by the reader)
+    alignas(64) std::atomic<uint32_t> frontier{0};
+    alignas(64) std::atomic<uint32_t> done_seq{0};
+    int status = 0; // 0: every tile is in; 1: finish after completion; -1: stream corrupt; -2: the bytes never came
+    uint32_t pos = 0, stop_tile = 0;
+    double wait_ms = 0, busy_ms = 0;
+
+    static constexpr uint32_t kPublishEvery = 32; // tiles between two stores of `frontier` while the device is ahead
+
+    void run_job()
+    {
+        using clk = std::chrono::steady_clock;
+        const auto t0 = clk::now();
+        HandCursor cur(*slot, t_start, t_count);
+        uint32_t published = 0;
+        status = 0;
+        while (cur.frontier < slot->ntiles) {
+            if (cur.pos >= cur.cap) {
+                status = 1;
+                break;
+            }
+            if (!cur.tile_in()) {
+                if (cur.frontier != published) // the device is behind: hand over what is in before waiting
+                    frontier.store(published = cur.frontier, std::memory_order_release);
+                if (!cur.wait_tile()) {
+                    status = -2;
+                    break;
+                }
+            }
+            const int rc = cur.take();
+            if (rc != 0) {
+                status = rc;
+                break;
+            }
+            if (cur.frontier - published >= kPublishEvery)
+                frontier.store(published = cur.frontier, std::memory_order_release);
+        }
+        pos = cur.pos;
+        stop_tile = cur.tile;
+        wait_ms = cur.wait_ms;
+        busy_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count() - cur.wait_ms;
+        frontier.store(cur.frontier, std::memory_order_release);
+    }
+    void loop()
+    {
+        (void)hipSetDevice(device); // hipEventQuery in wait_tile()
+        uint32_t seen = 0;
+        for (;;) {
+            // spin for a while, then sleep
+            const auto t_idle = std::chrono::steady_clock::now();
+            for (uint32_t spins = 1; job_seq.load(std::memory_order_acquire) == seen && !quit.load(std::memory_order_relaxed); spins++) {
+                __builtin_ia32_pause();
+                if ((spins & 0xFF) == 0 && std::chrono::steady_clock::now() - t_idle > std::chrono::microseconds(kSpinUs)) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    sleeping.store(true);
+                    cv.wait(lk, [&] { return quit.load() || job_seq.load() != seen; });
+                    sleeping.store(false);
+                }
+            }
+            if (quit.load())
+                return;
+            seen = job_seq.load(std::memory_order_acquire);
+            run_job();
+            done_seq.store(seen, std::memory_order_release);
+        }
+    }
+    static constexpr int kSpinUs = 400;
+    void post(const ScanSlot &s, uint32_t *ts, uint32_t *tc)
+    {
+        slot = &s, t_start = ts, t_count = tc;
+        frontier.store(0, std::memory_order_relaxed);
+        job_seq.fetch_add(1); // seq_cst, against `sleeping`
+        if (sleeping.load()) {
+            std::lock_guard<std::mutex> lk(mu);
+            cv.notify_one();
+        }
+    }
+    void stop()
+    {
+        if (!th.joinable())
+            return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit.store(true);
+            cv.notify_one();
+        }
+        th.join();
+    }
+};
+
+// The reader thread is kept near the caller: on a core that shares the caller's L3 (the records it has checked are
+// read again by the resolver), but neither the caller's own core nor its SMT sibling.  Best effort; silent on failure.
+static void place_reader_thread(std::thread &th)
+{
+    const int cpu = sched_getcpu();
+    if (cpu < 0)
+        return;
+    auto read_list = [](const char *fmt, int c, cpu_set_t *out) {
+        char path[160], buf[1024];
+        snprintf(path, sizeof path, fmt, c);
+        FILE *f = fopen(path, "r");
+        if (!f)
+            return false;
+        const bool got = fgets(buf, sizeof buf, f) != nullptr;
+        fclose(f);
+        if (!got)
+            return false;
+        CPU_ZERO(out);
+        for (char *p = buf; *p && *p != '\n';) { // "a-b,c,d-e"
+            char *e;
+            const long a = strtol(p, &e, 10);
+            if (e == p)
+                return false;
+            long b = a;
+            if (*e == '-')
+                b = strtol(e + 1, &e, 10);
+            for (long k = a; k <= b && k < CPU_SETSIZE; k++)
+                CPU_SET((int)k, out);
+            p = (*e == ',') ? e + 1 : e;
+        }
+        return true;
     };
+    cpu_set_t l3, smt, allowed, want;
+    if (!read_list("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu, &l3) ||
+        !read_list("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu, &smt) ||
+        sched_getaffinity(0, sizeof allowed, &allowed) != 0)
+        return;
+    CPU_ZERO(&want);
+    int n = 0;
+    for (int k = 0; k < CPU_SETSIZE; k++)
+        if (CPU_ISSET(k, &l3) && CPU_ISSET(k, &allowed) && !CPU_ISSET(k, &smt))
+            CPU_SET(k, &want), n++;
+    if (n > 0)
+        (void)pthread_setaffinity_np(th.native_handle(), sizeof want, &want);
+}
+
+// Streaming collect: consume the oldest scan WHILE its kernel is still running, so
+// that resolving overlaps the scan.  The hand-off stream (scan_kernel.h) is read strictly
+// sequentially -- one prefetchable stream of device-written lines, no directory to poll:
+// a marker says which tile follows, how many records, and what their XOR must be; the
+// records are checked where they lie (16-byte loads) and later resolved in place.  Tiles
+// reserve their ranges in COMPLETION order, so a tile that finished early waits (start and
+// count noted) until every tile before it is in; the resolver is fed whenever the device
+// leaves the host nothing to read, or a group of tiles has accumulated.
+// Returns 1 if a tile reported records on the loose list (or the stream is full): the
+// caller then finishes the launch through the collect-after-completion path, from tile
+// *resume_tile on.
+int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t_begin = clk::now();
 
     static const uint32_t kGroup = [] {
         const char *e = getenv("ADSB_GROUP");
@@ -560,12 +787,12 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
     std::vector<uint32_t> &t_count = d->tile_count; // ... and its record count (~0u: not in yet)
     t_start.assign(s.ntiles, 0u);
     t_count.assign(s.ntiles, ~0u);
-    uint32_t pos = 0;       // granules of the stream consumed
-    uint32_t frontier = 0;  // every tile below is in
     uint32_t delivered = 0; // every tile below has been handed to the resolver
     bool overflowed = false;
     double dbg[3] = {0, 0, 0};
     const bool dbg_on = getenv("ADSB_DEBUG_HOST") != nullptr;
+    double wait_ms = 0;
+    auto t_last_wait = t_begin;
     auto flush = [&](uint32_t upto) { // tiles [delivered, upto): their ranges, one after the other, are sorted
         clk::time_point tp;
         if (dbg_on)
@@ -598,64 +825,70 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
                         std::chrono::duration<double, std::micro>(clk::now() - t_begin).count(), upto, nc, wait_ms * 1e3);
         }
     };
-    while (frontier < s.ntiles) {
-        if (pos >= cap) { // the stream is full: the rest of the launch is on the loose list
-            overflowed = true;
-            break;
-        }
-        // marker {tile, n | flags, check}: valid once it and the XOR of the 2n granules
-        // behind it agree (16-byte loads; the bytes are re-read on every poll)
-        const __m128i *gp = reinterpret_cast<const __m128i *>(s.hand) + pos;
-        uint32_t tile = 0, nf = 0;
-        auto tile_in = [&] {
-            std::atomic_signal_fence(std::memory_order_seq_cst); // compiler: re-read the bytes on every poll
-            const __m128i mk = _mm_load_si128(gp);
-            alignas(16) uint32_t mw[4], a[4];
-            _mm_store_si128(reinterpret_cast<__m128i *>(mw), mk);
-            tile = mw[0], nf = mw[1];
-            const uint32_t n = nf & 0xFFFFu;
-            const bool fits = !(nf & adsb::kMarkNoFit);
-            if (tile >= s.ntiles || (fits && (uint64_t)pos + 1 + 2ull * n > cap))
-                return false; // not a marker of this launch (yet)
-            __m128i acc = _mm_setzero_si128();
-            if (fits)
-                for (uint32_t k = 1; k <= 2 * n; k++)
-                    acc = _mm_xor_si128(acc, _mm_load_si128(gp + k));
-            _mm_store_si128(reinterpret_cast<__m128i *>(a), acc);
-            uint32_t lo, hi;
-            adsb::marker_check(tile, nf, gen, a[0], a[1], a[2], a[3], lo, hi);
-            return mw[2] == lo && mw[3] == hi;
-        };
-        if (!tile_in()) {
-            // the device is behind: use the time to resolve what is complete, then wait
-            if (frontier > delivered) {
-                flush(frontier);
+    // the tiles of the last resident round finish in a burst at the kernel's end: take
+    // them in small batches, so that little is left to do once the last one is in
+    constexpr uint32_t kTailTiles = 768, kTailGroup = 64;
+    if (d->reader && s.ntiles >= d->reader_min_tiles) {
+        // two threads: the reader publishes its frontier, this one resolves behind it
+        StreamReader &rd = *d->reader;
+        rd.post(s, t_start.data(), t_count.data());
+        const uint32_t seq = rd.job_seq.load(std::memory_order_relaxed);
+        for (;;) {
+            const bool fin = rd.done_seq.load(std::memory_order_acquire) == seq; // read BEFORE the frontier: a finished reader's is final
+            const uint32_t f = rd.frontier.load(std::memory_order_acquire);
+            if (f > delivered && (fin || f - delivered >= kTailGroup)) {
+                flush(f);
                 continue;
             }
-            if (!wait_for(tile_in))
-                return d->fail("scan kernel finished without publishing granule %u (tile %u of %u pending)", pos, frontier,
-                               s.ntiles);
+            if (fin)
+                break;
+            const auto t_w = clk::now();
+            while (rd.frontier.load(std::memory_order_relaxed) == f && rd.done_seq.load(std::memory_order_relaxed) != seq)
+                for (int k = 0; k < 32; k++) // poll gently: every look takes the line away from the thread that writes it
+                    __builtin_ia32_pause();
+            t_last_wait = clk::now();
+            wait_ms += std::chrono::duration<double, std::milli>(t_last_wait - t_w).count();
         }
-        const uint32_t n = nf & 0xFFFFu;
-        if (t_count[tile] != ~0u)
-            return d->fail("hand-off stream corrupt at granule %u (tile %u twice)", pos, tile);
-        if (nf & (adsb::kMarkOver | adsb::kMarkNoFit)) { // finish after completion
-            overflowed = true;
-            break;
+        if (rd.status == -1)
+            return d->fail("hand-off stream corrupt at granule %u (tile %u twice)", rd.pos, rd.stop_tile);
+        if (rd.status == -2)
+            return d->fail("scan kernel finished without publishing granule %u (tile %u of %u pending)", rd.pos, delivered,
+                           s.ntiles);
+        overflowed = rd.status == 1;
+        if (dbg_on)
+            fprintf(stderr, "stream reader thread: busy %.1f us, waits %.1f us\n", rd.busy_ms * 1e3, rd.wait_ms * 1e3);
+    } else {
+        HandCursor cur(s, t_start.data(), t_count.data());
+        while (cur.frontier < s.ntiles) {
+            if (cur.pos >= cur.cap) { // the stream is full: the rest of the launch is on the loose list
+                overflowed = true;
+                break;
+            }
+            if (!cur.tile_in()) {
+                // the device is behind: use the time to resolve what is complete, then wait
+                if (cur.frontier > delivered) {
+                    flush(cur.frontier);
+                    continue;
+                }
+                if (!cur.wait_tile())
+                    return d->fail("scan kernel finished without publishing granule %u (tile %u of %u pending)", cur.pos,
+                                   cur.frontier, s.ntiles);
+            }
+            const int rc = cur.take();
+            if (rc < 0)
+                return d->fail("hand-off stream corrupt at granule %u (tile %u twice)", cur.pos, cur.tile);
+            if (rc == 1) { // finish after completion
+                overflowed = true;
+                break;
+            }
+            if (cur.frontier - delivered >= (s.ntiles - delivered > kTailTiles ? kGroup : kTailGroup))
+                flush(cur.frontier);
         }
-        t_start[tile] = pos + 1;
-        t_count[tile] = n;
-        pos += std::max(adsb::marker_granules(nf), adsb::stream_granules(n)); // what the tile reserved (it may have kept fewer records than it reserved for)
-        while (frontier < s.ntiles && t_count[frontier] != ~0u)
-            frontier++;
-        // the tiles of the last resident round finish in a burst at the kernel's end: take
-        // them in small batches, so that little is left to do once the last one is in
-        constexpr uint32_t kTailTiles = 768, kTailGroup = 64;
-        if (frontier - delivered >= (s.ntiles - delivered > kTailTiles ? kGroup : kTailGroup))
-            flush(frontier);
+        if (cur.frontier > delivered)
+            flush(cur.frontier);
+        wait_ms = cur.wait_ms;
+        t_last_wait = cur.t_last_wait;
     }
-    if (frontier > delivered)
-        flush(frontier);
     if (dbg_on)
         fprintf(stderr,
                 "stream collect: %.1f us in all, resolve %.1f us in %d batches, waits %.1f us; %.1f us after the last wait\n",
@@ -1363,6 +1596,21 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         d->res.log_into(reinterpret_cast<adsb::Resolver::LogEntry *>(d->h_frames[0] + 1), d->frames_cap - 1);
     }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        const char *e = getenv("ADSB_HOST_THREADS"); // A/B runs: overrides cfg.host_threads
+        const int want = e ? atoi(e) : d->cfg.host_threads;
+        if (const char *m = getenv("ADSB_READER_MIN_TILES"))
+            d->reader_min_tiles = (uint32_t)std::max(1, atoi(m));
+        if (want == 2) {
+            d->reader = new (std::nothrow) StreamReader;
+            if (d->reader) {
+                d->reader->device = d->device;
+                d->reader->th = std::thread([r = d->reader] { r->loop(); });
+                if (!(getenv("ADSB_READER_PLACE") && atoi(getenv("ADSB_READER_PLACE")) == 0))
+                    place_reader_thread(d->reader->th);
+            }
+        }
+    }
     d->no_streaming = getenv("ADSB_NO_STREAMING") && atoi(getenv("ADSB_NO_STREAMING")) != 0;
     d->dbg_async = getenv("ADSB_DEBUG_ASYNC") ? atoi(getenv("ADSB_DEBUG_ASYNC")) : 0;
     d->res.reset();
@@ -1374,6 +1622,10 @@ void adsb_destroy(adsb_decoder *d)
     if (!d)
         return;
     (void)hipSetDevice(d->device);
+    if (d->reader) {
+        d->reader->stop();
+        delete d->reader;
+    }
     for (hipStream_t cs : d->copy_stream)
         if (cs)
             (void)hipStreamSynchronize(cs);

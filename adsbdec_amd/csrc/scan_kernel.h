@@ -83,6 +83,12 @@ constexpr size_t lds_bytes(int passes)
 #ifndef ADSB_GATE_IN_LOOP
 #define ADSB_GATE_IN_LOOP 0 // experiment (classic kernel): preamble test + DF gate of a wave's previous pass inside the pass loop
 #endif
+#ifndef ADSB_PIPE_JITTER
+#define ADSB_PIPE_JITTER 0 // tuning builds: a pseudo-random pause (0..31 x this many s_sleep units) in front of every tile's Stage A
+#endif
+#ifndef ADSB_PIPE_FREE
+#define ADSB_PIPE_FREE 0 // tuning builds, with ADSB_PIPE_ABLATE=1: the arithmetic waves run without the per-tile barrier
+#endif
 #ifndef ADSB_PIPE_ROLES
 #define ADSB_PIPE_ROLES 0 // 1: the Stage B wave is one that shares its SIMD with another wave of the workgroup (measured: slower); 0: always wave 4
 #endif

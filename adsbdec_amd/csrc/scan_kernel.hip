@@ -1319,6 +1319,10 @@ void scan_pipe_kernel(const ScanArgs args)
         asm volatile("" : "+v"(lane));
         if (wave_id != b_wave) {
             if (tile_a >= 0) {
+#if ADSB_PIPE_JITTER // tuning builds: the workgroups of a CU drift apart instead of running their tiles in step
+                for (uint32_t j = (((uint32_t)tile_a * 2654435761u) >> 27) * ADSB_PIPE_JITTER; j > 0; j--)
+                    __builtin_amdgcn_s_sleep(1);
+#endif
                 uint32_t *pl = smem + (it & 1) * 3 * nplane;
                 const int64_t t0 = (int64_t)args.g_begin + (int64_t)kRun * own * (int64_t)tile_a;
 #if ADSB_TILE_CLOCK == 3
@@ -1363,9 +1367,14 @@ void scan_pipe_kernel(const ScanArgs args)
             if (lane_id == 0)
                 ctl[22 + (it & 1)] = (uint32_t)next;
         }
+#if ADSB_PIPE_FREE // tuning builds (with ADSB_PIPE_ABLATE=1 only: nothing reads the planes): no barrier, a fixed round-robin of tiles
+        tile_b = -1;
+        tile_a = tile_a >= 0 && tile_a + (int)gridDim.x < ntiles ? tile_a + (int)gridDim.x : -1;
+#else
         __syncthreads();
         tile_b = tile_a;
         tile_a = __builtin_amdgcn_readfirstlane((int)ctl[22 + (it & 1)]);
+#endif
     }
     if (args.profile && tid == 0) { // the launch's duration is (latest workgroup end) - (earliest workgroup start)
         unsigned long long *c64 = reinterpret_cast<unsigned long long *>(args.counters);

@@ -739,6 +739,19 @@ def main():
                 with_stats["table"] = {"try": got["try"], "ok": got["ok"]}
                 with_stats["parity_vs_oracle"] = True
             ds.close()
+            # the same statistics step with cfg.host_threads = 2 (a second host thread reads the hand-off stream)
+            d2 = capi.Decoder(df18=args.dense, device=local_rank, profile=True, collect_stats=True, host_threads=2)
+
+            def s2step(i=0):
+                p, m = ptrs[i % len(ptrs)]
+                return d2.decode_device_raw(p, m)
+            preroll(s2step, args.preroll_ms)
+            torch.cuda.synchronize()
+            s2dt, s2raw = timed_steps(s2step, 50, torch.cuda.synchronize)
+            with_stats["host_threads_2"] = {"value": round(n * 50 / s2dt / 1e6, 1), "ms_per_step": round(s2dt / 50 * 1e3, 4),
+                                            "frames": int(s2raw[1]),
+                                            "what": "opt-in: the reader thread shares the caller's L3 (placed by the library)"}
+            d2.close()
         if not args.dense:
             del xs[1:], ptrs[1:]
             torch.cuda.empty_cache()

@@ -99,6 +99,10 @@ typedef struct adsb_config {
                                   leaves the scan in flight; the frames of a call become drainable during the NEXT
                                   adsb_push / adsb_finish / adsb_sync instead of during the call itself (same frames,
                                   same order).  0 (default): frames are drainable when the call returns. */
+    int32_t host_threads;      /* 0 / 1 (default): the calling thread alone consumes the device's hand-off stream.
+                                  2: the handle owns a second thread that reads and checks the stream of large launches
+                                  while the caller resolves behind it; same frames, same order.  The thread spins for
+                                  ~0.4 ms after a launch, then sleeps until the next one. */
 } adsb_config;
 
 /* Counters accumulate over the life of the handle (adsb_reset keeps them: a caller that

@@ -655,6 +655,51 @@ def test_streaming_handoff_is_stable_over_many_launches(oracle, dec_factory, tor
         assert records(d.drain()) == exp, it
 
 
+def test_reader_thread_consumes_the_handoff_stream(capi, oracle, dec_factory, torch_cuda, monkeypatch):
+    """cfg.host_threads = 2: a second host thread reads and checks the hand-off stream while the caller resolves behind
+    it (decoder.hip StreamReader).  Same frames, same statistics, on every path a launch's collect can take: rotating
+    captures on one handle (stale bytes of the previous launch must not be taken), chunked pushes, a statistics run,
+    tiles that flag "finish after completion" (staged-list overflow, loose list, relaunch)."""
+    from oracle import gen_signal as G
+    monkeypatch.setenv("ADSB_READER_MIN_TILES", "1")   # also the small launches of this test go through the thread
+    caps = []
+    for seed, n, nfr in ((61, 1 << 22, 1500), (62, (1 << 22) - 300_000, 900), (63, (1 << 21) + 4096, 1100)):
+        x, _ = G.dense_capture(n, seed=seed, sigma=30.0, n_frames=nfr, amp=(150, 1800))
+        want, wstats = oracle.decode(x, df18=True)
+        caps.append((x, _dev(torch_cuda, x), records(want), wstats))
+    d = dec_factory(df18=True, host_threads=2)
+    for it in range(150):
+        _, t, exp, _ = caps[(it * 7 + it // 5) % 3]
+        d.reset()
+        d.push_device_final(t.data_ptr(), t.numel())
+        assert records(d.drain()) == exp, it
+    ds = dec_factory(df18=True, host_threads=2, collect_stats=True)
+    for x, t, exp, wstats in caps:
+        assert records(ds.decode(x)) == exp
+        assert ds.stats() == wstats
+        ds.reset()
+        got = []
+        for k in range(0, x.size, 300_000):
+            ds.push_async(x[k:k + 300_000])
+            got += ds.drain()
+        ds.finish()
+        got += ds.drain()
+        assert records(got) == exp
+        assert ds.stats() == wstats
+    xb = _back_to_back(400, 47)
+    wantb, wstatsb = oracle.decode(xb, df18=True)
+    tb = _dev(torch_cuda, xb)
+    for kw in (dict(debug_clist_cap=2), dict(debug_clist_cap=2, collect_stats=True, debug_cand_cap=16, debug_try_cap=64),
+               dict(all_candidates=True)):
+        db = dec_factory(df18=True, host_threads=2, **kw)
+        for _ in range(2):
+            db.reset()
+            db.push_device_final(tb.data_ptr(), tb.numel())
+            assert records(db.drain()) == records(wantb)
+            if kw.get("collect_stats"):
+                assert db.stats() == wstatsb
+
+
 @pytest.mark.parametrize("name", golden_cases())
 def test_golden_without_streaming_handoff(capi, dec_factory, torch_cuda, monkeypatch, name):
     """ADSB_NO_STREAMING=1 (read by adsb_create): every launch is collected after completion
