@@ -80,6 +80,15 @@ void netout(const uint8_t *frame, const int len, const uint64_t ts, const uint32
     putchar('\n');
 }
 
+#ifdef DROPIN /* oracle/_ref/ref_adsbdec_dropin: decodeiq is INTEGRATION.md's patch (dropin_decodeiq.c), no demod.c / valid.c */
+extern void dropin_eof(void);
+static int run_power(const char *path)
+{
+    (void)path;
+    fprintf(stderr, "-p needs the reference's deqframe: not in the drop-in build\n");
+    return 2;
+}
+#else
 static int run_power(const char *path)
 {
     FILE *f = fopen(path, "rb");
@@ -104,6 +113,7 @@ static int run_power(const char *path)
     fclose(f);
     return 0;
 }
+#endif
 
 /* fileInput (air.c:217-246): read() into one reused buffer, decodeiq(iqbuff, n/2).
  * The buffer has 4 spare samples so that a ragged last read over-reads inside the
@@ -119,6 +129,9 @@ static int run_capture(const char *path, size_t chunk)
     size_t n;
     while ((n = fread(iqbuff, sizeof *iqbuff, chunk, f)) > 0)
         ref_decodeiq(iqbuff, (int)n);
+#ifdef DROPIN
+    dropin_eof(); /* the patch's one line at EOF (air.c:241-244) */
+#endif
     free(iqbuff);
     fclose(f);
     return 0;
