@@ -299,6 +299,34 @@ def timed_steps(step, steps, fence, sync=None):
     return dt, raw
 
 
+def bind_near_gpu(torch, device):
+    """Multi-rank runs: keep this rank's host threads (the hand-off stream's consumer spins on device-written pinned
+    memory) on the CPUs of the GPU's own NUMA node.  Best effort -- returns what was done, for the JSON line."""
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        dom, bus, dev = (getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        if bus is None or dev is None:
+            return "none (torch does not report the PCI address)"
+        base = f"/sys/bus/pci/devices/{int(dom or 0):04x}:{int(bus):02x}:{int(dev):02x}.0"
+        with open(base + "/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return "none (numa_node = -1)"
+        with open(base + "/local_cpulist") as f:
+            text = f.read().strip()
+        cpus = set()
+        for part in text.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return "none (no allowed CPU on the GPU's node)"
+        os.sched_setaffinity(0, cpus)
+        return f"NUMA node {node} of GPU {device} ({len(cpus)} CPUs)"
+    except Exception as e:  # noqa: BLE001 -- never a reason to fail a bench run
+        return f"none ({type(e).__name__}: {e})"
+
+
 def self_launch(n):
     """`python bench.py --gpus N` from a plain shell: run the same command line under torch.distributed.run."""
     import socket
@@ -555,6 +583,8 @@ def main():
     if args.one_device_test:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    cpu_binding = bind_near_gpu(torch, local_rank) if world > 1 else "none (single rank: the scheduler's choice)"
+    args.cpu_binding = cpu_binding
     dist = None
     host_group = None
     if world > 1:
@@ -794,7 +824,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "samples_per_gpu": n, "frames_decoded_rank0": len(frames),
-                       "parity_vs_cpu": parity, "ranks_gated": world if parity else 0},
+                       "parity_vs_cpu": parity, "ranks_gated": world if parity else 0, "cpu_binding_rank0": cpu_binding},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
             "value_dropin": None if with_stats is None else {
                 "value": with_stats["value"], "unit": "Msamples/s", "ms_per_step": with_stats["ms_per_step"],
@@ -892,7 +922,7 @@ def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fenc
                                       "shared-memory board, rank 0 repairs the seams, hands out ts offsets and applies the "
                                       "end-of-file horizon" if resolved else
                                       "candidates gathered to one resolver (gloo, host-resident records)"),
-                       "shard_path": args.shard_path, "samples_total": total, "samples_rank0": sr.n_samples,
+                       "shard_path": args.shard_path, "cpu_binding_rank0": args.cpu_binding, "samples_total": total, "samples_rank0": sr.n_samples,
                        "frames_decoded": len(frames), "parity": parity,
                        "rank0_serial_us": round(float(np.median(serial)), 1) if serial else None,
                        "rank0_serial_what": "adsb_stitch_shards on rank 0 per step (median): seam repair O(ranks) + the walk of "

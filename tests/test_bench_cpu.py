@@ -76,3 +76,33 @@ def test_roofline_sources_are_named():
     p1b = dict(p1, big_launches=1600, big_ms=1600 * 0.26, kernel_ms=1600 * 0.26, offsets=1600 * 134216525)
     roof2, _ = bench.roofline_objects(p0, p1b, 200, "r3", clock=None, step_ms=1.2)
     assert roof2["launches_overlap"] is True and abs(roof2["achieved"] - 8 * 4 * 134216525 / 1.2e-3 / 1e9) < 1
+
+
+def test_bind_near_gpu_never_fails_a_run(monkeypatch, tmp_path):
+    """The multi-rank CPU binding is best effort: whatever torch or sysfs say, it returns a description."""
+    before = os.sched_getaffinity(0)
+
+    class Raises:
+        class cuda:
+            @staticmethod
+            def get_device_properties(_i):
+                raise RuntimeError("no device")
+    assert bench.bind_near_gpu(Raises, 0).startswith("none (RuntimeError")
+
+    class NoPci:
+        class cuda:
+            @staticmethod
+            def get_device_properties(_i):
+                return object()
+    assert bench.bind_near_gpu(NoPci, 0).startswith("none (torch does not report")
+
+    class Props:
+        pci_domain_id, pci_bus_id, pci_device_id = 0xFFFF, 0xFE, 0x1F   # no such device here
+
+    class Absent:
+        class cuda:
+            @staticmethod
+            def get_device_properties(_i):
+                return Props()
+    assert bench.bind_near_gpu(Absent, 0).startswith("none (")
+    assert os.sched_getaffinity(0) == before
