@@ -552,6 +552,9 @@ def main():
     ap.add_argument("--shard-path", choices=["resolved", "gather"], default="resolved",
                     help="shard mode: every rank resolves its own shard and rank 0 stitches (default), or every candidate "
                          "is gathered to one resolver on rank 0 (the checker path)")
+    ap.add_argument("--bind-cpu", choices=["on", "off"], default="on",
+                    help="bind this rank's host threads to the CPUs of its GPU's NUMA node (on a two-socket host an unbound "
+                         "run is sometimes 20 %% slower: profiles/r3_ab_runs.txt)")
     ap.add_argument("--one-device-test", action="store_true",
                     help="plumbing test only: every rank uses GPU 0 and gloo (numbers are meaningless)")
     args = ap.parse_args()
@@ -583,7 +586,7 @@ def main():
     if args.one_device_test:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    cpu_binding = bind_near_gpu(torch, local_rank) if world > 1 else "none (single rank: the scheduler's choice)"
+    cpu_binding = bind_near_gpu(torch, local_rank) if args.bind_cpu == "on" else "none (--bind-cpu off: the scheduler's choice)"
     args.cpu_binding = cpu_binding
     dist = None
     host_group = None
