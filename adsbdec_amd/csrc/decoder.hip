@@ -1605,8 +1605,13 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             d->reader = new (std::nothrow) StreamReader;
             if (d->reader) {
                 d->reader->device = d->device;
-                d->reader->th = std::thread([r = d->reader] { r->loop(); });
-                if (!(getenv("ADSB_READER_PLACE") && atoi(getenv("ADSB_READER_PLACE")) == 0))
+                try {
+                    d->reader->th = std::thread([r = d->reader] { r->loop(); });
+                } catch (...) { // no thread to be had: the calling thread consumes the stream alone, as without the option
+                    delete d->reader;
+                    d->reader = nullptr;
+                }
+                if (d->reader && !(getenv("ADSB_READER_PLACE") && atoi(getenv("ADSB_READER_PLACE")) == 0))
                     place_reader_thread(d->reader->th);
             }
         }
