@@ -510,17 +510,6 @@ void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uin
     }
 }
 
-// Streaming collect: consume the oldest scan WHILE its kernel is still running, so
-// that resolving overlaps the scan.  The hand-off stream (scan_kernel.h) is read strictly
-// sequentially -- one prefetchable stream of device-written lines, no directory to poll:
-// a marker says which tile follows, how many records, and what their XOR must be; the
-// records are checked where they lie (16-byte loads) and later resolved in place.  Tiles
-// reserve their ranges in COMPLETION order, so a tile that finished early waits (start and
-// count noted) until every tile before it is in; the resolver is fed whenever the device
-// leaves the host nothing to read, or a group of tiles has accumulated.
-// Returns 1 if a tile reported records on the loose list (or the stream is full): the
-// caller then finishes the launch through the collect-after-completion path, from tile
-// *resume_tile on.
 // The reading side of the streaming collect: where the host stands in a launch's hand-off stream.
 struct HandCursor {
     using clk = std::chrono::steady_clock;
@@ -622,6 +611,8 @@ struct StreamReader {
     std::atomic<bool> sleeping{false}, quit{false};
     std::atomic<uint32_t> job_seq{0};
     int device = 0;
+    bool place = false; // keep the thread on the caller's L3 (place_reader_thread)
+    int placed_l3 = -1;
     // the job (written by the caller before job_seq)
     const ScanSlot *slot = nullptr;
     uint32_t *t_start = nullptr, *t_count = nullptr;
@@ -716,49 +707,75 @@ struct StreamReader {
 };
 
 // The reader thread is kept near the caller: on a core that shares the caller's L3 (the records it has checked are
-// read again by the resolver), but neither the caller's own core nor its SMT sibling.  Best effort; silent on failure.
-static void place_reader_thread(std::thread &th)
+// read again by the resolver), but neither the caller's own core nor its SMT sibling.  Checked again at every job
+// (sched_getcpu is a vDSO call): a caller that has moved to another L3 takes the thread along -- left behind, on the
+// other socket of a two-socket host, the pair is 2.5 x slower than one thread.  Best effort; silent on failure.
+static bool read_cpu_list(const char *fmt, int c, cpu_set_t *out)
 {
-    const int cpu = sched_getcpu();
+    char path[160], buf[1024];
+    snprintf(path, sizeof path, fmt, c);
+    FILE *f = fopen(path, "r");
+    if (!f)
+        return false;
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got)
+        return false;
+    CPU_ZERO(out);
+    for (char *p = buf; *p && *p != '\n';) { // "a-b,c,d-e"
+        char *e;
+        const long a = strtol(p, &e, 10);
+        if (e == p)
+            return false;
+        long b = a;
+        if (*e == '-')
+            b = strtol(e + 1, &e, 10);
+        for (long k = a; k <= b && k < CPU_SETSIZE; k++)
+            CPU_SET((int)k, out);
+        p = (*e == ',') ? e + 1 : e;
+    }
+    return true;
+}
+
+// the L3 a CPU belongs to, named by the lowest CPU that shares it (-1: unknown); sysfs is read once per CPU
+static int l3_of_cpu(int cpu)
+{
+    static std::atomic<int> cache[CPU_SETSIZE]; // 0: not looked up yet; else id + 2
+    if (cpu < 0 || cpu >= CPU_SETSIZE)
+        return -1;
+    const int c = cache[cpu].load(std::memory_order_relaxed);
+    if (c != 0)
+        return c - 2;
+    cpu_set_t l3;
+    int id = -1;
+    if (read_cpu_list("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu, &l3))
+        for (int k = 0; k < CPU_SETSIZE; k++)
+            if (CPU_ISSET(k, &l3)) {
+                id = k;
+                break;
+            }
+    cache[cpu].store(id + 2, std::memory_order_relaxed);
+    return id;
+}
+
+// returns the L3 the thread was placed on (-1: not placed)
+static int place_reader_thread(std::thread &th, int cpu)
+{
     if (cpu < 0)
-        return;
-    auto read_list = [](const char *fmt, int c, cpu_set_t *out) {
-        char path[160], buf[1024];
-        snprintf(path, sizeof path, fmt, c);
-        FILE *f = fopen(path, "r");
-        if (!f)
-            return false;
-        const bool got = fgets(buf, sizeof buf, f) != nullptr;
-        fclose(f);
-        if (!got)
-            return false;
-        CPU_ZERO(out);
-        for (char *p = buf; *p && *p != '\n';) { // "a-b,c,d-e"
-            char *e;
-            const long a = strtol(p, &e, 10);
-            if (e == p)
-                return false;
-            long b = a;
-            if (*e == '-')
-                b = strtol(e + 1, &e, 10);
-            for (long k = a; k <= b && k < CPU_SETSIZE; k++)
-                CPU_SET((int)k, out);
-            p = (*e == ',') ? e + 1 : e;
-        }
-        return true;
-    };
+        return -1;
     cpu_set_t l3, smt, allowed, want;
-    if (!read_list("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu, &l3) ||
-        !read_list("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu, &smt) ||
+    if (!read_cpu_list("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu, &l3) ||
+        !read_cpu_list("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu, &smt) ||
         sched_getaffinity(0, sizeof allowed, &allowed) != 0)
-        return;
+        return -1;
     CPU_ZERO(&want);
     int n = 0;
     for (int k = 0; k < CPU_SETSIZE; k++)
         if (CPU_ISSET(k, &l3) && CPU_ISSET(k, &allowed) && !CPU_ISSET(k, &smt))
             CPU_SET(k, &want), n++;
-    if (n > 0)
-        (void)pthread_setaffinity_np(th.native_handle(), sizeof want, &want);
+    if (n == 0 || pthread_setaffinity_np(th.native_handle(), sizeof want, &want) != 0)
+        return -1;
+    return l3_of_cpu(cpu);
 }
 
 // Streaming collect: consume the oldest scan WHILE its kernel is still running, so
@@ -831,6 +848,12 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
     if (d->reader && s.ntiles >= d->reader_min_tiles) {
         // two threads: the reader publishes its frontier, this one resolves behind it
         StreamReader &rd = *d->reader;
+        if (rd.place) { // the caller may have moved since the thread was placed
+            const int cpu = sched_getcpu();
+            const int l3 = l3_of_cpu(cpu);
+            if (l3 >= 0 && l3 != rd.placed_l3)
+                rd.placed_l3 = place_reader_thread(rd.th, cpu);
+        }
         rd.post(s, t_start.data(), t_count.data());
         const uint32_t seq = rd.job_seq.load(std::memory_order_relaxed);
         for (;;) {
@@ -1611,8 +1634,11 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
                     delete d->reader;
                     d->reader = nullptr;
                 }
-                if (d->reader && !(getenv("ADSB_READER_PLACE") && atoi(getenv("ADSB_READER_PLACE")) == 0))
-                    place_reader_thread(d->reader->th);
+                if (d->reader) {
+                    d->reader->place = !(getenv("ADSB_READER_PLACE") && atoi(getenv("ADSB_READER_PLACE")) == 0);
+                    if (d->reader->place)
+                        d->reader->placed_l3 = place_reader_thread(d->reader->th, sched_getcpu());
+                }
             }
         }
     }

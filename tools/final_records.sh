@@ -8,7 +8,7 @@ run() { out=$1; shift; timeout 1200 python bench.py "$@" > $O/$out.json 2> $O/$o
 run r3_bench
 run r3_bench_shard_N1_2Gi --mode shard --steps 20 --warmup 3
 run r3_bench_shard_N1_2Gi_gather_path --mode shard --shard-path gather --steps 10 --warmup 2
-run r3_bench_shard_N2_one_device_plumbing --gpus 2 --one-device-test --mode shard --steps 10 --warmup 2
+run r3_bench_shard_N2_one_device_plumbing --gpus 2 --one-device-test --mode shard --samples 536870912 --steps 10 --warmup 2
 run r3_bench_stream_N2_one_device_plumbing --gpus 2 --one-device-test --steps 20 --warmup 3 --no-cpu-baseline --no-extras
 run r3_bench_stream_2Gi --samples 2147483632 --steps 20 --warmup 3 --no-cpu-baseline --no-extras
 timeout $((FZ + 300)) python tools/fuzz_parity.py --seconds $FZ --seed 900000 > $O/r3_fuzz_final.txt 2>&1; echo "fuzz exit $?"; tail -2 $O/r3_fuzz_final.txt | cut -c1-600
