@@ -16,6 +16,9 @@ namespace adsb {
 #ifndef ADSB_SLEEP_STAGGER
 #define ADSB_SLEEP_STAGGER 90 // s_sleep units (64 cycles) between the starts of a CU's first four workgroups; 0 = off
 #endif
+#ifndef ADSB_STAGED_WAIT
+#define ADSB_STAGED_WAIT 0 // experiment: Stage A starts on a run's first outputs while its last loads are still in flight
+#endif
 #ifndef ADSB_FMA_BIAS
 #define ADSB_FMA_BIAS 0 // fold the -2048 bias and the fs/4 sign into the FIR's products (exact: scan_kernel.hip fir_step)
 #endif

@@ -167,6 +167,58 @@ __device__ __forceinline__ void power_block(const f32x2 (&vv)[34], float *a)
     }
 }
 
+#if ADSB_STAGED_WAIT
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+// Slot s of a run from the loaded quads: air.c:64-67,79-82 (bias, fs/4 sign: see stage_a).
+template <int S>
+__device__ __forceinline__ f32x2 slot_value(const f32x4s (&tl)[17])
+{
+    const f32x4s q = tl[S >> 1];
+    const f32x2 f = (S & 1) ? f32x2{q.z, q.w} : f32x2{q.x, q.y};
+    const f32x2 mid = {2048.0f, 2048.0f};
+    return ((S & 1) == 0) ? (f - mid) : (mid - f);
+}
+template <int S0, int S1>
+__device__ __forceinline__ void make_slots(const f32x4s (&tl)[17], f32x2 (&vv)[34])
+{
+    if constexpr (S0 <= S1) {
+        vv[S0] = slot_value<S0>(tl);
+        make_slots<S0 + 1, S1>(tl, vv);
+    }
+}
+// power_block with the run's 17 loads still in flight: group J0.. waits only for the loads it reads (they return in
+// order), so the first outputs are computed while the last quads are still on their way.  The wait carries the quads
+// it releases (and the previous group's last output, which pins it behind that group) as operands: nothing reads a
+// quad before its wait.
+template <int J0, int N, int G>
+__device__ __forceinline__ void power_block_staged(f32x4s (&tl)[17], f32x2 (&vv)[34], float *a)
+{
+    if constexpr (N > 0) {
+        constexpr int g = (N < G) ? N : G;
+        constexpr int s_hi = J0 + g + 5;                 // last slot this group reads
+        constexpr int s_lo = (J0 == 0) ? 0 : J0 + 6;     // first slot not made yet
+        constexpr int l_hi = s_hi >> 1, l_lo = s_lo >> 1; // quads: l_lo may have been released already (odd s_lo)
+        static_assert(G == 4, "the operand lists below are written for groups of four outputs");
+        if constexpr (J0 == 0)
+            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(tl[4]) : "n"(16 - l_hi));
+        else
+            asm volatile("s_waitcnt vmcnt(%3)" : "+v"(tl[l_hi - 1]), "+v"(tl[l_hi]), "+v"(a[J0 - 1]) : "n"(16 - l_hi));
+        (void)l_lo;
+        make_slots<s_lo, s_hi>(tl, vv);
+        f32x2 s[g];
+        fir_group_step<J0, g, 0>(vv, s);
+#pragma unroll
+        for (int k = 0; k < g; k++) {
+            const f32x2 sq = s[k] * s[k];
+            float r;
+            asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(sq.x), "v"(sq.y));
+            a[J0 + k] = r;
+        }
+        power_block_staged<J0 + g, N - g, G>(tl, vv, a);
+    }
+}
+#endif
+
 // Same arithmetic for power samples at RUN-TIME indices (rare path: pw of a
 // CRC-valid candidate needs a[g], a[g+10], a[g+35], a[g+45]).  Rounds exactly like
 // power_sample<>: same products, same order (one static order per phase p = m mod
@@ -477,8 +529,10 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
                          "buffer_load_format_xyzw %13, %17, %18, 0 offen offset:112\n\t"
                          "buffer_load_format_xyzw %14, %17, %18, 0 offen offset:120\n\t"
                          "buffer_load_format_xyzw %15, %17, %18, 0 offen offset:128\n\t"
-                         "buffer_load_format_xyzw %16, %17, %18, 0 offen offset:136\n\t"
-                         "s_waitcnt vmcnt(0)"
+                         "buffer_load_format_xyzw %16, %17, %18, 0 offen offset:136"
+#if !ADSB_STAGED_WAIT
+                         "\n\ts_waitcnt vmcnt(0)"
+#endif
                          : "=&v"(tl[0]), "=&v"(tl[1]), "=&v"(tl[2]), "=&v"(tl[3]), "=&v"(tl[4]), "=&v"(tl[5]), "=&v"(tl[6]),
                            "=&v"(tl[7]), "=&v"(tl[8]), "=&v"(tl[9]), "=&v"(tl[10]), "=&v"(tl[11]), "=&v"(tl[12]),
                            "=&v"(tl[13]), "=&v"(tl[14]), "=&v"(tl[15]), "=&v"(tl[16])
@@ -513,6 +567,7 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
         // (samples n mod 4 in {2,3}).  The run starts at an even pair index, so the
         // sign is a compile-time property of the slot.  -(x-2048) == 2048-x exactly.
         f32x2 vv[34];
+#if !ADSB_STAGED_WAIT // (staged: the slots are made group by group, behind the wait for their quads: power_block_staged)
 #pragma unroll
         for (int s = 0; s < 34; s++) {
             const f32x4 q = tl[s >> 1];
@@ -524,6 +579,7 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
             vv[s] = ((s & 1) == 0) ? (f - mid) : (mid - f); // slot s <-> rel pair s-6: same parity
 #endif
         }
+#endif
 
 #if ADSB_PREHALO_DPP
         if (interior) {
@@ -536,7 +592,12 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
 #endif
         // a[0..27]: this run; a[28..43]: the first 16 samples of the next run (next lane)
         float a[44];
+#if ADSB_STAGED_WAIT
+        static_assert(!ADSB_FMA_BIAS && !ADSB_PREHALO_DPP && ADSB_ABLATE != 1 && ADSB_ABLATE != 3, "staged waits: the plain load path only");
+        power_block_staged<0, 28, ADSB_FIR_GROUP>(tl, vv, a); // (the ragged path's plain loads have landed: its waits fall through)
+#else
         power_block<0, 28, ADSB_FIR_GROUP>(vv, a);
+#endif
 #pragma unroll
         for (int k = 0; k < 16; k++)
             a[28 + k] = from_next_lane(a[k]);
