@@ -513,7 +513,11 @@ void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uin
 // The reading side of the streaming collect: where the host stands in a launch's hand-off stream.
 struct HandCursor {
     using clk = std::chrono::steady_clock;
-    const ScanSlot &s;
+    struct View { // the launch's stream: where it lies, how many tiles write into it, the launch's tag, its size in granules
+        const uint32_t *hand;
+        uint32_t ntiles;
+        hipEvent_t ev_ready; // behind the launch (null: nothing will ever complete these bytes -- adsb_handoff_walk)
+    } s;
     uint32_t *t_start, *t_count; // per tile: granule index of its first record, and its record count (~0u: not in yet)
     const uint32_t gen, cap;
     uint32_t pos = 0;      // granules of the stream consumed
@@ -523,7 +527,12 @@ struct HandCursor {
     clk::time_point t_last_wait;
 
     HandCursor(const ScanSlot &slot, uint32_t *ts, uint32_t *tc)
-        : s(slot), t_start(ts), t_count(tc), gen(slot.args.gen), cap(slot.args.hand_cap), t_last_wait(clk::now())
+        : s{slot.hand, slot.ntiles, slot.ev_ready[slot.ev_cur]}, t_start(ts), t_count(tc), gen(slot.args.gen),
+          cap(slot.args.hand_cap), t_last_wait(clk::now())
+    {
+    }
+    HandCursor(const uint32_t *stream, uint32_t granules, uint32_t ntiles, uint32_t gen_, uint32_t *ts, uint32_t *tc)
+        : s{stream, ntiles, nullptr}, t_start(ts), t_count(tc), gen(gen_), cap(granules), t_last_wait(clk::now())
     {
     }
     // marker {tile, n | flags, check}: valid once it and the XOR of the 2n granules
@@ -559,6 +568,8 @@ struct HandCursor {
         }();
         if (tile_in())
             return true;
+        if (!s.ev_ready)
+            return false;
         const auto t_w = clk::now();
         bool ok = false;
         uint64_t after_done = 0;
@@ -572,7 +583,7 @@ struct HandCursor {
             for (int k = 0; k < kPollPause; k++)
                 __builtin_ia32_pause();
             if ((spins & 0x3F) == 0) {
-                const hipError_t q = hipEventQuery(s.ev_ready[s.ev_cur]);
+                const hipError_t q = hipEventQuery(s.ev_ready);
                 if (q != hipErrorNotReady && (q != hipSuccess || ++after_done > 2000))
                     break; // the launch failed, or it completed long ago: the bytes will not come
             }
@@ -2321,6 +2332,40 @@ int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out)
         return -1;
     *out = r->r.stats();
     return 0;
+}
+
+long adsb_handoff_walk(const void *stream, size_t granules, uint32_t n_tiles, uint32_t gen, uint32_t *tile_start,
+                       uint32_t *tile_count, int *status)
+{
+    if (!stream || !tile_start || !tile_count || !status || granules > 0xFFFFFFFFull)
+        return -1;
+    // the checks read 16-byte granules with aligned loads: walk a 64-byte-aligned copy
+    const size_t bytes = granules * adsb::kGranuleWords * sizeof(uint32_t);
+    void *copy = nullptr;
+    if (posix_memalign(&copy, 64, bytes ? bytes : 64) != 0)
+        return -1;
+    std::memcpy(copy, stream, bytes);
+    for (uint32_t t = 0; t < n_tiles; t++)
+        tile_start[t] = 0, tile_count[t] = ~0u;
+    HandCursor cur(static_cast<const uint32_t *>(copy), (uint32_t)granules, n_tiles, gen, tile_start, tile_count);
+    *status = 0;
+    while (cur.frontier < n_tiles) {
+        if (cur.pos >= cur.cap) {
+            *status = 1;
+            break;
+        }
+        if (!cur.wait_tile()) { // (no launch behind these bytes: one look)
+            *status = 2;
+            break;
+        }
+        const int rc = cur.take();
+        if (rc != 0) {
+            *status = rc < 0 ? -1 : 1;
+            break;
+        }
+    }
+    free(copy);
+    return (long)cur.frontier;
 }
 
 } // extern "C"

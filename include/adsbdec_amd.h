@@ -228,6 +228,21 @@ int adsb_resolver_advance(adsb_resolver *r, uint64_t power_samples, uint64_t g_c
 long adsb_resolver_drain(adsb_resolver *r, adsb_frame *out, size_t cap);
 int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out);
 
+/* ---- diagnostics: the device -> host hand-off stream, walked without a device -------------
+ * The scan kernel hands its records to the host through ONE stream of 16-byte granules in pinned
+ * host memory: per tile a marker {tile, n | flags | lines reserved << 18,
+ * check_lo, check_hi} followed by n records of two granules; a tile counts only once its marker's
+ * check words agree with the XOR of its record granules, mixed with the launch's `gen`.
+ * adsb_handoff_walk applies exactly the rules the streaming collect applies (the same code) to an
+ * image of such a stream in ordinary memory: tile_start[t] / tile_count[t] (n_tiles entries each)
+ * receive the granule index of tile t's first record and its record count (~0u: not in), the
+ * return value is the number of leading tiles that are all in, and *status says why the walk
+ * ended: 0 every tile is in; 1 a tile asks to be finished after completion (flag 0x10000 /
+ * 0x20000) or the stream is full; 2 the bytes at the cursor are not (yet) a valid marker of this
+ * launch; -1 a tile appears twice.  No GPU is needed: this is how the host logic is tested. */
+long adsb_handoff_walk(const void *stream, size_t granules, uint32_t n_tiles, uint32_t gen,
+                       uint32_t *tile_start, uint32_t *tile_count, int *status);
+
 /* ---- shard planning -------------------------------------------
  * Splits the offsets [0, power_samples-ADSB_WINDOW] of one stream over n_shards
  * owners. Shard i owns offsets [g_begin[i], g_end[i]) (g_begin multiple of 28) and

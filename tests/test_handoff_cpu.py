@@ -1,0 +1,174 @@
+"""The host's reading of the device -> host hand-off stream (decoder.hip HandCursor), on CPU.
+
+adsb_handoff_walk runs the streaming collect's own marker / checksum / frontier code over an image of a stream in
+ordinary memory.  The images are built here from the documented format (include/adsbdec_amd.h, scan_kernel.h) with an
+independent restatement of the check words, so the test pins the format as well as the walk."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+M32 = 0xFFFFFFFF
+OVER, NOFIT, LINES_SHIFT = 0x10000, 0x20000, 18
+
+
+def rotl(x, k):
+    x &= M32
+    return ((x << k) | (x >> (32 - k))) & M32
+
+
+def check_words(tile, nf, gen, recs):
+    """scan_kernel.h marker_check: XOR of the record granules, mixed with the launch's gen, the tile and nf."""
+    a = [0, 0, 0, 0]
+    for g in np.asarray(recs, np.uint32).reshape(-1, 4):
+        for k in range(4):
+            a[k] ^= int(g[k])
+    lo = a[0] ^ rotl(a[2], 16) ^ gen ^ tile ^ rotl(nf, 11)
+    hi = a[1] ^ rotl(a[3], 16) ^ (~gen & M32) ^ rotl(tile, 7) ^ nf
+    return lo & M32, hi & M32
+
+
+def stream_granules(n):
+    return (1 + 2 * n + 3) & ~3
+
+
+class Image:
+    """A hand-off stream under construction: tiles are appended in COMPLETION order."""
+
+    def __init__(self, granules, gen, fill=0xDEADBEEF):
+        self.w = np.full(granules * 4, fill, np.uint32)
+        self.gen, self.pos, self.where = gen, 0, {}
+
+    def tile(self, tile, n, flags=0, lines=0, rng=None, gen=None, write_records=True):
+        rng = rng or np.random.default_rng(tile * 7 + n)
+        recs = rng.integers(0, 1 << 32, size=(2 * n, 4), dtype=np.uint64).astype(np.uint32)
+        if n:
+            recs[1::2, 2:] = 0                      # {w2, w3, 0, 0}
+        nf = n | flags | (lines << LINES_SHIFT)
+        lo, hi = check_words(tile, nf, self.gen if gen is None else gen, recs if not (flags & NOFIT) else [])
+        p = self.pos
+        self.w[4 * p:4 * p + 4] = (tile, nf, lo, hi)
+        if write_records and not (flags & NOFIT):
+            self.w[4 * (p + 1):4 * (p + 1 + 2 * n)] = recs.reshape(-1)
+        self.where[tile] = (p + 1, n)
+        self.pos += max(lines * 4, stream_granules(n))
+        return recs
+
+
+def walk(capi, img, n_tiles, gen=None, granules=None):
+    L = capi.load()
+    ts = (C.c_uint32 * max(1, n_tiles))()
+    tc = (C.c_uint32 * max(1, n_tiles))()
+    st = C.c_int(99)
+    buf = np.ascontiguousarray(img.w)
+    f = L.adsb_handoff_walk(buf.ctypes.data, granules if granules is not None else buf.size // 4, n_tiles,
+                            img.gen if gen is None else gen, ts, tc, C.byref(st))
+    return f, st.value, list(ts)[:n_tiles], list(tc)[:n_tiles]
+
+
+def test_tiles_in_completion_order_with_empty_and_full_tiles(capi):
+    img = Image(4096, gen=0x1234567)
+    order = [2, 0, 1, 5, 3, 4, 6]
+    counts = {0: 3, 1: 0, 2: 7, 3: 1, 4: 0, 5: 12, 6: 2}
+    for t in order:
+        img.tile(t, counts[t])
+    f, st, ts, tc = walk(capi, img, 7)
+    assert (f, st) == (7, 0)
+    assert tc == [counts[t] for t in range(7)]
+    assert ts == [img.where[t][0] for t in range(7)]
+    # tile ranges are whole 64-byte lines: marker + 2n granules, rounded up to 4
+    assert img.where[0][0] - 1 == stream_granules(7) and stream_granules(0) == 4 and stream_granules(2) == 8
+
+
+def test_frontier_stops_at_the_first_tile_that_is_not_in(capi):
+    img = Image(1024, gen=77)
+    for t in (0, 1, 3, 4):                       # tile 2 has not completed yet
+        img.tile(t, 2)
+    f, st, ts, tc = walk(capi, img, 5)
+    assert (f, st) == (2, 2)                     # walk ends at bytes that are no marker; tiles 0, 1 are complete in order
+    assert tc[:2] == [2, 2] and tc[2] == M32 and tc[3:] == [2, 2]
+
+
+def test_a_record_granule_that_has_not_landed_keeps_the_tile_out(capi):
+    img = Image(1024, gen=5)
+    img.tile(0, 4)
+    p = img.pos
+    img.tile(1, 6)
+    good = img.w.copy()
+    img.w[4 * (p + 3) + 1] ^= 0x00010000         # one bit of one record granule of tile 1 still stale
+    f, st, _, tc = walk(capi, img, 2)
+    assert (f, st) == (1, 2) and tc[1] == M32
+    img.w = good
+    assert walk(capi, img, 2)[:2] == (2, 0)
+
+
+def test_markers_of_another_launch_never_validate(capi):
+    img = Image(1024, gen=1000)
+    img.tile(0, 3)
+    img.tile(1, 3, gen=999)                      # left over from the previous launch at the same place
+    f, st, _, tc = walk(capi, img, 2)
+    assert (f, st) == (1, 2) and tc[1] == M32
+    assert walk(capi, img, 2, gen=999)[:2] == (0, 2)   # and the whole image read with the other launch's tag: tile 0 fails
+
+
+@pytest.mark.parametrize("flag", [OVER, NOFIT])
+def test_tiles_that_ask_to_be_finished_after_completion(capi, flag):
+    img = Image(1024, gen=31)
+    img.tile(0, 2)
+    img.tile(1, 5, flags=flag)
+    img.tile(2, 1)
+    f, st, _, tc = walk(capi, img, 3)
+    assert (f, st) == (1, 1)                     # the walk stops AT that tile: the launch is finished through the other path
+    assert tc[1] == M32
+
+
+def test_a_tile_that_reserved_more_lines_than_it_kept_records_for(capi):
+    img = Image(1024, gen=8)
+    img.tile(0, 2, lines=5)                      # reserved 5 lines (20 granules) for its staged list, kept 2 records
+    img.tile(1, 3)
+    f, st, ts, tc = walk(capi, img, 2)
+    assert (f, st) == (2, 0) and tc == [2, 3]
+    assert ts[1] == 20 + 1
+
+
+def test_a_tile_twice_is_corruption_and_foreign_tile_numbers_are_not_markers(capi):
+    img = Image(1024, gen=3)
+    img.tile(0, 1)
+    img.tile(0, 1, rng=np.random.default_rng(99))
+    assert walk(capi, img, 3)[:2] == (1, -1)
+    img = Image(1024, gen=3)
+    img.tile(0, 1)
+    img.tile(9, 1)                               # a valid-looking marker of a tile this launch does not have
+    assert walk(capi, img, 3)[:2] == (1, 2)
+
+
+def test_a_full_stream_and_a_range_that_runs_past_it(capi):
+    img = Image(16, gen=4)
+    img.tile(0, 1)                               # 4 granules
+    img.tile(1, 5)                               # 12 granules: the stream is exactly full
+    assert walk(capi, img, 3)[:2] == (2, 1)      # tile 2 can only be elsewhere
+    img = Image(64, gen=4)
+    img.tile(0, 1)
+    img.tile(1, 5)
+    assert walk(capi, img, 2, granules=12)[:2] == (1, 2)   # seen through a 12-granule window the second range does not fit
+
+
+def test_many_random_streams(capi):
+    rng = np.random.default_rng(2024)
+    for _ in range(200):
+        n_tiles = int(rng.integers(1, 40))
+        counts = rng.integers(0, 9, n_tiles)
+        img = Image(4 * int(sum(stream_granules(int(c)) + 8 for c in counts)) // 4 + 64, gen=int(rng.integers(1, 1 << 32)))
+        order = rng.permutation(n_tiles)
+        upto = int(rng.integers(0, n_tiles + 1))           # only the first `upto` completions have happened
+        for t in order[:upto]:
+            img.tile(int(t), int(counts[t]), lines=int(rng.integers(0, 4)) if rng.random() < 0.3 else 0, rng=rng)
+        done = set(int(t) for t in order[:upto])
+        want_front = next((t for t in range(n_tiles) if t not in done), n_tiles)
+        f, st, ts, tc = walk(capi, img, n_tiles)
+        assert f == want_front and st == (0 if upto == n_tiles else 2)
+        for t in range(n_tiles):
+            if t in done:
+                assert (ts[t], tc[t]) == img.where[t]
+            else:
+                assert tc[t] == M32
