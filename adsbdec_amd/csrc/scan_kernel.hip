@@ -649,8 +649,12 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
 #pragma unroll
         for (int m = 27; m >= 0; m--) { // bit m of each word <-> sample m of the run
             d = push_sign(d, __float_as_uint(dv[m]));    // a[m+5] - a[m] < 0:  a[m] > a[m+5]   (demod.c:34)
+#if ADSB_ABLATE_PLANES < 2
             e1 = push_sign(e1, __float_as_uint(e1v[m])); // 2 c[m+5] - c[m] < 0: c[m] > 2 c[m+5] (SN = 2, demod.c:83)
+#endif
+#if ADSB_ABLATE_PLANES < 1 // (kbench timing builds drop the E2 plane, or E1 and E2: how does the time follow the instruction count?)
             e2 = push_sign(e2, __float_as_uint(e2v[m])); // 2 c[m] - c[m+5] < 0: c[m+5] > 2 c[m]
+#endif
         }
         if (lane < kWaveRuns) { // lane 63 only feeds lane 62
             pl_d[v] = d;
