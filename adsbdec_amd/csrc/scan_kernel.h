@@ -16,6 +16,9 @@ namespace adsb {
 #ifndef ADSB_SLEEP_STAGGER
 #define ADSB_SLEEP_STAGGER 90 // s_sleep units (64 cycles) between the starts of a CU's first four workgroups; 0 = off
 #endif
+#ifndef ADSB_PREFETCH_NEXT
+#define ADSB_PREFETCH_NEXT 0 // Stage A touches the lines of the wave's next pass (one dword per 128-byte line) while it computes this one
+#endif
 #ifndef ADSB_ABLATE_PLANES
 #define ADSB_ABLATE_PLANES 0 // tools/kbench timing builds only (wrong results): 1 drops the E2 plane's arithmetic, 2 E1's and E2's
 #endif

@@ -448,6 +448,9 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * first_run(ps) - 8; }; // lane 0's
+#if ADSB_PREFETCH_NEXT
+    uint32_t pf = 0; // destination of the cache-touching load below: stays allocated until the next pass's loads have been waited for
+#endif
 #pragma unroll 1
     for (int pass = 0; pass < K; pass++) {
         const int v0 = first_run(pass); // first run of this wave in this pass
@@ -539,7 +542,29 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
                          : "v"(voff), "s"(rs)
                          : "memory");
 #endif
+#if ADSB_PREFETCH_NEXT
+            // (the block above ended with s_waitcnt vmcnt(0): the previous pass's touch has landed, `pf` is free again)
+            asm volatile("" : "+v"(pf));
+            // Touch the lines of this wave's NEXT pass (one dword per 128-byte line, result unused) while this pass is
+            // being computed: the next pass's 17 loads then find their lines in the L2 instead of waiting for HBM.
+            if (pass + 1 < K) {
+                const int64_t wn = pass_first_pair(pass + 1);
+                if (wn + kRun * 64 + 8 <= p_hi) { // wave-uniform; wn > wlo >= p_lo
+                    const uint64_t nb = (uint64_t)(xin + (wn - pbuf0));
+                    i32x4 rn;
+                    rn.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
+                    rn.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(nb >> 32) & 0xFFFFu));
+                    rn.z = 64 * kRun * 4 + 64;
+                    rn.w = rs.w;
+                    const int toff = min(lane * 128, 64 * kRun * 4 + 64 - 4);
+                    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(pf) : "v"(toff), "s"(rn) : "memory");
+                }
+            }
+#endif
         } else {
+#if ADSB_PREFETCH_NEXT
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf)); // a touch issued by the previous pass may still be in flight
+#endif
             // Stream start (the ring is zero-initialised, air.c:33: a missing pair is
             // 0x0800,0x0800 -> v = 0) and the ragged end of a buffer: plain loads, converted here
             int64_t pr0 = wlo + (int64_t)kRun * lane;
