@@ -429,6 +429,193 @@ __device__ __forceinline__ void gate_and_enqueue(const GateCtx &gc, const uint32
     }
 }
 
+#if ADSB_DOUBLE_BUFFER
+// ---- experiment: Stage A with the NEXT pass's loads in flight while this pass is computed (two register sets) ----
+// pass_compute_db is stage_a's own code behind the loads, verbatim (kept apart so that the shipped kernel's code
+// generation is not touched by the experiment).
+typedef float f32x4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pass_compute_db(f32x4d (&tl)[17], const int lane, const int v, uint32_t *pl_d, uint32_t *pl_e1,
+                                                uint32_t *pl_e2)
+{
+    typedef f32x4d f32x4;
+    // air.c:64-67,79-82: v = (float)x - 2048; pairs with odd index are negated
+    // (samples n mod 4 in {2,3}).  The run starts at an even pair index, so the
+    // sign is a compile-time property of the slot.  -(x-2048) == 2048-x exactly.
+    f32x2 vv[34];
+#if !ADSB_STAGED_WAIT // (staged: the slots are made group by group, behind the wait for their quads: power_block_staged)
+#pragma unroll
+    for (int s = 0; s < 34; s++) {
+        const f32x4 q = tl[s >> 1];
+        const f32x2 f = (s & 1) ? f32x2{q.z, q.w} : f32x2{q.x, q.y};
+#if ADSB_FMA_BIAS
+        vv[s] = f; // bias and fs/4 sign are folded into the FIR's products (fir_step)
+#else
+        const f32x2 mid = {2048.0f, 2048.0f};
+        vv[s] = ((s & 1) == 0) ? (f - mid) : (mid - f); // slot s <-> rel pair s-6: same parity
+#endif
+    }
+#endif
+
+#if ADSB_PREHALO_DPP
+    if (interior) {
+#pragma unroll
+        for (int sl = 0; sl < 6; sl++) { // lane 0 keeps what it loaded (no source lane: `old` stays)
+            vv[sl].x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(vv[sl].x), __float_as_int(vv[sl + 28].x), 0x138, 0xF, 0xF, false));
+            vv[sl].y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(vv[sl].y), __float_as_int(vv[sl + 28].y), 0x138, 0xF, 0xF, false));
+        }
+    }
+#endif
+    // a[0..27]: this run; a[28..43]: the first 16 samples of the next run (next lane)
+    float a[44];
+#if ADSB_STAGED_WAIT
+    static_assert(!ADSB_FMA_BIAS && !ADSB_PREHALO_DPP && ADSB_ABLATE != 1 && ADSB_ABLATE != 3, "staged waits: the plain load path only");
+    power_block_staged<0, 28, ADSB_FIR_GROUP>(tl, vv, a); // (the ragged path's plain loads have landed: its waits fall through)
+#else
+    power_block<0, 28, ADSB_FIR_GROUP>(vv, a);
+#endif
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        a[28 + k] = from_next_lane(a[k]);
+
+    // demod.c:102-105: every preamble sum is c[k] = (int)(a[k] + a[k+10]).  The
+    // truncated value is kept as a float (v_trunc_f32 == the C conversion for the
+    // magnitudes in the input domain); the integer comparisons `c > 2 c'` are
+    // decided by the SIGN of 2 c' - c, which one fused multiply-add gives exactly
+    // (a single rounding cannot change the sign of a non-zero difference and an
+    // exact zero stays zero).  These are the only FMAs in the kernel; the signal
+    // arithmetic above is mul-then-add.
+    //
+    // Packing: every operation here combines index k with k + 5 or k + 10, so the
+    // usual (k, k+1) register pairs cannot feed v_pk_* on both sides (5 is odd).
+    // Pairs (k, k+2) for k mod 5 in {0, 1} can -- the partner set is closed under
+    // +5 -- and leave k mod 5 == 4 as scalar operations: 4 of 5 values are packed.
+    float c[34], dv[28], e1v[28], e2v[28];
+#pragma unroll
+    for (int k = 0; k < 33; k++) {
+        if (k % 5 < 2) {
+            const f32x2 lo = {a[k], a[k + 2]}, hi = {a[k + 10], a[k + 12]};
+            const f32x2 sum = lo + hi;
+            c[k] = __builtin_truncf(sum.x);
+            c[k + 2] = __builtin_truncf(sum.y);
+        } else if (k % 5 == 4) {
+            c[k] = __builtin_truncf(a[k] + a[k + 10]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 28; m++) {
+        if (m % 5 < 2 && m + 2 < 28) {
+            const f32x2 am = {a[m], a[m + 2]}, an = {a[m + 5], a[m + 7]};
+            const f32x2 cm = {c[m], c[m + 2]}, cn = {c[m + 5], c[m + 7]};
+            const f32x2 two = {2.0f, 2.0f};
+            const f32x2 dd = an - am;
+            const f32x2 x1 = __builtin_elementwise_fma(cn, two, -cm);
+            const f32x2 x2 = __builtin_elementwise_fma(cm, two, -cn);
+            dv[m] = dd.x, dv[m + 2] = dd.y;
+            e1v[m] = x1.x, e1v[m + 2] = x1.y;
+            e2v[m] = x2.x, e2v[m + 2] = x2.y;
+        } else if (m % 5 == 4 || (m % 5 < 2 && m + 2 >= 28)) {
+            dv[m] = a[m + 5] - a[m];
+            e1v[m] = __builtin_fmaf(c[m + 5], 2.0f, -c[m]);
+            e2v[m] = __builtin_fmaf(c[m], 2.0f, -c[m + 5]);
+        }
+    }
+
+    uint32_t d = 0, e1 = 0, e2 = 0;
+#pragma unroll
+    for (int m = 27; m >= 0; m--) { // bit m of each word <-> sample m of the run
+        d = push_sign(d, __float_as_uint(dv[m]));    // a[m+5] - a[m] < 0:  a[m] > a[m+5]   (demod.c:34)
+#if ADSB_ABLATE_PLANES < 2
+        e1 = push_sign(e1, __float_as_uint(e1v[m])); // 2 c[m+5] - c[m] < 0: c[m] > 2 c[m+5] (SN = 2, demod.c:83)
+#endif
+#if ADSB_ABLATE_PLANES < 1 // (kbench timing builds drop the E2 plane, or E1 and E2: how does the time follow the instruction count?)
+        e2 = push_sign(e2, __float_as_uint(e2v[m])); // 2 c[m] - c[m+5] < 0: c[m+5] > 2 c[m]
+#endif
+    }
+    if (lane < kWaveRuns) { // lane 63 only feeds lane 62
+        pl_d[v] = d;
+        pl_e1[v] = e1;
+        pl_e2[v] = e2;
+    }
+}
+
+__device__ __forceinline__ void stage_a_db(const uint32_t *__restrict__ xin, const int64_t pbuf0, const int64_t p_lo,
+                                           const int64_t p_hi, const int64_t t0, const int K, const int wave, const int lane,
+                                           uint32_t *pl_d, uint32_t *pl_e1, uint32_t *pl_e2)
+{
+    typedef f32x4d f32x4;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto first_run = [&](int ps) { return kWaveRuns * (kWaves * ps + wave); };
+    auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * first_run(ps) - 8; };
+    // the loads of pass ps into q: 17 typed loads, NOT waited for (interior windows), or plain loads (ragged ends)
+    auto issue = [&](int ps, f32x4 (&q)[17]) {
+        const int64_t wlo = pass_first_pair(ps);
+        const bool interior = (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
+        if (interior) {
+            const uint64_t wbase = (uint64_t)(xin + (wlo - pbuf0));
+            i32x4 rs;
+            rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)wbase);
+            rs.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(wbase >> 32) & 0xFFFFu));
+            rs.z = 64 * kRun * 4 + 64;
+            rs.w = (int)(4u | 5u << 3 | 6u << 6 | 7u << 9 | 2u << 12 | 12u << 15);
+            const int voff = lane * (kRun * 4);
+            asm volatile("buffer_load_format_xyzw %0, %17, %18, 0 offen offset:8\n\t"
+                         "buffer_load_format_xyzw %1, %17, %18, 0 offen offset:16\n\t"
+                         "buffer_load_format_xyzw %2, %17, %18, 0 offen offset:24\n\t"
+                         "buffer_load_format_xyzw %3, %17, %18, 0 offen offset:32\n\t"
+                         "buffer_load_format_xyzw %4, %17, %18, 0 offen offset:40\n\t"
+                         "buffer_load_format_xyzw %5, %17, %18, 0 offen offset:48\n\t"
+                         "buffer_load_format_xyzw %6, %17, %18, 0 offen offset:56\n\t"
+                         "buffer_load_format_xyzw %7, %17, %18, 0 offen offset:64\n\t"
+                         "buffer_load_format_xyzw %8, %17, %18, 0 offen offset:72\n\t"
+                         "buffer_load_format_xyzw %9, %17, %18, 0 offen offset:80\n\t"
+                         "buffer_load_format_xyzw %10, %17, %18, 0 offen offset:88\n\t"
+                         "buffer_load_format_xyzw %11, %17, %18, 0 offen offset:96\n\t"
+                         "buffer_load_format_xyzw %12, %17, %18, 0 offen offset:104\n\t"
+                         "buffer_load_format_xyzw %13, %17, %18, 0 offen offset:112\n\t"
+                         "buffer_load_format_xyzw %14, %17, %18, 0 offen offset:120\n\t"
+                         "buffer_load_format_xyzw %15, %17, %18, 0 offen offset:128\n\t"
+                         "buffer_load_format_xyzw %16, %17, %18, 0 offen offset:136"
+                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]),
+                           "=&v"(q[7]), "=&v"(q[8]), "=&v"(q[9]), "=&v"(q[10]), "=&v"(q[11]), "=&v"(q[12]),
+                           "=&v"(q[13]), "=&v"(q[14]), "=&v"(q[15]), "=&v"(q[16])
+                         : "v"(voff), "s"(rs)
+                         : "memory");
+        } else {
+            int64_t pr0 = wlo + (int64_t)kRun * lane;
+            asm volatile("" : "+v"(pr0));
+#pragma unroll
+            for (int k = 0; k < 17; k++) {
+                const int64_t pa = pr0 + 2 * k + 2, pb = pa + 1;
+                const uint32_t d0 = (pa >= p_lo && pa < p_hi) ? xin[pa - pbuf0] : 0x08000800u;
+                const uint32_t d1 = (pb >= p_lo && pb < p_hi) ? xin[pb - pbuf0] : 0x08000800u;
+                q[k] = f32x4{(float)(d0 & 0xFFFFu), (float)(d0 >> 16), (float)(d1 & 0xFFFFu), (float)(d1 >> 16)};
+            }
+        }
+    };
+    // nothing reads a quad before this: the wait carries all 17 as operands
+    auto landed = [&](f32x4 (&q)[17]) {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]),
+                       "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]), "+v"(q[16]));
+    };
+    f32x4 qa[17], qb[17];
+    issue(0, qa);
+#pragma unroll 1
+    for (int pass = 0; pass < K; pass += 2) {
+        landed(qa);
+        if (pass + 1 < K)
+            issue(pass + 1, qb);
+        pass_compute_db(qa, lane, first_run(pass) + lane, pl_d, pl_e1, pl_e2);
+        if (pass + 1 < K) {
+            landed(qb);
+            if (pass + 2 < K)
+                issue(pass + 2, qa);
+            pass_compute_db(qb, lane, first_run(pass + 1) + lane, pl_d, pl_e1, pl_e2);
+        }
+    }
+}
+#endif
+
 // ------------------------------ Stage A ------------------------------
 // One tile's arithmetic for one of the tile's four Stage A waves: K passes, a run of 28 power samples per lane and
 // pass, three plane words per run into LDS.  No barrier, no divergence.
@@ -1282,7 +1469,11 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
                      off_end64 > (int64_t)kRun * own_runs ? kRun * own_runs : off_end64 < 0 ? 0 : (int)off_end64};
     stage_a<true>(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl_d, pl_e1, pl_e2, &gc);
 #else
+#if ADSB_DOUBLE_BUFFER
+    stage_a_db(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl_d, pl_e1, pl_e2);
+#else
     stage_a(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl_d, pl_e1, pl_e2);
+#endif
 #endif
 #if ADSB_TILE_CLOCK == 3
     uint32_t *tile_chk = qcount + 10;
