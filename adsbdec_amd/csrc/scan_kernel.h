@@ -16,6 +16,9 @@ namespace adsb {
 #ifndef ADSB_SLEEP_STAGGER
 #define ADSB_SLEEP_STAGGER 90 // s_sleep units (64 cycles) between the starts of a CU's first four workgroups; 0 = off
 #endif
+#ifndef ADSB_COALESCED_PROBE
+#define ADSB_COALESCED_PROBE 0 // tools/kbench with -DADSB_ABLATE=1: the pass's window read by coalesced loads (a probe of the memory side)
+#endif
 #ifndef ADSB_DOUBLE_BUFFER
 #define ADSB_DOUBLE_BUFFER 0 // experiment: the next pass's 17 loads are in flight while this pass is computed (two register sets; build with -DADSB_MIN_WAVES=2 or 3)
 #endif

@@ -646,6 +646,41 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
         // wave-uniform: every pair this wave loads lies inside the buffer
         const bool interior = (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
         f32x4 tl[17]; // tl[k]: pairs 2k+2, 2k+3 of the lane's 36 = slots 2k, 2k+1
+#if ADSB_ABLATE == 1 && ADSB_COALESCED_PROBE // kbench, loads only: the SAME window of 7 KiB per wave and pass read by 15 coalesced
+        // typed loads (adjacent lanes, adjacent 8 bytes: every 128-byte line is looked up once, not 17 times) -- what
+        // would the memory side deliver to a kernel that transposed its input through LDS?
+        if (interior) {
+            const uint64_t wbase = (uint64_t)(xin + (wlo - pbuf0));
+            i32x4 rs;
+            rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)wbase);
+            rs.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(wbase >> 32) & 0xFFFFu));
+            rs.z = 64 * kRun * 4 + 64;
+            rs.w = (int)(4u | 5u << 3 | 6u << 6 | 7u << 9 | 2u << 12 | 12u << 15);
+            const int voff = lane * 8, voff2 = lane * 8 + 4096; // (the instruction's own offset field ends at 4095)
+            tl[15] = tl[16] = f32x4{0, 0, 0, 0};
+            asm volatile("buffer_load_format_xyzw %0, %15, %17, 0 offen offset:0\n\t"
+                         "buffer_load_format_xyzw %1, %15, %17, 0 offen offset:512\n\t"
+                         "buffer_load_format_xyzw %2, %15, %17, 0 offen offset:1024\n\t"
+                         "buffer_load_format_xyzw %3, %15, %17, 0 offen offset:1536\n\t"
+                         "buffer_load_format_xyzw %4, %15, %17, 0 offen offset:2048\n\t"
+                         "buffer_load_format_xyzw %5, %15, %17, 0 offen offset:2560\n\t"
+                         "buffer_load_format_xyzw %6, %15, %17, 0 offen offset:3072\n\t"
+                         "buffer_load_format_xyzw %7, %15, %17, 0 offen offset:3584\n\t"
+                         "buffer_load_format_xyzw %8, %16, %17, 0 offen offset:0\n\t"
+                         "buffer_load_format_xyzw %9, %16, %17, 0 offen offset:512\n\t"
+                         "buffer_load_format_xyzw %10, %16, %17, 0 offen offset:1024\n\t"
+                         "buffer_load_format_xyzw %11, %16, %17, 0 offen offset:1536\n\t"
+                         "buffer_load_format_xyzw %12, %16, %17, 0 offen offset:2048\n\t"
+                         "buffer_load_format_xyzw %13, %16, %17, 0 offen offset:2560\n\t"
+                         "buffer_load_format_xyzw %14, %16, %17, 0 offen offset:3072\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(tl[0]), "=&v"(tl[1]), "=&v"(tl[2]), "=&v"(tl[3]), "=&v"(tl[4]), "=&v"(tl[5]), "=&v"(tl[6]),
+                           "=&v"(tl[7]), "=&v"(tl[8]), "=&v"(tl[9]), "=&v"(tl[10]), "=&v"(tl[11]), "=&v"(tl[12]),
+                           "=&v"(tl[13]), "=&v"(tl[14])
+                         : "v"(voff), "v"(voff2), "s"(rs)
+                         : "memory");
+        } else
+#endif
 #if ADSB_ABLATE == 3 // kbench: no loads at all -- the arithmetic alone
         if (interior) {
 #pragma unroll
