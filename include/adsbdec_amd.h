@@ -36,6 +36,9 @@
 extern "C" {
 #endif
 
+/* Bumped when an existing entry point or struct member changes meaning.  Additions do not bump it: new entry points are
+ * new symbols, and adsb_config grows at its end only -- adsb_create() reads no further than cfg->struct_size, so a caller
+ * built against a shorter adsb_config keeps working (the members it does not know default to 0). */
 #define ADSB_ABI_VERSION 3
 
 /* Constants of the path (adsbdec.h:1-3, air.c:32,47). */
