@@ -48,6 +48,25 @@ def test_create_without_gpu_fails_loudly(capi):
         capi.Decoder()
 
 
+def test_config_grows_at_its_end_only(capi):
+    """adsb_create reads no further than cfg.struct_size: a caller built against the round-2 adsb_config (64 bytes, no
+    host_threads) gets past the size check (and, here, fails for the lack of a GPU); a size from the future is refused."""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = capi.load()
+    cfg = capi.Config()
+    L.adsb_config_default(C.byref(cfg))
+    assert cfg.struct_size == C.sizeof(capi.Config) == 72 and capi.Config.host_threads.offset == 64
+    cfg.struct_size = 64
+    assert not L.adsb_create(C.byref(cfg))
+    assert b"no HIP device" in L.adsb_last_error(None)
+    cfg.struct_size = 4096
+    assert not L.adsb_create(C.byref(cfg))
+    assert b"struct_size" in L.adsb_last_error(None)
+
+
 @pytest.mark.parametrize("name", golden_cases())
 def test_resolver_replays_reference_order_on_golden(capi, oracle, name):
     x, rec = load_golden(name)
