@@ -57,7 +57,9 @@ class Config(C.Structure):
                 ("stage_samples", C.c_uint64), ("stream", C.c_void_p), ("all_candidates", C.c_int32),
                 ("fix_1bit", C.c_int32), ("debug_cand_cap", C.c_int32), ("debug_try_cap", C.c_int32),
                 ("debug_clist_cap", C.c_int32), ("push_overlap", C.c_int32),
-                ("host_threads", C.c_int32)]
+                ("host_threads", C.c_int32), ("debug_no_streaming", C.c_int32), ("debug_frames_cap", C.c_int32),
+                ("debug_reader_min_tiles", C.c_int32), ("debug_shard_head", C.c_int32), ("debug_passes", C.c_int32),
+                ("debug_stagger", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -177,7 +179,8 @@ class Decoder:
                  profile: bool = False, stage_samples: int = 0, stream: int | None = None,
                  debug_queue_cap: int = 0, all_candidates: bool = False, fix_1bit: bool = False,
                  debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0, push_overlap: bool = False,
-                 host_threads: int = 0):
+                 host_threads: int = 0, debug_no_streaming: bool = False, debug_frames_cap: int = 0,
+                 debug_reader_min_tiles: int = 0, debug_shard_head: int = 0, debug_passes: int = 0, debug_stagger: int = 0):
         L = load()
         cfg = Config()
         L.adsb_config_default(C.byref(cfg))
@@ -195,6 +198,12 @@ class Decoder:
         cfg.debug_clist_cap = debug_clist_cap
         cfg.push_overlap = int(push_overlap)
         cfg.host_threads = int(host_threads)
+        cfg.debug_no_streaming = int(debug_no_streaming)
+        cfg.debug_frames_cap = debug_frames_cap
+        cfg.debug_reader_min_tiles = debug_reader_min_tiles
+        cfg.debug_shard_head = debug_shard_head
+        cfg.debug_passes = debug_passes
+        cfg.debug_stagger = debug_stagger
         self._L = L
         self._fix = bool(fix_1bit)
         self._h = L.adsb_create(C.byref(cfg))

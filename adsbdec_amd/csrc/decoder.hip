@@ -29,6 +29,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +51,15 @@
 namespace {
 
 thread_local std::string g_create_error;
+
+// The shipped library reads NO environment variable: what a test must be able to force is a member of adsb_config
+// (debug_*).  Builds with -DADSB_TUNING (tools/build_variant.sh; never the one in adsbdec_amd/lib) keep a few knobs for
+// A/B runs and diagnosis: ADSB_CHUNK_MI, ADSB_ALT_STREAMS, ADSB_DEBUG_HOST, ADSB_DEBUG_TIMELINE, ADSB_DEBUG_ASYNC.
+#ifdef ADSB_TUNING
+inline const char *tuning_env(const char *name) { return getenv(name); }
+#else
+inline const char *tuning_env(const char *) { return nullptr; }
+#endif
 
 constexpr uint64_t kDefaultStageSamples = 32ull << 20; // 64 MiB per staging buffer
 constexpr uint64_t kStageSlack = 4096;                 // samples kept free for alignment padding
@@ -97,14 +107,14 @@ struct ScanSlot {
 };
 
 constexpr int kSlots = 4;
-// Offsets per launch (ADSB_CHUNK_MI overrides, for tuning runs).  With the streaming
+// Offsets per launch.  With the streaming
 // hand-off the host already overlaps a launch while it runs, so launches are as large
 // as the record buffers sensibly allow (each launch carries ~20 us of ramp and tail);
 // the collect-after-completion path needs several launches in flight to overlap at all.
 static uint64_t chunk_offsets(bool streaming)
 {
     static const uint64_t forced = [] {
-        const char *e = getenv("ADSB_CHUNK_MI");
+        const char *e = tuning_env("ADSB_CHUNK_MI");
         const uint64_t mi = e ? strtoull(e, nullptr, 10) : 0;
         return (mi >= 1 && mi <= 512) ? mi : 0;
     }();
@@ -130,7 +140,7 @@ struct adsb_decoder {
     // alternate between the two, so that launch k+1's first tiles fill the slots launch k's last tiles leave empty
     // (a launch drains for about one tile life, ~40 us of falling occupancy; on one stream the next launch cannot
     // start before the previous one -- and the report kernel behind it -- has ended).  Staged scans stay on `stream`,
-    // behind their copies.  ADSB_ALT_STREAMS=0 turns it off; a caller-supplied cfg.stream does too.
+    // behind their copies.  A caller-supplied cfg.stream turns it off.
     hipStream_t stream2 = nullptr;
     bool alt_next = false; // scan_submit: the launches being submitted may alternate
     std::string err;
@@ -162,8 +172,9 @@ struct adsb_decoder {
     std::vector<uint32_t> order, scratch_a, scratch_b, gather, tile_start, tile_count;
     StreamReader *reader = nullptr;    // cfg.host_threads = 2: the thread that reads the hand-off stream (slot_collect_streaming)
     uint32_t reader_min_tiles = 1024; // launches below this many tiles are collected by the calling thread alone
-    bool no_streaming = false; // ADSB_NO_STREAMING=1: always collect after completion
-    int dbg_async = 0;         // ADSB_DEBUG_ASYNC (diagnosis, tools/async_race.py): 1 = wait for every async copy,
+    bool no_streaming = false; // cfg.debug_no_streaming: always collect after completion
+    uint64_t shard_head = 16384; // offsets of a resolved shard whose candidates are ALL kept for the stitcher (cfg.debug_shard_head)
+    int dbg_async = 0;         // tuning builds only (ADSB_DEBUG_ASYNC, tools/async_race.py): 1 = wait for every async copy,
                                // 2 = copies on the scan stream, 4 = tail copies not ordered before the next copy (the old race)
     // device-side visited-try count (scan_kernel.h TryCountArgs)
     uint64_t *d_carry[2] = {nullptr, nullptr};
@@ -318,11 +329,7 @@ int slot_reserve_hand(adsb_decoder *d, ScanSlot &s, size_t want_granules)
 {
     // fine-grained (coherent) so that the host sees the device's stores while the
     // kernel is still running
-    static const unsigned mem_flags = [] {
-        const char *e = getenv("ADSB_TILE_MEM");
-        const int v = e ? atoi(e) : 0;
-        return v == 1 ? hipHostMallocDefault : v == 2 ? hipHostMallocNonCoherent : hipHostMallocCoherent;
-    }();
+    constexpr unsigned mem_flags = hipHostMallocCoherent;
     if (want_granules > s.hand_cap) {
         if (s.hand)
             HIP_TRY(d, hipHostFree(s.hand));
@@ -561,11 +568,7 @@ struct HandCursor {
     // spin until tile_in(); gives up (false) once the kernel has long finished
     bool wait_tile()
     {
-        static const int kPollPause = [] {
-            const char *e = getenv("ADSB_POLL_PAUSE");
-            const int v = e ? atoi(e) : -1;
-            return v >= 0 ? v : 4; // measured: 0..256 make no difference to the kernel or the step
-        }();
+        constexpr int kPollPause = 4; // measured: 0..256 make no difference to the kernel or the step
         if (tile_in())
             return true;
         if (!s.ev_ready)
@@ -805,11 +808,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
 
-    static const uint32_t kGroup = [] {
-        const char *e = getenv("ADSB_GROUP");
-        const int v = e ? atoi(e) : 0;
-        return (uint32_t)(v > 0 ? v : 512); // tiles resolved per batch while the host is behind the device
-    }();
+    constexpr uint32_t kGroup = 512; // tiles resolved per batch while the host is behind the device
     std::vector<uint32_t> &order = d->order;     // a batch's records in ascending g (granule indices)
     std::vector<uint32_t> &t_start = d->tile_start; // per tile: granule index of its first record ...
     std::vector<uint32_t> &t_count = d->tile_count; // ... and its record count (~0u: not in yet)
@@ -818,7 +817,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
     uint32_t delivered = 0; // every tile below has been handed to the resolver
     bool overflowed = false;
     double dbg[3] = {0, 0, 0};
-    const bool dbg_on = getenv("ADSB_DEBUG_HOST") != nullptr;
+    const bool dbg_on = tuning_env("ADSB_DEBUG_HOST") != nullptr;
     double wait_ms = 0;
     auto t_last_wait = t_begin;
     auto flush = [&](uint32_t upto) { // tiles [delivered, upto): their ranges, one after the other, are sorted
@@ -848,7 +847,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
         if (dbg_on) {
             dbg[1] += std::chrono::duration<double, std::micro>(clk::now() - tp).count();
             dbg[2] += 1;
-            if (getenv("ADSB_DEBUG_TIMELINE"))
+            if (tuning_env("ADSB_DEBUG_TIMELINE"))
                 fprintf(stderr, "  t=%.1f us: tiles < %u resolved (%zu records), waited %.1f us so far\n",
                         std::chrono::duration<double, std::micro>(clk::now() - t_begin).count(), upto, nc, wait_ms * 1e3);
         }
@@ -1103,50 +1102,6 @@ int slot_collect(adsb_decoder *d)
             return -1;
         partial = rc == 1;
     }
-#if ADSB_TILE_CLOCK == 3
-    if (getenv("ADSB_CLOCK_OUT")) { // tuning builds: mean duration of each phase of a tile (thread 0's stamps, scan_kernel.hip)
-        HIP_TRY(d, hipStreamSynchronize(d->stream));
-        std::vector<uint32_t> h((size_t)s.ntiles * 9);
-        HIP_TRY(d, hipMemcpy(h.data(), s.args.tile_clock, h.size() * 4, hipMemcpyDeviceToHost));
-        double sum[7] = {0, 0, 0, 0, 0, 0, 0};
-        size_t n = 0;
-        for (uint32_t i = 0; i < s.ntiles; i++) {
-            const uint32_t *o = &h[8 * (size_t)i];
-            bool ok = true;
-            for (int k = 1; k < 8; k++)
-                ok &= o[k] != 0 && o[k] >= o[k - 1];
-            if (!ok)
-                continue;
-            for (int k = 0; k < 7; k++)
-                sum[k] += (o[k + 1] - o[k]) * 0.01;
-            n++;
-        }
-        double arrive = 0;
-        for (uint32_t i = 0; i < s.ntiles; i++)
-            arrive += h[8 * (size_t)s.ntiles + i] * 0.01 / 4;
-        if (n)
-            fprintf(stderr, "waves reach the barrier behind stage A %.2f us after the tile's begin on average (it opens at the time printed next)\n", arrive / s.ntiles);
-        if (n)
-            fprintf(stderr, "tile phases (us, thread 0, mean over %zu of %u tiles): stage A %.2f | gate + slicer %.2f | wait for the other "
-                    "waves %.2f | filter + rank %.2f | barrier %.2f | bytes, pw, reservation back %.2f | wait for the other records %.2f\n",
-                    n, s.ntiles, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n);
-    }
-#elif ADSB_TILE_CLOCK
-    if (const char *path = getenv("ADSB_CLOCK_OUT")) {
-        HIP_TRY(d, hipStreamSynchronize(d->stream));
-        std::vector<uint32_t> h((size_t)s.ntiles * 4);
-        HIP_TRY(d, hipMemcpy(h.data(), s.args.tile_clock, h.size() * 4, hipMemcpyDeviceToHost));
-        uint32_t t0c = ~0u;
-        for (uint32_t i = 0; i < s.ntiles; i++)
-            t0c = std::min(t0c, h[4 * i]);
-        if (FILE *f = fopen(path, "w")) {
-            for (uint32_t i = 0; i < s.ntiles; i++)
-                fprintf(f, "%u %.2f %.2f %u %u %u\n", i, (h[4 * i] - t0c) * 0.01, (h[4 * i + 1] - t0c) * 0.01, h[4 * i + 3] & 15u,
-                        (h[4 * i + 2] >> 8) & 15u, (h[4 * i + 2] >> 13) & 7u);
-            fclose(f);
-        }
-    }
-#endif
     if (s.streaming && !partial && (!s.tries_on_device || s.try_regions)) {
         // Every tile has been published and consumed and none used the loose list -- nor, in a statistics
         // run, the launch-wide try list: a tile that falls back to overflow rounds flags its marker, and
@@ -1316,17 +1271,9 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
         a.g_begin = g_begin;
         a.g_end = g_stop;
         a.df18 = d->cfg.df18 ? 1 : 0;
-        a.pipe = adsb::choose_pipe(n_off) ? 1 : 0;
-        a.passes = adsb::choose_passes(n_off, d->n_cus, a.pipe != 0);
-        a.stagger = a.pipe ? 0u : adsb::choose_stagger(n_off, d->n_cus, a.passes);
-#if ADSB_TILE_CLOCK
-        {   // tuning builds: per-tile device timestamps of the LAST launch, dumped at collect
-            static uint32_t *dclk = nullptr;
-            if (!dclk)
-                HIP_TRY(d, hipMalloc(&dclk, (size_t)(1u << 20) * 16));
-            a.tile_clock = dclk;
-        }
-#endif
+        a.passes = (d->cfg.debug_passes >= 2 && d->cfg.debug_passes <= adsb::kMaxPasses) ? d->cfg.debug_passes
+                                                                                         : adsb::choose_passes(n_off, d->n_cus);
+        a.stagger = adsb::checked_stagger(n_off, a.passes, d->cfg.debug_stagger);
         a.synd = d->d_synd;
         a.queue_cap = (d->cfg.debug_queue_cap >= 256 && d->cfg.debug_queue_cap <= adsb::kQueueCap)
                           ? d->cfg.debug_queue_cap
@@ -1512,6 +1459,10 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return nullptr;
         }
         std::memcpy(&cfg, cfg_in, cfg_in->struct_size);
+        // ABI 2 called this member `reserved0` and did not ask for it to be zero: it only means push_overlap for
+        // callers whose struct already has the member behind it
+        if (cfg_in->struct_size < offsetof(adsb_config, host_threads) + sizeof(int32_t))
+            cfg.push_overlap = 0;
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1563,7 +1514,7 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipStreamCreate", e);
         d->own_stream = true;
     }
-    if (d->own_stream && !(getenv("ADSB_ALT_STREAMS") && atoi(getenv("ADSB_ALT_STREAMS")) == 0) &&
+    if (d->own_stream && !(tuning_env("ADSB_ALT_STREAMS") && atoi(tuning_env("ADSB_ALT_STREAMS")) == 0) &&
         (e = hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate(second scan stream)", e);
     for (int i = 0; i < adsb_decoder::kCopyStreams; i++)
@@ -1611,8 +1562,8 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipMalloc(try counters)", e);
         d->d_carry_n = reinterpret_cast<uint32_t *>(d->d_try_acc + 4);
         d->frames_cap = 1u << 16; // accepted frames between two count passes (a 128 Mi-offset launch at 1 k frames/s: 13 k)
-        if (const char *fc = getenv("ADSB_DEBUG_FRAMES_CAP")) // tests: start small, so that the regrow path runs
-            d->frames_cap = std::max<size_t>(8, strtoull(fc, nullptr, 10));
+        if (cfg.debug_frames_cap > 0) // tests: start small, so that the regrow path runs
+            d->frames_cap = std::max<size_t>(8, (size_t)cfg.debug_frames_cap);
         for (int i = 0; i < adsb_decoder::kFrameBufs; i++)
             if ((e = hipHostMalloc(&d->h_frames[i], d->frames_cap * sizeof(adsb::TryFrame), hipHostMallocDefault)) != hipSuccess ||
                 (e = hipEventCreate(&d->ev_frames[i])) != hipSuccess)
@@ -1631,11 +1582,9 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
     }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     {
-        const char *e = getenv("ADSB_HOST_THREADS"); // A/B runs: overrides cfg.host_threads
-        const int want = e ? atoi(e) : d->cfg.host_threads;
-        if (const char *m = getenv("ADSB_READER_MIN_TILES"))
-            d->reader_min_tiles = (uint32_t)std::max(1, atoi(m));
-        if (want == 2) {
+        if (cfg.debug_reader_min_tiles > 0)
+            d->reader_min_tiles = (uint32_t)cfg.debug_reader_min_tiles;
+        if (d->cfg.host_threads == 2) {
             d->reader = new (std::nothrow) StreamReader;
             if (d->reader) {
                 d->reader->device = d->device;
@@ -1646,15 +1595,17 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
                     d->reader = nullptr;
                 }
                 if (d->reader) {
-                    d->reader->place = !(getenv("ADSB_READER_PLACE") && atoi(getenv("ADSB_READER_PLACE")) == 0);
+                    d->reader->place = true;
                     if (d->reader->place)
                         d->reader->placed_l3 = place_reader_thread(d->reader->th, sched_getcpu());
                 }
             }
         }
     }
-    d->no_streaming = getenv("ADSB_NO_STREAMING") && atoi(getenv("ADSB_NO_STREAMING")) != 0;
-    d->dbg_async = getenv("ADSB_DEBUG_ASYNC") ? atoi(getenv("ADSB_DEBUG_ASYNC")) : 0;
+    d->no_streaming = cfg.debug_no_streaming != 0;
+    if (cfg.debug_shard_head > 0)
+        d->shard_head = (uint64_t)cfg.debug_shard_head;
+    d->dbg_async = tuning_env("ADSB_DEBUG_ASYNC") ? atoi(tuning_env("ADSB_DEBUG_ASYNC")) : 0;
     d->res.reset();
     return d;
 }
@@ -1740,10 +1691,14 @@ int adsb_reset(adsb_decoder *d)
         for (ScanSlot &sl : d->slots) {
             // normally the report kernel behind each scan has left the counters zero; after a failed launch it may not have
             HIP_TRY(d, hipMemsetAsync(sl.d_counters, 0, adsb::kDevCounterWords * sizeof(uint32_t), d->stream));
+            sl.launch_stream = nullptr; // every stream has been drained: nothing of the slot's past to order against ...
             sl.busy = false;
             sl.count_pending = false;
             sl.prof_pending[0] = sl.prof_pending[1] = false;
         }
+        // ... except these fills: the slot's next launch may go to the second scan stream, which nothing orders behind
+        // d->stream -- a late fill would zero the counters of a running scan
+        HIP_TRY(d, hipStreamSynchronize(d->stream));
     }
     else if (wait_last_copy(d)) // a late asynchronous copy must not land in stage[0] beside the next stream's
         return -1;
@@ -1921,7 +1876,7 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
     d->n_samples = total;
     if (final) {
         using clk = std::chrono::steady_clock;
-        const bool dbg_on = getenv("ADSB_DEBUG_HOST") != nullptr;
+        const bool dbg_on = tuning_env("ADSB_DEBUG_HOST") != nullptr;
         const auto t0 = clk::now();
         if (g_end > d->g_scanned) {
             d->alt_next = true; // in place: nothing on d->stream has to precede these launches
@@ -2151,11 +2106,7 @@ int adsb_scan_shard_resolved_walk(adsb_decoder *d, const void *device_samples, u
     HIP_TRY(d, hipSetDevice(d->device));
     if (scan_drain(d))
         return -1;
-    static const uint64_t head_span = [] {
-        const char *e = getenv("ADSB_SHARD_HEAD"); // tests shrink it to reach the stitcher's fallback
-        const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
-        return v ? v : (uint64_t)16384;
-    }();
+    const uint64_t head_span = d->shard_head; // (tests shrink it to reach the stitcher's fallback)
     std::vector<adsb_candidate> hv;
     const uint64_t head_end = std::min<uint64_t>(g_end, g_begin + head_span);
     d->sink = ScanSink{};

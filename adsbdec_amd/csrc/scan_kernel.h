@@ -6,49 +6,13 @@
 
 namespace adsb {
 
-// Tuning knobs; the defaults are what ships. tools/kbench.hip overrides them with -D.
-#ifndef ADSB_ABLATE
-#define ADSB_ABLATE 0 // kbench only: 1 = loads only, 2 = front end + bit planes only, 3 = no loads (arithmetic alone)
-#endif
-#ifndef ADSB_FIR_GROUP
-#define ADSB_FIR_GROUP 4 // FIR outputs advanced together (independent chains interleaved)
-#endif
-#ifndef ADSB_SLEEP_STAGGER
-#define ADSB_SLEEP_STAGGER 90 // s_sleep units (64 cycles) between the starts of a CU's first four workgroups; 0 = off
-#endif
-#ifndef ADSB_COALESCED_PROBE
-#define ADSB_COALESCED_PROBE 0 // tools/kbench with -DADSB_ABLATE=1: the pass's window read by coalesced loads (a probe of the memory side)
-#endif
-#ifndef ADSB_DOUBLE_BUFFER
-#define ADSB_DOUBLE_BUFFER 0 // experiment: the next pass's 17 loads are in flight while this pass is computed (two register sets; build with -DADSB_MIN_WAVES=2 or 3)
-#endif
-#ifndef ADSB_PREFETCH_NEXT
-#define ADSB_PREFETCH_NEXT 0 // Stage A touches the lines of the wave's next pass (one dword per 128-byte line) while it computes this one
-#endif
-#ifndef ADSB_ABLATE_PLANES
-#define ADSB_ABLATE_PLANES 0 // tools/kbench timing builds only (wrong results): 1 drops the E2 plane's arithmetic, 2 E1's and E2's
-#endif
-#ifndef ADSB_STAGED_WAIT
-#define ADSB_STAGED_WAIT 0 // experiment: Stage A starts on a run's first outputs while its last loads are still in flight
-#endif
-#ifndef ADSB_FMA_BIAS
-#define ADSB_FMA_BIAS 0 // fold the -2048 bias and the fs/4 sign into the FIR's products (exact: scan_kernel.hip fir_step)
-#endif
-#ifndef ADSB_STAGEB_PRIO
-#define ADSB_STAGEB_PRIO 0 // s_setprio level of a workgroup's waves from the end of Stage A on (0 = unchanged)
-#endif
-#ifndef ADSB_PREHALO_DPP
-#define ADSB_PREHALO_DPP 0 // experiment: pre-halo pairs from the previous lane by DPP instead of three more loads
-#endif
-#ifndef ADSB_MIN_WAVES
-#define ADSB_MIN_WAVES 4 // __launch_bounds__ second argument (waves per SIMD)
-#endif
+// Launch shape (what every measurement of DESIGN.md was taken with; the experiments that set other values are history)
+constexpr int kFirGroup = 4;       // FIR outputs advanced together (independent accumulation chains interleaved)
+constexpr int kSleepStagger = 90;  // s_sleep units (64 cycles) between the starts of a CU's first four workgroups
+constexpr int kMinWaves = 4;       // __launch_bounds__ second argument: waves per SIMD (100 VGPRs)
 
 constexpr int kRun = 28;        // power samples per thread run (4 x 7: see scan_kernel.hip)
-#ifndef ADSB_THREADS
-#define ADSB_THREADS 256
-#endif
-constexpr int kThreads = ADSB_THREADS; // 4 wavefronts (experiment: 512 = 8)
+constexpr int kThreads = 256;   // 4 wavefronts
 constexpr int kWaves = kThreads / 64;
 constexpr int kWaveRuns = 63;   // distinct runs per wave and pass (lane 63 re-computes the next wave's first run)
 constexpr int kPassRuns = kWaves * kWaveRuns;   // 252
@@ -66,10 +30,7 @@ constexpr int kGranuleWords = 4;
 constexpr int kCounterWords = 8; // the launch counters as the host sees them (ScanArgs::report)
 // On the device every counter has a 128-byte line of its own (ScanArgs::counters[i * kCounterPad]; the two
 // 64-bit profile maxima are counters 4 and 5).  All of a launch's tiles hit them with device-scope atomics.
-#ifndef ADSB_COUNTER_PAD
-#define ADSB_COUNTER_PAD 32
-#endif
-constexpr int kCounterPad = ADSB_COUNTER_PAD;
+constexpr int kCounterPad = 32;
 constexpr int kDevCounterWords = 6 * kCounterPad;
 constexpr uint32_t kMarkOver = 0x10000u;  // marker flag: some records of the tile are on the loose list
 constexpr uint32_t kMarkNoFit = 0x20000u; // marker flag: the tile's range ran past the array (records are loose)
@@ -87,45 +48,10 @@ constexpr size_t lds_bytes(int passes)
 {
     return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6);
 }
-// the pipelined kernel (ScanArgs::pipe): two sets of planes, queue, 32 control words, 64 staged candidates
-#ifndef ADSB_PIPE_PRIO
-#define ADSB_PIPE_PRIO 3 // s_setprio level of the pipelined kernel's Stage B wave (0 = like the others)
-#endif
-#ifndef ADSB_EARLY_RESERVE
-#define ADSB_EARLY_RESERVE 0 // 1: the tile reserves its hand-off range before the never-visited filter, for the staged count (kernel -2 %, but the
-                             // stream gets four times sparser and the host, which chases it marker by marker, takes twice as long: off)
-#endif
-#ifndef ADSB_GATE_IN_LOOP
-#define ADSB_GATE_IN_LOOP 0 // experiment (classic kernel): preamble test + DF gate of a wave's previous pass inside the pass loop
-#endif
-#ifndef ADSB_PIPE_JITTER
-#define ADSB_PIPE_JITTER 0 // tuning builds: a pseudo-random pause (0..31 x this many s_sleep units) in front of every tile's Stage A
-#endif
-#ifndef ADSB_PIPE_FREE
-#define ADSB_PIPE_FREE 0 // tuning builds, with ADSB_PIPE_ABLATE=1: the arithmetic waves run without the per-tile barrier
-#endif
-#ifndef ADSB_PIPE_ROLES
-#define ADSB_PIPE_ROLES 0 // 1: the Stage B wave is one that shares its SIMD with another wave of the workgroup (measured: slower); 0: always wave 4
-#endif
-#ifndef ADSB_PIPE_ABLATE
-#define ADSB_PIPE_ABLATE 0 // tuning builds: 1 = Stage B does no work
-#endif
-#ifndef ADSB_PIPE_WAVES
-#define ADSB_PIPE_WAVES 5 // waves per SIMD its register budget is set for: 5 = 96 VGPRs, four workgroups per CU; 4 = 128, three
-#endif
-constexpr int kPipeMaxPasses = ADSB_PIPE_WAVES >= 5 ? 5 : 7; // 36 KiB x 4 workgroups, or 48 KiB x 3, of a CU's 160 KiB
-#ifndef ADSB_PIPE_MIN_OFFSETS
-#define ADSB_PIPE_MIN_OFFSETS (~0ull) // launches of at least this many offsets use the pipelined kernel (choose_pipe)
-#endif
-constexpr uint64_t kPipeMinOffsets = ADSB_PIPE_MIN_OFFSETS;
-constexpr size_t lds_bytes_pipe(int passes)
-{
-    return sizeof(uint32_t) * (size_t)(6 * (kPassRuns * passes + kPlanePad) + kQueueCap + 32 + 64 * 6);
-}
-
 // Tile geometry of a launch.  Every tile takes K = `passes` passes, except that the first
 // `stagger` tiles (a multiple of 4, K >= 5; 0 = off, the default) cycle through K-3, K-2,
-// K-1, K -- an experiment in spreading tile completions that did not pay (choose_stagger).
+// K-1, K -- an experiment in spreading tile completions that did not pay; kept as a test knob
+// (adsb_config.debug_stagger) because it exercises the tile geometry functions.
 __host__ __device__ inline int tile_passes(uint32_t tile, uint32_t stagger, int k)
 {
     return tile < stagger ? k - 3 + (int)(tile & 3u) : k;
@@ -165,13 +91,6 @@ __host__ __device__ inline void marker_check(uint32_t tile, uint32_t nf, uint32_
     hi = a1 ^ (a3 << 16 | a3 >> 16) ^ ~gen ^ (tile << 7 | tile >> 25) ^ nf;
 }
 
-#ifndef ADSB_SAME_DATA
-#define ADSB_SAME_DATA 0 // tools/kbench: all tiles read the same samples
-#endif
-#ifndef ADSB_TILE_CLOCK
-#define ADSB_TILE_CLOCK 0 // tools/kbench: per-tile timestamps
-#endif
-
 struct ScanArgs {
     const uint32_t *x;   // (I,Q) pairs; x[0] is stream pair index pbuf0 (16-byte aligned, pbuf0 % 4 == 0)
     int64_t pbuf0;
@@ -180,10 +99,9 @@ struct ScanArgs {
     uint64_t g_end;      // one past the last offset
     int df18;            // demod.c:26
     int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
-    int pipe;            // 1: the pipelined kernel (persistent five-wave workgroups, Stage B on a wave of its own;
-                         // passes <= kPipeMaxPasses, stagger == 0); 0: the classic one-workgroup-per-tile kernel
-    uint32_t n_tiles;    // tile_count() of the launch (launch_scan fills it in)
-    uint32_t *tile_clock; // ADSB_TILE_CLOCK builds only: 4 dwords per tile {begin, end (100 MHz), HW_ID, XCC_ID}
+    int reserved0;       // three members of round 3's experiments, kept as padding: with the kernel-argument layout
+    uint32_t reserved1;  // unchanged, the gfx950 code of scan_kernel<> is instruction for instruction what round 3
+    uint32_t *reserved2; // measured (profiles/r4_isa_identity.txt); removing them re-allocates every scalar register
     uint32_t stagger;    // the first `stagger` tiles take K-3..K passes in turn (tile_passes)
     int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
     int all_candidates;  // 1: emit every CRC-valid offset (no never-visited filter)
@@ -206,7 +124,7 @@ struct ScanArgs {
     uint32_t fix_mul;
     const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
     // Device counters, zero at launch: [0] loose candidates, [1] tries (may exceed the
-    // capacities), [2] hand-off granules, [3] the pipelined kernel's tile counter; with `profile` [4..5] max over tiles of
+    // capacities), [2] hand-off granules, [3] unused; with `profile` [4..5] max over tiles of
     // ~(start) and [6..7] max of end on the device's 100 MHz clock (64-bit).  launch_scan
     // puts one wave behind the scan (report_kernel) that writes them to `report` (pinned
     // host, same layout, word [3] = gen; null: no report) and zeroes them.
@@ -266,14 +184,11 @@ void make_syndrome_table(uint32_t *out /* kSyndWords */);
 // Host: perfect hash of the single-bit syndromes of bits 5..111 of a long frame:
 // tab[(syn * mul) >> 23] = (syn << 8) | bit. Returns the multiplier.
 uint32_t make_fix_table(uint32_t *tab /* kFixSlots */);
-// Host: choose the passes-per-tile for a launch of n_offsets on a device with
-// `slots` resident workgroups (balances halo overhead against tail quantisation).
-int choose_passes(uint64_t n_offsets, int cus, bool pipe = false);
-// Host: which kernel scans a launch of n_offsets (ScanArgs::pipe).  ADSB_PIPE=0/1 forces one (read per launch).
-bool choose_pipe(uint64_t n_offsets);
-// Host: how many leading tiles to stagger (tile_passes): 0 unless ADSB_STAGGER is set
-// (measured: no gain, see choose_stagger).
-uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes);
+// Host: choose the passes-per-tile for a launch of n_offsets on a device with `cus` compute units
+// (balances halo overhead against tail quantisation).
+int choose_passes(uint64_t n_offsets, int cus);
+// Host: a forced stagger (adsb_config.debug_stagger), made valid for the launch (multiple of 4, K >= 5, enough tiles), else 0.
+uint32_t checked_stagger(uint64_t n_offsets, int passes, int forced);
 hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream);
 
 } // namespace adsb

@@ -45,11 +45,10 @@
 //  as one write-through store of adjacent lanes into the host's hand-off stream
 //  (scan_kernel.h), or -- fallbacks -- through the launch-wide loose list.
 //
-//  Two kernels share stage_a() and stage_b<>(): scan_kernel, the one that ships -- a workgroup of four waves per tile, Stage A,
-//  a barrier, Stage B between barriers -- and scan_pipe_kernel (ScanArgs::pipe, ADSB_PIPE=1), round 3's experiment:
-//  persistent five-wave workgroups in which a wave of its own runs Stage B of tile t while the other four run Stage A of
-//  tile t + 1.  It is bit-identical and 45 % slower (Stage B is a latency chain that one wave cannot run as fast as Stage A
-//  feeds it: DESIGN.md section 4, profiles/r3_ab_runs.txt); every -m gpu test runs with both.
+//  One workgroup of four waves per tile: Stage A, a barrier, Stage B between barriers.  (A pipelined variant -- persistent
+//  five-wave workgroups, Stage B of tile t on a wave of its own beside Stage A of tile t + 1 -- was built in round 3,
+//  bit-identical and 45 % slower; it and the other experiments that lost are in the history of this file, see
+//  DESIGN_HISTORY.md.)
 //
 //  A workgroup owns owned_runs(K) = 252 K - 44 runs and computes 252 K (+1): the halo
 //  (the 1196-sample reach of a long frame) costs 44 runs of planes per tile (2 % at
@@ -105,27 +104,11 @@ __device__ __forceinline__ void fir_step(const f32x2 (&vv)[34], f32x2 &s)
     constexpr int p = J % 7;
     constexpr int age = (STEP <= p) ? (p - STEP) : (6 - (STEP - p - 1));
     constexpr int slot = J - age + 6;
-#if ADSB_FMA_BIAS
-    // vv holds the RAW sample values f = (float)x here.  The product the reference rounds is
-    // t * v with v = f - 2048 (even pairs) or 2048 - f (odd pairs, fs/4 sign): as a real number that
-    // is t*f - 2048*t, and 2048*t is exact in binary32 (a power-of-two multiple of t), so ONE fused
-    // multiply-add fma(+-t, f, -+2048 t) rounds exactly the same real number once -- the same bits
-    // as sub, then mul -- and the 34 bias subtractions per pass are gone.
-    constexpr float sg = (slot & 1) ? -1.0f : 1.0f;
-    constexpr f32x2 t = {sg * tap<12 - 2 * age>(), sg * tap<13 - 2 * age>()};
-    constexpr f32x2 c = {-sg * 2048.0f * tap<12 - 2 * age>(), -sg * 2048.0f * tap<13 - 2 * age>()};
-    const f32x2 prod = __builtin_elementwise_fma(t, vv[slot], c);
-    if constexpr (STEP == 0)
-        s = prod;
-    else
-        s = s + prod;
-#else
     constexpr f32x2 t = {tap<12 - 2 * age>(), tap<13 - 2 * age>()};
     if constexpr (STEP == 0)
         s = t * vv[slot]; // 0.0f + x == x up to the sign of zero, which the square erases
     else
         s = s + t * vv[slot];
-#endif
 }
 
 // G consecutive outputs advanced together, one FIR step at a time: G independent
@@ -167,57 +150,6 @@ __device__ __forceinline__ void power_block(const f32x2 (&vv)[34], float *a)
     }
 }
 
-#if ADSB_STAGED_WAIT
-typedef float f32x4s __attribute__((ext_vector_type(4)));
-// Slot s of a run from the loaded quads: air.c:64-67,79-82 (bias, fs/4 sign: see stage_a).
-template <int S>
-__device__ __forceinline__ f32x2 slot_value(const f32x4s (&tl)[17])
-{
-    const f32x4s q = tl[S >> 1];
-    const f32x2 f = (S & 1) ? f32x2{q.z, q.w} : f32x2{q.x, q.y};
-    const f32x2 mid = {2048.0f, 2048.0f};
-    return ((S & 1) == 0) ? (f - mid) : (mid - f);
-}
-template <int S0, int S1>
-__device__ __forceinline__ void make_slots(const f32x4s (&tl)[17], f32x2 (&vv)[34])
-{
-    if constexpr (S0 <= S1) {
-        vv[S0] = slot_value<S0>(tl);
-        make_slots<S0 + 1, S1>(tl, vv);
-    }
-}
-// power_block with the run's 17 loads still in flight: group J0.. waits only for the loads it reads (they return in
-// order), so the first outputs are computed while the last quads are still on their way.  The wait carries the quads
-// it releases (and the previous group's last output, which pins it behind that group) as operands: nothing reads a
-// quad before its wait.
-template <int J0, int N, int G>
-__device__ __forceinline__ void power_block_staged(f32x4s (&tl)[17], f32x2 (&vv)[34], float *a)
-{
-    if constexpr (N > 0) {
-        constexpr int g = (N < G) ? N : G;
-        constexpr int s_hi = J0 + g + 5;                 // last slot this group reads
-        constexpr int s_lo = (J0 == 0) ? 0 : J0 + 6;     // first slot not made yet
-        constexpr int l_hi = s_hi >> 1, l_lo = s_lo >> 1; // quads: l_lo may have been released already (odd s_lo)
-        static_assert(G == 4, "the operand lists below are written for groups of four outputs");
-        if constexpr (J0 == 0)
-            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(tl[4]) : "n"(16 - l_hi));
-        else
-            asm volatile("s_waitcnt vmcnt(%3)" : "+v"(tl[l_hi - 1]), "+v"(tl[l_hi]), "+v"(a[J0 - 1]) : "n"(16 - l_hi));
-        (void)l_lo;
-        make_slots<s_lo, s_hi>(tl, vv);
-        f32x2 s[g];
-        fir_group_step<J0, g, 0>(vv, s);
-#pragma unroll
-        for (int k = 0; k < g; k++) {
-            const f32x2 sq = s[k] * s[k];
-            float r;
-            asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(sq.x), "v"(sq.y));
-            a[J0 + k] = r;
-        }
-        power_block_staged<J0 + g, N - g, G>(tl, vv, a);
-    }
-}
-#endif
 
 // Same arithmetic for power samples at RUN-TIME indices (rare path: pw of a
 // CRC-valid candidate needs a[g], a[g+10], a[g+35], a[g+45]).  Rounds exactly like
@@ -388,245 +320,15 @@ __device__ __forceinline__ uint32_t take28(const uint32_t *w)
 
 } // namespace
 
-// Experiment (-DADSB_GATE_IN_LOOP=1, classic kernel only): the preamble test + DF gate of a run, and the enqueue of its
-// survivors, as one call -- so that a wave can gate the 63 runs of its previous pass inside the pass loop (the planes they
-// need are its own: waves then own CONTIGUOUS runs of the tile) instead of after the workgroup barrier.  Same logic as
-// the gate loop of stage_b.
-struct GateCtx {
-    uint32_t *queue, *qcount, *qover;
-    uint32_t qcap, df18_mask;
-    int off_end;
-};
-__device__ __forceinline__ void gate_and_enqueue(const GateCtx &gc, const uint32_t *pl_d, const uint32_t *pl_e1, const uint32_t *pl_e2,
-                                                 const int vq, const bool active)
-{
-    const int nvalid = active ? gc.off_end - kRun * vq : 0;
-    const int v = nvalid > 0 ? vq : 0;
-    const uint32_t e2w[2] = {pl_e2[v + 1], pl_e2[v + 2]};
-    const uint32_t dw[4] = {pl_d[v + 2], pl_d[v + 3], pl_d[v + 4], pl_d[v + 5]};
-    const uint32_t b0 = take28u<80 - 56>(dw), b1 = take28u<90 - 56>(dw), b2 = take28u<100 - 56>(dw), b3 = take28u<110 - 56>(dw),
-                   b4 = take28u<120 - 56>(dw);
-    const uint32_t hi = ADSB_BITOP3(b0, b1, b2, A & ~B & ~C);
-    const uint32_t lo = ADSB_BITOP3(b3, b4, gc.df18_mask, (A ^ B) & (B | C));
-    const uint32_t h11 = ADSB_BITOP3(b0, b1, b2, ~A & B & ~C);
-    const uint32_t m11 = ADSB_BITOP3(h11, b3, b4, A & B & C);
-    const uint32_t df = ADSB_BITOP3(hi, lo, m11, (A & B) | C);
-    uint32_t gate = ADSB_BITOP3(pl_e1[v], take28u<30 - 28>(e2w), df, A & B & C);
-    gate &= nvalid >= kRun ? 0x0FFFFFFFu : nvalid > 0 ? (1u << nvalid) - 1u : 0u;
-    const int n = __popc(gate);
-    if (n) {
-        uint32_t slot = atomicAdd(gc.qcount, (uint32_t)n);
-        if (slot + n <= gc.qcap) {
-            while (gate) {
-                const int j = __ffs(gate) - 1;
-                gate &= gate - 1;
-                const uint32_t code = ((b1 >> j) & 1u) ? 0u : ((b4 >> j) & 1u) ? 1u : 2u;
-                gc.queue[slot++] = ((uint32_t)vq << 7) | ((uint32_t)j << 2) | code;
-            }
-        } else {
-            *gc.qover = 1;
-        }
-    }
-}
-
-#if ADSB_DOUBLE_BUFFER
-// ---- experiment: Stage A with the NEXT pass's loads in flight while this pass is computed (two register sets) ----
-// pass_compute_db is stage_a's own code behind the loads, verbatim (kept apart so that the shipped kernel's code
-// generation is not touched by the experiment).
-typedef float f32x4d __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void pass_compute_db(f32x4d (&tl)[17], const int lane, const int v, uint32_t *pl_d, uint32_t *pl_e1,
-                                                uint32_t *pl_e2)
-{
-    typedef f32x4d f32x4;
-    // air.c:64-67,79-82: v = (float)x - 2048; pairs with odd index are negated
-    // (samples n mod 4 in {2,3}).  The run starts at an even pair index, so the
-    // sign is a compile-time property of the slot.  -(x-2048) == 2048-x exactly.
-    f32x2 vv[34];
-#if !ADSB_STAGED_WAIT // (staged: the slots are made group by group, behind the wait for their quads: power_block_staged)
-#pragma unroll
-    for (int s = 0; s < 34; s++) {
-        const f32x4 q = tl[s >> 1];
-        const f32x2 f = (s & 1) ? f32x2{q.z, q.w} : f32x2{q.x, q.y};
-#if ADSB_FMA_BIAS
-        vv[s] = f; // bias and fs/4 sign are folded into the FIR's products (fir_step)
-#else
-        const f32x2 mid = {2048.0f, 2048.0f};
-        vv[s] = ((s & 1) == 0) ? (f - mid) : (mid - f); // slot s <-> rel pair s-6: same parity
-#endif
-    }
-#endif
-
-#if ADSB_PREHALO_DPP
-    if (interior) {
-#pragma unroll
-        for (int sl = 0; sl < 6; sl++) { // lane 0 keeps what it loaded (no source lane: `old` stays)
-            vv[sl].x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(vv[sl].x), __float_as_int(vv[sl + 28].x), 0x138, 0xF, 0xF, false));
-            vv[sl].y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(vv[sl].y), __float_as_int(vv[sl + 28].y), 0x138, 0xF, 0xF, false));
-        }
-    }
-#endif
-    // a[0..27]: this run; a[28..43]: the first 16 samples of the next run (next lane)
-    float a[44];
-#if ADSB_STAGED_WAIT
-    static_assert(!ADSB_FMA_BIAS && !ADSB_PREHALO_DPP && ADSB_ABLATE != 1 && ADSB_ABLATE != 3, "staged waits: the plain load path only");
-    power_block_staged<0, 28, ADSB_FIR_GROUP>(tl, vv, a); // (the ragged path's plain loads have landed: its waits fall through)
-#else
-    power_block<0, 28, ADSB_FIR_GROUP>(vv, a);
-#endif
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        a[28 + k] = from_next_lane(a[k]);
-
-    // demod.c:102-105: every preamble sum is c[k] = (int)(a[k] + a[k+10]).  The
-    // truncated value is kept as a float (v_trunc_f32 == the C conversion for the
-    // magnitudes in the input domain); the integer comparisons `c > 2 c'` are
-    // decided by the SIGN of 2 c' - c, which one fused multiply-add gives exactly
-    // (a single rounding cannot change the sign of a non-zero difference and an
-    // exact zero stays zero).  These are the only FMAs in the kernel; the signal
-    // arithmetic above is mul-then-add.
-    //
-    // Packing: every operation here combines index k with k + 5 or k + 10, so the
-    // usual (k, k+1) register pairs cannot feed v_pk_* on both sides (5 is odd).
-    // Pairs (k, k+2) for k mod 5 in {0, 1} can -- the partner set is closed under
-    // +5 -- and leave k mod 5 == 4 as scalar operations: 4 of 5 values are packed.
-    float c[34], dv[28], e1v[28], e2v[28];
-#pragma unroll
-    for (int k = 0; k < 33; k++) {
-        if (k % 5 < 2) {
-            const f32x2 lo = {a[k], a[k + 2]}, hi = {a[k + 10], a[k + 12]};
-            const f32x2 sum = lo + hi;
-            c[k] = __builtin_truncf(sum.x);
-            c[k + 2] = __builtin_truncf(sum.y);
-        } else if (k % 5 == 4) {
-            c[k] = __builtin_truncf(a[k] + a[k + 10]);
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < 28; m++) {
-        if (m % 5 < 2 && m + 2 < 28) {
-            const f32x2 am = {a[m], a[m + 2]}, an = {a[m + 5], a[m + 7]};
-            const f32x2 cm = {c[m], c[m + 2]}, cn = {c[m + 5], c[m + 7]};
-            const f32x2 two = {2.0f, 2.0f};
-            const f32x2 dd = an - am;
-            const f32x2 x1 = __builtin_elementwise_fma(cn, two, -cm);
-            const f32x2 x2 = __builtin_elementwise_fma(cm, two, -cn);
-            dv[m] = dd.x, dv[m + 2] = dd.y;
-            e1v[m] = x1.x, e1v[m + 2] = x1.y;
-            e2v[m] = x2.x, e2v[m + 2] = x2.y;
-        } else if (m % 5 == 4 || (m % 5 < 2 && m + 2 >= 28)) {
-            dv[m] = a[m + 5] - a[m];
-            e1v[m] = __builtin_fmaf(c[m + 5], 2.0f, -c[m]);
-            e2v[m] = __builtin_fmaf(c[m], 2.0f, -c[m + 5]);
-        }
-    }
-
-    uint32_t d = 0, e1 = 0, e2 = 0;
-#pragma unroll
-    for (int m = 27; m >= 0; m--) { // bit m of each word <-> sample m of the run
-        d = push_sign(d, __float_as_uint(dv[m]));    // a[m+5] - a[m] < 0:  a[m] > a[m+5]   (demod.c:34)
-#if ADSB_ABLATE_PLANES < 2
-        e1 = push_sign(e1, __float_as_uint(e1v[m])); // 2 c[m+5] - c[m] < 0: c[m] > 2 c[m+5] (SN = 2, demod.c:83)
-#endif
-#if ADSB_ABLATE_PLANES < 1 // (kbench timing builds drop the E2 plane, or E1 and E2: how does the time follow the instruction count?)
-        e2 = push_sign(e2, __float_as_uint(e2v[m])); // 2 c[m] - c[m+5] < 0: c[m+5] > 2 c[m]
-#endif
-    }
-    if (lane < kWaveRuns) { // lane 63 only feeds lane 62
-        pl_d[v] = d;
-        pl_e1[v] = e1;
-        pl_e2[v] = e2;
-    }
-}
-
-__device__ __forceinline__ void stage_a_db(const uint32_t *__restrict__ xin, const int64_t pbuf0, const int64_t p_lo,
-                                           const int64_t p_hi, const int64_t t0, const int K, const int wave, const int lane,
-                                           uint32_t *pl_d, uint32_t *pl_e1, uint32_t *pl_e2)
-{
-    typedef f32x4d f32x4;
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    auto first_run = [&](int ps) { return kWaveRuns * (kWaves * ps + wave); };
-    auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * first_run(ps) - 8; };
-    // the loads of pass ps into q: 17 typed loads, NOT waited for (interior windows), or plain loads (ragged ends)
-    auto issue = [&](int ps, f32x4 (&q)[17]) {
-        const int64_t wlo = pass_first_pair(ps);
-        const bool interior = (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
-        if (interior) {
-            const uint64_t wbase = (uint64_t)(xin + (wlo - pbuf0));
-            i32x4 rs;
-            rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)wbase);
-            rs.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(wbase >> 32) & 0xFFFFu));
-            rs.z = 64 * kRun * 4 + 64;
-            rs.w = (int)(4u | 5u << 3 | 6u << 6 | 7u << 9 | 2u << 12 | 12u << 15);
-            const int voff = lane * (kRun * 4);
-            asm volatile("buffer_load_format_xyzw %0, %17, %18, 0 offen offset:8\n\t"
-                         "buffer_load_format_xyzw %1, %17, %18, 0 offen offset:16\n\t"
-                         "buffer_load_format_xyzw %2, %17, %18, 0 offen offset:24\n\t"
-                         "buffer_load_format_xyzw %3, %17, %18, 0 offen offset:32\n\t"
-                         "buffer_load_format_xyzw %4, %17, %18, 0 offen offset:40\n\t"
-                         "buffer_load_format_xyzw %5, %17, %18, 0 offen offset:48\n\t"
-                         "buffer_load_format_xyzw %6, %17, %18, 0 offen offset:56\n\t"
-                         "buffer_load_format_xyzw %7, %17, %18, 0 offen offset:64\n\t"
-                         "buffer_load_format_xyzw %8, %17, %18, 0 offen offset:72\n\t"
-                         "buffer_load_format_xyzw %9, %17, %18, 0 offen offset:80\n\t"
-                         "buffer_load_format_xyzw %10, %17, %18, 0 offen offset:88\n\t"
-                         "buffer_load_format_xyzw %11, %17, %18, 0 offen offset:96\n\t"
-                         "buffer_load_format_xyzw %12, %17, %18, 0 offen offset:104\n\t"
-                         "buffer_load_format_xyzw %13, %17, %18, 0 offen offset:112\n\t"
-                         "buffer_load_format_xyzw %14, %17, %18, 0 offen offset:120\n\t"
-                         "buffer_load_format_xyzw %15, %17, %18, 0 offen offset:128\n\t"
-                         "buffer_load_format_xyzw %16, %17, %18, 0 offen offset:136"
-                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]),
-                           "=&v"(q[7]), "=&v"(q[8]), "=&v"(q[9]), "=&v"(q[10]), "=&v"(q[11]), "=&v"(q[12]),
-                           "=&v"(q[13]), "=&v"(q[14]), "=&v"(q[15]), "=&v"(q[16])
-                         : "v"(voff), "s"(rs)
-                         : "memory");
-        } else {
-            int64_t pr0 = wlo + (int64_t)kRun * lane;
-            asm volatile("" : "+v"(pr0));
-#pragma unroll
-            for (int k = 0; k < 17; k++) {
-                const int64_t pa = pr0 + 2 * k + 2, pb = pa + 1;
-                const uint32_t d0 = (pa >= p_lo && pa < p_hi) ? xin[pa - pbuf0] : 0x08000800u;
-                const uint32_t d1 = (pb >= p_lo && pb < p_hi) ? xin[pb - pbuf0] : 0x08000800u;
-                q[k] = f32x4{(float)(d0 & 0xFFFFu), (float)(d0 >> 16), (float)(d1 & 0xFFFFu), (float)(d1 >> 16)};
-            }
-        }
-    };
-    // nothing reads a quad before this: the wait carries all 17 as operands
-    auto landed = [&](f32x4 (&q)[17]) {
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]),
-                       "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]), "+v"(q[16]));
-    };
-    f32x4 qa[17], qb[17];
-    issue(0, qa);
-#pragma unroll 1
-    for (int pass = 0; pass < K; pass += 2) {
-        landed(qa);
-        if (pass + 1 < K)
-            issue(pass + 1, qb);
-        pass_compute_db(qa, lane, first_run(pass) + lane, pl_d, pl_e1, pl_e2);
-        if (pass + 1 < K) {
-            landed(qb);
-            if (pass + 2 < K)
-                issue(pass + 2, qa);
-            pass_compute_db(qb, lane, first_run(pass + 1) + lane, pl_d, pl_e1, pl_e2);
-        }
-    }
-}
-#endif
-
 // ------------------------------ Stage A ------------------------------
 // One tile's arithmetic for one of the tile's four Stage A waves: K passes, a run of 28 power samples per lane and
 // pass, three plane words per run into LDS.  No barrier, no divergence.
-template <bool kGateInLoop = false>
 __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const int64_t pbuf0, const int64_t p_lo,
                                         const int64_t p_hi, const int64_t t0, const int K, const int wave, const int lane,
-                                        uint32_t *pl_d, uint32_t *pl_e1, uint32_t *pl_e2, const GateCtx *gc = nullptr)
+                                        uint32_t *pl_d, uint32_t *pl_e1, uint32_t *pl_e2)
 {
-    // first run of wave w in pass ps: interleaved (a pass of the four waves is 252 consecutive runs), or -- gate in the
-    // loop -- contiguous per wave (wave w owns runs [63 K w, 63 K (w + 1)))
-    auto first_run = [&](int ps) { return kGateInLoop ? kWaveRuns * (K * wave + ps) : kWaveRuns * (kWaves * ps + wave); };
+    // first run of wave w in pass ps: a pass of the four waves is 252 consecutive runs
+    auto first_run = [&](int ps) { return kWaveRuns * (kWaves * ps + wave); };
     // Input: the 34 pairs (6 of pre-halo + 28) a run needs are 17 TYPED buffer loads of 8
     // bytes per lane (buffer_load_format_xyzw, data format 16_16_16_16, number format
     // USCALED): the load path itself converts the four uint16 to four floats -- exactly, and
@@ -635,9 +337,6 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * first_run(ps) - 8; }; // lane 0's
-#if ADSB_PREFETCH_NEXT
-    uint32_t pf = 0; // destination of the cache-touching load below: stays allocated until the next pass's loads have been waited for
-#endif
 #pragma unroll 1
     for (int pass = 0; pass < K; pass++) {
         const int v0 = first_run(pass); // first run of this wave in this pass
@@ -646,98 +345,14 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
         // wave-uniform: every pair this wave loads lies inside the buffer
         const bool interior = (wlo >= p_lo) && (wlo + kRun * 64 + 8 <= p_hi);
         f32x4 tl[17]; // tl[k]: pairs 2k+2, 2k+3 of the lane's 36 = slots 2k, 2k+1
-#if ADSB_ABLATE == 1 && ADSB_COALESCED_PROBE // kbench, loads only: the SAME window of 7 KiB per wave and pass read by 15 coalesced
-        // typed loads (adjacent lanes, adjacent 8 bytes: every 128-byte line is looked up once, not 17 times) -- what
-        // would the memory side deliver to a kernel that transposed its input through LDS?
         if (interior) {
             const uint64_t wbase = (uint64_t)(xin + (wlo - pbuf0));
-            i32x4 rs;
-            rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)wbase);
-            rs.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(wbase >> 32) & 0xFFFFu));
-            rs.z = 64 * kRun * 4 + 64;
-            rs.w = (int)(4u | 5u << 3 | 6u << 6 | 7u << 9 | 2u << 12 | 12u << 15);
-            const int voff = lane * 8, voff2 = lane * 8 + 4096; // (the instruction's own offset field ends at 4095)
-            tl[15] = tl[16] = f32x4{0, 0, 0, 0};
-            asm volatile("buffer_load_format_xyzw %0, %15, %17, 0 offen offset:0\n\t"
-                         "buffer_load_format_xyzw %1, %15, %17, 0 offen offset:512\n\t"
-                         "buffer_load_format_xyzw %2, %15, %17, 0 offen offset:1024\n\t"
-                         "buffer_load_format_xyzw %3, %15, %17, 0 offen offset:1536\n\t"
-                         "buffer_load_format_xyzw %4, %15, %17, 0 offen offset:2048\n\t"
-                         "buffer_load_format_xyzw %5, %15, %17, 0 offen offset:2560\n\t"
-                         "buffer_load_format_xyzw %6, %15, %17, 0 offen offset:3072\n\t"
-                         "buffer_load_format_xyzw %7, %15, %17, 0 offen offset:3584\n\t"
-                         "buffer_load_format_xyzw %8, %16, %17, 0 offen offset:0\n\t"
-                         "buffer_load_format_xyzw %9, %16, %17, 0 offen offset:512\n\t"
-                         "buffer_load_format_xyzw %10, %16, %17, 0 offen offset:1024\n\t"
-                         "buffer_load_format_xyzw %11, %16, %17, 0 offen offset:1536\n\t"
-                         "buffer_load_format_xyzw %12, %16, %17, 0 offen offset:2048\n\t"
-                         "buffer_load_format_xyzw %13, %16, %17, 0 offen offset:2560\n\t"
-                         "buffer_load_format_xyzw %14, %16, %17, 0 offen offset:3072\n\t"
-                         "s_waitcnt vmcnt(0)"
-                         : "=&v"(tl[0]), "=&v"(tl[1]), "=&v"(tl[2]), "=&v"(tl[3]), "=&v"(tl[4]), "=&v"(tl[5]), "=&v"(tl[6]),
-                           "=&v"(tl[7]), "=&v"(tl[8]), "=&v"(tl[9]), "=&v"(tl[10]), "=&v"(tl[11]), "=&v"(tl[12]),
-                           "=&v"(tl[13]), "=&v"(tl[14])
-                         : "v"(voff), "v"(voff2), "s"(rs)
-                         : "memory");
-        } else
-#endif
-#if ADSB_ABLATE == 3 // kbench: no loads at all -- the arithmetic alone
-        if (interior) {
-#pragma unroll
-            for (int k = 0; k < 17; k++) {
-                const float q = (float)((lane * 17 + k + pass) & 4095);
-                tl[k] = f32x4{q, q + 1.0f, 2048.0f, q + 3.0f};
-            }
-        } else
-#endif
-        if (interior) {
-#if ADSB_SAME_DATA // kbench only: every tile reads the first tile's samples (cache-resident): compute without HBM
-            const uint64_t wbase = (uint64_t)(xin + (wlo - t0 + 8));
-#else
-            const uint64_t wbase = (uint64_t)(xin + (wlo - pbuf0));
-#endif
             i32x4 rs;
             rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)wbase);
             rs.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(wbase >> 32) & 0xFFFFu)); // stride 0: raw buffer
             rs.z = 64 * kRun * 4 + 64;                                                        // bytes
             rs.w = (int)(4u | 5u << 3 | 6u << 6 | 7u << 9 /* dst_sel xyzw */ | 2u << 12 /* USCALED */ | 12u << 15 /* 16_16_16_16 */);
             const int voff = lane * (kRun * 4);
-#if ADSB_PREHALO_DPP
-            // Experiment: the six pre-halo pairs (slots 0..5) are the previous lane's slots 28..33;
-            // only lane 0 (whose predecessor is another wave) loads them, the others take them by
-            // DPP after the bias step -- 14 loads and 14 x 54 tag look-ups instead of 17 x 54.
-            tl[0] = tl[1] = tl[2] = f32x4{2048.0f, 2048.0f, 2048.0f, 2048.0f};
-            if (lane == 0)
-                asm volatile("buffer_load_format_xyzw %0, %3, %4, 0 offen offset:8\n\t"
-                             "buffer_load_format_xyzw %1, %3, %4, 0 offen offset:16\n\t"
-                             "buffer_load_format_xyzw %2, %3, %4, 0 offen offset:24"
-                             : "=&v"(tl[0]), "=&v"(tl[1]), "=&v"(tl[2])
-                             : "v"(voff), "s"(rs)
-                             : "memory");
-            asm volatile("buffer_load_format_xyzw %0, %14, %15, 0 offen offset:32\n\t"
-                         "buffer_load_format_xyzw %1, %14, %15, 0 offen offset:40\n\t"
-                         "buffer_load_format_xyzw %2, %14, %15, 0 offen offset:48\n\t"
-                         "buffer_load_format_xyzw %3, %14, %15, 0 offen offset:56\n\t"
-                         "buffer_load_format_xyzw %4, %14, %15, 0 offen offset:64\n\t"
-                         "buffer_load_format_xyzw %5, %14, %15, 0 offen offset:72\n\t"
-                         "buffer_load_format_xyzw %6, %14, %15, 0 offen offset:80\n\t"
-                         "buffer_load_format_xyzw %7, %14, %15, 0 offen offset:88\n\t"
-                         "buffer_load_format_xyzw %8, %14, %15, 0 offen offset:96\n\t"
-                         "buffer_load_format_xyzw %9, %14, %15, 0 offen offset:104\n\t"
-                         "buffer_load_format_xyzw %10, %14, %15, 0 offen offset:112\n\t"
-                         "buffer_load_format_xyzw %11, %14, %15, 0 offen offset:120\n\t"
-                         "buffer_load_format_xyzw %12, %14, %15, 0 offen offset:128\n\t"
-                         "buffer_load_format_xyzw %13, %14, %15, 0 offen offset:136\n\t"
-                         "s_waitcnt vmcnt(0)"
-                         : "=&v"(tl[3]), "=&v"(tl[4]), "=&v"(tl[5]), "=&v"(tl[6]), "=&v"(tl[7]), "=&v"(tl[8]), "=&v"(tl[9]),
-                           "=&v"(tl[10]), "=&v"(tl[11]), "=&v"(tl[12]), "=&v"(tl[13]), "=&v"(tl[14]), "=&v"(tl[15]),
-                           "=&v"(tl[16])
-                         : "v"(voff), "s"(rs)
-                         : "memory");
-            // lane 0's three loads were issued before the block above, so its vmcnt(0) covers them;
-            // the compiler must not read tl[0..2] before this point
-            asm volatile("" : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]));
-#else
             asm volatile("buffer_load_format_xyzw %0, %17, %18, 0 offen offset:8\n\t"
                          "buffer_load_format_xyzw %1, %17, %18, 0 offen offset:16\n\t"
                          "buffer_load_format_xyzw %2, %17, %18, 0 offen offset:24\n\t"
@@ -755,38 +370,13 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
                          "buffer_load_format_xyzw %14, %17, %18, 0 offen offset:120\n\t"
                          "buffer_load_format_xyzw %15, %17, %18, 0 offen offset:128\n\t"
                          "buffer_load_format_xyzw %16, %17, %18, 0 offen offset:136"
-#if !ADSB_STAGED_WAIT
                          "\n\ts_waitcnt vmcnt(0)"
-#endif
                          : "=&v"(tl[0]), "=&v"(tl[1]), "=&v"(tl[2]), "=&v"(tl[3]), "=&v"(tl[4]), "=&v"(tl[5]), "=&v"(tl[6]),
                            "=&v"(tl[7]), "=&v"(tl[8]), "=&v"(tl[9]), "=&v"(tl[10]), "=&v"(tl[11]), "=&v"(tl[12]),
                            "=&v"(tl[13]), "=&v"(tl[14]), "=&v"(tl[15]), "=&v"(tl[16])
                          : "v"(voff), "s"(rs)
                          : "memory");
-#endif
-#if ADSB_PREFETCH_NEXT
-            // (the block above ended with s_waitcnt vmcnt(0): the previous pass's touch has landed, `pf` is free again)
-            asm volatile("" : "+v"(pf));
-            // Touch the lines of this wave's NEXT pass (one dword per 128-byte line, result unused) while this pass is
-            // being computed: the next pass's 17 loads then find their lines in the L2 instead of waiting for HBM.
-            if (pass + 1 < K) {
-                const int64_t wn = pass_first_pair(pass + 1);
-                if (wn + kRun * 64 + 8 <= p_hi) { // wave-uniform; wn > wlo >= p_lo
-                    const uint64_t nb = (uint64_t)(xin + (wn - pbuf0));
-                    i32x4 rn;
-                    rn.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
-                    rn.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(nb >> 32) & 0xFFFFu));
-                    rn.z = 64 * kRun * 4 + 64;
-                    rn.w = rs.w;
-                    const int toff = min(lane * 128, 64 * kRun * 4 + 64 - 4);
-                    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(pf) : "v"(toff), "s"(rn) : "memory");
-                }
-            }
-#endif
         } else {
-#if ADSB_PREFETCH_NEXT
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf)); // a touch issued by the previous pass may still be in flight
-#endif
             // Stream start (the ring is zero-initialised, air.c:33: a missing pair is
             // 0x0800,0x0800 -> v = 0) and the ragged end of a buffer: plain loads, converted here
             int64_t pr0 = wlo + (int64_t)kRun * lane;
@@ -799,52 +389,21 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
                 tl[k] = f32x4{(float)(d0 & 0xFFFFu), (float)(d0 >> 16), (float)(d1 & 0xFFFFu), (float)(d1 >> 16)};
             }
         }
-#if ADSB_ABLATE == 1
-        {   // kbench: price the loads alone
-            float acc = 0;
-#pragma unroll
-            for (int k = 0; k < 17; k++)
-                acc += tl[k].x + tl[k].y + tl[k].z + tl[k].w;
-            if (lane < kWaveRuns)
-                pl_d[v] = __float_as_uint(acc);
-            continue;
-        }
-#endif
         // air.c:64-67,79-82: v = (float)x - 2048; pairs with odd index are negated
         // (samples n mod 4 in {2,3}).  The run starts at an even pair index, so the
         // sign is a compile-time property of the slot.  -(x-2048) == 2048-x exactly.
         f32x2 vv[34];
-#if !ADSB_STAGED_WAIT // (staged: the slots are made group by group, behind the wait for their quads: power_block_staged)
 #pragma unroll
         for (int s = 0; s < 34; s++) {
             const f32x4 q = tl[s >> 1];
             const f32x2 f = (s & 1) ? f32x2{q.z, q.w} : f32x2{q.x, q.y};
-#if ADSB_FMA_BIAS
-            vv[s] = f; // bias and fs/4 sign are folded into the FIR's products (fir_step)
-#else
             const f32x2 mid = {2048.0f, 2048.0f};
             vv[s] = ((s & 1) == 0) ? (f - mid) : (mid - f); // slot s <-> rel pair s-6: same parity
-#endif
         }
-#endif
 
-#if ADSB_PREHALO_DPP
-        if (interior) {
-#pragma unroll
-            for (int sl = 0; sl < 6; sl++) { // lane 0 keeps what it loaded (no source lane: `old` stays)
-                vv[sl].x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(vv[sl].x), __float_as_int(vv[sl + 28].x), 0x138, 0xF, 0xF, false));
-                vv[sl].y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(vv[sl].y), __float_as_int(vv[sl + 28].y), 0x138, 0xF, 0xF, false));
-            }
-        }
-#endif
         // a[0..27]: this run; a[28..43]: the first 16 samples of the next run (next lane)
         float a[44];
-#if ADSB_STAGED_WAIT
-        static_assert(!ADSB_FMA_BIAS && !ADSB_PREHALO_DPP && ADSB_ABLATE != 1 && ADSB_ABLATE != 3, "staged waits: the plain load path only");
-        power_block_staged<0, 28, ADSB_FIR_GROUP>(tl, vv, a); // (the ragged path's plain loads have landed: its waits fall through)
-#else
-        power_block<0, 28, ADSB_FIR_GROUP>(vv, a);
-#endif
+        power_block<0, 28, kFirGroup>(vv, a);
 #pragma unroll
         for (int k = 0; k < 16; k++)
             a[28 + k] = from_next_lane(a[k]);
@@ -896,64 +455,28 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
 #pragma unroll
         for (int m = 27; m >= 0; m--) { // bit m of each word <-> sample m of the run
             d = push_sign(d, __float_as_uint(dv[m]));    // a[m+5] - a[m] < 0:  a[m] > a[m+5]   (demod.c:34)
-#if ADSB_ABLATE_PLANES < 2
             e1 = push_sign(e1, __float_as_uint(e1v[m])); // 2 c[m+5] - c[m] < 0: c[m] > 2 c[m+5] (SN = 2, demod.c:83)
-#endif
-#if ADSB_ABLATE_PLANES < 1 // (kbench timing builds drop the E2 plane, or E1 and E2: how does the time follow the instruction count?)
             e2 = push_sign(e2, __float_as_uint(e2v[m])); // 2 c[m] - c[m+5] < 0: c[m+5] > 2 c[m]
-#endif
         }
         if (lane < kWaveRuns) { // lane 63 only feeds lane 62
             pl_d[v] = d;
             pl_e1[v] = e1;
             pl_e2[v] = e2;
         }
-        if constexpr (kGateInLoop) {
-            // the 63 runs of this wave's PREVIOUS pass: the planes they reach into (up to five runs further) are the ones
-            // just stored, by this wave -- its LDS operations execute in order, no barrier needed
-            if (pass > 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                gate_and_enqueue(*gc, pl_d, pl_e1, pl_e2, v - kWaveRuns, lane < kWaveRuns);
-            }
-        }
     }
 }
 
 // ------------------------------ Stage B ------------------------------
 // Everything behind a tile's planes: gate, survivor queue, slicer + CRC, never-visited filter, ranking, finishing and
-// the hand-off.  NT threads work on it: the tile's four waves between workgroup barriers (scan_kernel, NT = 256), or ONE
-// wave on its own while the other four already compute the next tile's planes (scan_pipe_kernel, NT = 64: every
-// "barrier" is then only a fence inside the wave, whose LDS operations execute in order).
-template <int NT>
-__device__ __forceinline__ void tile_sync()
-{
-    if constexpr (NT == 64) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else {
-        __syncthreads();
-    }
-}
-
-struct StageStamps {
-    uint32_t st[8];
-};
-#if ADSB_TILE_CLOCK == 3 // phase stamps of the tile (100 MHz clock), thread 0: see the dump in decoder.hip
-#define ADSB_STAMP(i) do { if (tid == 0) stamps.st[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define ADSB_STAMP(i) do { } while (0)
-#endif
-
+// the hand-off, by the tile's four waves between workgroup barriers.
 // LDS of Stage B: queue[queue_cap], ctl[32] (qcount, qover, cl_n, cl_over, tile_n, tile_over, tile_base, try_base,
 // tile_res, tile_fit, tile_chk[4]; the rest is the kernel's), cl_rec[clist_cap * kCandWords].
-template <bool kStats, int NT>
+template <bool kStats>
 __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t tile, const int K, const int64_t t0, const int tid,
                                         const uint32_t *pl_d, const uint32_t *pl_e1, const uint32_t *pl_e2, uint32_t *queue,
-                                        uint32_t *qcount, uint32_t *cl_rec, const int clist_cap, StageStamps &stamps)
+                                        uint32_t *qcount, uint32_t *cl_rec, const int clist_cap)
 {
+    constexpr int NT = kThreads;
     constexpr int kFallbackChunks = 256 / NT; // a fallback round takes one bit position of 256 runs: <= 256 entries
     const uint32_t *__restrict__ xin = args.x;
     const int64_t pbuf0 = args.pbuf0, p_lo = args.p_lo, p_hi = args.p_hi;
@@ -992,13 +515,6 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             rec[5] = wds[3];
         }
     };
-    ADSB_STAMP(1);
-#if ADSB_STAGEB_PRIO
-    // From here on the tile is a chain of short, latency-bound phases between workgroup barriers, often with one
-    // wave working while three wait: at equal priority each of its instructions queues behind the Stage A streams
-    // of the three other workgroups on the SIMD.  Raised priority lets the chain through.
-    __builtin_amdgcn_s_setprio(ADSB_STAGEB_PRIO);
-#endif
     const int64_t off_end64 = (int64_t)args.g_end - t0; // offsets of this tile that exist
     const int off_end = off_end64 > (int64_t)kRun * own ? kRun * own : off_end64 < 0 ? 0 : (int)off_end64;
     const uint32_t df18_mask = args.df18 ? ~0u : 0u;
@@ -1014,39 +530,19 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     // the tile is redone chunk by chunk, one bit position (offset within the run)
     // per round: <= 256 entries, which cannot overflow (queue_cap >= 256).
     constexpr int kGateBatch = 4; // chunks whose gate words are computed together
-#if ADSB_PIPE_ABLATE == 1 // tuning builds: Stage B finds nothing (every tile still publishes its empty marker)
-    int ch_lo = 0, ch_hi = NT == 64 ? 0 : nchunks, grp = -1;
-#else
     int ch_lo = 0, ch_hi = nchunks, grp = -1;
-#endif
     for (;;) {
-#if ADSB_GATE_IN_LOOP
-        if (NT == kThreads && grp < 0) { // (the queue has been filling since the pass loop: the kernel cleared its counters)
-            if (tid == 0) {
-                *cl_n = 0;
-                *cl_over = 0;
-            }
-        } else
-#endif
         if (tid == 0) {
             *qcount = 0;
             *qover = 0;
             *cl_n = 0;
             *cl_over = 0;
         }
-        tile_sync<NT>();
+        __syncthreads();
         // Whole-tile rounds see every CRC-valid candidate of the tile, which is what
         // the never-visited filter below needs; fallback rounds emit directly.
         const bool stage_cands = (grp < 0) && !args.all_candidates;
 
-#if ADSB_GATE_IN_LOOP
-        if (NT == kThreads && grp < 0) {
-            // the pass loop has gated everything but each wave's LAST pass (its reach is the next wave's first): 4 x 63 runs
-            GateCtx gc{queue, qcount, qover, qcap, df18_mask, off_end};
-            const int w = tid >> 6, l = tid & 63;
-            gate_and_enqueue(gc, pl_d, pl_e1, pl_e2, kWaveRuns * (K * w + K - 1) + l, l < kWaveRuns);
-        } else
-#endif
 #pragma unroll 1
         for (int base = ch_lo; base < ch_hi; base += kGateBatch) {
             // Two steps per batch of chunks.  First every gate word: plane reads and word-wide logic with no
@@ -1113,7 +609,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                 }
             }
         }
-        tile_sync<NT>();
+        __syncthreads();
         const bool over = *qover != 0;
         const int qn = over ? 0 : (int)*qcount;
         // valid.c:46,68: every DF-gate pass that is visited is a Try -- the queue entries ARE the tries.  A
@@ -1204,7 +700,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         if (kStats && qn) { // (qn is workgroup-uniform)
             if (tid == 0)
                 *try_base = try_res;
-            tile_sync<NT>(); // (the slicer only reads the queue)
+            __syncthreads(); // (the slicer only reads the queue)
             const uint32_t tb = *try_base;
             uint32_t *dst = args.tries + (try_region ? (size_t)tile * kTryRegion : (size_t)args.try_list_first + tb);
             const uint32_t room = try_region ? (uint32_t)kTryRegion : (tb < args.try_cap ? args.try_cap - tb : 0u);
@@ -1214,7 +710,6 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                     dst[q] = ((tile_rel + (uint32_t)kRun * (ent >> 7) + ((ent >> 2) & 31u)) << 2) | (ent & 3u);
             }
         }
-        ADSB_STAMP(2);
         if (stage_cands) {
             // Drop candidates the greedy scan (demod.c:89,128,134,141) can never visit.
             // Let c' be the closest candidate before c, with c inside c' (c.g < c'.g +
@@ -1224,8 +719,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             // could (they start at >= c'.g - 1199, i.e. inside this tile, and the staged
             // list is complete), and none does, c is unreachable.  These are the +-1/2
             // sample shifted copies of every real frame: 3 of 4 records.
-            tile_sync<NT>();
-            ADSB_STAMP(3);
+            __syncthreads();
             const int ncl = min((int)*cl_n, clist_cap); // <= kClistCap <= NT: one entry per thread
             const bool complete = *cl_over == 0;
             // The tile reserves its range of the hand-off stream -- one marker granule plus two per record, in whole
@@ -1235,12 +729,6 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             // filter and the finishing instead of behind the filter.
             uint32_t res_need = 0, res_base = 0;
             const bool reserves = tid == 0 && args.hand;
-#if ADSB_EARLY_RESERVE
-            if (reserves) {
-                res_need = stream_granules((uint32_t)ncl);
-                res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
-            }
-#endif
             bool keep = false;
             uint32_t rank = 0; // kept entries with a smaller offset: the record's place behind the tile's marker
             const uint32_t *ri = cl_rec + tid * kCandWords;
@@ -1320,15 +808,11 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                     cl_rec[tid * kCandWords + 1] |= 0x10000u; // staged word 1, bit 16: kept
                 }
             }
-            ADSB_STAMP(4);
-            tile_sync<NT>();
-            ADSB_STAMP(5);
-#if !ADSB_EARLY_RESERVE
+            __syncthreads();
             if (reserves) { // the result is not looked at before this thread's own record is finished
                 res_need = stream_granules(*tile_n);
                 res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
             }
-#endif
             if (keep && !one_wave) {
                 const uint32_t gi = ri[0];
                 for (int j = 0; j < ncl; j++)
@@ -1351,9 +835,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                 *tile_lines = res_need >> 2;
                 *tile_res = 1;
             }
-            ADSB_STAMP(6);
-            tile_sync<NT>(); // tile_base / tile_fit are in, and every staged entry has been read
-            ADSB_STAMP(7);
+            __syncthreads(); // tile_base / tile_fit are in, and every staged entry has been read
             const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
             if (keep) {
                 if (to_stream) {
@@ -1373,7 +855,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             }
             if (to_stream) {
                 // the tile's range {marker, records} leaves as one store of adjacent lanes
-                tile_sync<NT>();
+                __syncthreads();
                 const uint32_t nk = *tile_n;
                 // no fallback rounds will follow (they emit loose records): the marker is final
                 const bool marker_now = !over;
@@ -1410,7 +892,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             if (ch_lo >= nchunks)
                 break;
         }
-        tile_sync<NT>(); // queue is rewritten
+        __syncthreads(); // queue is rewritten
     }
 
 
@@ -1420,7 +902,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         // L2 per tile (measured: 4.5x slower kernel), and without one nothing orders these
         // stores on their way to host memory (measured: a flag does overtake the records)
         // -- which is why the marker carries a checksum of the records (scan_kernel.h).
-        tile_sync<NT>();
+        __syncthreads();
         if (tid == 0 && *tile_res != 2) {
             uint32_t b = *tile_base, fit = *tile_fit;
             uint32_t lines = *tile_lines;
@@ -1442,7 +924,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
 
 // The classic kernel: one workgroup of four waves per tile; Stage A, a barrier, Stage B between barriers.
 template <bool kStats>
-__global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const ScanArgs args)
+__global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int K = tile_passes(blockIdx.x, args.stagger, args.passes);
@@ -1455,29 +937,18 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
     uint32_t *cl_rec = qcount + 16; // kClistCap records of kCandWords
 
     const int tid = threadIdx.x;
-#if ADSB_SLEEP_STAGGER
     // The four workgroups that start together on a CU at the head of a large launch (blocks b, b + 256,
     // b + 512, b + 768 with the observed round-robin placement; nothing depends on it) begin 0, 1, 2, 3 x
-    // ADSB_SLEEP_STAGGER x 64 cycles apart (2.6 us steps), so that their load phases do not coincide from
+    // kSleepStagger x 64 cycles apart (2.6 us steps), so that their load phases do not coincide from
     // the first pass on.  Measured in bench.py: -3.2 .. -4.0 % kernel time on one MI355X box, +-0.5 % on
     // another; steps of 1.2 us did nothing, steps of 3.7 us and more were worse than 2.6.
-    if (gridDim.x >= 256u * ADSB_MIN_WAVES * 4 / kWaves && blockIdx.x < 256u * ADSB_MIN_WAVES * 4 / kWaves) {
+    if (gridDim.x >= 256u * kMinWaves * 4 / kWaves && blockIdx.x < 256u * kMinWaves * 4 / kWaves) {
         const uint32_t slot = blockIdx.x >> 8;
         for (uint32_t i = 0; i < slot; i++)
-            __builtin_amdgcn_s_sleep(ADSB_SLEEP_STAGGER);
+            __builtin_amdgcn_s_sleep(kSleepStagger);
     }
-#endif
     // cfg.profile: the launch's duration is (latest tile end) - (earliest tile start)
     const uint64_t prof_begin = args.profile ? __builtin_amdgcn_s_memrealtime() : 0;
-#if ADSB_TILE_CLOCK
-    // kbench only: when and where each tile ran (100 MHz clock, HW_ID, XCC_ID) -> args.tile_clock[4 * tile ..]
-    const uint64_t clk_begin = __builtin_amdgcn_s_memrealtime();
-    const uint64_t cyc_begin = __builtin_amdgcn_s_memtime(); // shader clock: (d cycles) / (d realtime at 100 MHz) = the clock the chip holds
-#endif
-    StageStamps stamps{};
-#if ADSB_TILE_CLOCK == 3
-    stamps.st[0] = (uint32_t)clk_begin;
-#endif
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int64_t t0 = // first owned offset
@@ -1492,70 +963,10 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
 
     // kernel arguments are only ever used by value (taking their address would
     // demote the sample pointer to a flat/scratch access)
-#if ADSB_GATE_IN_LOOP
-    if (tid == 0) {
-        qcount[0] = 0; // survivors queued
-        qcount[1] = 0; // queue overflow
-    }
-    __syncthreads();
-    const int64_t off_end64 = (int64_t)args.g_end - t0;
-    const int own_runs = kPassRuns * K - kReachRuns;
-    const GateCtx gc{queue, qcount, qcount + 1, (uint32_t)args.queue_cap, args.df18 ? ~0u : 0u,
-                     off_end64 > (int64_t)kRun * own_runs ? kRun * own_runs : off_end64 < 0 ? 0 : (int)off_end64};
-    stage_a<true>(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl_d, pl_e1, pl_e2, &gc);
-#else
-#if ADSB_DOUBLE_BUFFER
-    stage_a_db(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl_d, pl_e1, pl_e2);
-#else
     stage_a(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl_d, pl_e1, pl_e2);
-#endif
-#endif
-#if ADSB_TILE_CLOCK == 3
-    uint32_t *tile_chk = qcount + 10;
-    if (lane == 0) // when each wave reaches the barrier behind Stage A: how long the four wait for each other
-        tile_chk[wave] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
     __syncthreads();
-#if ADSB_TILE_CLOCK == 3
-    const uint32_t arrive_sum = tile_chk[0] + tile_chk[1] + tile_chk[2] + tile_chk[3] - 4u * (uint32_t)clk_begin;
-    __syncthreads();
-#endif
-#if ADSB_ABLATE != 0
-    if (pl_d[(tid * 29) % (kPassRuns * K)] == 0x12345678u) // kbench: keep Stage A alive, skip the rest
-        atomicAdd(&args.counters[0 * kCounterPad], 1u);
-    return;
-#endif
-#if ADSB_STAGEB_PRIO
-    // From here on the tile is a chain of short, latency-bound phases between workgroup barriers, often with one
-    // wave working while three wait: at equal priority each of its instructions queues behind the Stage A streams
-    // of the three other workgroups on the SIMD.  Raised priority lets the chain through.
-    __builtin_amdgcn_s_setprio(ADSB_STAGEB_PRIO);
-#endif
-    stage_b<kStats, kThreads>(args, blockIdx.x, K, t0, tid, pl_d, pl_e1, pl_e2, queue, qcount, cl_rec, args.clist_cap, stamps);
+    stage_b<kStats>(args, blockIdx.x, K, t0, tid, pl_d, pl_e1, pl_e2, queue, qcount, cl_rec, args.clist_cap);
 
-#if ADSB_TILE_CLOCK
-    __syncthreads();
-    if (tid == 0 && args.tile_clock) {
-        const uint64_t clk_end = __builtin_amdgcn_s_memrealtime();
-#if ADSB_TILE_CLOCK == 3
-        uint32_t *o = args.tile_clock + 8 * (size_t)blockIdx.x; // eight stamps per tile
-        for (int i = 0; i < 7; i++)
-            o[i] = stamps.st[i];
-        o[7] = (uint32_t)clk_end;
-        args.tile_clock[8 * (size_t)gridDim.x + blockIdx.x] = arrive_sum; // behind the stamps: sum over the waves of (arrival - begin)
-#else
-        uint32_t *o = args.tile_clock + 4 * (size_t)blockIdx.x;
-        o[0] = (uint32_t)clk_begin;
-        o[1] = (uint32_t)clk_end;
-#if ADSB_TILE_CLOCK == 2
-        o[2] = (uint32_t)(__builtin_amdgcn_s_memtime() - cyc_begin); // shader cycles of this tile
-#else
-        o[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
-#endif
-        o[3] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_REG_XCC_ID[3:0]
-#endif
-    }
-#endif
     if (args.profile) { // the launch's duration is (latest tile end) - (earliest tile start)
         __syncthreads();
         if (tid == 64) { // not wave 0: that one has just issued the tile's write-through stores
@@ -1563,139 +974,6 @@ __global__ __launch_bounds__(kThreads, ADSB_MIN_WAVES) void scan_kernel(const Sc
             atomicMax(&c64[2 * kCounterPad], ~(unsigned long long)prof_begin); // = counters 4 and 5
             atomicMax(&c64[(5 * kCounterPad) / 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
         }
-    }
-}
-
-// The pipelined kernel (ScanArgs::pipe): PERSISTENT workgroups of FIVE waves.  Waves 0..3 run Stage A of tile i + 1
-// into one set of planes while wave 4 runs the whole of Stage B for tile i from the other set -- gate, slicer,
-// filter, finishing, hand-off, as one sequential wave with no workgroup barrier inside -- and the five meet at ONE
-// barrier per tile.  Why: in the classic kernel a tile spends a quarter of its life (11.7 of 45.6 us) in Stage B,
-// a chain of short latency-bound phases during which its four waves issue next to nothing while still holding
-// their slots; here the four arithmetic waves of a workgroup never leave Stage A.  Tiles come from a device counter
-// (counters[3]), fetched one tile ahead, so the dispatcher's gap between two tiles of a slot is gone as well, and a
-// workgroup's first tile is its block index.  LDS: two sets of planes + queue + staged list = 36 KiB at five
-// passes per tile, four workgroups (twenty waves, 96 VGPRs each) per CU.
-constexpr int kPipeThreads = 320;
-constexpr int kPipeWave = 4;    // the wave that runs Stage B
-constexpr int kPipeClist = 64;  // staged candidates per tile: one per lane of the Stage B wave
-template <bool kStats>
-__global__ __attribute__((amdgpu_flat_work_group_size(kPipeThreads, kPipeThreads), amdgpu_waves_per_eu(ADSB_PIPE_WAVES, ADSB_PIPE_WAVES)))
-void scan_pipe_kernel(const ScanArgs args)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int K = args.passes;
-    const int nplane = kPassRuns * K + kPlanePad;
-    uint32_t *queue = smem + 6 * nplane;
-    uint32_t *ctl = queue + kQueueCap; // [0..14] Stage B's, [16..20] the waves' SIMDs, [22..23] the next tile of the workgroup (two in rotation)
-    uint32_t *cl_rec = ctl + 32;
-    const int tid = threadIdx.x;
-    const int lane_id = tid & 63;
-    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int own = kPassRuns * K - kReachRuns;
-    const int ntiles = (int)args.n_tiles;
-    // Roles by SIMD.  The workgroup's five waves sit on the CU's four SIMDs, so two of them share one: the LATER of such
-    // a pair runs Stage B, and the four arithmetic waves are spread as evenly over the SIMDs as the placement allows --
-    // with a fixed role (wave 4 = Stage B) a SIMD can end up holding five arithmetic waves of different workgroups and
-    // another three, and every workgroup then waits for its wave on the crowded one at every tile's barrier.
-    int wave = wave_id, b_wave = kPipeWave;
-#if ADSB_PIPE_ROLES
-    {
-        const uint32_t simd = (__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u; // HW_REG_HW_ID.SIMD_ID
-        if (lane_id == 0)
-            ctl[16 + wave_id] = simd;
-        __syncthreads();
-        const uint32_t s0 = __builtin_amdgcn_readfirstlane((int)ctl[16]), s1 = __builtin_amdgcn_readfirstlane((int)ctl[17]),
-                       s2 = __builtin_amdgcn_readfirstlane((int)ctl[18]), s3 = __builtin_amdgcn_readfirstlane((int)ctl[19]),
-                       s4 = __builtin_amdgcn_readfirstlane((int)ctl[20]);
-        b_wave = (s4 == s0 || s4 == s1 || s4 == s2 || s4 == s3) ? 4 : (s3 == s0 || s3 == s1 || s3 == s2) ? 3 : (s2 == s0 || s2 == s1) ? 2 : 1;
-        wave = (wave_id > b_wave ? wave_id - 1 : wave_id) & 3; // (meaningless for the Stage B wave itself)
-    }
-#endif
-#if ADSB_SLEEP_STAGGER
-    // the workgroups that begin together on a CU start 0, 1, 2, 3 x 2.6 us apart (see scan_kernel)
-    if (gridDim.x >= 1024u) {
-        const uint32_t slot = (blockIdx.x >> 8) & 3u;
-        for (uint32_t i = 0; i < slot; i++)
-            __builtin_amdgcn_s_sleep(ADSB_SLEEP_STAGGER);
-    }
-#endif
-    const uint64_t prof_begin = args.profile ? __builtin_amdgcn_s_memrealtime() : 0;
-    if (tid < 2 * kPlanePad) { // plane words past the last computed run are read (never used) by Stage B
-        uint32_t *b = smem + (tid >= kPlanePad ? 3 * nplane : 0) + kPassRuns * K + (tid & (kPlanePad - 1));
-        b[0] = 0;
-        b[nplane] = 0;
-        b[2 * nplane] = 0;
-    }
-    StageStamps stamps{};
-    int tile_a = (int)blockIdx.x < ntiles ? (int)blockIdx.x : -1, tile_b = -1;
-    for (int it = 0; tile_a >= 0 || tile_b >= 0; it++) {
-        // (opaque to the optimiser: lane-dependent addresses are then recomputed per tile -- a few instructions --
-        // instead of being hoisted out of this loop, kept alive across both stages and spilled for it)
-        int lane = lane_id;
-        asm volatile("" : "+v"(lane));
-        if (wave_id != b_wave) {
-            if (tile_a >= 0) {
-#if ADSB_PIPE_JITTER // tuning builds: the workgroups of a CU drift apart instead of running their tiles in step
-                for (uint32_t j = (((uint32_t)tile_a * 2654435761u) >> 27) * ADSB_PIPE_JITTER; j > 0; j--)
-                    __builtin_amdgcn_s_sleep(1);
-#endif
-                uint32_t *pl = smem + (it & 1) * 3 * nplane;
-                const int64_t t0 = (int64_t)args.g_begin + (int64_t)kRun * own * (int64_t)tile_a;
-#if ADSB_TILE_CLOCK == 3
-                const uint32_t a_begin = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
-                stage_a(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl, pl + nplane, pl + 2 * nplane);
-#if ADSB_TILE_CLOCK == 3 // tuning builds: how long Stage A of a tile takes on wave 0 (x 4: the dump divides by the four waves)
-                if (tid == 0 && args.tile_clock)
-                    args.tile_clock[8 * (size_t)ntiles + tile_a] = 4u * ((uint32_t)__builtin_amdgcn_s_memrealtime() - a_begin);
-#endif
-            }
-        } else {
-#if ADSB_PIPE_PRIO
-            // This wave's share of a tile is about that of one arithmetic wave, but as ONE latency-bound chain: at
-            // equal priority its SIMD gives it a fifth of the issue slots and the other four waves end every tile
-            // waiting for it at the barrier (measured: 48 us per tile against 24 us of Stage A).
-            __builtin_amdgcn_s_setprio(ADSB_PIPE_PRIO);
-#endif
-            int next = -1;
-            if (tile_a >= 0 && lane_id == 0) { // this workgroup's tile after tile_a; the answer is needed at the barrier
-                const uint32_t k = gridDim.x + atomicAdd(&args.counters[3 * kCounterPad], 1u);
-                next = k < (uint32_t)ntiles ? (int)k : -1;
-            }
-            if (tile_b >= 0) {
-                const uint32_t *pl = smem + ((it & 1) ^ 1) * 3 * nplane;
-                const int64_t t0 = (int64_t)args.g_begin + (int64_t)kRun * own * (int64_t)tile_b;
-                const int clcap = args.clist_cap < kPipeClist ? args.clist_cap : kPipeClist;
-#if ADSB_TILE_CLOCK == 3 // ... and the phases of Stage B on its wave (same stamps as the classic kernel)
-                stamps = StageStamps{};
-                stamps.st[0] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
-                stage_b<kStats, 64>(args, (uint32_t)tile_b, K, t0, lane, pl, pl + nplane, pl + 2 * nplane, queue, ctl, cl_rec, clcap, stamps);
-#if ADSB_TILE_CLOCK == 3
-                if (lane_id == 0 && args.tile_clock) {
-                    uint32_t *o = args.tile_clock + 8 * (size_t)tile_b;
-                    for (int i = 0; i < 7; i++)
-                        o[i] = stamps.st[i];
-                    o[7] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-                }
-#endif
-            }
-            if (lane_id == 0)
-                ctl[22 + (it & 1)] = (uint32_t)next;
-        }
-#if ADSB_PIPE_FREE // tuning builds (with ADSB_PIPE_ABLATE=1 only: nothing reads the planes): no barrier, a fixed round-robin of tiles
-        tile_b = -1;
-        tile_a = tile_a >= 0 && tile_a + (int)gridDim.x < ntiles ? tile_a + (int)gridDim.x : -1;
-#else
-        __syncthreads();
-        tile_b = tile_a;
-        tile_a = __builtin_amdgcn_readfirstlane((int)ctl[22 + (it & 1)]);
-#endif
-    }
-    if (args.profile && tid == 0) { // the launch's duration is (latest workgroup end) - (earliest workgroup start)
-        unsigned long long *c64 = reinterpret_cast<unsigned long long *>(args.counters);
-        atomicMax(&c64[2 * kCounterPad], ~(unsigned long long)prof_begin); // = counters 4 and 5
-        atomicMax(&c64[(5 * kCounterPad) / 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 
@@ -1905,35 +1183,12 @@ uint32_t make_fix_table(uint32_t *tab)
     }
 }
 
-bool choose_pipe(uint64_t n_offsets)
-{
-    if (const char *e = getenv("ADSB_PIPE")) // tuning, tests, A/B runs
-        return atoi(e) != 0;
-    return n_offsets >= kPipeMinOffsets;
-}
-
-int choose_passes(uint64_t n_offsets, int cus, bool pipe)
+int choose_passes(uint64_t n_offsets, int cus)
 {
     // Estimated time = rounds x passes, rounds = ceil(tiles / resident workgroups);
     // long tiles amortise the 44-run halo, short ones fill the last round better.
     if (cus <= 0)
         cus = 256;
-    const int k_max = pipe ? kPipeMaxPasses : kMaxPasses;
-    if (const char *e = getenv("ADSB_PASSES")) { // tuning and tests
-        const int k = atoi(e);
-        if (k >= 2 && k <= kMaxPasses)
-            return std::min(k, k_max);
-    }
-    if (pipe) {
-        // Persistent workgroups take tiles from a counter: no rounds to quantise.  Five passes (the most that
-        // fits four workgroups' double-buffered planes into a CU's LDS) once every workgroup gets a few tiles;
-        // below that, the longest tile that still gives every resident workgroup one.
-        const uint64_t groups = (uint64_t)cus * 4;
-        for (int k = kPipeMaxPasses; k > 2; k--)
-            if (n_offsets / (uint64_t)tile_offsets(k) >= groups)
-                return k;
-        return 2;
-    }
     // Large launches: tiles retire at a steady rate in index order (each CU favours its older
     // workgroups, so there are no "rounds" to quantise), and a longer tile only amortises its
     // 44-run halo better.  Measured in bench.py at 128 Mi offsets: K = 5 / 6 / 7 / 8 / 10 ->
@@ -1942,12 +1197,12 @@ int choose_passes(uint64_t n_offsets, int cus, bool pipe)
         return 7;
     int best = 2;
     double best_cost = 1e300;
-    for (int k = 2; k <= 6; k++) { // measured: 4..6 passes are best at every launch size (tools/kbench)
+    for (int k = 2; k <= 6; k++) { // measured: 4..6 passes are best at every launch size
         const uint64_t per = (uint64_t)tile_offsets(k);
         const uint64_t tiles = (n_offsets + per - 1) / per;
         int per_cu = (int)(160 * 1024 / lds_bytes(k));
-        if (per_cu > ADSB_MIN_WAVES)
-            per_cu = ADSB_MIN_WAVES; // register-limited: __launch_bounds__(256, ADSB_MIN_WAVES)
+        if (per_cu > kMinWaves)
+            per_cu = kMinWaves; // register-limited: __launch_bounds__(256, kMinWaves)
         if (per_cu < 1)
             continue;
         const uint64_t slots = (uint64_t)cus * per_cu;
@@ -1964,16 +1219,8 @@ int choose_passes(uint64_t n_offsets, int cus, bool pipe)
     return best;
 }
 
-uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes)
+uint32_t checked_stagger(uint64_t n_offsets, int passes, int forced)
 {
-    // Off unless ADSB_STAGGER asks for it (read per launch: tests switch it).  Measured on
-    // MI355X with per-tile device timestamps (tools/kbench -DADSB_TILE_CLOCK): equal tiles
-    // already complete at a steady 25.6 tiles/us in index order -- each CU favours its
-    // older workgroups, so a round's tiles finish spread over ~20 us -- and a staggered
-    // first round only added smaller tiles (kernel +4 %).
-    (void)cus;
-    const char *e = getenv("ADSB_STAGGER");
-    const int forced = e ? atoi(e) : 0;
     if (passes < 5 || forced <= 0)
         return 0;
     const uint32_t st = (uint32_t)forced & ~3u;
@@ -1981,55 +1228,16 @@ uint32_t choose_stagger(uint64_t n_offsets, int cus, int passes)
     return tiles >= 2ull * st ? st : 0u;
 }
 
-// Workgroups of the pipelined kernel that are resident at once (they are persistent: that is the grid).
-static int pipe_resident_groups(bool stats, int passes)
+hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream)
 {
-    static int cache[2][kMaxPasses + 1];
-    int &c = cache[stats ? 1 : 0][passes];
-    if (c == 0) {
-        int dev = 0, cus = 256, per_cu = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const hipError_t e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_pipe_kernel<true>, kPipeThreads, lds_bytes_pipe(passes))
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_pipe_kernel<false>, kPipeThreads, lds_bytes_pipe(passes));
-        if (e != hipSuccess || per_cu < 1)
-            per_cu = 1;
-        if (const char *f = getenv("ADSB_PIPE_GROUPS_PER_CU")) // tuning
-            per_cu = std::max(1, atoi(f));
-        c = std::max(1, cus) * per_cu;
-    }
-    return c;
-}
-
-hipError_t launch_scan(const ScanArgs &args_in, bool stats, hipStream_t stream)
-{
-    ScanArgs args = args_in;
     if (args.g_end <= args.g_begin)
         return hipSuccess;
-    const uint64_t n = args.g_end - args.g_begin;
-    const uint64_t per = (uint64_t)tile_offsets(args.passes);
-    const uint64_t blocks = tile_count(n, args.stagger, args.passes);
-    args.n_tiles = (uint32_t)blocks;
-    const size_t lds = args.pipe ? lds_bytes_pipe(args.passes) : lds_bytes(args.passes);
-    if (getenv("ADSB_DEBUG_LAUNCH"))
-        fprintf(stderr, "launch_scan: n=%llu passes=%d per=%llu blocks=%llu lds=%zu pipe=%d prior_err=%d\n",
-                (unsigned long long)n, args.passes, (unsigned long long)per, (unsigned long long)blocks, lds, args.pipe,
-                (int)hipPeekAtLastError());
-    if (args.pipe) {
-        if (args.stagger != 0 || args.passes > kPipeMaxPasses)
-            return hipErrorInvalidValue;
-        const unsigned grid = (unsigned)std::min<uint64_t>(blocks, (uint64_t)pipe_resident_groups(stats, args.passes));
-        if (getenv("ADSB_DEBUG_LAUNCH"))
-            fprintf(stderr, "launch_scan: pipelined kernel, %u persistent workgroups for %llu tiles\n", grid, (unsigned long long)blocks);
-        if (stats)
-            hipLaunchKernelGGL(scan_pipe_kernel<true>, dim3(grid), dim3(kPipeThreads), lds, stream, args);
-        else
-            hipLaunchKernelGGL(scan_pipe_kernel<false>, dim3(grid), dim3(kPipeThreads), lds, stream, args);
-    } else if (stats) {
-        hipLaunchKernelGGL(scan_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args);
-    } else {
-        hipLaunchKernelGGL(scan_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), lds, stream, args);
-    }
+    const unsigned blocks = tile_count(args.g_end - args.g_begin, args.stagger, args.passes);
+    const size_t lds = lds_bytes(args.passes);
+    if (stats)
+        hipLaunchKernelGGL(scan_kernel<true>, dim3(blocks), dim3(kThreads), lds, stream, args);
+    else
+        hipLaunchKernelGGL(scan_kernel<false>, dim3(blocks), dim3(kThreads), lds, stream, args);
     if (args.report)
         hipLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, stream, args.counters, args.report, args.gen);
     return hipGetLastError();

@@ -251,7 +251,7 @@ def roofline_objects(p0, p1, steps, profiles_tag="r3", clock=None, step_ms=None)
                 "kernel_ms_per_step": round(kernel_ms / steps, 4),
                 "limited_by": "VALU issue (every product and sum of the 14-tap FIR is rounded separately: "
                               "784 flops per 28 outputs), not HBM: see roofline_valu and DESIGN.md section 4"}
-    if step_ms and n_big / steps > 1.5 and os.environ.get("ADSB_ALT_STREAMS", "1") != "0":
+    if step_ms and n_big / steps > 1.5:
         # a multi-launch stream: consecutive launches run on two alternating streams and overlap, so a launch's own duration
         # (two resident) says nothing about the rate -- price the whole step instead (a lower bound: it includes the host's share)
         total_bytes = 4.0 * (p1["offsets"] - p0["offsets"]) / steps

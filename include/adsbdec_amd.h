@@ -38,7 +38,10 @@ extern "C" {
 
 /* Bumped when an existing entry point or struct member changes meaning.  Additions do not bump it: new entry points are
  * new symbols, and adsb_config grows at its end only -- adsb_create() reads no further than cfg->struct_size, so a caller
- * built against a shorter adsb_config keeps working (the members it does not know default to 0). */
+ * built against a shorter adsb_config keeps working (the members it does not know default to 0).
+ * 3: `push_overlap` took the place of ABI 2's `reserved0`; it is only honoured when struct_size covers `host_threads`
+ *    (a caller built against ABI 2 that left garbage in reserved0 keeps ABI 2's behaviour).
+ * 4: adsb_shard_head / adsb_shard_part carry the statistics of a resolved shard (round 4). */
 #define ADSB_ABI_VERSION 3
 
 /* Constants of the path (adsbdec.h:1-3, air.c:32,47). */
@@ -106,6 +109,13 @@ typedef struct adsb_config {
                                   2: the handle owns a second thread that reads and checks the stream of large launches
                                   while the caller resolves behind it; same frames, same order.  The thread spins for
                                   ~0.4 ms after a launch, then sleeps until the next one. */
+    /* more test knobs (0 = default).  The library reads no environment variable: whatever a test has to force is here. */
+    int32_t debug_no_streaming;     /* 1: every launch is collected after completion (no hand-off stream)              */
+    int32_t debug_frames_cap;       /* collect_stats: accepted frames the upload buffers start with (regrow path)      */
+    int32_t debug_reader_min_tiles; /* host_threads = 2: launches of at least this many tiles go through the thread    */
+    int32_t debug_shard_head;       /* resolved shards: offsets whose candidates are all kept for the stitcher (16384) */
+    int32_t debug_passes;           /* passes per tile of every launch (2..32) instead of the cost model's choice      */
+    int32_t debug_stagger;          /* leading tiles of staggered size (scan_kernel.h tile_passes)                      */
 } adsb_config;
 
 /* Counters accumulate over the life of the handle (adsb_reset keeps them: a caller that

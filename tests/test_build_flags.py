@@ -24,8 +24,8 @@ def test_no_fused_multiply_add_in_scan_kernel(isa):
     of 2*c' - c on already-truncated integers (exact by construction, see
     scan_kernel.hip); anything else fused is a contraction bug."""
     fused = re.findall(r"^\s*(v_(?:pk_)?(?:fma|mac|mad|fmac|dot)\w*f(?:32|16)\w*)", isa, flags=re.M)
-    kernels = len(re.findall(r"^\s*\.amdhsa_kernel\s.*scan_(?:pipe_)?kernel", isa, flags=re.M))
-    assert kernels == 4  # scan_kernel<true|false>, scan_pipe_kernel<true|false> (count_tries_kernel has no float math)
+    kernels = len(re.findall(r"^\s*\.amdhsa_kernel\s.*scan_kernel", isa, flags=re.M))
+    assert kernels == 2  # scan_kernel<true|false> (count_tries_kernel has no float math)
     assert set(fused) <= {"v_fma_f32", "v_pk_fma_f32"}, f"contracted arithmetic in the ISA: {sorted(set(fused))}"
     # 28 E1 + 28 E2 sign tests per instantiation; a packed one decides two of them
     lanes = sum(2 if f.startswith("v_pk_") else 1 for f in fused)
@@ -38,31 +38,28 @@ def test_no_fused_multiply_add_in_scan_kernel(isa):
 
 
 def test_no_scratch_and_gfx950_only(isa):
-    """The classic kernels use no scratch at all.  The pipelined kernel is held to 96 VGPRs (five waves per SIMD) and
-    may park a few LOOP-INVARIANT values in scratch -- stored once per workgroup, reloaded once per tile -- but its
-    Stage A pass loop, where the time goes, must hold at most one reload and no store."""
+    """No kernel of the library spills: 0 bytes of scratch each, at most 128 VGPRs (four waves per SIMD)."""
     assert ".amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"" in isa
     sizes = dict(re.findall(r"^\s*\.amdhsa_kernel\s+(\S+)\n(?:.*\n)*?\s*\.amdhsa_private_segment_fixed_size\s+(\d+)", isa, flags=re.M))
-    assert len(sizes) >= 6
+    assert len(sizes) == 4 and not any("pipe" in k for k in sizes)   # scan_kernel<true|false>, count_tries_kernel, report_kernel
     for name, size in sizes.items():
-        if "scan_pipe_kernel" in name:
-            assert int(size) <= 128, f"{name} spills {size} bytes per lane"
-        else:
-            assert int(size) == 0, f"{name} spills to scratch"
-    for name in sizes:
-        if "scan_pipe_kernel" not in name:
-            continue
-        body = isa[isa.index(f"\n{name}:"):]
-        body = body[:body.index(".amdhsa_kernel")]
-        first, last = body.index("buffer_load_format_xyzw"), body.rindex("buffer_load_format_xyzw")
-        # the pass loop (depth 2 inside the tile loop): from its header, the last loop label in front of the loads,
-        # to the first block behind them that belongs to the tile loop only
-        head = body.rindex("Loop Header", 0, first)
-        tail = last + re.search(r"in Loop: Header=\S+ Depth=1\b", body[last:]).start()
-        loop = body[head:tail]
-        assert "ds_write_b32" in loop and 500 < loop.count("\n") < 2500
-        assert "scratch_store" not in loop
-        assert len(re.findall(r"scratch_load", loop)) <= 1
+        assert int(size) == 0, f"{name} spills to scratch"
+    for name, vgprs in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", isa):
+        assert int(vgprs) <= 128, (name, vgprs)
+
+
+def test_shipped_library_reads_no_environment():
+    """Round 3 shipped its tuning laboratory (19 ADSB_* environment knobs, one of which switched an ordering rule off).
+    The library in adsbdec_amd/lib carries no such name and does not import getenv; the kernel source has no build knob."""
+    from adsbdec_amd import _build
+    lib = _build.build()
+    names = subprocess.run(["strings", lib], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert not [n for n in names if n.startswith("ADSB_")]
+    dyn = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in dyn
+    for f in ("scan_kernel.hip", "scan_kernel.h"):
+        src = open(os.path.join(ROOT, "adsbdec_amd", "csrc", f)).read()
+        assert "#if" not in src.replace("#ifndef ADSBDEC", ""), f
 
 
 def test_atomic_optimizer_off_and_bitop3_gate(isa):
@@ -71,5 +68,5 @@ def test_atomic_optimizer_off_and_bitop3_gate(isa):
     wave-wide DPP scan: +3.9 % kernel time), and the gate words are formed by gfx950's v_bitop3_b32."""
     from adsbdec_amd import _build
     assert "-amdgpu-atomic-optimizer-strategy=None" in _build.HIP_FLAGS
-    assert len(re.findall(r"^\s*v_bitop3_b32", isa, flags=re.M)) >= 48   # 6 per chunk, 4 chunks per batch, two paths, four kernels
+    assert len(re.findall(r"^\s*v_bitop3_b32", isa, flags=re.M)) >= 24   # 6 per chunk, 4 chunks per batch, two paths, two kernels
     assert re.search(r"^\s*ds_add_rtn_u32", isa, flags=re.M)

@@ -22,12 +22,6 @@ from conftest import ROOT, records
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["classic", "pipe"])
-def kernel_variant(request, monkeypatch):
-    """Every test runs with both scan kernels (scan_kernel.hip): the classic one-workgroup-per-tile kernel and the
-    pipelined one (persistent five-wave workgroups, Stage B on a wave of its own).  ADSB_PIPE is read per launch."""
-    monkeypatch.setenv("ADSB_PIPE", "1" if request.param == "pipe" else "0")
-    return request.param
 sys.path.insert(0, ROOT)
 
 

@@ -13,14 +13,6 @@ from conftest import golden_cases, golden_records, load_golden, records, shard_p
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["classic", "pipe"])
-def kernel_variant(request, monkeypatch):
-    """Every test runs with both scan kernels (scan_kernel.hip): the classic one-workgroup-per-tile kernel and the
-    pipelined one (persistent five-wave workgroups, Stage B on a wave of its own).  ADSB_PIPE is read per launch."""
-    monkeypatch.setenv("ADSB_PIPE", "1" if request.param == "pipe" else "0")
-    return request.param
-
-
 @pytest.fixture(scope="module")
 def torch_cuda():
     import torch
@@ -286,14 +278,13 @@ def test_statistics_read_patterns(capi, oracle, dec_factory, torch_cuda):
     assert d.stats() == wstats and d.stats() == wstats
 
 
-def test_accepted_frame_log_regrows(capi, oracle, torch_cuda, monkeypatch):
+def test_accepted_frame_log_regrows(capi, oracle, torch_cuda):
     """Statistics runs: the resolver logs the frames it accepts straight into the page-locked array the count pass uploads
     from; when a pass has more frames than the array holds, the rest goes to a vector and the arrays are regrown.  Start
-    with room for 8 frames (ADSB_DEBUG_FRAMES_CAP, read at adsb_create) and decode streams with hundreds of frames per
+    with room for 8 frames (cfg.debug_frames_cap) and decode streams with hundreds of frames per
     launch, several streams on one handle, chunked and in one piece: the Try/Ok table must equal the oracle's every time."""
     from oracle import gen_signal as G
-    monkeypatch.setenv("ADSB_DEBUG_FRAMES_CAP", "8")
-    d = capi.Decoder(df18=True, collect_stats=True)
+    d = capi.Decoder(df18=True, collect_stats=True, debug_frames_cap=8)
     try:
         for seed, n, nfr in ((41, 3 << 20, 900), (42, 1 << 20, 300), (43, (2 << 20) + 6, 1500)):
             x, _ = G.dense_capture(n, seed=seed, sigma=30.0, n_frames=nfr, amp=(200, 1800))
@@ -336,15 +327,14 @@ def test_stream_of_2_to_32_samples_is_refused(capi, dec_factory, torch_cuda):
     d.finish()
 
 
-@pytest.mark.parametrize("passes", ["7", "10"])
-def test_try_counting_with_more_than_64_frames_per_tile(oracle, dec_factory, monkeypatch, passes):
+@pytest.mark.parametrize("passes", [7, 10])
+def test_try_counting_with_more_than_64_frames_per_tile(oracle, dec_factory, passes):
     """Statistics runs count the tries on the device, one wave per tile, against the window of accepted frames
     that can shadow the tile's offsets -- one frame per lane.  Short frames packed back to back (640 offsets
     apart: the greedy scan lands exactly on the next preamble, demod.c:128) put 75+ accepted frames into the
     window of a 7-pass tile, more than a wave holds: the per-try binary search takes over.  Tile size forced
-    through ADSB_PASSES (launches this small would take 2..6 passes)."""
+    through cfg.debug_passes (launches this small would take 2..6 passes)."""
     from oracle import gen_signal as G
-    monkeypatch.setenv("ADSB_PASSES", passes)
     rng = np.random.default_rng(11)
     n = 3 << 19
     frames = [(5_000 + 1_280 * i, G.make_frame(11, rng), float(rng.uniform(600, 1500)), float(rng.uniform(0, 6.28)))
@@ -353,7 +343,7 @@ def test_try_counting_with_more_than_64_frames_per_tile(oracle, dec_factory, mon
     x = G.synth(n, frames, 25.0, 5)
     want, wstats = oracle.decode(x, df18=True)
     assert len(want) > 1000 and sum(wstats["try"].values()) > len(want)
-    d = dec_factory(df18=True, collect_stats=True)
+    d = dec_factory(df18=True, collect_stats=True, debug_passes=passes)
     assert records(d.decode(x)) == records(want)
     assert d.stats() == wstats
     t = __import__("torch").from_numpy(x.view(np.int16)).cuda()
@@ -368,8 +358,8 @@ def test_async_small_staging_seam_is_ordered(capi, dec_factory, stats):
     """Regression for a race found in round 2: with a 64 Ki-sample staging buffer every asynchronous piece
     compacts the buffer, and the next piece's host-to-device copy (copy engine, own stream) lands right behind the
     compaction's tail copy (scan stream) -- inside one cache line.  Unordered, one of the two writes was lost in
-    5-35 % of the runs and a frame straddling the seam disappeared (tools/async_race.py reproduces it with
-    ADSB_DEBUG_ASYNC=4).  The copy streams now wait for the tail copy; 150 decodes, odd push sizes included."""
+    5-35 % of the runs and a frame straddling the seam disappeared (tools/async_race.py reproduces it on a
+    -DADSB_TUNING build with the ordering rule switched off).  The copy streams now wait for the tail copy; 150 decodes, odd push sizes included."""
     from oracle import gen_signal as G
     x, _ = G.dense_capture((5 << 20) + 6, seed=61, sigma=30.0, n_frames=1200, amp=(150, 1800))
     ref = dec_factory(df18=True, collect_stats=stats)
@@ -655,25 +645,25 @@ def test_streaming_handoff_is_stable_over_many_launches(oracle, dec_factory, tor
         assert records(d.drain()) == exp, it
 
 
-def test_reader_thread_consumes_the_handoff_stream(capi, oracle, dec_factory, torch_cuda, monkeypatch):
+def test_reader_thread_consumes_the_handoff_stream(capi, oracle, dec_factory, torch_cuda):
     """cfg.host_threads = 2: a second host thread reads and checks the hand-off stream while the caller resolves behind
     it (decoder.hip StreamReader).  Same frames, same statistics, on every path a launch's collect can take: rotating
     captures on one handle (stale bytes of the previous launch must not be taken), chunked pushes, a statistics run,
     tiles that flag "finish after completion" (staged-list overflow, loose list, relaunch)."""
     from oracle import gen_signal as G
-    monkeypatch.setenv("ADSB_READER_MIN_TILES", "1")   # also the small launches of this test go through the thread
+    rd = dict(host_threads=2, debug_reader_min_tiles=1)   # also the small launches of this test go through the thread
     caps = []
     for seed, n, nfr in ((61, 1 << 22, 1500), (62, (1 << 22) - 300_000, 900), (63, (1 << 21) + 4096, 1100)):
         x, _ = G.dense_capture(n, seed=seed, sigma=30.0, n_frames=nfr, amp=(150, 1800))
         want, wstats = oracle.decode(x, df18=True)
         caps.append((x, _dev(torch_cuda, x), records(want), wstats))
-    d = dec_factory(df18=True, host_threads=2)
+    d = dec_factory(df18=True, **rd)
     for it in range(150):
         _, t, exp, _ = caps[(it * 7 + it // 5) % 3]
         d.reset()
         d.push_device_final(t.data_ptr(), t.numel())
         assert records(d.drain()) == exp, it
-    ds = dec_factory(df18=True, host_threads=2, collect_stats=True)
+    ds = dec_factory(df18=True, collect_stats=True, **rd)
     for x, t, exp, wstats in caps:
         assert records(ds.decode(x)) == exp
         assert ds.stats() == wstats
@@ -691,7 +681,7 @@ def test_reader_thread_consumes_the_handoff_stream(capi, oracle, dec_factory, to
     tb = _dev(torch_cuda, xb)
     for kw in (dict(debug_clist_cap=2), dict(debug_clist_cap=2, collect_stats=True, debug_cand_cap=16, debug_try_cap=64),
                dict(all_candidates=True)):
-        db = dec_factory(df18=True, host_threads=2, **kw)
+        db = dec_factory(df18=True, **rd, **kw)
         for _ in range(2):
             db.reset()
             db.push_device_final(tb.data_ptr(), tb.numel())
@@ -701,12 +691,11 @@ def test_reader_thread_consumes_the_handoff_stream(capi, oracle, dec_factory, to
 
 
 @pytest.mark.parametrize("name", golden_cases())
-def test_golden_without_streaming_handoff(capi, dec_factory, torch_cuda, monkeypatch, name):
-    """ADSB_NO_STREAMING=1 (read by adsb_create): every launch is collected after completion
+def test_golden_without_streaming_handoff(capi, dec_factory, torch_cuda, name):
+    """cfg.debug_no_streaming: every launch is collected after completion
     from the launch-wide lists -- the fallback the streaming path drops to on overflow."""
-    monkeypatch.setenv("ADSB_NO_STREAMING", "1")
     x, rec = load_golden(name)
-    d = dec_factory(df18=rec["df18"], collect_stats=True)
+    d = dec_factory(df18=rec["df18"], collect_stats=True, debug_no_streaming=True)
     assert records(d.decode(x)) == golden_records(rec)
     assert d.stats() == rec["stats"]
     t = _dev(torch_cuda, x)
@@ -717,12 +706,11 @@ def test_golden_without_streaming_handoff(capi, dec_factory, torch_cuda, monkeyp
 
 
 @pytest.mark.parametrize("seed,sigma,nfr,df18", [(111, 8.0, 80, False), (112, 300.0, 60, True)])
-def test_seeded_without_streaming_handoff(oracle, dec_factory, monkeypatch, seed, sigma, nfr, df18):
+def test_seeded_without_streaming_handoff(oracle, dec_factory, seed, sigma, nfr, df18):
     from oracle import gen_signal as G
-    monkeypatch.setenv("ADSB_NO_STREAMING", "1")
     x, _ = G.dense_capture((3 << 20) + 4 * seed, seed=seed, sigma=sigma, n_frames=nfr, amp=(150, 1900))
     want, wstats = oracle.decode(x, df18=df18)
-    d = dec_factory(df18=df18, collect_stats=True)
+    d = dec_factory(df18=df18, collect_stats=True, debug_no_streaming=True)
     assert records(d.decode(x, chunk=1 << 20)) == records(want)
     assert d.stats() == wstats
     assert records(d.decode(x, chunk=1 << 20, mode="async")) == records(want)
@@ -844,7 +832,7 @@ def test_shard_candidates_equal_oracle_exhaustive(capi, oracle, dec_factory, tor
 
 
 @pytest.mark.parametrize("n_shards", [2, 5, 8, 13])
-def test_resolved_shards_equal_the_sequential_decode(capi, oracle, dec_factory, torch_cuda, n_shards, monkeypatch):
+def test_resolved_shards_equal_the_sequential_decode(capi, oracle, dec_factory, torch_cuda, n_shards):
     """adsb_scan_shard_resolved + adsb_stitch_shards (every shard resolved on its own, rank 0 only repairs seams, hands
     out ts offsets and applies the end-of-file horizon) against the oracle: a noisy capture with overlapping frames, and
     frames packed back to back so that every seam cuts through one; with a head window too small to decide such a seam
@@ -861,20 +849,14 @@ def test_resolved_shards_equal_the_sequential_decode(capi, oracle, dec_factory, 
         assert rc == 0
         arr, n = res.collect()
         assert records(capi._frames_to_dicts(arr, n)) == records(want)
-    # (ADSB_SHARD_HEAD is read once per process: the small-window case runs in a child)
-    code = ("import sys, numpy as np, torch; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
-            "from adsbdec_amd import capi, sharding\n"
-            "from test_gpu_parity import _back_to_back\n"
-            "x = _back_to_back(1100, 45); t = torch.from_numpy(x.view(np.int16)).cuda()\n"
-            "d = capi.Decoder(df18=True)\n"
-            f"res, rc = sharding.decode_sharded(d, t.data_ptr(), x.size, {n_shards})\n"
-            "print('RC', rc)\n")
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, timeout=600,
-                       env=dict(os.environ, ADSB_SHARD_HEAD="600"))
-    assert p.returncode == 0, p.stderr.decode()[-2000:]
-    assert "RC -3" in p.stdout.decode() or "RC 0" in p.stdout.decode()
+    # a head window of 600 offsets cannot decide a seam that cuts through back-to-back frames: -3 (or 0 where no seam does)
+    t = _dev(torch_cuda, xb)
+    d = dec_factory(df18=True, debug_shard_head=600)
+    res, rc = sharding.decode_sharded(d, t.data_ptr(), xb.size, n_shards)
+    assert rc in (0, -3)
+    if rc == 0:
+        arr, n = res.collect()
+        assert records(capi._frames_to_dicts(arr, n)) == records(oracle.decode(xb, df18=True)[0])
 
 
 def _bench_line(extra, timeout=900):
@@ -974,20 +956,17 @@ def test_cli_matches_golden_avr_mlat_beast(capi, tmp_path):
     assert subprocess.run([capi.CLI_PATH, "-e"], capture_output=True).returncode == 1
 
 
-def test_staggered_tile_sizes(oracle, dec_factory, torch_cuda, monkeypatch):
-    """Large launches give their first resident round of tiles K-3..K passes in turn
-    (scan_kernel.h tile_passes) so that tiles do not complete in bursts; that only
-    happens from ~140 M samples on, so force it here on a small capture (ADSB_PASSES /
-    ADSB_STAGGER are read per launch) and compare with the oracle, statistics included."""
+def test_staggered_tile_sizes(oracle, dec_factory, torch_cuda):
+    """Staggered tile sizes (the first tiles of a launch take K-3..K passes in turn, scan_kernel.h tile_passes)
+    were an experiment that did not pay and are off; the tile geometry functions stay covered by forcing it on a
+    small capture (cfg.debug_passes / cfg.debug_stagger) and comparing with the oracle, statistics included."""
     from oracle import gen_signal as G
     x, _ = G.dense_capture(1 << 22, seed=77, sigma=25.0, n_frames=1200, amp=(150, 1800))
     want, wstats = oracle.decode(x, df18=True)
     t = _dev(torch_cuda, x)
     for passes, stagger in ((5, 8), (6, 16), (5, 60)):
-        monkeypatch.setenv("ADSB_PASSES", str(passes))
-        monkeypatch.setenv("ADSB_STAGGER", str(stagger))
         for stats in (False, True):
-            d = dec_factory(df18=True, collect_stats=stats)
+            d = dec_factory(df18=True, collect_stats=stats, debug_passes=passes, debug_stagger=stagger)
             d.reset()
             d.push_device_final(t.data_ptr(), t.numel())
             assert records(d.drain()) == records(want)

@@ -49,8 +49,9 @@ def test_create_without_gpu_fails_loudly(capi):
 
 
 def test_config_grows_at_its_end_only(capi):
-    """adsb_create reads no further than cfg.struct_size: a caller built against the round-2 adsb_config (64 bytes, no
-    host_threads) gets past the size check (and, here, fails for the lack of a GPU); a size from the future is refused."""
+    """adsb_create reads no further than cfg.struct_size: callers built against the round-2 adsb_config (64 bytes, no
+    host_threads) and the round-3 one (72 bytes, no debug_no_streaming ...) get past the size check (and, here, fail for
+    the lack of a GPU); a size from the future is refused."""
     import ctypes as C
     import torch
     if torch.cuda.is_available():
@@ -58,10 +59,12 @@ def test_config_grows_at_its_end_only(capi):
     L = capi.load()
     cfg = capi.Config()
     L.adsb_config_default(C.byref(cfg))
-    assert cfg.struct_size == C.sizeof(capi.Config) == 72 and capi.Config.host_threads.offset == 64
-    cfg.struct_size = 64
-    assert not L.adsb_create(C.byref(cfg))
-    assert b"no HIP device" in L.adsb_last_error(None)
+    assert cfg.struct_size == C.sizeof(capi.Config) >= 96
+    assert capi.Config.host_threads.offset == 64 and capi.Config.debug_no_streaming.offset == 68
+    for old_size in (64, 72):
+        cfg.struct_size = old_size
+        assert not L.adsb_create(C.byref(cfg))
+        assert b"no HIP device" in L.adsb_last_error(None)
     cfg.struct_size = 4096
     assert not L.adsb_create(C.byref(cfg))
     assert b"struct_size" in L.adsb_last_error(None)

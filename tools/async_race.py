@@ -43,8 +43,10 @@ def main():
     print("frames", len(want), "stats", wstats, flush=True)
     configs = []
     for stats in (False, True):
-        for env in ({}, {"ADSB_NO_STREAMING": "1"}, {"ADSB_DEBUG_ASYNC": "4"}):
-            configs.append((f"async stage=64Ki stats={int(stats)} {env}", dict(stage=1 << 16, stats=stats, mode="async", env=env)))
+        # ADSB_DEBUG_ASYNC is only read by a -DADSB_TUNING build (tools/build_variant.sh tuning -DADSB_TUNING; load it with
+        # ADSB_LIB_PATH): 4 switches the ordering rule of the tail copy off -- the old race.  The shipped library ignores it.
+        for env, kw in (({}, {}), ({}, {"debug_no_streaming": True}), ({"ADSB_DEBUG_ASYNC": "4"}, {})):
+            configs.append((f"async stage=64Ki stats={int(stats)} {env} {kw}", dict(stage=1 << 16, stats=stats, mode="async", env=env, kw=kw)))
     configs += [
         ("sync  stage=64Ki stats=0 chunk 1Mi", dict(stage=1 << 16, stats=False, mode="sync", env={})),
         ("async stage=default stats=0", dict(stage=0, stats=False, mode="async", env={})),
@@ -67,10 +69,9 @@ def main():
     for name, c in configs:
         if only and only not in name:
             continue
-        for k in ("ADSB_NO_STREAMING", "ADSB_DEBUG_ASYNC"):
-            os.environ.pop(k, None)
+        os.environ.pop("ADSB_DEBUG_ASYNC", None)
         os.environ.update(c["env"])
-        d = capi.Decoder(df18=True, collect_stats=c["stats"], stage_samples=c["stage"], push_overlap=c.get("overlap", False))
+        d = capi.Decoder(df18=True, collect_stats=c["stats"], stage_samples=c["stage"], push_overlap=c.get("overlap", False), **c.get("kw", {}))
         bad_f = bad_s = 0
         first = None
         for i in range(iters):

@@ -69,17 +69,13 @@ def run(seconds: float, seed: int = 1, log=print):
             reader = len(decs) % 2 == 1
             decs[k] = capi.Decoder(df18=df18, collect_stats=stats, fix_1bit=fix, push_overlap=overlap,
                                    stage_samples=[0, 1 << 17, 1 << 16][len(decs) % 3],
-                                   host_threads=2 if reader else 0, **tight[caps])
+                                   host_threads=2 if reader else 0, debug_reader_min_tiles=1 if reader else 0, **tight[caps])
             decs[k].fuzz_reader = reader
         return decs[k]
 
     t0, it, frames_total, ref_checked, tight_runs = time.time(), 0, 0, 0, 0
     modes = [0] * 9
-    pipe_runs = 0
     stitch_fallbacks = [0]
-    pipe_before = os.environ.get("ADSB_PIPE")
-    min_tiles_before = os.environ.get("ADSB_READER_MIN_TILES")
-    os.environ["ADSB_READER_MIN_TILES"] = "1"   # read by adsb_create: the fuzz's small launches go through the thread too
     reader_runs = 0
     pinned = capi.PinnedBuffers(2, 1 << 20)
     bufs = pinned.__enter__()
@@ -104,12 +100,9 @@ def run(seconds: float, seed: int = 1, log=print):
         d = dec(df18, stats, fix, caps, overlap=(mode == 8))
         modes[mode] += 1
         reader_runs += int(getattr(d, "fuzz_reader", False))
-        # either scan kernel (scan_kernel.hip; ADSB_PIPE is read per launch): the classic one, or the pipelined one
-        pipe = bool(rng.integers(0, 3) == 0)
-        os.environ["ADSB_PIPE"] = "1" if pipe else "0"
-        pipe_runs += int(pipe)
+        rng.integers(0, 3)     # (round 3 drew the scan kernel here; the draw stays so that a seed still means the same capture and mode)
         d.reset()
-        what = f"seed={seed} mode={mode} pipe={int(pipe)} n={x.size} df18={df18} stats={stats} fix={fix} caps={tight[caps]}"
+        what = f"seed={seed} mode={mode} n={x.size} df18={df18} stats={stats} fix={fix} caps={tight[caps]}"
         tight_runs += 1 if caps else 0
         if mode == 0:      # host pushes, random chunking
             pos = 0
@@ -206,21 +199,13 @@ def run(seconds: float, seed: int = 1, log=print):
                    captures_by_mode=dict(host_push=modes[0], device_final=modes[1], device_split_aligned=modes[2],
                                          device_split_unaligned=modes[3], shards=modes[4], host_push_async=modes[5],
                                          mixed_async_sync_device=modes[6], resolved_shards=modes[7], push_overlap=modes[8]),
-                   with_the_pipelined_kernel=pipe_runs, with_the_reader_thread=reader_runs, stitcher_fallbacks=stitch_fallbacks[0],
+                   with_the_reader_thread=reader_runs, stitcher_fallbacks=stitch_fallbacks[0],
                    also_checked_against_real_reference_chain=ref_checked,
                    with_shrunken_record_buffers=tight_runs,
                    relaunches=sum(int(d.profile()["relaunches"]) for d in decs_all))
     for d in decs_all:
         d.close()
     pinned.__exit__(None, None, None)
-    if min_tiles_before is None:
-        os.environ.pop("ADSB_READER_MIN_TILES", None)
-    else:
-        os.environ["ADSB_READER_MIN_TILES"] = min_tiles_before
-    if pipe_before is None:
-        os.environ.pop("ADSB_PIPE", None)
-    else:
-        os.environ["ADSB_PIPE"] = pipe_before
     log(f"fuzz ok: {summary}")
     return summary
 

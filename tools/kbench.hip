@@ -1,6 +1,8 @@
-// kbench.hip -- stand-alone timing of adsb::scan_kernel variants (tile shape via
-// -DADSB_THREADS / -DADSB_PASSES, ablations via -DADSB_ABLATE). Not part of the library.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I adsbdec_amd/csrc tools/kbench.hip -o kbench
+// kbench.hip -- stand-alone timing of the shipped adsb::scan_kernel on device-generated noise (kernel time only: no host
+// consumer).  Not part of the library.   kbench [Mi samples] [iterations] [passes] [sigma]; KB_HAND=1: hand-off stream on.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None -I adsbdec_amd/csrc tools/kbench.hip -o tools/bin/kbench
+// (The ablation builds of rounds 2-3 -- loads only, Stage A only, cache-resident input, per-tile clocks, the pipelined kernel --
+// were #if branches of scan_kernel.hip; they left the tree with round 4 and live in its history: DESIGN_HISTORY.md.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -55,9 +57,8 @@ int main(int argc, char **argv)
         CK(hipHostMalloc(&hand, gran * 16, hipHostMallocCoherent));
         a.hand = hand; a.hand_cap = (uint32_t)gran; a.gen = 12345;
     }
-    a.pipe = getenv("KB_PIPE") && atoi(getenv("KB_PIPE")) ? 1 : 0; // the pipelined kernel (persistent five-wave workgroups)
-    a.passes = argc > 3 && atoi(argv[3]) > 0 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256, a.pipe != 0);
-    a.stagger = a.pipe ? 0u : adsb::choose_stagger(a.g_end - a.g_begin, 256, a.passes); // ADSB_STAGGER=0 turns it off
+    a.passes = argc > 3 && atoi(argv[3]) > 0 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256);
+    a.stagger = 0;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++) { CK(hipMemset(counters, 0, adsb::kDevCounterWords * 4)); CK(adsb::launch_scan(a, false, 0)); }
     CK(hipDeviceSynchronize());
@@ -67,36 +68,6 @@ int main(int argc, char **argv)
         CK(hipEventRecord(e0, 0)); CK(adsb::launch_scan(a, false, 0)); CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms);
     }
-#if ADSB_TILE_CLOCK
-    {   // one more launch with the per-tile clock buffer; dump "tile begin_us end_us xcc cu" to stdout
-        const uint32_t nt = adsb::tile_count(a.g_end - a.g_begin, a.stagger, a.passes);
-        uint32_t *dclk; CK(hipMalloc(&dclk, (size_t)nt * 16)); CK(hipMemset(dclk, 0, (size_t)nt * 16));
-        a.tile_clock = dclk;
-         CK(adsb::launch_scan(a, false, 0)); CK(hipDeviceSynchronize());
-        std::vector<uint32_t> h((size_t)nt * 4); CK(hipMemcpy(h.data(), dclk, h.size() * 4, hipMemcpyDeviceToHost));
-        uint32_t t0c = ~0u; for (uint32_t i = 0; i < nt; i++) t0c = std::min(t0c, h[4 * i]);
-#if ADSB_TILE_CLOCK == 2
-        {   // the clock the chip holds while this kernel runs: shader cycles / device real time (100 MHz) per tile
-            std::vector<double> ghz;
-            for (uint32_t i = 0; i < nt; i++) {
-                const double us = (h[4 * i + 1] - h[4 * i]) * 0.01;
-                if (us > 5.0)
-                    ghz.push_back(h[4 * i + 2] / us * 1e-3);
-            }
-            std::sort(ghz.begin(), ghz.end());
-            if (!ghz.empty())
-                printf("in-kernel shader clock over %zu tiles: median %.3f GHz (p5 %.3f, p95 %.3f)\n", ghz.size(), ghz[ghz.size() / 2],
-                       ghz[ghz.size() / 20], ghz[ghz.size() - 1 - ghz.size() / 20]);
-        }
-#endif
-        FILE *f = fopen(getenv("ADSB_CLOCK_OUT") ? getenv("ADSB_CLOCK_OUT") : "tile_clock.txt", "w");
-        for (uint32_t i = 0; i < nt; i++)
-            fprintf(f, "%u %.2f %.2f %u %u %u\n", i, (h[4 * i] - t0c) * 0.01, (h[4 * i + 1] - t0c) * 0.01, h[4 * i + 3] & 15u,
-                    (h[4 * i + 2] >> 8) & 15u, (h[4 * i + 2] >> 13) & 7u); // xcc, cu_id, sh/se bits
-        fclose(f);
-        a.tile_clock = nullptr;
-    }
-#endif
     // the clock governor needs ~20 ms of load to settle: with 200 iterations or
     // more, only the second half counts
     if (t.size() >= 200)
@@ -105,9 +76,7 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
     const uint32_t hc[2] = {report[0], report[1]}; // the last tile's report (the device counters are zero again)
     double med = t[t.size() / 2];
-    printf("pipe=%d passes=%d stagger=%u ablate=%d minwaves=%d tile=%d lds=%zu | median %.4f ms min %.4f | %.1f GB/s alg | %.1f Gsamples/s | cands=%u\n",
-           a.pipe, a.passes, a.stagger, a.pipe ? ADSB_PIPE_ABLATE : ADSB_ABLATE, a.pipe ? ADSB_PIPE_WAVES : ADSB_MIN_WAVES, adsb::tile_offsets(a.passes),
-           a.pipe ? adsb::lds_bytes_pipe(a.passes) : adsb::lds_bytes(a.passes), med, t[0],
-           2.0 * n / med / 1e6, n / med / 1e6, hc[0]);
+    printf("passes=%d tile=%d lds=%zu | median %.4f ms min %.4f | %.1f GB/s alg | %.1f Gsamples/s | cands=%u\n", a.passes,
+           adsb::tile_offsets(a.passes), adsb::lds_bytes(a.passes), med, t[0], 2.0 * n / med / 1e6, n / med / 1e6, hc[0]);
     return 0;
 }
