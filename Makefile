@@ -22,8 +22,12 @@ $(LIBDIR)/format.c.o: $(CSRC)/format.c $(HDRS)
 	@mkdir -p $(LIBDIR)
 	$(CC) -O2 -fPIC -Wall -c $< -o $@
 
-$(LIB): $(LIBDIR)/scan_kernel.hip.o $(LIBDIR)/decoder.hip.o $(LIBDIR)/format.c.o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm
+$(LIBDIR)/multi.cpp.o: $(CSRC)/multi.cpp $(HDRS)
+	@mkdir -p $(LIBDIR)
+	g++ -O2 -fPIC -std=c++17 -Wall -Wextra -pthread -c $< -o $@
+
+$(LIB): $(LIBDIR)/scan_kernel.hip.o $(LIBDIR)/decoder.hip.o $(LIBDIR)/format.c.o $(LIBDIR)/multi.cpp.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm -lpthread
 
 $(CLI): $(CSRC)/cli/adsbdec_amd_cli.c $(LIB) include/adsbdec_amd.h
 	$(CC) -O2 -Wall -o $@ $< -Iinclude -L$(LIBDIR) -ladsbdec_amd -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib

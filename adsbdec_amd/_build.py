@@ -22,6 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 HIP_SOURCES = ["scan_kernel.hip", "decoder.hip"]
 C_SOURCES = ["format.c"]
+CXX_SOURCES = ["multi.cpp"]  # host-only C++ over the C-ABI (no HIP): the multi-GPU driver
 HEADERS = ["scan_kernel.h", "resolver.hpp", "stitch.hpp", os.path.join(ROOT, "include", "adsbdec_amd.h")]
 # -ffp-contract=off: the reference arithmetic is binary32 multiply THEN add
 # (SURVEY Q3); a fused multiply-add would change rounding.
@@ -64,8 +65,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if force or _newer(obj, [src] + hdrs):
             _run(["gcc", "-O2", "-fPIC", "-Wall", "-c", src, "-o", obj])
         objs.append(obj)
+    for s in CXX_SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIBDIR, s + ".o")
+        if force or _newer(obj, [src] + hdrs):
+            _run(["g++", "-O2", "-fPIC", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-c", src, "-o", obj])
+        objs.append(obj)
     if force or _newer(LIB, objs):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lm"])
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lm", "-lpthread"])
     cli_src = os.path.join(CSRC, "cli", "adsbdec_amd_cli.c")
     if os.path.exists(cli_src) and (force or _newer(CLI, [cli_src, LIB] + hdrs)):
         _run(["gcc", "-O2", "-Wall", "-o", CLI, cli_src, "-I", os.path.join(ROOT, "include"),

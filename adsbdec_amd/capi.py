@@ -38,12 +38,14 @@ class Stats(C.Structure):
 class ShardHead(C.Structure):
     _fields_ = [("g_begin", C.c_uint64), ("g_end", C.c_uint64), ("n_frames", C.c_uint64), ("n_head", C.c_uint64),
                 ("head_end", C.c_uint64), ("skipped", C.c_uint64), ("status", C.c_uint64), ("n_bases", C.c_uint64),
-                ("walk_final", C.c_uint64), ("reserved", C.c_uint64)]
+                ("walk_final", C.c_uint64), ("has_tries", C.c_uint64), ("tries", C.c_uint64 * 3)]
 
 
 class ShardPart(C.Structure):
     _fields_ = [("head", C.POINTER(ShardHead)), ("frames", C.POINTER(Frame)), ("head_cands", C.POINTER(Candidate)),
-                ("bases", C.POINTER(C.c_uint64))]
+                ("bases", C.POINTER(C.c_uint64)),
+                ("head_tries", C.POINTER(C.c_uint64)), ("n_head_tries", C.c_uint64), ("head_tries_end", C.c_uint64),
+                ("tail_tries", C.POINTER(C.c_uint64)), ("n_tail_tries", C.c_uint64), ("tail_from", C.c_uint64)]
 
 
 class ShardFix(C.Structure):
@@ -60,6 +62,12 @@ class Config(C.Structure):
                 ("host_threads", C.c_int32), ("debug_no_streaming", C.c_int32), ("debug_frames_cap", C.c_int32),
                 ("debug_reader_min_tiles", C.c_int32), ("debug_shard_head", C.c_int32), ("debug_passes", C.c_int32),
                 ("debug_stagger", C.c_int32)]
+
+
+class MultiInfo(C.Structure):
+    _fields_ = [("shards", C.c_int32), ("fallback", C.c_int32), ("calls_walked", C.c_uint64), ("calls_jumped", C.c_uint64),
+                ("create_ms", C.c_double), ("workers_ms", C.c_double), ("stitch_us", C.c_double), ("serial_us", C.c_double),
+                ("total_ms", C.c_double)]
 
 
 class Profile(C.Structure):
@@ -113,6 +121,10 @@ SYMBOLS = {
                                      C.c_size_t, C.POINTER(C.c_size_t)]),
     "adsb_stitch_shards_ex": (C.c_int, [C.POINTER(ShardPart), C.c_int, C.c_uint64, C.POINTER(ShardFix), C.POINTER(Frame),
                                         C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+    "adsb_stitch_shards_stats": (C.c_int, [C.POINTER(ShardPart), C.c_int, C.c_uint64, C.POINTER(ShardFix), C.POINTER(Frame),
+                                           C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(Stats)]),
+    "adsb_shard_begin": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_size_t]),
+    "adsb_shard_end": (C.c_int, [C.c_void_p, C.POINTER(ShardHead), C.POINTER(C.POINTER(Frame)), C.POINTER(C.POINTER(Candidate))]),
     "adsb_shard_walk": (C.c_size_t, [C.POINTER(ShardHead), C.POINTER(Frame), C.c_uint64, C.POINTER(C.c_uint64), C.c_size_t]),
     "adsb_shard_apply_fix": (None, [C.POINTER(Frame), C.c_size_t, C.c_int64]),
     "adsb_resolver_start_chain": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
@@ -122,6 +134,26 @@ SYMBOLS = {
     "adsb_resolver_skipped": (C.c_uint64, [C.c_void_p]),
     "adsb_plan_shards": (C.c_int, [C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "adsb_scan_shard_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64,
+                                       C.c_uint64, C.POINTER(Candidate), C.c_size_t,
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_size_t,
+                                       C.POINTER(C.c_size_t)]),
+    "adsb_multi_create": (C.c_void_p, [C.POINTER(Config), C.c_int, C.POINTER(C.c_int)]),
+    "adsb_multi_destroy": (None, [C.c_void_p]),
+    "adsb_multi_devices": (C.c_int, [C.c_void_p]),
+    "adsb_multi_decode_host": (C.c_long, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(Frame))]),
+    "adsb_multi_decode_file": (C.c_long, [C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(Frame))]),
+    "adsb_multi_decode_device": (C.c_long, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.POINTER(Frame))]),
+    "adsb_multi_plan": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "adsb_multi_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "adsb_multi_decode_streams_host": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "adsb_multi_decode_streams_file": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p)]),
+    "adsb_multi_stream_frames": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.POINTER(Frame))]),
+    "adsb_multi_stream_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Stats)]),
+    "adsb_multi_get_info": (C.c_int, [C.c_void_p, C.POINTER(MultiInfo)]),
+    "adsb_multi_worker_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Profile)]),
+    "adsb_multi_last_error": (C.c_char_p, [C.c_void_p]),
     "adsb_scan_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64,
                                   C.c_uint64, C.POINTER(Candidate), C.c_size_t,
                                   C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_size_t,
@@ -172,40 +204,46 @@ def format_frame(fr: dict, outformat: int) -> bytes:
     return buf.raw[:n]
 
 
-class Decoder:
-    """One stream (== the statics of air.c / demod.c / valid.c)."""
+def make_config(df18: bool = False, device: int = -1, collect_stats: bool = False,
+                profile: bool = False, stage_samples: int = 0, stream: int | None = None,
+                debug_queue_cap: int = 0, all_candidates: bool = False, fix_1bit: bool = False,
+                debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0, push_overlap: bool = False,
+                host_threads: int = 0, debug_no_streaming: bool = False, debug_frames_cap: int = 0,
+                debug_reader_min_tiles: int = 0, debug_shard_head: int = 0, debug_passes: int = 0, debug_stagger: int = 0):
+    """adsb_config from keywords (adsb_config_default + the members named)."""
+    cfg = Config()
+    load().adsb_config_default(C.byref(cfg))
+    cfg.df18 = int(df18)
+    cfg.device = device
+    cfg.collect_stats = int(collect_stats)
+    cfg.profile = int(profile)
+    cfg.stage_samples = stage_samples
+    cfg.stream = stream
+    cfg.debug_queue_cap = debug_queue_cap
+    cfg.all_candidates = int(all_candidates)
+    cfg.fix_1bit = int(fix_1bit)
+    cfg.debug_cand_cap = debug_cand_cap
+    cfg.debug_try_cap = debug_try_cap
+    cfg.debug_clist_cap = debug_clist_cap
+    cfg.push_overlap = int(push_overlap)
+    cfg.host_threads = int(host_threads)
+    cfg.debug_no_streaming = int(debug_no_streaming)
+    cfg.debug_frames_cap = debug_frames_cap
+    cfg.debug_reader_min_tiles = debug_reader_min_tiles
+    cfg.debug_shard_head = debug_shard_head
+    cfg.debug_passes = debug_passes
+    cfg.debug_stagger = debug_stagger
+    return cfg
 
-    def __init__(self, df18: bool = False, device: int = -1, collect_stats: bool = False,
-                 profile: bool = False, stage_samples: int = 0, stream: int | None = None,
-                 debug_queue_cap: int = 0, all_candidates: bool = False, fix_1bit: bool = False,
-                 debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0, push_overlap: bool = False,
-                 host_threads: int = 0, debug_no_streaming: bool = False, debug_frames_cap: int = 0,
-                 debug_reader_min_tiles: int = 0, debug_shard_head: int = 0, debug_passes: int = 0, debug_stagger: int = 0):
+
+class Decoder:
+    """One stream (== the statics of air.c / demod.c / valid.c).  Keywords: make_config."""
+
+    def __init__(self, **cfg_kw):
         L = load()
-        cfg = Config()
-        L.adsb_config_default(C.byref(cfg))
-        cfg.df18 = int(df18)
-        cfg.device = device
-        cfg.collect_stats = int(collect_stats)
-        cfg.profile = int(profile)
-        cfg.stage_samples = stage_samples
-        cfg.stream = stream
-        cfg.debug_queue_cap = debug_queue_cap
-        cfg.all_candidates = int(all_candidates)
-        cfg.fix_1bit = int(fix_1bit)
-        cfg.debug_cand_cap = debug_cand_cap
-        cfg.debug_try_cap = debug_try_cap
-        cfg.debug_clist_cap = debug_clist_cap
-        cfg.push_overlap = int(push_overlap)
-        cfg.host_threads = int(host_threads)
-        cfg.debug_no_streaming = int(debug_no_streaming)
-        cfg.debug_frames_cap = debug_frames_cap
-        cfg.debug_reader_min_tiles = debug_reader_min_tiles
-        cfg.debug_shard_head = debug_shard_head
-        cfg.debug_passes = debug_passes
-        cfg.debug_stagger = debug_stagger
+        cfg = make_config(**cfg_kw)
         self._L = L
-        self._fix = bool(fix_1bit)
+        self._fix = bool(cfg_kw.get("fix_1bit"))
         self._h = L.adsb_create(C.byref(cfg))
         if not self._h:
             raise AdsbError("adsb_create failed: " + (L.adsb_last_error(None) or b"").decode())

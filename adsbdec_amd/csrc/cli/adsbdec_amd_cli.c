@@ -11,6 +11,13 @@
  *     -x            EXTENSION, not in the reference: repair single-bit errors in DF17/18
  *                   frames (the reference's -e flag is parsed but does nothing and exits
  *                   with the usage text, main.c:40,60,85-87; that behaviour is kept for -e)
+ *     -d k          EXTENSION: decode on GPU k of the node (default: the first one)
+ *     -G n | a,b,c  EXTENSION: shard the file over n GPUs (or over the GPUs listed; an ordinal may repeat) through
+ *                   the library's multi-GPU driver (adsb_multi_decode_file): same bytes on stdout and stderr.
+ *                   With several -f (one capture each) the captures are decoded side by side, one per GPU, and
+ *                   capture k's packets go to <file k>.avr / .mlat / .beast instead of stdout.
+ * The GPU runtime initialises every device it can see, which takes longer the more there are: before its first call
+ * this program narrows ROCR_VISIBLE_DEVICES to the devices it is going to use (unless the variable is already set).
  * -s / -l (TCP sinks), the live Airspy input and anything else print the usage
  * text and exit 1, like the reference's default: branch (main.c:85-87).
  *
@@ -132,11 +139,14 @@ static void *locker_main(void *arg)
 static void usage(void)
 {
     printf("adsbdec_amd : MI355X offline ADS-B decoder (adsbdec -f compatible)\n\n");
-    printf("usage : adsbdec_amd_cli [-a] [-m] [-b] -f filename\n\n");
+    printf("usage : adsbdec_amd_cli [-a] [-m] [-b] [-d gpu | -G gpus] -f filename [-f filename ...]\n\n");
     printf("\t-a : decode DF18 too\n");
     printf("\t-m : output avrmlat format (ie : with 12Mhz timestamp)\n");
     printf("\t-b : output binary beast format\n");
     printf("\t-x : (extension) repair 1-bit CRC errors in DF17/18 frames\n");
+    printf("\t-d k : (extension) use GPU k\n");
+    printf("\t-G n | a,b,.. : (extension) shard the file over n GPUs / the GPUs listed; several -f: one capture per GPU,\n");
+    printf("\t     packets of capture k written to <file k>.avr | .mlat | .beast\n");
     printf("\t-f : input from filename (raw 16 bits real: uint16 carrying the 12-bit ADC code centred on 2048;\n");
     printf("\t     bit-identical to adsbdec for codes 0..4095, see adsbdec_amd.h for the wider domain)\n");
 }
@@ -154,15 +164,173 @@ static int flush_frames(adsb_decoder *dec, int outformat)
     return n < 0 ? -1 : 0;
 }
 
+static void print_stats(const adsb_stats *st) /* valid.c:84-100 */
+{
+    unsigned long long tot = st->ok[0] + st->ok[1] + st->ok[2];
+    fprintf(stderr, "\t%10d\t%10d\t%10d\n", 11, 17, 18);
+    fprintf(stderr, "Try :\t%10llu\t%10llu\t%10llu\n", (unsigned long long)st->try_[0], (unsigned long long)st->try_[1],
+            (unsigned long long)st->try_[2]);
+    fprintf(stderr, "Ok :\t%10llu\t%10llu\t%10llu\n", (unsigned long long)st->ok[0], (unsigned long long)st->ok[1],
+            (unsigned long long)st->ok[2]);
+    fprintf(stderr, "Total :\t%10llu\n", tot); /* tot_fi is uninitialised there */
+}
+
+static int write_frames(FILE *out, const adsb_frame *fr, long n, int outformat)
+{
+    char pkt[256];
+    for (long i = 0; i < n; i++) {
+        int len = adsb_format_frame(&fr[i], outformat, pkt);
+        if (fwrite(pkt, 1, (size_t)len, out) != (size_t)len)
+            return -1;
+    }
+    return 0;
+}
+
+#define MAX_GPUS 64
+#define MAX_FILES 64
+
+/* "-G 4" -> 0,1,2,3; "-G 0,2,2" -> as listed.  Returns the count, 0 on a malformed argument. */
+static int parse_gpus(const char *arg, int *devs)
+{
+    int n = 0;
+    if (!strchr(arg, ',')) {
+        char *end;
+        long k = strtol(arg, &end, 10);
+        if (*end || k < 1 || k > MAX_GPUS)
+            return 0;
+        for (n = 0; n < k; n++)
+            devs[n] = n;
+        return n;
+    }
+    for (const char *p = arg; *p;) {
+        char *end;
+        long k = strtol(p, &end, 10);
+        if (end == p || k < 0 || k > 1023 || n == MAX_GPUS)
+            return 0;
+        devs[n++] = (int)k;
+        p = (*end == ',') ? end + 1 : end;
+        if (*end && *end != ',')
+            return 0;
+    }
+    return n;
+}
+
+/* Narrow the runtime's view to the devices in use, BEFORE its first call (it initialises every device it sees), and
+ * renumber devs[] to the ordinals the runtime will then hand out.  A caller's own ROCR_VISIBLE_DEVICES is left alone. */
+static void restrict_visible_devices(int *devs, int n)
+{
+    if (getenv("ROCR_VISIBLE_DEVICES") || getenv("HIP_VISIBLE_DEVICES") || getenv("ADSB_CLI_ALL_DEVICES"))
+        return;
+    int uniq[MAX_GPUS], nu = 0;
+    char list[8 * MAX_GPUS] = "";
+    for (int i = 0; i < n; i++) {
+        int at = -1;
+        for (int k = 0; k < nu; k++)
+            if (uniq[k] == devs[i])
+                at = k;
+        if (at < 0) {
+            at = nu;
+            uniq[nu++] = devs[i];
+            snprintf(list + strlen(list), sizeof list - strlen(list), "%s%d", nu > 1 ? "," : "", devs[i]);
+        }
+        devs[i] = at;
+    }
+    setenv("ROCR_VISIBLE_DEVICES", list, 1);
+}
+
+/* -G: the library's multi-GPU driver.  One file: sharded over the devices, same bytes as the one-device run.  Several: one
+ * capture per device, packets into <file>.<format>. */
+static int run_multi(const adsb_config *cfg, int *devs, int ndev, char **files, int nfiles, int outformat, int timing)
+{
+    const double t_start = now_ms();
+    adsb_multi *m = adsb_multi_create(cfg, ndev, devs);
+    if (!m) {
+        fprintf(stderr, "adsb_multi_create() failed: %s\n", adsb_multi_last_error(NULL));
+        return 255;
+    }
+    const double t_init = now_ms();
+    int rc = 0;
+    if (nfiles == 1) {
+        const adsb_frame *fr = NULL;
+        const long n = adsb_multi_decode_file(m, files[0], &fr);
+        adsb_stats st;
+        if (n < 0) {
+            fprintf(stderr, "adsb_multi_decode_file() failed: %s\n", adsb_multi_last_error(m));
+            rc = 255;
+        } else {
+            if (write_frames(stdout, fr, n, outformat) != 0)
+                rc = 1;
+            fflush(stdout);
+            if (timing) {
+                adsb_multi_info inf;
+                adsb_multi_get_info(m, &inf);
+                fprintf(stderr, "timing: runtime init %.1f ms, decode %.1f ms (%d shards, slowest worker %.1f ms, stitch + gather %.0f us%s), total %.1f ms\n",
+                        t_init - t_start, now_ms() - t_init, inf.shards, inf.workers_ms, inf.serial_us,
+                        inf.fallback ? ", FELL BACK to one device" : "", now_ms() - t_start);
+            }
+            if (adsb_multi_get_stats(m, &st) == 0)
+                print_stats(&st);
+        }
+    } else {
+        if (adsb_multi_decode_streams_file(m, nfiles, (const char *const *)files) != 0) {
+            fprintf(stderr, "adsb_multi_decode_streams_file() failed: %s\n", adsb_multi_last_error(m));
+            rc = 255;
+        }
+        static const char *ext[3] = {"avr", "mlat", "beast"};
+        for (int k = 0; k < nfiles && rc == 0; k++) {
+            const adsb_frame *fr = NULL;
+            const long n = adsb_multi_stream_frames(m, k, &fr);
+            char path[4096];
+            snprintf(path, sizeof path, "%s.%s", files[k], ext[outformat]);
+            FILE *out = n >= 0 ? fopen(path, "wb") : NULL;
+            if (!out || write_frames(out, fr, n, outformat) != 0 || fclose(out) != 0) {
+                fprintf(stderr, "%s: cannot write\n", path);
+                rc = 1;
+                break;
+            }
+            adsb_stats st;
+            fprintf(stderr, "== %s: %ld frames -> %s\n", files[k], n, path);
+            if (adsb_multi_stream_stats(m, k, &st) == 0)
+                print_stats(&st);
+        }
+        if (timing)
+            fprintf(stderr, "timing: runtime init %.1f ms, decode %.1f ms, total %.1f ms\n", t_init - t_start, now_ms() - t_init,
+                    now_ms() - t_start);
+    }
+    fflush(stderr);
+    _exit(rc); /* (no teardown: see the end of main) */
+}
+
 int main(int argc, char **argv)
 {
     const char *filename = NULL;
+    char *files[MAX_FILES];
+    int nfiles = 0, devs[MAX_GPUS], ndev = 0, device = -1;
     int outformat = 0, df18 = 0, fix1 = 0, c;
 
-    while ((c = getopt(argc, argv, "f:g:ambx")) != EOF) {
+    while ((c = getopt(argc, argv, "f:g:ambxd:G:")) != EOF) {
         switch (c) {
         case 'f':
             filename = optarg;
+            if (nfiles < MAX_FILES)
+                files[nfiles++] = optarg;
+            break;
+        case 'd': {
+            char *end;
+            long k = strtol(optarg, &end, 10);
+            if (*end || k < 0 || k > 1023) {
+                usage();
+                return 1;
+            }
+            device = (int)k;
+            break;
+        }
+        case 'G':
+            ndev = parse_gpus(optarg, devs);
+            if (ndev == 0) {
+                usage();
+                return 1;
+            }
             break;
         case 'g':
             break;
@@ -183,12 +351,27 @@ int main(int argc, char **argv)
             return 1;
         }
     }
-    if (!filename) {
+    if (!filename || (nfiles > 1 && ndev == 0) || (ndev && device >= 0)) { /* several captures need -G; -d and -G exclude each other */
         usage();
         return 1;
     }
 
     const int timing = getenv("ADSB_CLI_TIMING") != NULL;
+    if (ndev) {
+        adsb_config mcfg;
+        adsb_config_default(&mcfg);
+        mcfg.df18 = df18;
+        mcfg.fix_1bit = fix1;
+        mcfg.collect_stats = 1; /* the reference always prints Try/Ok */
+        restrict_visible_devices(devs, ndev);
+        return run_multi(&mcfg, devs, ndev, files, nfiles, outformat, timing);
+    }
+    if (device >= 0) {
+        restrict_visible_devices(&device, 1);
+    } else if (!getenv("ROCR_VISIBLE_DEVICES") && !getenv("HIP_VISIBLE_DEVICES") && !getenv("ADSB_CLI_ALL_DEVICES")) {
+        int first = 0;
+        restrict_visible_devices(&first, 1); /* one device is all this run uses: do not start the others */
+    }
     const int use_register = !(getenv("ADSB_CLI_REGISTER") && atoi(getenv("ADSB_CLI_REGISTER")) == 0);
     const double t_start = now_ms();
 
@@ -217,6 +400,7 @@ int main(int argc, char **argv)
     cfg.df18 = df18;
     cfg.fix_1bit = fix1;
     cfg.collect_stats = 1; /* the reference always prints Try/Ok */
+    cfg.device = device;   /* (-1: the current one; after the narrowing above, 0) */
     adsb_decoder *dec = adsb_create(&cfg);
     if (!dec) {
         fprintf(stderr, "adsb_create() failed: %s\n", adsb_last_error(NULL));
@@ -294,15 +478,8 @@ int main(int argc, char **argv)
                 t_init - t_start, t_done - t_init, rg.t_reg, t_done - t_start);
 
     adsb_stats st;
-    if (adsb_get_stats(dec, &st) == 0) { /* valid.c:84-100 */
-        unsigned long long tot = st.ok[0] + st.ok[1] + st.ok[2];
-        fprintf(stderr, "\t%10d\t%10d\t%10d\n", 11, 17, 18);
-        fprintf(stderr, "Try :\t%10llu\t%10llu\t%10llu\n", (unsigned long long)st.try_[0],
-                (unsigned long long)st.try_[1], (unsigned long long)st.try_[2]);
-        fprintf(stderr, "Ok :\t%10llu\t%10llu\t%10llu\n", (unsigned long long)st.ok[0],
-                (unsigned long long)st.ok[1], (unsigned long long)st.ok[2]);
-        fprintf(stderr, "Total :\t%10llu\n", tot); /* tot_fi is uninitialised there */
-    }
+    if (adsb_get_stats(dec, &st) == 0)
+        print_stats(&st);
     /* no adsb_destroy / unregister / free: the process ends here, and tearing the GPU runtime
      * down cleanly costs tens of milliseconds that an offline decode has no use for */
     fflush(stderr);

@@ -227,6 +227,15 @@ struct adsb_decoder {
     hipEvent_t ev_tail = nullptr; // behind a staging compaction's tail copy (process_stage): the copy streams wait for it
     uint64_t piece = 0;        // pieces pushed asynchronously so far
 
+    // Shard-stream mode (adsb_shard_begin .. adsb_shard_end): the stream starts at sample shard_first instead of 0, ends
+    // behind offset shard_g_end instead of at the end-of-file horizon, and the resolver runs in chain mode.
+    bool shard_on = false;
+    uint64_t shard_g_begin = 0, shard_g_end = 0;
+    size_t shard_bases_cap = 0;
+    std::vector<adsb_candidate> shard_hv;
+    uint16_t *win_buf = nullptr; // adsb_scan_shard_host: device copy of the caller's window
+    size_t win_cap = 0; // head candidates (handed out in place by adsb_shard_end)
+
     int fail(const char *fmt, ...)
     {
         char buf[512];
@@ -252,6 +261,23 @@ namespace {
 inline uint64_t power_samples_produced(uint64_t n_samples)
 {
     return 2 * (n_samples / 4); // air.c:59-92: two power samples per four input samples
+}
+
+// One past the last offset that can be scanned once `n_samples` samples of the stream are in: the whole 1196-sample
+// window of an offset must have been produced.  A stream produces power samples in twos (air.c:59-92); a shard's samples
+// end where its last owned window does (adsb_plan_shards), which need not be a whole quad, and its scan never goes
+// beyond the offsets it owns.
+uint64_t scannable_end(const adsb_decoder *d, uint64_t n_samples, bool final)
+{
+    uint64_t m = power_samples_produced(n_samples);
+    if (d->shard_on)
+        m = n_samples / 2; // every complete pair
+    uint64_t g_end = m >= ADSB_WINDOW ? m - ADSB_WINDOW + 1 : 0;
+    if (!final)
+        g_end = round_down(g_end, 28);
+    if (d->shard_on && g_end > d->shard_g_end)
+        g_end = d->shard_g_end;
+    return g_end;
 }
 
 constexpr size_t kTryStateBytes = 4 * sizeof(unsigned long long) + 4 * sizeof(uint32_t); // d_try_acc + d_carry_n
@@ -1310,9 +1336,7 @@ uint64_t line_aligned_keep(uint64_t want, uint64_t n_samples, uint64_t floor_fir
 int process_stage(adsb_decoder *d, bool final, bool in_flight = false)
 {
     const uint64_t m_real = power_samples_produced(d->n_samples);
-    uint64_t g_end = m_real >= ADSB_WINDOW ? m_real - ADSB_WINDOW + 1 : 0;
-    if (!final)
-        g_end = round_down(g_end, 28);
+    const uint64_t g_end = scannable_end(d, d->n_samples, final);
     bool launched = false;
     if (g_end > d->g_scanned) {
         if (scan_submit(d, d->stage[d->cur], d->stage_first, d->stage_fill, d->g_scanned, g_end))
@@ -1642,6 +1666,7 @@ void adsb_destroy(adsb_decoder *d)
             (void)hipFree(d->stage[i]);
     if (d->d_synd) (void)hipFree(d->d_synd);
     if (d->d_fix) (void)hipFree(d->d_fix);
+    if (d->win_buf) (void)hipFree(d->win_buf);
     for (int i = 0; i < 2; i++)
         if (d->d_carry[i]) (void)hipFree(d->d_carry[i]);
     if (d->d_frames) (void)hipFree(d->d_frames);
@@ -1703,6 +1728,7 @@ int adsb_reset(adsb_decoder *d)
     else if (wait_last_copy(d)) // a late asynchronous copy must not land in stage[0] beside the next stream's
         return -1;
     d->piece = 0;
+    d->shard_on = false;
     d->final_follows = false;
     d->deferred_n = 0;
     d->deferred_slot = nullptr;
@@ -1805,7 +1831,7 @@ int adsb_sync(adsb_decoder *d)
 
 int adsb_host_register(void *p, size_t bytes)
 {
-    return (p && bytes && hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) ? 0 : -1;
+    return (p && bytes && hipHostRegister(p, bytes, hipHostRegisterPortable) == hipSuccess) ? 0 : -1;
 }
 
 int adsb_host_unregister(void *p)
@@ -1816,7 +1842,7 @@ int adsb_host_unregister(void *p)
 void *adsb_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) // (every device of the process may copy from it)
         return nullptr;
     return p;
 }
@@ -1840,6 +1866,8 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
         return -1;
     if (d->finished)
         return d->fail("adsb_push_device after adsb_finish");
+    if (final && d->shard_on)
+        return d->fail("a shard stream ends with adsb_shard_end");
     if (stream_too_long(d, n))
         return -1;
     if (n && !device_samples)
@@ -1863,16 +1891,14 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
 
     // In-place scan.  First the seam: offsets whose window starts in earlier data.
     const uint64_t first = d->n_samples; // stream index of p[0]
-    if (first != 0) {
+    if (first != d->stage_first || d->stage_fill != 0) { // (not at the very start of a stream or of a shard: nothing earlier exists)
         if (push_copy(d, p, kSeamSamples, hipMemcpyDeviceToDevice))
             return -1;
     }
     // Bulk: every offset whose whole window lies inside this buffer.
     const uint64_t total = first + n;
     const uint64_t m_real = power_samples_produced(total);
-    uint64_t g_end = m_real >= ADSB_WINDOW ? m_real - ADSB_WINDOW + 1 : 0;
-    if (!final)
-        g_end = round_down(g_end, 28);
+    const uint64_t g_end = scannable_end(d, total, final);
     d->n_samples = total;
     if (final) {
         using clk = std::chrono::steady_clock;
@@ -1968,6 +1994,8 @@ int adsb_finish(adsb_decoder *d)
         return -1;
     if (d->finished)
         return 0;
+    if (d->shard_on)
+        return d->fail("a shard stream ends with adsb_shard_end");
     HIP_TRY(d, hipSetDevice(d->device));
     if (process_stage(d, true))
         return -1;
@@ -2070,6 +2098,27 @@ int adsb_scan_shard(adsb_decoder *d, const void *device_samples, uint64_t first_
     return 0;
 }
 
+int adsb_scan_shard_host(adsb_decoder *d, const uint16_t *host_samples, uint64_t first_sample, size_t n, uint64_t g_begin,
+                         uint64_t g_end, adsb_candidate *cands, size_t cand_cap, size_t *n_cands, uint64_t *tries, size_t try_cap,
+                         size_t *n_tries)
+{
+    if (!d || !host_samples || !n_cands || !n_tries)
+        return -1;
+    HIP_TRY(d, hipSetDevice(d->device));
+    if (n > d->win_cap) {
+        if (d->win_buf)
+            HIP_TRY(d, hipFree(d->win_buf));
+        d->win_buf = nullptr;
+        d->win_cap = 0;
+        const size_t cap = (n + 65535) & ~(size_t)65535;
+        HIP_TRY(d, hipMalloc(&d->win_buf, cap * sizeof(uint16_t)));
+        d->win_cap = cap;
+    }
+    // (a plain copy: the scan's launches may go to either compute stream, and a window is a few hundred KB)
+    HIP_TRY(d, hipMemcpy(d->win_buf, host_samples, n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return adsb_scan_shard(d, d->win_buf, first_sample, n, g_begin, g_end, cands, cand_cap, n_cands, tries, try_cap, n_tries);
+}
+
 // The same scan, resolved on the fly by this handle's own resolver in chain mode (resolver.hpp): the streaming
 // hand-off feeds it while the kernel runs, exactly like a stream's scan; the frames come out with shard-local ts.
 int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n, uint64_t g_begin,
@@ -2089,8 +2138,6 @@ int adsb_scan_shard_resolved_walk(adsb_decoder *d, const void *device_samples, u
         return -1;
     std::memset(head, 0, sizeof *head);
     head->status = 1;
-    if (d->cfg.collect_stats)
-        return d->fail("adsb_scan_shard_resolved: statistics of a sharded stream go through adsb_scan_shard");
     if (d->n_samples != 0 || d->res.pending() != 0) // (it runs this handle's own resolver: a stream in progress would be lost)
         return d->fail("adsb_scan_shard_resolved: the handle holds a stream (adsb_reset it, or use a handle of its own)");
     if (first_sample % 8 || (uintptr_t)device_samples % 16)
@@ -2120,6 +2167,16 @@ int adsb_scan_shard_resolved_walk(adsb_decoder *d, const void *device_samples, u
         rc = scan_drain(d);
     if (rc == 0)
         d->res.advance(0, g_end);
+    if (rc == 0 && d->cfg.collect_stats) { // the shard's own Try count: every try of [g_begin, g_end) against the speculative frames
+        rc = count_tries_pass(d, nullptr, 0, 0, true);
+        if (rc == 0)
+            rc = read_tries(d);
+        if (rc == 0) {
+            head->has_tries = 1;
+            for (int k = 0; k < 3; k++)
+                head->tries[k] = d->res.stats().try_[k];
+        }
+    }
     const adsb_frame *fp = nullptr;
     const size_t nf = rc == 0 ? d->res.take(&fp) : 0;
     head->g_begin = g_begin;
@@ -2139,10 +2196,90 @@ int adsb_scan_shard_resolved_walk(adsb_decoder *d, const void *device_samples, u
             std::memcpy(head_cands, hv.data(), hv.size() * sizeof(adsb_candidate));
         head->status = 0;
     }
-    d->res.reset(); // (the head vector dies with this call)
-    if (rc)
+    const bool fit = head->status == 0;
+    std::string why = d->err;
+    if (adsb_reset(d) != 0) // (the head vector dies with this call; the device's Try accumulators start from zero again)
         return -1;
-    return head->status == 0 ? 0 : -2;
+    if (rc) {
+        d->err = why;
+        return -1;
+    }
+    return fit ? 0 : -2;
+}
+
+// ---- a shard fed piecewise: the same chain-mode resolution, driven by the handle's ordinary stream machinery --------------
+int adsb_shard_begin(adsb_decoder *d, uint64_t first_sample, uint64_t g_begin, uint64_t g_end, uint64_t total_samples,
+                     uint64_t *bases, size_t bases_cap)
+{
+    if (!d)
+        return -1;
+    if (first_sample % 8)
+        return d->fail("adsb_shard_begin: first_sample must be a multiple of 8 samples");
+    if (g_begin % 28 || g_end < g_begin)
+        return d->fail("adsb_shard_begin: g_begin must be a multiple of 28 and g_end >= g_begin");
+    if (first_sample > (g_begin >= 6 ? 2 * (g_begin - 6) : 0))
+        return d->fail("adsb_shard_begin: the samples must start at least 6 pairs before the first owned offset");
+    if (g_end > g_begin && 2 * (g_end - 1 + ADSB_WINDOW) > total_samples)
+        return d->fail("adsb_shard_begin: the shard's last window lies beyond the stream");
+    if (adsb_reset(d) != 0)
+        return -1;
+    d->shard_on = true;
+    d->shard_g_begin = g_begin;
+    d->shard_g_end = g_end;
+    d->n_samples = first_sample;
+    d->stage_first = first_sample;
+    d->g_scanned = g_begin;
+    d->shard_hv.clear();
+    d->res.start_chain(g_begin, std::min<uint64_t>(g_end, g_begin + d->shard_head), &d->shard_hv);
+    d->shard_bases_cap = (bases && bases_cap) ? bases_cap : 0;
+    if (d->shard_bases_cap)
+        d->res.start_walk(g_begin, g_end, total_samples, bases, bases_cap);
+    return 0;
+}
+
+int adsb_shard_end(adsb_decoder *d, adsb_shard_head *head, const adsb_frame **frames, const adsb_candidate **head_cands)
+{
+    if (!d || !head || !frames || !head_cands)
+        return -1;
+    std::memset(head, 0, sizeof *head);
+    head->status = 1;
+    *frames = nullptr;
+    *head_cands = nullptr;
+    if (!d->shard_on)
+        return d->fail("adsb_shard_end without adsb_shard_begin");
+    const uint64_t g_begin = d->shard_g_begin, g_end = d->shard_g_end;
+    if (g_end > g_begin && d->n_samples / 2 < g_end - 1 + ADSB_WINDOW)
+        return d->fail("adsb_shard_end: %llu samples of the stream are in, the shard's last window ends at sample %llu",
+                       (unsigned long long)d->n_samples, (unsigned long long)(2 * (g_end - 1 + ADSB_WINDOW)));
+    HIP_TRY(d, hipSetDevice(d->device));
+    if (process_stage(d, true)) // scans what is left, collects everything in flight, runs the chain to g_end
+        return -1;
+    if (d->g_scanned < g_end)
+        return d->fail("internal: shard scanned to %llu of %llu", (unsigned long long)d->g_scanned, (unsigned long long)g_end);
+    if (d->cfg.collect_stats) {
+        if (count_tries_pass(d, nullptr, 0, 0, true) || read_tries(d))
+            return -1;
+        head->has_tries = 1;
+        for (int k = 0; k < 3; k++)
+            head->tries[k] = d->res.stats().try_[k];
+    }
+    if (wait_last_copy(d)) // every borrowed buffer is free again
+        return -1;
+    d->finished = true; // (no further push: the next stream or shard starts with adsb_reset / adsb_shard_begin)
+    const size_t nf = d->res.take(frames);
+    *head_cands = d->shard_hv.empty() ? nullptr : d->shard_hv.data();
+    head->g_begin = g_begin;
+    head->g_end = g_end;
+    head->n_frames = nf;
+    head->n_head = d->shard_hv.size();
+    head->head_end = std::min<uint64_t>(g_end, g_begin + d->shard_head);
+    head->skipped = d->res.skipped();
+    if (d->shard_bases_cap) { // (more bases than the caller's array holds: the stitcher must not use it)
+        head->n_bases = d->res.walk_bases() <= d->shard_bases_cap ? d->res.walk_bases() : 0;
+        head->walk_final = d->res.walk_final() ? 1 : 0;
+    }
+    head->status = 0;
+    return 0;
 }
 
 int adsb_stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
@@ -2155,6 +2292,14 @@ int adsb_stitch_shards_ex(const adsb_shard_part *parts, int n_parts, uint64_t to
                           adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t walk_stats[2])
 {
     return adsb::stitch_shards(parts, n_parts, total_samples, fix, new_frames, new_cap, n_new_total, walk_stats);
+}
+
+int adsb_stitch_shards_stats(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
+                             adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t walk_stats[2], adsb_stats *stats)
+{
+    if (!stats)
+        return -1;
+    return adsb::stitch_shards(parts, n_parts, total_samples, fix, new_frames, new_cap, n_new_total, walk_stats, stats);
 }
 
 size_t adsb_shard_walk(adsb_shard_head *head, const adsb_frame *frames, uint64_t total_samples, uint64_t *bases, size_t cap)

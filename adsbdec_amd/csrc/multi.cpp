@@ -1,0 +1,785 @@
+// multi.cpp -- ONE process, several GPUs: the host of BASELINE configs[3] / configs[4] in C++ behind the C-ABI
+// (adsb_multi_*, include/adsbdec_amd.h).  north_star: "the host stays in C ... sample buffers are chunked and sharded
+// across the 8 GPUs of one node with a one-frame overlap so no RCCL collectives are needed (host gathers decoded frames)".
+//
+// What it stands behind in the reference: fileInput's loop (air.c:217-246) -- one producer, frames handed to netout in
+// ascending order (output.c:159-182) -- for a capture that is cut into one contiguous shard per device.  The sequential
+// rules the gather has to preserve are demod.c:86,99 (ts), demod.c:125-141 (greedy skip) and air.c:94-99 (the deqframe
+// call pattern and its end-of-file horizon); stitch.hpp replays them over the shards' results.
+//
+// Structure: a worker thread per device, each with a decoder handle of its own (created by the worker: the GPU runtime's
+// start is per device and slow, so the devices come up in parallel).  A decode posts one job to every worker:
+//   shard   copy the shard's halo'd slice over the device's own link in pieces (adsb_shard_begin, adsb_push_async per
+//           piece: the copy of piece k+1 overlaps the scan of piece k, the chain is resolved while the kernel runs),
+//           adsb_shard_end; with statistics also the two small windows of tries the stitcher needs (adsb_scan_shard_host)
+//   stream  an ordinary stream of its own (configs[3]: N captures on N devices)
+// and the calling thread stitches (adsb_stitch_shards[_stats]) and gathers the frames.  A seam that cannot be decided from
+// the head candidates (-3) sends the whole capture through ONE handle as an ordinary stream: slower, same bytes.
+//
+// Host-only code on purpose: nothing but the public C-ABI of the library is called from here (no HIP), so the threading
+// can be built against a fake backend and run under ThreadSanitizer (tests/cpp/multi_tsan.cpp).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/adsbdec_amd.h"
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+thread_local std::string g_multi_create_error;
+
+constexpr uint64_t kPieceSamples = 16ull << 20;   // 32 MiB per host-to-device piece
+constexpr uint64_t kMinShardOffsets = 1ull << 17; // smaller shards are not worth a device (and statistics want the stream's
+                                                  // last ADSB_TAIL_OFFSETS offsets and a head window inside ONE shard)
+constexpr uint64_t kHeadTryReach = 1200;          // a frame that starts inside the head window ends at most this far behind it
+
+enum class JobKind { None, Shard, Stream, Quit };
+
+struct Source { // where the samples of a job come from: exactly one of the three
+    const uint16_t *mem = nullptr; // host memory, mem[0] = stream sample 0
+    int fd = -1;                   // a file of uint16 samples (pread by the worker itself)
+    const void *dev = nullptr;     // the worker's slice, resident in ITS device's HBM (dev[0] = stream sample `first`)
+};
+
+struct StreamResult {
+    int rc = 0;
+    std::string err;
+    std::vector<adsb_frame> frames;
+    adsb_stats stats{};
+    double ms = 0;
+};
+
+struct Job {
+    JobKind kind = JobKind::None;
+    Source src;
+    uint64_t total = 0;                       // samples of the whole stream
+    uint64_t first = 0, n = 0, g_begin = 0, g_end = 0; // Shard: the plan's entry
+    bool stats = false;
+    uint64_t tail_first_offset = 0;           // Shard + stats: tries from here on are wanted as the tail window
+    // Stream: streams [stream_lo, stream_lo + stream_step, ...) of the caller's arrays, results into `results`
+    const Source *streams = nullptr;
+    const uint64_t *stream_n = nullptr;
+    int n_streams = 0, stream_lo = 0, stream_step = 1;
+    StreamResult *results = nullptr;
+};
+
+struct Worker {
+    int index = 0, device = 0;
+    adsb_config cfg{};
+    std::thread th;
+    adsb_decoder *dec = nullptr;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t posted = 0, done = 0; // jobs posted / finished (under mu)
+    Job job;
+    // result of the last job
+    int rc = 0;
+    std::string err;
+    double ms = 0, create_ms = 0;
+    adsb_shard_head head{};
+    const adsb_frame *frames = nullptr;
+    const adsb_candidate *head_cands = nullptr;
+    std::vector<uint64_t> bases, head_tries, tail_tries;
+    uint64_t head_tries_end = 0, tail_from = ~0ull;
+    std::vector<adsb_candidate> scratch_cands, head_buf; // head_buf / frames_buf: results of a device-resident slice
+    std::vector<adsb_frame> frames_buf;
+    uint16_t *ring[2] = {nullptr, nullptr}; // page-locked pieces of a file source
+    uint64_t ring_samples = 0, piece = kPieceSamples;
+
+    int fail(const char *fmt, ...)
+    {
+        char buf[640];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return rc = -1;
+    }
+    int fail_dec(const char *what)
+    {
+        const char *e = dec ? adsb_last_error(dec) : adsb_last_error(nullptr);
+        return fail("device %d (worker %d): %s failed: %s", device, index, what, e ? e : "");
+    }
+};
+
+} // namespace
+
+struct adsb_multi {
+    adsb_config cfg{};
+    std::vector<std::unique_ptr<Worker>> w;
+    std::string err;
+    std::vector<adsb_frame> out, new_frames;
+    std::vector<StreamResult> streams;
+    adsb_stats stats{};
+    bool have_stats = false;
+    adsb_multi_info info{};
+    double create_ms = 0;
+    uint64_t piece_samples = kPieceSamples;
+
+    long fail(const char *fmt, ...)
+    {
+        char buf[768];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return -1;
+    }
+};
+
+namespace {
+
+// The next piece of a source: memory is pushed where it lies; a file is read into one of two page-locked buffers in turn
+// (adsb_push_async borrows a buffer until the NEXT push returns, so two suffice).
+const uint16_t *fetch(Worker &w, const Source &src, uint64_t at, uint64_t n, int turn)
+{
+    if (src.mem)
+        return src.mem + at;
+    if (!w.ring[0] || w.ring_samples < n) {
+        const uint64_t cap = std::max(n, w.piece);
+        for (uint16_t *&b : w.ring) {
+            if (b)
+                adsb_host_free(b);
+            b = static_cast<uint16_t *>(adsb_host_alloc(2 * cap));
+            if (!b) {
+                w.ring_samples = 0;
+                w.fail("device %d (worker %d): cannot page-lock a %llu-byte read buffer", w.device, w.index, (unsigned long long)(2 * cap));
+                return nullptr;
+            }
+        }
+        w.ring_samples = cap;
+    }
+    uint16_t *dst = w.ring[turn & 1];
+    uint64_t got = 0;
+    while (got < 2 * n) {
+        const ssize_t k = pread(src.fd, reinterpret_cast<char *>(dst) + got, 2 * n - got, (off_t)(2 * at + got));
+        if (k <= 0) {
+            w.fail("device %d (worker %d): read of samples %llu.. failed or fell short", w.device, w.index, (unsigned long long)at);
+            return nullptr;
+        }
+        got += (uint64_t)k;
+    }
+    return dst;
+}
+
+// DF-gate passes of the offsets [g_lo, g_hi) of the job's stream, through a stateless scan of just that window.
+int window_tries(Worker &w, const Job &j, uint64_t g_lo, uint64_t g_hi, std::vector<uint64_t> &out)
+{
+    out.clear();
+    if (g_hi <= g_lo)
+        return 0;
+    const uint64_t s0 = g_lo >= 8 ? 2 * (g_lo - 8) : 0;
+    const uint64_t s1 = std::min<uint64_t>(j.total, 2 * (g_hi - 1 + ADSB_WINDOW));
+    size_t nc = 0, nt = 0;
+    size_t cap_c = std::max<size_t>(w.scratch_cands.size(), 4096), cap_t = std::max<size_t>(out.capacity(), 8192);
+    for (int attempt = 0; attempt < 3; attempt++) {
+        w.scratch_cands.resize(cap_c);
+        out.resize(cap_t);
+        int rc;
+        if (j.src.dev) {
+            rc = adsb_scan_shard(w.dec, static_cast<const uint16_t *>(j.src.dev) + (s0 - j.first), s0, (size_t)(s1 - s0), g_lo, g_hi,
+                                 w.scratch_cands.data(), cap_c, &nc, out.data(), cap_t, &nt);
+        } else {
+            const uint16_t *p = fetch(w, j.src, s0, s1 - s0, 0);
+            if (!p)
+                return -1;
+            rc = adsb_scan_shard_host(w.dec, p, s0, (size_t)(s1 - s0), g_lo, g_hi, w.scratch_cands.data(), cap_c, &nc, out.data(),
+                                      cap_t, &nt);
+        }
+        if (rc == 0) {
+            out.resize(nt);
+            return 0;
+        }
+        if (rc != -2)
+            return w.fail_dec("adsb_scan_shard (tries of a window)");
+        cap_c = std::max(cap_c, nc + 64);
+        cap_t = std::max(cap_t, nt + 64);
+    }
+    return w.fail("device %d (worker %d): window of tries kept growing", w.device, w.index);
+}
+
+int feed(Worker &w, const Source &src, uint64_t first, uint64_t n, uint64_t piece)
+{
+    int turn = 0;
+    for (uint64_t at = first; at < first + n; at += piece, turn++) {
+        const uint64_t len = std::min(piece, first + n - at);
+        const uint16_t *p = fetch(w, src, at, len, turn);
+        if (!p)
+            return -1;
+        if (adsb_push_async(w.dec, p, (size_t)len))
+            return w.fail_dec("adsb_push_async");
+    }
+    return 0;
+}
+
+void run_shard(Worker &w, const Job &j, uint64_t piece)
+{
+    w.head = adsb_shard_head{};
+    w.head.status = 1;
+    w.frames = nullptr;
+    w.head_cands = nullptr;
+    w.head_tries.clear();
+    w.tail_tries.clear();
+    w.head_tries_end = 0;
+    w.tail_from = ~0ull;
+    if (j.g_end <= j.g_begin) { // nothing to own (a stream shorter than one window)
+        w.head.g_begin = j.g_begin;
+        w.head.g_end = j.g_end;
+        w.head.status = 0;
+        w.head.has_tries = j.stats ? 1 : 0;
+        return;
+    }
+    // (the two windows are scanned outside the shard's stream: before it starts, and after it has ended -- a stateless
+    // scan does not touch the resolver, so the frames adsb_shard_end handed out stay where they are)
+    if (j.stats) {
+        const uint64_t head_span = w.cfg.debug_shard_head > 0 ? (uint64_t)w.cfg.debug_shard_head : 16384;
+        w.head_tries_end = std::min(j.g_end, j.g_begin + head_span + kHeadTryReach);
+        if (window_tries(w, j, j.g_begin, w.head_tries_end, w.head_tries))
+            return;
+    }
+    const uint64_t calls = (j.g_end - j.g_begin) / 39780 + 8; // one deqframe call per 39 780 offsets, and a few
+    if (w.bases.size() < calls)
+        w.bases.resize(calls);
+    if (j.src.dev) {
+        // resident in this device's HBM: one call, one launch per 128 Mi offsets, resolved while the kernel runs
+        if (w.frames_buf.empty())
+            w.frames_buf.resize(65536 + (size_t)(j.n / 8000)); // ~1 frame per 20 k samples at 1 k frames/s
+        if (w.head_buf.empty())
+            w.head_buf.resize(4096);
+        for (int attempt = 0;; attempt++) {
+            const int rc = adsb_scan_shard_resolved_walk(w.dec, j.src.dev, j.first, (size_t)j.n, j.g_begin, j.g_end, j.total, &w.head,
+                                                         w.frames_buf.data(), w.frames_buf.size(), w.head_buf.data(), w.head_buf.size(),
+                                                         w.bases.data(), w.bases.size());
+            if (rc == 0)
+                break;
+            if (rc != -2 || attempt == 2) {
+                w.head.status = 1;
+                w.fail_dec("adsb_scan_shard_resolved_walk");
+                return;
+            }
+            w.frames_buf.resize(std::max<size_t>(w.frames_buf.size(), (size_t)w.head.n_frames + 64));
+            w.head_buf.resize(std::max<size_t>(w.head_buf.size(), (size_t)w.head.n_head + 64));
+        }
+        w.frames = w.frames_buf.data();
+        w.head_cands = w.head_buf.data();
+    } else {
+    if (adsb_shard_begin(w.dec, j.first, j.g_begin, j.g_end, j.total, w.bases.data(), w.bases.size())) {
+        w.fail_dec("adsb_shard_begin");
+        return;
+    }
+    if (feed(w, j.src, j.first, j.n, piece))
+        return;
+    if (adsb_shard_end(w.dec, &w.head, &w.frames, &w.head_cands)) {
+        w.head.status = 1;
+        w.fail_dec("adsb_shard_end");
+        return;
+    }
+    }
+    if (j.stats && j.g_end > j.tail_first_offset) {
+        w.tail_from = std::max(j.g_begin, j.tail_first_offset - j.tail_first_offset % 28);
+        if (window_tries(w, j, w.tail_from, j.g_end, w.tail_tries))
+            w.head.status = 1;
+    }
+}
+
+void run_streams(Worker &w, const Job &j, uint64_t piece)
+{
+    for (int s = j.stream_lo; s < j.n_streams; s += j.stream_step) {
+        StreamResult &r = j.results[s];
+        const auto t0 = clk::now();
+        r = StreamResult{};
+        w.err.clear();
+        w.rc = 0;
+        const adsb_frame *fp = nullptr;
+        long nf = -1;
+        if (adsb_reset(w.dec)) {
+            w.fail_dec("adsb_reset");
+        } else if (feed(w, j.streams[s], 0, j.stream_n[s], piece) == 0) {
+            if (adsb_finish(w.dec))
+                w.fail_dec("adsb_finish");
+            else if ((nf = adsb_take(w.dec, &fp)) < 0)
+                w.fail_dec("adsb_take");
+        }
+        if (w.rc == 0 && w.cfg.collect_stats && adsb_get_stats(w.dec, &r.stats))
+            w.fail_dec("adsb_get_stats");
+        if (w.rc == 0 && nf > 0)
+            r.frames.assign(fp, fp + nf);
+        r.rc = w.rc;
+        r.err = w.err;
+        r.ms = ms_since(t0);
+    }
+}
+
+void worker_main(Worker *w, uint64_t piece)
+{
+    {   // the handle is created here, on the worker's own thread: the devices' runtimes come up side by side
+        const auto t0 = clk::now();
+        adsb_config cfg = w->cfg;
+        cfg.device = w->device;
+        cfg.stream = nullptr;
+        w->dec = adsb_create(&cfg);
+        if (!w->dec)
+            w->fail_dec("adsb_create");
+        w->create_ms = ms_since(t0);
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->done = 1; // "job" 1 is the start-up
+        w->cv.notify_all();
+    }
+    uint64_t seen = 1;
+    for (;;) {
+        Job j;
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->posted > seen; });
+            seen = w->posted;
+            j = w->job;
+        }
+        if (j.kind == JobKind::Quit)
+            break;
+        const auto t0 = clk::now();
+        w->rc = 0;
+        w->err.clear();
+        try {
+            if (!w->dec)
+                w->fail("device %d (worker %d): no decoder handle (adsb_create failed at start-up)", w->device, w->index);
+            else if (j.kind == JobKind::Shard)
+                run_shard(*w, j, piece);
+            else if (j.kind == JobKind::Stream)
+                run_streams(*w, j, piece);
+        } catch (const std::exception &e) { // (bad_alloc of a result vector: the job fails, the thread lives)
+            w->fail("device %d (worker %d): %s", w->device, w->index, e.what());
+        }
+        w->ms = ms_since(t0);
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->done = seen;
+        w->cv.notify_all();
+    }
+    if (w->dec)
+        adsb_destroy(w->dec);
+    for (uint16_t *b : w->ring)
+        if (b)
+            adsb_host_free(b);
+}
+
+void post(Worker &w, const Job &j)
+{
+    std::lock_guard<std::mutex> lk(w.mu);
+    w.job = j;
+    w.posted++;
+    w.cv.notify_all();
+}
+
+void wait_done(Worker &w)
+{
+    std::unique_lock<std::mutex> lk(w.mu);
+    w.cv.wait(lk, [&] { return w.done == w.posted; });
+}
+
+// How many shards a stream of `total` samples is cut into on n workers, and the plan.
+int plan(int n_workers, uint64_t total, std::vector<uint64_t> (&p)[4])
+{
+    const uint64_t m = 2 * (total / 4);
+    const uint64_t n_off = m >= ADSB_WINDOW ? m - ADSB_WINDOW + 1 : 0;
+    int n = (int)std::min<uint64_t>((uint64_t)n_workers, std::max<uint64_t>(1, n_off / kMinShardOffsets));
+    for (auto &v : p)
+        v.assign((size_t)n, 0);
+    adsb_plan_shards(total, n, p[0].data(), p[1].data(), p[2].data(), p[3].data());
+    return n;
+}
+
+// One ordinary stream through worker 0: what an undecidable seam falls back to (same bytes as the sharded decode).
+long whole_stream(adsb_multi *m, const Source &src, uint64_t total)
+{
+    m->streams.assign(1, StreamResult{});
+    Job j;
+    j.kind = JobKind::Stream;
+    j.streams = &src;
+    j.stream_n = &total;
+    j.n_streams = 1;
+    j.results = m->streams.data();
+    post(*m->w[0], j);
+    wait_done(*m->w[0]);
+    StreamResult &r = m->streams[0];
+    if (r.rc)
+        return m->fail("fallback decode on one device failed: %s", r.err.c_str());
+    m->out.swap(r.frames);
+    m->stats = r.stats;
+    m->have_stats = m->cfg.collect_stats != 0;
+    return (long)m->out.size();
+}
+
+long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices, int n_slices, uint64_t total,
+                    const adsb_frame **frames)
+{
+    if (!m || !frames)
+        return -1;
+    *frames = nullptr;
+    m->err.clear();
+    m->have_stats = false;
+    m->info = adsb_multi_info{};
+    if (total >= (1ull << 32))
+        return m->fail("stream of 2^32 samples or more: the reference's sample counter wraps there (air.c:34)");
+    const auto t_begin = clk::now();
+    std::vector<uint64_t> p[4];
+    const int n = plan((int)m->w.size(), total, p);
+    if (slices && n_slices != n)
+        return m->fail("adsb_multi_decode_device: %d slices given, the plan for %llu samples has %d shards (adsb_multi_plan)", n_slices,
+                       (unsigned long long)total, n);
+    const bool stats = m->cfg.collect_stats != 0;
+    const uint64_t m_ref = 2 * ((total + 3) / 4);
+    for (int i = 0; i < n; i++) {
+        Job j;
+        j.kind = JobKind::Shard;
+        j.src = src;
+        if (slices)
+            j.src.dev = slices[i];
+        j.total = total;
+        j.g_begin = p[0][i];
+        j.g_end = p[1][i];
+        j.first = p[2][i];
+        j.n = p[3][i];
+        j.stats = stats;
+        j.tail_first_offset = m_ref > ADSB_TAIL_OFFSETS ? m_ref - ADSB_TAIL_OFFSETS : 0;
+        post(*m->w[i], j);
+    }
+    double worker_ms = 0;
+    for (int i = 0; i < n; i++) {
+        wait_done(*m->w[i]);
+        worker_ms = std::max(worker_ms, m->w[i]->ms);
+    }
+    for (int i = 0; i < n; i++)
+        if (m->w[i]->rc || m->w[i]->head.status)
+            return m->fail("shard %d of %d: %s", i, n, m->w[i]->err.empty() ? "failed" : m->w[i]->err.c_str());
+    // ---- the serial part, on the calling thread: seams, ts offsets, horizon (and statistics), then the gather
+    const auto t_serial = clk::now();
+    std::vector<adsb_shard_part> parts((size_t)n);
+    std::vector<adsb_shard_fix> fix((size_t)n);
+    for (int i = 0; i < n; i++) {
+        Worker &w = *m->w[i];
+        adsb_shard_part &q = parts[i];
+        std::memset(&q, 0, sizeof q);
+        q.head = &w.head;
+        q.frames = w.frames;
+        q.head_cands = w.head_cands;
+        q.bases = w.head.n_bases ? w.bases.data() : nullptr;
+        q.tail_from = ~0ull;
+        if (stats) {
+            q.head_tries = w.head_tries.data();
+            q.n_head_tries = w.head_tries.size();
+            q.head_tries_end = w.head_tries_end;
+            q.tail_tries = w.tail_tries.data();
+            q.n_tail_tries = w.tail_tries.size();
+            q.tail_from = w.tail_from;
+        }
+    }
+    if (m->new_frames.size() < 4096)
+        m->new_frames.resize(4096);
+    size_t n_new = 0;
+    uint64_t ws[2] = {0, 0};
+    int rc;
+    for (;;) {
+        rc = stats ? adsb_stitch_shards_stats(parts.data(), n, total, fix.data(), m->new_frames.data(), m->new_frames.size(), &n_new,
+                                              ws, &m->stats)
+                   : adsb_stitch_shards_ex(parts.data(), n, total, fix.data(), m->new_frames.data(), m->new_frames.size(), &n_new, ws);
+        if (rc != -1 || m->new_frames.size() >= (1u << 22))
+            break;
+        m->new_frames.resize(m->new_frames.size() * 8); // (-1 is also "new_cap too small": seams that accept many frames)
+    }
+    m->info.shards = n;
+    m->info.calls_walked = ws[0];
+    m->info.calls_jumped = ws[1];
+    m->info.workers_ms = worker_ms;
+    if (rc == -3) {
+        if (slices)
+            return m->fail("a seam cannot be decided from the head candidates and the capture is not in host memory: decode it as "
+                           "one stream (adsb_decode_device) on one device");
+        m->info.fallback = 1;
+        const long k = whole_stream(m, src, total);
+        if (k >= 0)
+            *frames = m->out.data();
+        m->info.total_ms = ms_since(t_begin);
+        return k;
+    }
+    if (rc != 0)
+        return m->fail("adsb_stitch_shards failed (%d)", rc);
+    const double stitch_us = 1e3 * ms_since(t_serial);
+    size_t count = 0;
+    for (int i = 0; i < n; i++)
+        count += (size_t)(fix[i].n_new + fix[i].keep);
+    m->out.resize(count);
+    adsb_frame *o = m->out.data();
+    for (int i = 0; i < n; i++) {
+        if (fix[i].n_new)
+            std::memcpy(o, m->new_frames.data() + fix[i].new_first, fix[i].n_new * sizeof(adsb_frame));
+        o += fix[i].n_new;
+        if (fix[i].keep) {
+            std::memcpy(o, m->w[i]->frames + fix[i].drop_front, fix[i].keep * sizeof(adsb_frame));
+            adsb_shard_apply_fix(o, (size_t)fix[i].keep, fix[i].ts_sub); // demod.c:86,99: ts counts from the stream's start
+        }
+        o += fix[i].keep;
+    }
+    m->have_stats = stats;
+    m->info.stitch_us = stitch_us;
+    m->info.serial_us = 1e3 * ms_since(t_serial);
+    m->info.total_ms = ms_since(t_begin);
+    *frames = count ? m->out.data() : nullptr;
+    return (long)count;
+}
+
+int decode_streams(adsb_multi *m, const std::vector<Source> &src, const std::vector<uint64_t> &n)
+{
+    m->err.clear();
+    m->info = adsb_multi_info{};
+    const auto t0 = clk::now();
+    const int ns = (int)src.size(), nw = (int)m->w.size();
+    m->streams.assign((size_t)ns, StreamResult{});
+    const int used = std::min(ns, nw);
+    for (int i = 0; i < used; i++) {
+        Job j;
+        j.kind = JobKind::Stream;
+        j.streams = src.data();
+        j.stream_n = n.data();
+        j.n_streams = ns;
+        j.stream_lo = i;
+        j.stream_step = nw;
+        j.results = m->streams.data();
+        post(*m->w[i], j);
+    }
+    for (int i = 0; i < used; i++) {
+        wait_done(*m->w[i]);
+        m->info.workers_ms = std::max(m->info.workers_ms, m->w[i]->ms);
+    }
+    m->info.shards = used;
+    m->info.total_ms = ms_since(t0);
+    for (int s = 0; s < ns; s++)
+        if (m->streams[s].rc)
+            return (int)m->fail("stream %d of %d: %s", s, ns, m->streams[s].err.c_str());
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+adsb_multi *adsb_multi_create(const adsb_config *cfg_in, int n_devices, const int *devices)
+{
+    if (n_devices <= 0 || n_devices > 64) {
+        g_multi_create_error = "adsb_multi_create: n_devices must be 1..64";
+        return nullptr;
+    }
+    adsb_multi *m = new (std::nothrow) adsb_multi();
+    if (!m) {
+        g_multi_create_error = "out of memory";
+        return nullptr;
+    }
+    adsb_config_default(&m->cfg);
+    if (cfg_in) {
+        if (cfg_in->struct_size == 0 || cfg_in->struct_size > sizeof m->cfg) {
+            g_multi_create_error = "adsb_config.struct_size is not one this library knows";
+            delete m;
+            return nullptr;
+        }
+        std::memcpy(&m->cfg, cfg_in, cfg_in->struct_size);
+        m->cfg.struct_size = sizeof m->cfg;
+    }
+    if (m->cfg.stage_samples) // a piece must fit the staging buffer beside the tail it keeps
+        m->piece_samples = std::max<uint64_t>(1u << 15, std::min<uint64_t>(kPieceSamples, m->cfg.stage_samples / 2));
+    for (int i = 0; i < n_devices; i++) {
+        std::unique_ptr<Worker> w(new Worker());
+        w->index = i;
+        w->device = devices ? devices[i] : i;
+        w->cfg = m->cfg;
+        w->piece = m->piece_samples;
+        m->w.push_back(std::move(w));
+    }
+    for (auto &w : m->w)
+        w->th = std::thread(worker_main, w.get(), m->piece_samples);
+    bool ok = true;
+    for (auto &w : m->w) {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->done >= 1; });
+        w->posted = 1;
+        if (!w->dec && ok) {
+            g_multi_create_error = w->err;
+            ok = false;
+        }
+        m->create_ms = std::max(m->create_ms, w->create_ms);
+    }
+    if (!ok) {
+        adsb_multi_destroy(m);
+        return nullptr;
+    }
+    return m;
+}
+
+void adsb_multi_destroy(adsb_multi *m)
+{
+    if (!m)
+        return;
+    Job q;
+    q.kind = JobKind::Quit;
+    for (auto &w : m->w)
+        if (w->th.joinable()) {
+            post(*w, q);
+            w->th.join();
+        }
+    delete m;
+}
+
+int adsb_multi_devices(const adsb_multi *m) { return m ? (int)m->w.size() : 0; }
+
+int adsb_multi_plan(const adsb_multi *m, uint64_t total_samples, uint64_t *g_begin, uint64_t *g_end, uint64_t *first_sample,
+                    uint64_t *n_samples)
+{
+    if (!m || !g_begin || !g_end || !first_sample || !n_samples)
+        return -1;
+    std::vector<uint64_t> p[4];
+    const int n = plan((int)m->w.size(), total_samples, p);
+    uint64_t *dst[4] = {g_begin, g_end, first_sample, n_samples};
+    for (int k = 0; k < 4; k++)
+        std::memcpy(dst[k], p[k].data(), (size_t)n * sizeof(uint64_t));
+    return n;
+}
+
+long adsb_multi_decode_host(adsb_multi *m, const uint16_t *samples, size_t n, const adsb_frame **frames)
+{
+    if (!m || (n && !samples))
+        return -1;
+    Source s;
+    s.mem = samples;
+    static const uint16_t none = 0;
+    if (!samples)
+        s.mem = &none;
+    return decode_sharded(m, s, nullptr, 0, n, frames);
+}
+
+long adsb_multi_decode_file(adsb_multi *m, const char *path, const adsb_frame **frames)
+{
+    if (!m || !path || !frames)
+        return -1;
+    const int fd = open(path, O_RDONLY);
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        if (fd >= 0)
+            close(fd);
+        return m->fail("%s: not a readable regular file (each device reads its own slice: pipes go through adsb_push)", path);
+    }
+    Source s;
+    s.fd = fd;
+    const long k = decode_sharded(m, s, nullptr, 0, (uint64_t)sb.st_size / 2, frames); // a trailing odd byte is dropped (air.c:239)
+    close(fd);
+    return k;
+}
+
+long adsb_multi_decode_device(adsb_multi *m, uint64_t total_samples, const void *const *slices, int n_slices,
+                              const adsb_frame **frames)
+{
+    if (!m || !slices)
+        return -1;
+    for (int i = 0; i < n_slices; i++)
+        if (!slices[i])
+            return m->fail("adsb_multi_decode_device: slice %d is NULL", i);
+    return decode_sharded(m, Source{}, slices, n_slices, total_samples, frames);
+}
+
+int adsb_multi_decode_streams_host(adsb_multi *m, int n_streams, const uint16_t *const *samples, const size_t *n)
+{
+    if (!m || n_streams <= 0 || !samples || !n)
+        return -1;
+    std::vector<Source> src((size_t)n_streams);
+    std::vector<uint64_t> len((size_t)n_streams);
+    for (int s = 0; s < n_streams; s++) {
+        if (n[s] && !samples[s])
+            return (int)m->fail("adsb_multi_decode_streams_host: stream %d is NULL", s);
+        static const uint16_t none = 0;
+        src[s].mem = samples[s] ? samples[s] : &none;
+        len[s] = n[s];
+    }
+    return decode_streams(m, src, len);
+}
+
+int adsb_multi_decode_streams_file(adsb_multi *m, int n_streams, const char *const *paths)
+{
+    if (!m || n_streams <= 0 || !paths)
+        return -1;
+    std::vector<Source> src((size_t)n_streams);
+    std::vector<uint64_t> len((size_t)n_streams);
+    int rc = 0;
+    for (int s = 0; s < n_streams && rc == 0; s++) {
+        struct stat sb;
+        src[s].fd = paths[s] ? open(paths[s], O_RDONLY) : -1;
+        if (src[s].fd < 0 || fstat(src[s].fd, &sb) != 0 || !S_ISREG(sb.st_mode))
+            rc = (int)m->fail("%s: not a readable regular file", paths[s] ? paths[s] : "(null)");
+        else
+            len[s] = (uint64_t)sb.st_size / 2;
+    }
+    if (rc == 0)
+        rc = decode_streams(m, src, len);
+    for (Source &s : src)
+        if (s.fd >= 0)
+            close(s.fd);
+    return rc;
+}
+
+long adsb_multi_stream_frames(const adsb_multi *m, int stream, const adsb_frame **frames)
+{
+    if (!m || !frames || stream < 0 || (size_t)stream >= m->streams.size() || m->streams[stream].rc)
+        return -1;
+    const auto &f = m->streams[stream].frames;
+    *frames = f.empty() ? nullptr : f.data();
+    return (long)f.size();
+}
+
+int adsb_multi_stream_stats(const adsb_multi *m, int stream, adsb_stats *out)
+{
+    if (!m || !out || stream < 0 || (size_t)stream >= m->streams.size() || m->streams[stream].rc)
+        return -1;
+    *out = m->streams[stream].stats;
+    return 0;
+}
+
+int adsb_multi_get_stats(const adsb_multi *m, adsb_stats *out)
+{
+    if (!m || !out || !m->have_stats)
+        return -1;
+    *out = m->stats;
+    return 0;
+}
+
+int adsb_multi_worker_profile(const adsb_multi *m, int worker, adsb_profile *out)
+{
+    if (!m || !out || worker < 0 || (size_t)worker >= m->w.size() || !m->w[worker]->dec)
+        return -1;
+    return adsb_get_profile(m->w[worker]->dec, out); // (no job is running: the decode calls return behind their workers)
+}
+
+int adsb_multi_get_info(const adsb_multi *m, adsb_multi_info *out)
+{
+    if (!m || !out)
+        return -1;
+    *out = m->info;
+    out->create_ms = m->create_ms;
+    return 0;
+}
+
+const char *adsb_multi_last_error(const adsb_multi *m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
+
+} // extern "C"

@@ -31,6 +31,10 @@ public:
         base_ = 0;
         chain_ = false;
         w_on_ = false;
+        w_n_ = 0;
+        w_final_ = w_stop_ = false;
+        w_acc_.clear();
+        w_acc_head_ = 0;
         head_end_ = 0;
         head_ = nullptr;
         skipped_ = 0;
@@ -146,9 +150,11 @@ public:
         w_mref_ = 2 * ((total_samples + 3) / 4);
         w_bases_ = bases;
         w_cap_ = cap;
-        w_n_ = w_k_ = 0;
+        w_n_ = 0;
         w_last_end_ = 0;
         w_final_ = w_stop_ = false;
+        w_acc_.clear();
+        w_acc_head_ = 0;
         walk_record();
     }
     size_t walk_bases() const { return w_n_; }
@@ -297,9 +303,12 @@ private:
             }
             if (limit > base_)
                 break; // the chain has not passed the limit yet: a frame below it may still be accepted
-            while (w_k_ < out_.size() && out_[w_k_].g < limit) {
-                w_last_end_ = out_[w_k_].g + 80 + 80 * (uint64_t)out_[w_k_].len;
-                w_k_++;
+            // (the walk has its own record of the accepted frames: the output queue may have been drained meanwhile)
+            while (w_acc_head_ < w_acc_.size() && w_acc_[w_acc_head_].first < limit)
+                w_last_end_ = w_acc_[w_acc_head_++].second;
+            if (w_acc_head_ == w_acc_.size()) {
+                w_acc_.clear();
+                w_acc_head_ = 0;
             }
             w_base_ = w_last_end_ > limit ? w_last_end_ : limit;
             walk_record();
@@ -447,6 +456,8 @@ private:
             stats_.ok[df_slot(f.frame[0])]++;
             stats_.fixed += f.reserved & 1u;
             skipped_ += span - 1;
+            if (w_on_ && !w_stop_)
+                w_acc_.emplace_back(g, g + span);
             if (log_on_) {
                 if (ext_n_ < ext_cap_ && log_.empty())
                     ext_[ext_n_++] = LogEntry{g, (uint32_t)span, 0};
@@ -461,7 +472,9 @@ private:
     bool w_on_ = false, w_final_ = false, w_stop_ = false; // the call walk beside the chain (start_walk)
     uint64_t w_base_ = 0, w_end_ = 0, w_mref_ = 0, w_last_end_ = 0;
     uint64_t *w_bases_ = nullptr;
-    size_t w_cap_ = 0, w_n_ = 0, w_k_ = 0;
+    size_t w_cap_ = 0, w_n_ = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> w_acc_; // (g, end) of accepted frames the walk has not passed yet
+    size_t w_acc_head_ = 0;
     bool chain_ = false;   // chain mode (start_chain)
     uint64_t head_end_ = 0;
     std::vector<adsb_candidate> *head_ = nullptr;

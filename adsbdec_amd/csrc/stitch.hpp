@@ -16,9 +16,15 @@
 //      (a frame that straddles a call's limit moves the next call's base), so the call chain is walked once over the
 //      accepted frames' positions: one compare per frame and a handful of operations per call -- the only part whose
 //      cost grows with the stream (~27 k calls and ~107 k frames for 2 Gi samples).
-// Host-only code: no HIP in here, tested on CPU (tests/test_host_logic.py, tests/test_distributed_cpu.py).
+//   4. statistics (optional).  valid.c:46,68 count a Try for every VISITED offset that passes the DF gate.  Every shard has
+//      counted its own against its speculative chain, on the device; that count is right except where the true chain
+//      differs: between a shard's first offset and the point where the repaired chain is the speculative one again, and
+//      beyond the horizon.  For those two windows the shards hand over the DF-gate passes themselves (a few hundred words)
+//      and the difference is counted here.
+// Host-only code: no HIP in here, tested on CPU (tests/test_host_logic.py).
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -65,10 +71,13 @@ inline size_t walk_shard_calls(const adsb_frame *F, uint64_t nF, uint64_t g_begi
 // Returns 0, -1 (bad arguments / capacity), or -3: a seam cannot be decided from the head candidates alone (the chain did
 // not re-synchronise inside the head window); the caller then falls back to gathering every candidate to one resolver.
 inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
-                         adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t *walk_stats = nullptr)
+                         adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t *walk_stats = nullptr,
+                         adsb_stats *stats = nullptr)
 {
     if (!parts || n_parts <= 0 || !fix || !n_new_total || (new_cap && !new_frames))
         return -1;
+    int64_t tries[3] = {0, 0, 0};
+    std::vector<uint64_t> entry(stats ? (size_t)n_parts : 0); // per shard: offsets below are jumped by a frame of an earlier shard
     size_t n_new = 0;
     uint64_t skipped_global = 0; // offsets jumped by all final frames before the current shard
     uint64_t e_prev = 0;         // end of the last final frame so far
@@ -121,6 +130,40 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
                 break; // the next candidate the true chain meets is the next speculative frame
             }
             drop = fi;
+        }
+        if (stats) {
+            if (!h.has_tries)
+                return -1;
+            for (int k = 0; k < 3; k++)
+                tries[k] += (int64_t)h.tries[k];
+            entry[i] = e_prev > h.g_begin ? e_prev : h.g_begin;
+            if (e_prev > h.g_begin) {
+                // The shard counted its tries against its speculative frames.  From e_prev on the true chain is the frames
+                // accepted above, then the speculative frames that stand; the two are the same chain from X on: behind the
+                // last dropped frame, the last new one and e_prev (a candidate both accepted lies at or behind all three).
+                uint64_t X = e_prev;
+                if (drop)
+                    X = std::max(X, F[drop - 1].g + frame_span(F[drop - 1]));
+                if (n_new > new_first)
+                    X = std::max(X, new_frames[n_new - 1].g + frame_span(new_frames[n_new - 1]));
+                if (std::min(X, h.g_end) > parts[i].head_tries_end || (parts[i].n_head_tries && !parts[i].head_tries))
+                    return -3; // the window of tries handed over does not reach that far
+                uint64_t di = 0;            // cursor into the dropped frames F[0 .. drop)
+                size_t ni = new_first;      // ... and into the frames accepted instead
+                for (uint64_t q = 0; q < parts[i].n_head_tries; q++) {
+                    const uint64_t g = parts[i].head_tries[q] >> 2;
+                    if (g >= X)
+                        break;
+                    while (di < drop && F[di].g + frame_span(F[di]) <= g)
+                        di++;
+                    while (ni < n_new && new_frames[ni].g + frame_span(new_frames[ni]) <= g)
+                        ni++;
+                    const bool seen_spec = !(di < drop && F[di].g < g);   // not strictly inside a speculative frame
+                    const bool seen_true = g >= e_prev && !(ni < n_new && new_frames[ni].g < g);
+                    const unsigned code = (unsigned)(parts[i].head_tries[q] & 3u);
+                    tries[code < 3 ? code : 2] += (int)seen_true - (int)seen_spec;
+                }
+            }
         }
         x.drop_front = drop;
         x.new_first = new_first;
@@ -215,6 +258,30 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
         walk_stats[0] = walked;
         walk_stats[1] = jumped;
     }
+    if (stats) {
+        // Nothing at or beyond the horizon is visited (air.c:94-99): the shards counted those tries too -- unless they lie in
+        // a frame of the chain as it stands BEFORE the cut below -- so take them out again.
+        for (int p = 0; p < n_parts; p++) {
+            const adsb_shard_head &h = *parts[p].head;
+            if (h.g_end <= horizon || h.g_end <= h.g_begin)
+                continue;
+            if (parts[p].tail_from == ~0ull || parts[p].tail_from > std::max(horizon, h.g_begin) ||
+                (parts[p].n_tail_tries && !parts[p].tail_tries))
+                return -3;
+            const uint64_t n_here = fix[p].n_new + fix[p].keep;
+            uint64_t q = 0;
+            for (uint64_t t = 0; t < parts[p].n_tail_tries; t++) {
+                const uint64_t g = parts[p].tail_tries[t] >> 2;
+                if (g < horizon)
+                    continue;
+                while (q < n_here && frame_at(p, q).g + frame_span(frame_at(p, q)) <= g)
+                    q++;
+                const bool seen = g >= entry[p] && !(q < n_here && frame_at(p, q).g < g);
+                const unsigned code = (unsigned)(parts[p].tail_tries[t] & 3u);
+                tries[code < 3 ? code : 2] -= (int)seen;
+            }
+        }
+    }
     // frames at or beyond the horizon are never visited: cut them (they can only sit at the very end)
     for (int p = n_parts - 1; p >= 0; p--) {
         adsb_shard_fix &x = fix[p];
@@ -229,6 +296,21 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
             break;
     }
     *n_new_total = n_new;
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        for (int k = 0; k < 3; k++) {
+            if (tries[k] < 0)
+                return -1;
+            stats->try_[k] = (uint64_t)tries[k];
+        }
+        for (int p = 0; p < n_parts; p++)
+            for (uint64_t q = 0; q < fix[p].n_new + fix[p].keep; q++) { // valid.c:53,75
+                const adsb_frame &f = frame_at(p, q);
+                const unsigned df = f.frame[0] >> 3;
+                stats->ok[df == 11 ? 0 : df == 17 ? 1 : 2]++;
+                stats->fixed += f.reserved & 1u;
+            }
+    }
     return 0;
 }
 

@@ -327,6 +327,56 @@ def bind_near_gpu(torch, device):
         return f"none ({type(e).__name__}: {e})"
 
 
+class Ranks:
+    """What the ranks of a multi-process run (stream mode: one process and one independent stream per GPU, BASELINE
+    configs[3]) share: nothing on the data path -- only the barriers around the timed region, the max of their
+    times and the AND of their parity flags.  All of it is CPU-side, so the one process group is gloo; RCCL is not
+    initialised at all (it would move nothing).  A rank that dies takes the job down: the others' next collective fails
+    (connection reset) or times out, and they exit non-zero naming the step they were in (tests/test_distributed_cpu.py)."""
+
+    def __init__(self, world=1, rank=0, timeout_s=900.0):
+        self.world, self.rank, self.dist = world, rank, None
+        if world > 1:
+            import datetime
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+            self.dist = dist
+
+    def _collective(self, what, fn):
+        try:
+            return fn()
+        except Exception as e:      # gloo: "Connection closed by peer", a timeout ... -- another rank is gone
+            raise SystemExit(f"rank {self.rank}: lost the other ranks at `{what}` ({type(e).__name__}: {str(e)[:200]}): "
+                             "a rank of this job died or hung; this rank gives up") from e
+
+    def fence(self, sync=None, what="barrier"):
+        if sync is not None:
+            sync()
+        if self.world > 1:
+            self._collective(what, self.dist.barrier)
+
+    def max_over(self, dt, what="max of the ranks' times"):
+        if self.world == 1:
+            return dt
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        self._collective(what, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX))
+        return float(t.item())
+
+    def all_ok(self, ok, what="AND of the ranks' parity flags"):
+        if self.world == 1:
+            return bool(ok)
+        import torch
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        self._collective(what, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN))
+        return bool(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+            self.dist = None
+
+
 def self_launch(n):
     """`python bench.py --gpus N` from a plain shell: run the same command line under torch.distributed.run."""
     import socket
@@ -481,6 +531,45 @@ def multi_stream_host_fed(torch, capi, x_dev, df18, counts=(1, 2, 4)):
     return out
 
 
+def host_fed_sharded(torch, capi, x_dev, df18, want_key, want_stats, counts=(1, 2, 4)):
+    """The library's multi-GPU driver (adsb_multi_decode_host: one process, a worker thread and a handle per device) on ONE
+    capture in page-locked host memory, with K handles on THIS device: what `adsbdec_amd_cli -G K -f file` runs, Try/Ok
+    table included.  One GPU has one link, so K > 1 measures the driver's plumbing (plan, K copy/scan/resolve pipelines side
+    by side, stitch, gather), not scaling; frames and statistics are gated against the stream decode of the same capture."""
+    from adsbdec_amd import sharding
+    n = x_dev.numel()
+    host = torch.empty(n, dtype=torch.int16, pin_memory=True)
+    host.copy_(x_dev)
+    torch.cuda.synchronize()
+    dev = torch.cuda.current_device()
+    out = {"samples": n, "unit": "Msamples/s",
+           "what": "adsb_multi_decode_host of one page-locked capture, collect_stats=1, K handles on one device; best of 3 calls "
+                   "(PCIe-inclusive: never `value`); serial_us = stitch + gather on the calling thread behind the last worker"}
+    for k in counts:
+        md = sharding.MultiDecoder(k, [dev] * k, df18=df18, collect_stats=True)
+        md.decode_host(host.data_ptr(), n)
+        best, raw, inf = 1e9, None, None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            raw = md.decode_host(host.data_ptr(), n)
+            dt = time.perf_counter() - t0
+            if dt < best:
+                best, inf = dt, md.info()
+        if frames_key(capi._frames_to_dicts(raw[0], raw[1])) != want_key:
+            raise SystemExit(f"PARITY FAILURE (host-fed sharded, {k} handles): frames differ from the stream decode")
+        st = md.stats()
+        if want_stats is not None and (st["try"] != want_stats["try"] or st["ok"] != want_stats["ok"]):
+            raise SystemExit(f"PARITY FAILURE (host-fed sharded, {k} handles): Try/Ok {st} != {want_stats}")
+        out[f"handles_{k}"] = {"value": round(n / best / 1e6, 1), "ms": round(best * 1e3, 3), "shards": int(inf["shards"]),
+                               "serial_us": round(inf["serial_us"], 1), "stitch_us": round(inf["stitch_us"], 1),
+                               "slowest_worker_ms": round(inf["workers_ms"], 3), "fallback": int(inf["fallback"]),
+                               "frames": int(raw[1]), "create_ms": round(inf["create_ms"], 1)}
+        md.close()
+    out["parity"] = "frames and Try/Ok table equal to the one-handle stream decode of the same capture" + (
+        "" if want_stats is None else " (itself gated against the oracle)")
+    return out
+
+
 def host_fed_rates(torch, capi, x_dev, df18):
     """PCIe-inclusive decode rates from page-locked host memory (128 Mi samples)."""
     n = min(x_dev.numel(), 128 << 20)
@@ -549,9 +638,9 @@ def main():
     ap.add_argument("--stats", action="store_true", help="also reproduce valid.c's Try counters (collect_stats=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold / dense / host-fed legs (profiling runs)")
-    ap.add_argument("--shard-path", choices=["resolved", "gather"], default="resolved",
-                    help="shard mode: every rank resolves its own shard and rank 0 stitches (default), or every candidate "
-                         "is gathered to one resolver on rank 0 (the checker path)")
+    ap.add_argument("--shard-source", choices=["device", "host", "file"], default="device",
+                    help="shard mode: the slices are resident in their devices' HBM (default), or one capture in page-locked host "
+                         "memory / in a tmpfs file is fed to the devices by the library's workers (PCIe-inclusive)")
     ap.add_argument("--bind-cpu", choices=["on", "off"], default="on",
                     help="bind this rank's host threads to the CPUs of its GPU's NUMA node (on a two-socket host an unbound "
                          "run is sometimes 20 %% slower: profiles/r3_ab_runs.txt)")
@@ -560,11 +649,11 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.mode != "shard":
         # Plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) and relay rank 0's
         # line.  This parent has not touched the GPU and never does: the workers are children, not an exec.
         return self_launch(args.gpus)
-    if world != args.gpus:
+    if world != args.gpus and not (args.mode == "shard" and world == 1):   # (shard mode is one process however many devices)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     global _REAL_STDOUT
@@ -588,44 +677,20 @@ def main():
     torch.cuda.set_device(local_rank)
     cpu_binding = bind_near_gpu(torch, local_rank) if args.bind_cpu == "on" else "none (--bind-cpu off: the scheduler's choice)"
     args.cpu_binding = cpu_binding
-    dist = None
-    host_group = None
-    if world > 1:
-        # No data-path collective exists in either mode: the ranks only meet at the barriers around
-        # the timed region, for the max of their times, the parity flags, and -- shard mode -- the exchange of
-        # host-resident records.  All of that is CPU-side, so the one process group is gloo; RCCL is not
-        # initialised at all (it would move nothing).
-        import datetime
-        import torch.distributed as dist
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
-        host_group = dist.group.WORLD
+    ranks = Ranks(world, rank)   # (no data-path collective exists in either mode: see the class)
+    dist = ranks.dist
     if not os.path.exists(capi.LIB_PATH):
         if rank == 0:
             _build.build()
-        if world > 1:
-            dist.barrier()
+        ranks.fence(what="waiting for rank 0's build")
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+    def fence(sync=True):
+        ranks.fence(torch.cuda.synchronize if sync else None)
 
-    def max_over_ranks(dt):
-        if world == 1:
-            return dt
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def all_ranks_ok(ok):
-        if world == 1:
-            return bool(ok)
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(t.item())
+    max_over_ranks, all_ranks_ok = ranks.max_over, ranks.all_ok
 
     if args.mode == "shard":
-        return run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fence, max_over_ranks, all_ranks_ok)
+        return run_shard(args, torch, capi, rank, world, fence)
 
     n = (args.samples or (256 << 20))
     n -= n % 28
@@ -718,7 +783,7 @@ def main():
         if world > 1:        # one rank (re)builds the checker's shared object, the others load it afterwards
             if rank == 0:
                 O.build()
-            dist.barrier()
+            ranks.fence(what="waiting for rank 0's build of the checker")
         ok, why = True, ""
         try:
             first = 0
@@ -740,10 +805,16 @@ def main():
     e2e = None
     with_stats = None
     multi = None
+    sharded = None
     cli = None
     if rank == 0 and world == 1 and not args.no_extras:
         e2e = host_fed_rates(torch, capi, xs[0], args.dense)
         multi = multi_stream_host_fed(torch, capi, xs[0], args.dense)
+        dsx = capi.Decoder(df18=args.dense, device=local_rank, collect_stats=True)
+        px, mx = ptrs[0]
+        want_x = frames_key(capi._frames_to_dicts(*dsx.decode_device_raw(px, mx)))
+        sharded = host_fed_sharded(torch, capi, xs[0], args.dense, want_x, dsx.stats())
+        dsx.close()
         cli = cli_whole_process(xs[0].cpu().numpy().view(np.uint16), capi, args.dense)
         if not args.stats:
             # the same step with valid.c's Try/Ok table reproduced too (the reference always keeps it and prints
@@ -835,112 +906,144 @@ def main():
                         "program and the INTEGRATION.md patch run (the reference always keeps and prints valid.c's Try/Ok table); "
                         "`value` is the step without that table"},
             "value_cold": value_cold, "with_stats": with_stats, "dense": dense, "e2e_host_fed": e2e,
-            "multi_stream_host_fed": multi, "cli_whole_process": cli,
+            "multi_stream_host_fed": multi, "e2e_host_fed_sharded": sharded, "cli_whole_process": cli,
         }
         emit_line(line)
     dec.close()
-    if world > 1:
-        dist.destroy_process_group()
+    ranks.close()
 
 
-def run_shard(args, torch, capi, dist, host_group, rank, local_rank, world, fence, max_over_ranks, all_ranks_ok):
-    """BASELINE configs[4]: one stream, time-sharded over the ranks (see the module docstring)."""
-    total = args.samples or (2 << 30)
-    total -= total % 28
-    from adsbdec_amd import sharding
-    solo = dict(rank=rank, world=1) if world == 1 else {}
-    if args.shard_path == "gather":   # the checker path: every candidate to one resolver on rank 0
-        sr = sharding.ShardRank(total, df18=True, device=local_rank, group=host_group, profile=True, **solo)
-    else:
-        sr = sharding.ResolvedShard(total, df18=True, device=local_rank, group=host_group, profile=True, **solo)
-    dec = sr.dec
-    lo, hi = sr.first_sample, sr.first_sample + sr.n_samples
-    x, _ = make_workload(torch, total, seed=9, lo=lo, hi=hi)
+def pinned_capture(torch, total, seed, chunk=64 << 20):
+    """The synthetic stream in page-locked host memory (built on the device slice by slice and copied over)."""
+    host = torch.empty(total, dtype=torch.int16, pin_memory=True)
+    for lo in range(0, total, chunk):
+        hi = min(total, lo + chunk)
+        host[lo:hi].copy_(make_workload(torch, total, seed=seed, lo=lo, hi=hi)[0])
     torch.cuda.synchronize()
-    xptr = x.data_ptr()
+    return host
 
-    def step(_i=0):
-        return sr.step(xptr)    # scan + resolve my shard -> (rank 0) stitch / gather + resolve
 
-    def frames_of(got):
-        if got is None:
-            return None
-        arr, n = got.collect() if isinstance(got, sharding.ShardResult) else (got[0], got[1])
-        return capi._frames_to_dicts(arr, n)
+def run_shard(args, torch, capi, rank, world, fence):
+    """BASELINE configs[4]: ONE stream, time-sharded over N devices by the library's own multi-GPU driver
+    (adsb_multi_*, csrc/multi.cpp): one process, a worker thread and a handle per device, no collective."""
+    from adsbdec_amd import sharding
+    n_dev = args.gpus
+    if world > 1 and rank != 0:
+        # Started as N ranks (torchrun): the driver of this mode is ONE process with a thread per device, so rank 0 runs
+        # it over all N devices and the other ranks only keep the job's shape (they never touch a GPU).
+        fence(sync=False)
+        return
+    devices = [0] * n_dev if args.one_device_test else list(range(n_dev))
+    source = args.shard_source
+    total = args.samples or ((2 << 30) if source == "device" else (512 << 20))
+    total -= total % 28
+    md = sharding.MultiDecoder(n_dev, devices, df18=True, profile=True, collect_stats=args.stats)
+    plan = md.plan(total)
+    keep = []
+    if source == "device":
+        ptrs = []
+        for i, p in enumerate(plan):
+            with torch.cuda.device(devices[i]):
+                t, _ = make_workload(torch, total, seed=9, lo=p["first_sample"], hi=p["first_sample"] + p["n_samples"])
+                torch.cuda.synchronize()
+            keep.append(t)
+            ptrs.append(t.data_ptr())
+
+        def step(_i=0):
+            return md.decode_device(total, ptrs)
+    else:
+        host = pinned_capture(torch, total, 9)
+        keep.append(host)
+        if source == "file":
+            import tempfile
+            tf = tempfile.NamedTemporaryFile(suffix=".u16", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)
+            host.numpy().tofile(tf.name)
+            keep.append(tf)
+
+            def step(_i=0):
+                return md.decode_file(tf.name)
+        else:
+            def step(_i=0):
+                return md.decode_host(host.data_ptr(), total)
 
     step()
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
-        step()
+    preroll(step, args.preroll_ms, at_least=1)
     for _ in range(args.warmup):
         step()
-    fence()
-    p0 = dec.profile()
-    serial, walk = [], None
-    t_all = time.perf_counter()
-    fence()
+    torch.cuda.synchronize()
+    prof0 = [md.worker_profile(i) for i in range(len(plan))]
+    serial, stitch, workers = [], [], []
     t0 = time.perf_counter()
     raw = None
     for _ in range(args.steps):
         raw = step()
-        if isinstance(raw, sharding.ShardResult):
-            serial.append(raw.serial_us)
-            walk = (raw.calls_walked, raw.calls_jumped)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    fence()
-    dt = max_over_ranks(dt)
-    p1 = dec.profile()
-    roofline, roofline_valu = roofline_objects(p0, p1, args.steps, step_ms=dt / args.steps * 1e3)
+        inf = md.info()
+        serial.append(inf["serial_us"])
+        stitch.append(inf["stitch_us"])
+        workers.append(inf["workers_ms"])
+    dt = time.perf_counter() - t0            # (every call returns behind its workers: nothing is left in flight)
+    prof1 = [md.worker_profile(i) for i in range(len(plan))]
+    info = md.info()
+    roofline, roofline_valu = roofline_objects(prof0[0], prof1[0], args.steps, step_ms=dt / args.steps * 1e3)
     value = total * args.steps / dt / 1e6
-    del t_all
+    frames = capi._frames_to_dicts(raw[0], raw[1])
+    stats_table = md.stats() if args.stats else None
 
-    if rank == 0:
-        cpu, parity = None, None
-        frames = frames_of(raw)
-        if world == 1:
-            if not args.no_cpu_baseline:
-                cpu, want = cpu_reference(x.cpu().numpy().view(np.uint16), True)
-                gate(frames, want, "sharded stream vs the CPU path")
-                parity = "equal to the CPU path on the whole stream"
-        else:
-            # the N = 1 result, computed here: rank 0 builds the whole stream and decodes it alone
-            del x
-            torch.cuda.empty_cache()
+    cpu, parity = None, None
+    if not args.no_cpu_baseline:
+        if source == "device":
             whole, _ = make_workload(torch, total, seed=9)
-            d1 = capi.Decoder(df18=True, device=local_rank)
-            d1.push_device_final(whole.data_ptr(), whole.numel())
-            gate(frames, d1.drain(), f"{world}-way sharded stream vs the single-GPU decode of the same stream")
-            d1.close()
-            parity = "equal to the single-GPU decode of the same stream (computed by rank 0 after the timed region)"
-        resolved = args.shard_path != "gather"
-        line = {
-            "metric": "Msamples/s demodulated (20MSPS uint16 real), whole job",
-            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "preroll_ms": args.preroll_ms, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4]: ONE stream of {total} uint16 samples time-sharded over {world} "
-                                   "rank(s), halo 8 pairs + one 1196-sample window, -a, 1-bit repair off; "
-                                   + ("every rank resolves its own shard while its kernel runs and writes its frames to a "
-                                      "shared-memory board, rank 0 repairs the seams, hands out ts offsets and applies the "
-                                      "end-of-file horizon" if resolved else
-                                      "candidates gathered to one resolver (gloo, host-resident records)"),
-                       "shard_path": args.shard_path, "cpu_binding_rank0": args.cpu_binding, "samples_total": total, "samples_rank0": sr.n_samples,
-                       "frames_decoded": len(frames), "parity": parity,
-                       "rank0_serial_us": round(float(np.median(serial)), 1) if serial else None,
-                       "rank0_serial_what": "adsb_stitch_shards on rank 0 per step (median): seam repair O(ranks) + the walk of "
-                                            "the deqframe call chain over the accepted frames for the end-of-file horizon "
-                                            "O(calls + frames)" if serial else None,
-                       "deqframe_calls_walked_by_rank0": None if walk is None else walk[0],
-                       "deqframe_calls_jumped": None if walk is None else walk[1],
-                       "fallback_steps": getattr(sr, "fallbacks", None)},
-            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
-        }
-        emit_line(line)
-    sr.close()
+            x_host = None
+        else:
+            whole = keep[0].cuda()
+            x_host = keep[0].numpy().view(np.uint16)
+        # the N = 1 answer: the whole stream through one handle as one ordinary stream
+        d1 = capi.Decoder(df18=True, device=devices[0], collect_stats=args.stats)
+        d1.push_device_final(whole.data_ptr(), whole.numel())
+        gate(frames, d1.drain(), f"{len(plan)}-way sharded stream vs the single-handle decode of the same stream")
+        if args.stats and d1.stats() != stats_table:
+            raise SystemExit(f"PARITY FAILURE: Try/Ok table of the sharded stream {stats_table} != single-handle decode {d1.stats()}")
+        d1.close()
+        parity = "equal to the single-handle decode of the same stream (one device, after the timed region)"
+        if total <= (512 << 20):             # ... and, where the CPU gets through it in reasonable time, to the CPU path
+            if x_host is None:
+                x_host = whole.cpu().numpy().view(np.uint16)
+            cpu, want = cpu_reference(x_host, True)
+            gate(frames, want, "sharded stream vs the CPU path")
+            parity += "; equal to the CPU path on the whole stream"
+        del whole
+    line = {
+        "metric": "Msamples/s demodulated (20MSPS uint16 real), whole job",
+        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": n_dev, "steps": args.steps,
+        "warmup": args.warmup, "preroll_ms": args.preroll_ms, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4]: ONE stream of {total} uint16 samples time-sharded over {len(plan)} "
+                               f"device handle(s) by adsb_multi_decode_{source} (one process, one worker thread per handle), halo 8 "
+                               "pairs + one 1196-sample window, -a, 1-bit repair off; "
+                               + {"device": "every slice resident in its device's HBM",
+                                  "host": "the capture in page-locked host memory, every worker copies its slice over its device's "
+                                          "link in 32 MiB pieces (PCIe-inclusive: never the headline `value`)",
+                                  "file": "the capture in a tmpfs file, every worker preads its slice into page-locked buffers "
+                                          "(read + PCIe inclusive: never the headline `value`)"}[source]
+                               + "; every shard is resolved while its kernels run, the calling thread repairs the seams, hands out "
+                                 "ts offsets, applies the end-of-file horizon and gathers the frames",
+                   "shard_source": source, "devices": devices, "shards": len(plan), "samples_total": total,
+                   "samples_shard0": plan[0]["n_samples"], "frames_decoded": len(frames), "parity": parity,
+                   "statistics": stats_table, "fallback_steps": int(info["fallback"]),
+                   "serial_us": round(float(np.median(serial)), 1),
+                   "serial_what": "per step (median), on the calling thread behind the last worker: adsb_stitch_shards -- seam repair "
+                                  "O(shards) + the walk of the deqframe call chain for the end-of-file horizon -- and the gather of "
+                                  "the frames into one array (ts offsets applied on the way)",
+                   "stitch_us": round(float(np.median(stitch)), 1),
+                   "slowest_worker_ms": round(float(np.median(workers)), 4),
+                   "deqframe_calls_walked": int(info["calls_walked"]), "deqframe_calls_jumped": int(info["calls_jumped"]),
+                   "create_ms": round(info["create_ms"], 1)},
+        "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
+    }
+    emit_line(line)
+    md.close()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        fence(sync=False)
 
 
 if __name__ == "__main__":

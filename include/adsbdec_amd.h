@@ -42,7 +42,7 @@ extern "C" {
  * 3: `push_overlap` took the place of ABI 2's `reserved0`; it is only honoured when struct_size covers `host_threads`
  *    (a caller built against ABI 2 that left garbage in reserved0 keeps ABI 2's behaviour).
  * 4: adsb_shard_head / adsb_shard_part carry the statistics of a resolved shard (round 4). */
-#define ADSB_ABI_VERSION 3
+#define ADSB_ABI_VERSION 4
 
 /* Constants of the path (adsbdec.h:1-3, air.c:32,47). */
 #define ADSB_PULSEW 5
@@ -273,6 +273,14 @@ int adsb_scan_shard(adsb_decoder *d, const void *device_samples, uint64_t first_
                     uint64_t g_begin, uint64_t g_end, adsb_candidate *cands, size_t cand_cap,
                     size_t *n_cands, uint64_t *tries, size_t try_cap, size_t *n_tries);
 
+/* adsb_scan_shard for a (small) window whose samples are in HOST memory: copied to a device buffer of the handle's own,
+ * scanned there.  Like adsb_scan_shard it touches neither the handle's stream nor its resolver, so it may be called
+ * between adsb_shard_end and the use of the frames that call handed out.  This is how a host-fed shard delivers the two
+ * windows of tries adsb_stitch_shards_stats asks for. */
+int adsb_scan_shard_host(adsb_decoder *d, const uint16_t *host_samples, uint64_t first_sample, size_t n,
+                         uint64_t g_begin, uint64_t g_end, adsb_candidate *cands, size_t cand_cap,
+                         size_t *n_cands, uint64_t *tries, size_t try_cap, size_t *n_tries);
+
 /* ---- time-sharded stream, resolved where the records are (BASELINE configs[4]) ---------------
  * adsb_scan_shard + one resolver on one rank funnels every candidate of the stream through a single thread.  The
  * scalable form: every rank resolves its OWN shard while its kernel runs -- the greedy rule of demod.c:89,128,134,141
@@ -288,7 +296,10 @@ typedef struct adsb_shard_head {
     uint64_t status;         /* 0 = ok                                                                           */
     uint64_t n_bases;        /* the shard's own walk of the deqframe call chain (adsb_shard_part.bases); 0 = none */
     uint64_t walk_final;     /* 1: that walk ended because the stream does (air.c:94: no further call fires)      */
-    uint64_t reserved;
+    uint64_t has_tries;      /* 1: tries[] is filled (the handle was created with collect_stats)                 */
+    uint64_t tries[3];       /* valid.c:46,68 for the offsets of this shard as the SPECULATIVE chain visits them: DF-gate
+                                passes in [g_begin, g_end) that lie in no speculative frame, per DF (11, 17, 18); counted
+                                on the device.  adsb_stitch_shards_stats turns the sum into the stream's Try row. */
 } adsb_shard_head;
 
 typedef struct adsb_shard_part { /* one shard as the stitcher sees it (plain host pointers, e.g. into shared memory) */
@@ -297,6 +308,14 @@ typedef struct adsb_shard_part { /* one shard as the stitcher sees it (plain hos
     const adsb_candidate *head_cands;
     const uint64_t *bases;       /* head->n_bases call bases from the guessed entry base g_begin on, or NULL: lets the
                                     stitcher's end-of-file walk jump over the shard once it meets one of them */
+    /* Statistics only (adsb_stitch_shards_stats; NULL / 0 otherwise).  The shard's own Try count is right except where
+     * the true chain differs from the speculative one: behind a seam, and beyond the end-of-file horizon.  For those
+     * two windows the stitcher needs the DF-gate passes themselves, (g << 2) | code ascending, as adsb_scan_shard
+     * returns them: */
+    const uint64_t *head_tries;  /* EVERY pass with g_begin <= g < head_tries_end (>= min(g_end, head_end + 1200))   */
+    uint64_t n_head_tries, head_tries_end;
+    const uint64_t *tail_tries;  /* EVERY pass with tail_from <= g < g_end: shards that reach into the stream's last  */
+    uint64_t n_tail_tries, tail_from; /* ADSB_TAIL_OFFSETS offsets (tail_from <= the horizon); tail_from = ~0: none    */
 } adsb_shard_part;
 
 typedef struct adsb_shard_fix { /* the stitcher's verdict for one shard; its final frames are, in this order,      */
@@ -307,8 +326,8 @@ typedef struct adsb_shard_fix { /* the stitcher's verdict for one shard; its fin
 
 /* Scan the owned offsets of a device-resident shard (same buffer rules as adsb_scan_shard) and resolve them on the
  * fly.  frames / head_cands receive at most frame_cap / head_cap entries; -2 if a capacity was too small (head->n_frames
- * / n_head say what is needed).  collect_stats must be off (statistics of a sharded stream go through adsb_scan_shard), and
- * the handle must not hold a stream of its own (fresh or adsb_reset): the call runs the handle's resolver. */
+ * / n_head say what is needed).  With collect_stats the shard's own Try count comes back in head->tries.
+ * The handle must not hold a stream of its own (fresh or adsb_reset): the call runs the handle's resolver. */
 int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n,
                              uint64_t g_begin, uint64_t g_end, adsb_shard_head *head, adsb_frame *frames,
                              size_t frame_cap, adsb_candidate *head_cands, size_t head_cap);
@@ -329,6 +348,28 @@ int adsb_stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total
 /* The same; walk_stats[0] = calls of the deqframe chain walked here, [1] = calls skipped by jumping onto shards' own walks. */
 int adsb_stitch_shards_ex(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
                           adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t walk_stats[2]);
+/* The same, and the stream's statistics (valid.c:84-100) from the shards' own Try counts: `stats->try_` = sum of
+ * head->tries, corrected behind every repaired seam and beyond the end-of-file horizon from the parts' head_tries /
+ * tail_tries; ok / fixed from the final frames.  -3 also when one of those windows does not cover what the correction
+ * needs (the caller falls back to adsb_scan_shard + one resolver, like for an undecidable seam). */
+int adsb_stitch_shards_stats(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
+                             adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t walk_stats[2],
+                             adsb_stats *stats);
+/* Offsets at the end of a stream inside which the end-of-file horizon (air.c:94-99) always lies:
+ * every offset below (power samples - ADSB_TAIL_OFFSETS) is visited or jumped whatever the traffic. */
+#define ADSB_TAIL_OFFSETS 42181
+
+/* ---- a shard fed PIECEWISE (host-fed multi-GPU path): the handle becomes a stream that starts at sample
+ * first_sample and owns the offsets [g_begin, g_end) (adsb_plan_shards).  Between the two calls feed it exactly the
+ * plan's samples with adsb_push / adsb_push_async / adsb_push_device -- copy and scan of successive pieces overlap as
+ * for any stream -- and it is resolved in chain mode on the fly, like adsb_scan_shard_resolved_walk does for a buffer
+ * that is resident in HBM.  adsb_shard_end hands the shard's speculative frames and head candidates out IN PLACE: the
+ * pointers stay valid until the next adsb_reset / adsb_shard_begin / adsb_destroy of the handle.  With collect_stats
+ * the shard's own Try count is in head->tries.  bases / bases_cap as adsb_scan_shard_resolved_walk (may be NULL / 0). */
+int adsb_shard_begin(adsb_decoder *d, uint64_t first_sample, uint64_t g_begin, uint64_t g_end, uint64_t total_samples,
+                     uint64_t *bases, size_t bases_cap);
+int adsb_shard_end(adsb_decoder *d, adsb_shard_head *head, const adsb_frame **frames, const adsb_candidate **head_cands);
+
 /* ts_final = ts_local - ts_sub, in place, for frames[0 .. n). */
 void adsb_shard_apply_fix(adsb_frame *frames, size_t n, int64_t ts_sub);
 /* The host-side resolver in the same chain mode (tests; hosts that hold candidates themselves): call before the first
@@ -341,6 +382,67 @@ int adsb_resolver_start_walk(adsb_resolver *r, uint64_t g_begin, uint64_t g_end,
 size_t adsb_resolver_walk_result(const adsb_resolver *r, int *final);
 long adsb_resolver_head(adsb_resolver *r, adsb_candidate *out, size_t cap);
 uint64_t adsb_resolver_skipped(const adsb_resolver *r);
+
+/* ---- ONE process, several GPUs (csrc/multi.cpp) ---------------------------------------------------------------
+ * The host of BASELINE configs[3] / configs[4]: a worker thread and a decoder handle per device; no collective on the
+ * data path.  Stands where fileInput's loop (air.c:217-246) hands its buffers to decodeiq and the frames
+ * come back in ascending order for netout (output.c:159-182). */
+typedef struct adsb_multi adsb_multi;
+
+typedef struct adsb_multi_info { /* of the last adsb_multi_decode_* call */
+    int32_t shards;        /* shards the capture was cut into (streams decoded side by side, for the stream calls)     */
+    int32_t fallback;      /* 1: a seam could not be decided from the head candidates; the capture then went through
+                              ONE device as an ordinary stream (same frames)                                         */
+    uint64_t calls_walked; /* deqframe calls the end-of-file walk replayed on the calling thread ...                   */
+    uint64_t calls_jumped; /* ... and skipped by jumping onto the shards' own walks                                    */
+    double create_ms;      /* adsb_multi_create: the slowest worker's adsb_create (the devices start side by side)     */
+    double workers_ms;     /* the slowest worker's share of the call                                                  */
+    double stitch_us;      /* adsb_stitch_shards[_stats] on the calling thread                                        */
+    double serial_us;      /* everything behind the last worker: stitch + gather into one array                       */
+    double total_ms;
+} adsb_multi_info;
+
+/* n_devices workers; devices[i] = HIP ordinal of worker i (NULL: 0 .. n_devices-1).  An ordinal may repeat: several
+ * handles on one device (plumbing tests on a one-GPU box).  cfg as for adsb_create (device and stream are ignored);
+ * each worker creates its own handle, so the devices' runtimes come up in parallel.  NULL on failure
+ * (adsb_multi_last_error(NULL)). */
+adsb_multi *adsb_multi_create(const adsb_config *cfg, int n_devices, const int *devices);
+void adsb_multi_destroy(adsb_multi *m);
+int adsb_multi_devices(const adsb_multi *m);
+
+/* configs[4]: ONE capture, time-sharded: adsb_plan_shards over as many devices as the capture is worth (at least 128 Ki
+ * offsets per shard), each worker feeds its halo'd slice to its device in 32 MiB pieces -- the copy of a piece overlaps
+ * the scan of the one before, the shard is resolved while its kernels run -- and the calling thread stitches
+ * (adsb_stitch_shards, adsb_shard_apply_fix) and gathers.  Returns the number of frames, in the reference's order, *frames
+ * valid until the next call on m; -1 on failure.  With cfg.collect_stats the stream's Try/Ok table is available from
+ * adsb_multi_get_stats afterwards.
+ *   _host:   the capture lies in host memory (page-lock it -- adsb_host_register / adsb_host_alloc -- or every piece goes
+ *            through the runtime's bounce buffers);
+ *   _file:   every worker reads its own slice of a regular file (pread) into page-locked buffers of its own;
+ *   _device: slice i is resident in the HBM of worker i's device and holds the samples adsb_multi_plan says (16-byte
+ *            aligned); n_slices must be the plan's shard count. */
+long adsb_multi_decode_host(adsb_multi *m, const uint16_t *samples, size_t n, const adsb_frame **frames);
+long adsb_multi_decode_file(adsb_multi *m, const char *path, const adsb_frame **frames);
+long adsb_multi_decode_device(adsb_multi *m, uint64_t total_samples, const void *const *slices, int n_slices,
+                              const adsb_frame **frames);
+/* The plan those calls use for a stream of total_samples: fills the first <return value> entries (arrays of
+ * adsb_multi_devices(m) entries), as adsb_plan_shards does. */
+int adsb_multi_plan(const adsb_multi *m, uint64_t total_samples, uint64_t *g_begin, uint64_t *g_end,
+                    uint64_t *first_sample, uint64_t *n_samples);
+int adsb_multi_get_stats(const adsb_multi *m, adsb_stats *out);
+
+/* configs[3]: n_streams INDEPENDENT captures, stream s on worker s mod adsb_multi_devices(m), each with its own ts and
+ * statistics -- N times what `adsbdec -f` does, side by side.  0 / -1; results per stream afterwards. */
+int adsb_multi_decode_streams_host(adsb_multi *m, int n_streams, const uint16_t *const *samples, const size_t *n);
+int adsb_multi_decode_streams_file(adsb_multi *m, int n_streams, const char *const *paths);
+long adsb_multi_stream_frames(const adsb_multi *m, int stream, const adsb_frame **frames);
+int adsb_multi_stream_stats(const adsb_multi *m, int stream, adsb_stats *out);
+
+int adsb_multi_get_info(const adsb_multi *m, adsb_multi_info *out);
+/* adsb_get_profile of worker `worker`'s handle (launches, kernel time on the device clock with cfg.profile ...). */
+int adsb_multi_worker_profile(const adsb_multi *m, int worker, adsb_profile *out);
+/* Last error text of m, or of the last failed adsb_multi_create() when m == NULL; names the device and worker. */
+const char *adsb_multi_last_error(const adsb_multi *m);
 
 int adsb_abi_version(void);
 

@@ -1,18 +1,19 @@
-"""world_size-2 gloo test of the multi-rank path on CPU: each rank scans
-its planned shard, candidate records are gathered on rank 0 with no data-path
-collective other than that gather, and one resolver reproduces the sequential
-reference.  On CPU the per-shard scan is the oracle's exhaustive evaluation (a
-test stand-in for the HIP kernel; the GPU version of this test is in
-test_gpu_parity.py)."""
+"""world_size-2 gloo tests, on CPU, of the multi-PROCESS shape bench.py runs at N > 1 (stream mode, BASELINE configs[3]):
+one process and one independent stream per GPU, no data-path collective -- the ranks only meet at the
+barriers around the timed region, for the max of their times and for the AND of their parity flags (bench.Ranks).
+
+On CPU each rank's "decode" is the host resolver over the oracle's exhaustive candidate list of ITS stream (a test
+stand-in for the HIP kernel; the GPU version is tests/test_gpu_parity.py::test_two_rank_independent_streams_...).
+Also here: a rank that dies mid-job -- the survivors must give up non-zero, quickly, and say where.
+(The time-sharded mode, configs[4], is ONE process with a worker thread per device -- csrc/multi.cpp -- and has no ranks.)"""
 import os
 import pickle
 import socket
 import sys
+import time
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import ROOT, records
@@ -26,81 +27,75 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _stream_of(rank):
+    from oracle import gen_signal as G
+    return G.dense_capture((1 << 19) + 4 * rank, seed=44 + rank, sigma=50.0, n_frames=150 + 20 * rank)[0]
+
+
+def _worker(rank, world, port, out_dir, die_at):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from adsbdec_amd import capi, sharding
-    from oracle import gen_signal as G, oracle as O
-    x, _ = G.dense_capture(1 << 19, seed=44, sigma=50.0, n_frames=150)   # same stream on every rank
-    plan = capi.plan_shards(x.size, world)[rank]
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from conftest import shard_power
-    a, off = shard_power(O, x, plan)
-    cands, tries = O.scan_all(a, plan["g_begin"] - off, plan["g_end"] - off, True)
-    cands = [(g + off, pw, fr) for g, pw, fr in cands]
-    tries = tries + np.uint64(off << 2)
-    frames, stats = sharding.gather_and_resolve(cands, tries, x.size, dst=0)
-    # the tensor path of the GPU bench (ShardRank: fixed-layout adsb_candidate arrays, one gather per
-    # step), with the oracle's records standing in for adsb_scan_shard
-    sr = sharding.ShardRank(x.size, df18=True, group=sharding.gloo_group(), collect_stats=True)
-    assert (sr.g_begin, sr.g_end) == (plan["g_begin"], plan["g_end"])
-    tensor_out = None
-    for _ in range(2):                      # buffers are reused from step to step
-        sr.load_records(cands, tries)
-        got = sr.exchange()
-        if rank == 0:
-            arr, n, st = got
-            tensor_out = (capi._frames_to_dicts(arr, n), st)
-        else:
-            assert got is None
-    # the scalable path (ResolvedShard): every rank resolves its own shard, writes frames + head candidates into its
-    # region of a shared-memory board, rank 0 stitches (seams, ts offsets, horizon), every rank fixes its own ts
-    rs = sharding.ResolvedShard(x.size, df18=True, group=sharding.gloo_group(), timeout_s=60)
-    assert (rs.g_begin, rs.g_end) == (plan["g_begin"], plan["g_end"])
-    resolved_out = None
-    for _ in range(3):                      # the board is reused from step to step
-        res = rs.step(cands=cands)
-        if rank == 0:
-            arr, n = res.collect()
-            resolved_out = (capi._frames_to_dicts(arr, n), res.serial_us, rs.fallbacks)
-        else:
-            assert res is None
-    # a rank whose scan fails: everybody raises, rank 0 names it
+    import bench
+    from adsbdec_amd import capi
+    from oracle import oracle as O
+    t_start = time.time()
     try:
-        rs.step(cands=cands if rank == 0 else [(rs.g_begin, 1, b"\x8d" * 14)] * (rs.board.frame_cap + 1))
-        raised2 = None
-    except sharding.ShardError as e:
-        raised2 = str(e)
-    assert raised2 is not None and ("rank 1" in raised2 or rank == 1), raised2
-    rs.close()
-    # error propagation: rank 1 reports a failed scan, rank 0 must raise and name it
-    if rank == 1:
-        sr._hdr[0] = sharding._ERR
-    try:
-        sr.exchange()
-        raised = None
-    except sharding.ShardError as e:
-        raised = str(e)
-    assert (raised is not None and "rank 1" in raised) if rank == 0 else raised is None
-    if rank == 0:
-        with open(out_path, "wb") as f:
-            pickle.dump((frames, stats, tensor_out, resolved_out), f)
-    dist.barrier()
-    dist.destroy_process_group()
+        ranks = bench.Ranks(world, rank, timeout_s=20.0)
+        x = _stream_of(rank)                       # every rank has a stream of its own
+        a = O.power(x)
+        g_end = a.size - 1195
+        cands, tries = O.scan_all(a, 0, g_end, True)
+        ranks.fence(what="opening barrier")
+        if die_at == "step" and rank == 1:
+            os._exit(9)                            # SIGKILL's moral equivalent: no goodbye to the process group
+        t0 = time.perf_counter()
+        r = capi.Resolver()
+        r.feed(cands, tries)
+        r.advance(2 * ((x.size + 3) // 4), g_end)
+        frames, stats = r.drain(), r.stats()
+        dt = time.perf_counter() - t0 + (0.25 if rank == 1 else 0.0)   # rank 1 is "slower": the job's time is the max
+        ranks.fence(what="closing barrier")
+        dt_max = ranks.max_over(dt)
+        want, wstats = O.decode(x, df18=True)
+        ok = records(frames) == records(want) and stats == wstats
+        all_ok = ranks.all_ok(ok)
+        # a mismatch on ONE rank fails the job on every rank
+        all_ok_2 = ranks.all_ok(rank != 1)
+        with open(os.path.join(out_dir, f"r{rank}.pkl"), "wb") as f:
+            pickle.dump(dict(n=len(frames), ok=ok, all_ok=all_ok, all_ok_2=all_ok_2, dt=dt, dt_max=dt_max), f)
+        ranks.close()
+    except SystemExit as e:
+        with open(os.path.join(out_dir, f"r{rank}.exit"), "w") as f:
+            f.write(f"{time.time() - t_start:.1f}\n{e}")
+        os._exit(3)
 
 
-def test_two_rank_shard_gather_resolve(tmp_path, oracle, capi):
-    from oracle import gen_signal as G
-    out = str(tmp_path / "r0.pkl")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    frames, stats, tensor_out, resolved_out = pickle.load(open(out, "rb"))
-    x, _ = G.dense_capture(1 << 19, seed=44, sigma=50.0, n_frames=150)
-    want, wstats = oracle.decode(x, df18=True)
-    assert records(frames) == records(want)
-    assert stats == wstats
-    assert records(tensor_out[0]) == records(want)
-    assert tensor_out[1] == wstats
-    assert records(resolved_out[0]) == records(want) and resolved_out[2] == 0
-    assert resolved_out[1] < 5000          # the stitcher's serial part, microseconds (two shards, 512 Ki samples)
+def _spawn(world, out_dir, die_at=None):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, out_dir, die_at)) for r in range(world)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(120)
+    return [p.exitcode for p in ps]
+
+
+def test_two_ranks_two_streams_gated_on_every_rank(tmp_path, oracle, capi):
+    assert _spawn(2, str(tmp_path)) == [0, 0]
+    res = [pickle.load(open(tmp_path / f"r{r}.pkl", "rb")) for r in range(2)]
+    for r in res:
+        assert r["ok"] and r["all_ok"] and not r["all_ok_2"]
+        assert r["dt_max"] == pytest.approx(res[1]["dt"]) and r["dt_max"] >= res[0]["dt"] + 0.2
+    assert res[0]["n"] != res[1]["n"] and min(res[0]["n"], res[1]["n"]) > 50     # two different streams
+
+
+def test_a_dead_rank_takes_the_job_down_quickly(tmp_path, oracle, capi):
+    """Rank 1 disappears between the opening barrier and the closing one (os._exit: no clean-up, like an OOM kill).  Rank 0
+    must not hang in its next collective: it exits non-zero within the group's deadline (20 s here) and names the step."""
+    codes = _spawn(2, str(tmp_path), die_at="step")
+    assert codes[1] == 9 and codes[0] == 3, codes
+    took, why = open(tmp_path / "r0.exit").read().split("\n", 1)
+    assert float(took) < 60
+    assert "rank 0: lost the other ranks at `closing barrier`" in why and "died or hung" in why

@@ -131,18 +131,21 @@ def test_config4_2Gi_one_stream_in_8_shards(capi, oracle, torch_cuda):
             else:
                 n_plain = len(got)
             _ts_checksum(got)
-            # the scalable form of the same job: every shard resolved on its own while its kernel runs
-            # (adsb_scan_shard_resolved), then only seams, ts offsets and the end-of-file horizon (adsb_stitch_shards)
+            # the scalable form of the same job, through the product's own driver: adsb_multi_decode_device with 8 handles
+            # on this GPU -- every shard resolved while its kernels run AND counting its own tries on the device, then only
+            # seams, ts offsets, the end-of-file horizon and the corrections of the Try table (adsb_stitch_shards_stats)
             from adsbdec_amd import sharding
-            d2 = capi.Decoder(df18=True, fix_1bit=fix)
+            md = sharding.MultiDecoder(8, [0] * 8, df18=True, fix_1bit=fix, collect_stats=True)
             try:
-                res, rc = sharding.decode_sharded(d2, t.data_ptr(), x.size, 8)
-                assert rc == 0
-                arr, n = res.collect()
-                assert records(capi._frames_to_dicts(arr, n)) == records(want)
-                assert res.serial_us < 2000        # the serial part of a 2 Gi-sample stream, microseconds (Python timer around the C call)
+                plan = md.plan(x.size)
+                assert len(plan) == 8
+                raw = md.decode_device(x.size, [t.data_ptr() + 2 * p["first_sample"] for p in plan])
+                assert records(capi._frames_to_dicts(*raw)) == records(want)
+                assert md.stats() == wstats
+                inf = md.info()
+                assert inf["fallback"] == 0 and inf["serial_us"] < 20_000   # stitch + the gather of ~100 k frames, microseconds
             finally:
-                d2.close()
+                md.close()
         finally:
             d.close()
             r.close()

@@ -833,11 +833,11 @@ def test_shard_candidates_equal_oracle_exhaustive(capi, oracle, dec_factory, tor
 
 @pytest.mark.parametrize("n_shards", [2, 5, 8, 13])
 def test_resolved_shards_equal_the_sequential_decode(capi, oracle, dec_factory, torch_cuda, n_shards):
-    """adsb_scan_shard_resolved + adsb_stitch_shards (every shard resolved on its own, rank 0 only repairs seams, hands
-    out ts offsets and applies the end-of-file horizon) against the oracle: a noisy capture with overlapping frames, and
+    """adsb_scan_shard_resolved_walk + adsb_stitch_shards (every shard resolved on its own, the stitcher only repairs seams,
+    hands out ts offsets and applies the end-of-file horizon) against the oracle: a noisy capture with overlapping frames, and
     frames packed back to back so that every seam cuts through one; with a head window too small to decide such a seam
-    the stitcher must say so (-3) rather than guess."""
-    from adsbdec_amd import sharding
+    the stitcher must say so (-3) rather than guess.  (The product's driver of these calls is adsb_multi_*: test_gpu_multi.py.)"""
+    import shard_helpers
     from oracle import gen_signal as G
     xa, _ = G.dense_capture((3 << 20) + 4, seed=91, sigma=40.0, n_frames=1500, amp=(200, 1800))
     xb = _back_to_back(1100, 45)
@@ -845,18 +845,15 @@ def test_resolved_shards_equal_the_sequential_decode(capi, oracle, dec_factory, 
         want, _ = oracle.decode(x, df18=True)
         t = _dev(torch_cuda, x)
         d = dec_factory(df18=True)
-        res, rc = sharding.decode_sharded(d, t.data_ptr(), x.size, n_shards)
-        assert rc == 0
-        arr, n = res.collect()
-        assert records(capi._frames_to_dicts(arr, n)) == records(want)
+        rc, got, _, _, _ = shard_helpers.from_device(capi, d, t.data_ptr(), x.size, n_shards).stitch()
+        assert rc == 0 and got == records(want)
     # a head window of 600 offsets cannot decide a seam that cuts through back-to-back frames: -3 (or 0 where no seam does)
     t = _dev(torch_cuda, xb)
     d = dec_factory(df18=True, debug_shard_head=600)
-    res, rc = sharding.decode_sharded(d, t.data_ptr(), xb.size, n_shards)
+    rc, got, _, _, _ = shard_helpers.from_device(capi, d, t.data_ptr(), xb.size, n_shards).stitch()
     assert rc in (0, -3)
     if rc == 0:
-        arr, n = res.collect()
-        assert records(capi._frames_to_dicts(arr, n)) == records(oracle.decode(xb, df18=True)[0])
+        assert got == records(oracle.decode(xb, df18=True)[0])
 
 
 def _bench_line(extra, timeout=900):
@@ -871,28 +868,6 @@ def _bench_line(extra, timeout=900):
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, f"stdout must carry rank 0's JSON line and nothing else, got {len(lines)} lines: {lines[:3]}"
     return json.loads(lines[0])
-
-
-@pytest.mark.parametrize("ranks", [2, 3])
-def test_two_rank_sharded_stream_with_the_hip_kernel(ranks):
-    """BASELINE configs[4] plumbing with the HIP kernel in MORE THAN ONE PROCESS: two (three) ranks
-    (both on this GPU: --one-device-test, gloo) each scan their halo'd shard of one stream,
-    resolve it speculatively, and rank 0 stitches the seams; bench.py's own gate then compares
-    with the single-GPU decode of the whole stream.  (tests/test_distributed_cpu.py covers the
-    same exchange on CPU.)"""
-    line = _bench_line(["--gpus", str(ranks), "--mode", "shard", "--one-device-test", "--samples", str(64 << 20), "--steps", "3",
-                        "--warmup", "1", "--preroll-ms", "0"])
-    assert line["n_gpus"] == ranks and line["scaling"] == "strong"
-    assert line["config"]["parity"].startswith("equal to the single-GPU decode")
-    assert line["config"]["frames_decoded"] > 3000
-    assert line["config"]["shard_path"] == "resolved" and line["config"]["fallback_steps"] == 0
-    assert line["config"]["rank0_serial_us"] is not None
-    if ranks != 2:
-        return
-    # the checker path (every candidate gathered to one resolver) must give the same
-    line = _bench_line(["--gpus", "2", "--mode", "shard", "--shard-path", "gather", "--one-device-test", "--samples", str(32 << 20),
-                        "--steps", "2", "--warmup", "1", "--preroll-ms", "0"])
-    assert line["config"]["parity"].startswith("equal to the single-GPU decode")
 
 
 def test_two_rank_independent_streams_are_gated_on_every_rank():

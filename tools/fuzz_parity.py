@@ -9,14 +9,16 @@ and prints the seed of the first mismatch.
 import argparse
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # shard_helpers
 import torch  # noqa: E402
 
-from adsbdec_amd import capi  # noqa: E402
+from adsbdec_amd import capi, sharding  # noqa: E402
 from oracle import gen_signal as G  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
@@ -74,7 +76,8 @@ def run(seconds: float, seed: int = 1, log=print):
         return decs[k]
 
     t0, it, frames_total, ref_checked, tight_runs = time.time(), 0, 0, 0, 0
-    modes = [0] * 9
+    modes = [0] * 10
+    multis, multi_fallbacks = {}, [0]
     stitch_fallbacks = [0]
     reader_runs = 0
     pinned = capi.PinnedBuffers(2, 1 << 20)
@@ -94,9 +97,7 @@ def run(seconds: float, seed: int = 1, log=print):
             assert rstats == {k: wstats[k] for k in ("try", "ok")}, f"oracle stats != real reference chain, seed={seed}"
             ref_checked += 1
         caps = int(rng.integers(1, len(tight))) if rng.random() < 0.2 else 0
-        mode = int(rng.integers(0, 9))
-        if mode == 7 and stats:
-            mode = 4               # statistics of a sharded stream go through the every-candidate path
+        mode = int(rng.integers(0, 10))
         d = dec(df18, stats, fix, caps, overlap=(mode == 8))
         modes[mode] += 1
         reader_runs += int(getattr(d, "fuzz_reader", False))
@@ -135,16 +136,40 @@ def run(seconds: float, seed: int = 1, log=print):
             got += d.drain()
         elif mode == 8:    # cfg.push_overlap: adsb_push from ONE page-locked buffer that is scribbled over after every call
             got = d.decode(x, chunk=int(rng.choice([1000, 4096, 65536 + 4, 1 << 18, 1 << 20, max(1, x.size)])), mode="overlap")
-        elif mode == 7:    # every shard resolved on its own (adsb_scan_shard_resolved) + the stitcher; -3 = honest fallback
-            from adsbdec_amd import sharding
+        elif mode == 7:    # every shard resolved on its own (adsb_scan_shard_resolved_walk, statistics included) + the stitcher;
+            import shard_helpers                                   # -3 = honest fallback
             t = torch.from_numpy(x.view(np.int16)).cuda()
-            res, rc = sharding.decode_sharded(d, t.data_ptr(), x.size, int(rng.integers(1, 7)))
+            rc, got_recs, gstats, _, _ = shard_helpers.from_device(capi, d, t.data_ptr(), x.size, int(rng.integers(1, 7)),
+                                                                   stats=stats).stitch(with_stats=stats)
             assert rc in (0, -3), f"stitcher failed ({rc}) " + what
             if rc == 0:
-                arr, n = res.collect()
-                assert key(capi._frames_to_dicts(arr, n)) == key(want), "MISMATCH (resolved shards) " + what
+                assert [r for r in got_recs] == [(f["g"], f["ts"], f["pw"], f["frame"]) for f in want], "MISMATCH (resolved shards) " + what
+                if stats:
+                    assert gstats == {k: wstats[k] for k in ("try", "ok")}, f"STATS MISMATCH (resolved shards) {gstats} != {wstats} " + what
             else:
                 stitch_fallbacks[0] += 1
+            it += 1
+            seed += 1
+            frames_total += len(want)
+            continue
+        elif mode == 9:    # the library's multi-GPU driver (adsb_multi_decode_host / _file): K handles on this device
+            k = int(rng.integers(1, 5))
+            mk = (df18, stats, fix, k)
+            if mk not in multis:
+                multis[mk] = sharding.MultiDecoder(k, [0] * k, df18=df18, collect_stats=stats, fix_1bit=fix,
+                                                   stage_samples=[0, 1 << 18][k % 2])
+            md = multis[mk]
+            if rng.random() < 0.3:
+                with tempfile.NamedTemporaryFile(suffix=".u16", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None) as tf:
+                    x.tofile(tf.name)
+                    raw = md.decode_file(tf.name)
+            else:
+                raw = md.decode_host(np.ascontiguousarray(x))
+            got = capi._frames_to_dicts(raw[0], raw[1])
+            assert key(got) == key(want), "MISMATCH (multi driver) " + what
+            if stats:
+                assert md.stats() == wstats, f"STATS MISMATCH (multi driver) {md.stats()} != {wstats} " + what
+            multi_fallbacks[0] += md.info()["fallback"]
             it += 1
             seed += 1
             frames_total += len(want)
@@ -198,13 +223,17 @@ def run(seconds: float, seed: int = 1, log=print):
                    seconds=round(time.time() - t0, 1), mismatches=0,
                    captures_by_mode=dict(host_push=modes[0], device_final=modes[1], device_split_aligned=modes[2],
                                          device_split_unaligned=modes[3], shards=modes[4], host_push_async=modes[5],
-                                         mixed_async_sync_device=modes[6], resolved_shards=modes[7], push_overlap=modes[8]),
+                                         mixed_async_sync_device=modes[6], resolved_shards=modes[7], push_overlap=modes[8],
+                                         multi_gpu_driver=modes[9]),
+                   multi_driver_fallbacks=multi_fallbacks[0],
                    with_the_reader_thread=reader_runs, stitcher_fallbacks=stitch_fallbacks[0],
                    also_checked_against_real_reference_chain=ref_checked,
                    with_shrunken_record_buffers=tight_runs,
                    relaunches=sum(int(d.profile()["relaunches"]) for d in decs_all))
     for d in decs_all:
         d.close()
+    for md in multis.values():
+        md.close()
     pinned.__exit__(None, None, None)
     log(f"fuzz ok: {summary}")
     return summary
