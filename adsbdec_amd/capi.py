@@ -81,6 +81,7 @@ class Profile(C.Structure):
 SYMBOLS = {
     "adsb_abi_version": (C.c_int, []),
     "adsb_config_default": (None, [C.POINTER(Config)]),
+    "adsb_config_init": (None, [C.POINTER(Config), C.c_size_t]),
     "adsb_create": (C.c_void_p, [C.POINTER(Config)]),
     "adsb_destroy": (None, [C.c_void_p]),
     "adsb_reset": (C.c_int, [C.c_void_p]),
@@ -212,7 +213,7 @@ def make_config(df18: bool = False, device: int = -1, collect_stats: bool = Fals
                 debug_reader_min_tiles: int = 0, debug_shard_head: int = 0, debug_passes: int = 0, debug_stagger: int = 0):
     """adsb_config from keywords (adsb_config_default + the members named)."""
     cfg = Config()
-    load().adsb_config_default(C.byref(cfg))
+    load().adsb_config_init(C.byref(cfg), C.sizeof(cfg))
     cfg.df18 = int(df18)
     cfg.device = device
     cfg.collect_stats = int(collect_stats)

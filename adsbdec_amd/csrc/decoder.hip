@@ -1466,12 +1466,20 @@ extern "C" {
 
 int adsb_abi_version(void) { return ADSB_ABI_VERSION; }
 
-void adsb_config_default(adsb_config *cfg)
+void adsb_config_init(adsb_config *cfg, size_t struct_size)
 {
-    std::memset(cfg, 0, sizeof *cfg);
-    cfg->struct_size = sizeof *cfg;
+    if (!cfg || struct_size < offsetof(adsb_config, device) + sizeof(int32_t))
+        return;
+    if (struct_size > sizeof *cfg) // a caller from the future: this library fills what it knows, adsb_create refuses the rest
+        struct_size = sizeof *cfg;
+    std::memset(cfg, 0, struct_size);
+    cfg->struct_size = (uint32_t)struct_size;
     cfg->device = -1;
 }
+
+// The symbol binaries built against ABI <= 3 call: their adsb_config ended behind host_threads (72 bytes); writing this
+// library's longer struct into it would run over the caller's stack (found in round 4 by a stale test binary).
+void (adsb_config_default)(adsb_config *cfg) { adsb_config_init(cfg, offsetof(adsb_config, host_threads) + 2 * sizeof(int32_t)); }
 
 adsb_decoder *adsb_create(const adsb_config *cfg_in)
 {

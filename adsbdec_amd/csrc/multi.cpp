@@ -264,6 +264,10 @@ void run_shard(Worker &w, const Job &j, uint64_t piece)
             w.frames_buf.resize(65536 + (size_t)(j.n / 8000)); // ~1 frame per 20 k samples at 1 k frames/s
         if (w.head_buf.empty())
             w.head_buf.resize(4096);
+        if (adsb_reset(w.dec)) { // (the handle may hold the stream of an earlier job)
+            w.fail_dec("adsb_reset");
+            return;
+        }
         for (int attempt = 0;; attempt++) {
             const int rc = adsb_scan_shard_resolved_walk(w.dec, j.src.dev, j.first, (size_t)j.n, j.g_begin, j.g_end, j.total, &w.head,
                                                          w.frames_buf.data(), w.frames_buf.size(), w.head_buf.data(), w.head_buf.size(),

@@ -137,7 +137,12 @@ typedef struct adsb_profile {
     double big_ms;             /* sum of their durations on the device clock (profile=1) */
 } adsb_profile;
 
+/* Defaults.  The struct's size is the CALLER's (the library's own adsb_config may be longer: it grows at its end), so it
+ * is passed along: adsb_config_default(&cfg) compiles to adsb_config_init(&cfg, sizeof cfg).  The function of the same name
+ * that the library still exports serves binaries built against ABI <= 3, whose struct had 72 bytes: it fills exactly those. */
+void adsb_config_init(adsb_config *cfg, size_t struct_size);
 void adsb_config_default(adsb_config *cfg);
+#define adsb_config_default(cfg) adsb_config_init((cfg), sizeof(adsb_config))
 
 /* Allocates the stream state that air.c:33-34,49-50 / demod.c:86 / valid.c:30-31
  * keep in statics. NULL on failure (adsb_last_error(NULL) has the reason). */

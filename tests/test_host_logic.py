@@ -77,8 +77,11 @@ def test_config_grows_at_its_end_only(capi):
         pytest.skip("a GPU is present")
     L = capi.load()
     cfg = capi.Config()
-    L.adsb_config_default(C.byref(cfg))
-    assert cfg.struct_size == C.sizeof(capi.Config) >= 96
+    C.memset(C.byref(cfg), 0xEE, C.sizeof(cfg))
+    L.adsb_config_default(C.byref(cfg))      # the legacy symbol: exactly ABI 3's 72 bytes, nothing behind them
+    assert cfg.struct_size == 72 and cfg.device == -1 and cfg.host_threads == 0 and cfg.debug_frames_cap == -286331154
+    L.adsb_config_init(C.byref(cfg), C.sizeof(cfg))
+    assert cfg.struct_size == C.sizeof(capi.Config) >= 96 and cfg.debug_stagger == 0
     assert capi.Config.host_threads.offset == 64 and capi.Config.debug_no_streaming.offset == 68
     for old_size in (64, 72):
         cfg.struct_size = old_size
