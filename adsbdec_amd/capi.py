@@ -38,7 +38,8 @@ class Stats(C.Structure):
 class ShardHead(C.Structure):
     _fields_ = [("g_begin", C.c_uint64), ("g_end", C.c_uint64), ("n_frames", C.c_uint64), ("n_head", C.c_uint64),
                 ("head_end", C.c_uint64), ("skipped", C.c_uint64), ("status", C.c_uint64), ("n_bases", C.c_uint64),
-                ("walk_final", C.c_uint64), ("has_tries", C.c_uint64), ("tries", C.c_uint64 * 3)]
+                ("walk_final", C.c_uint64), ("has_tries", C.c_uint64), ("tries", C.c_uint64 * 3), ("ok", C.c_uint64 * 3),
+                ("fixed", C.c_uint64)]
 
 
 class ShardPart(C.Structure):
@@ -67,7 +68,7 @@ class Config(C.Structure):
 class MultiInfo(C.Structure):
     _fields_ = [("shards", C.c_int32), ("fallback", C.c_int32), ("calls_walked", C.c_uint64), ("calls_jumped", C.c_uint64),
                 ("create_ms", C.c_double), ("workers_ms", C.c_double), ("stitch_us", C.c_double), ("serial_us", C.c_double),
-                ("total_ms", C.c_double)]
+                ("total_ms", C.c_double), ("workers_bound", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -88,6 +89,7 @@ SYMBOLS = {
     "adsb_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_push_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "adsb_sync": (C.c_int, [C.c_void_p]),
+    "adsb_device_cpulist": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "adsb_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "adsb_host_unregister": (C.c_int, [C.c_void_p]),
     "adsb_push_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -118,6 +120,9 @@ SYMBOLS = {
     "adsb_scan_shard_resolved_walk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64,
                                                 C.POINTER(ShardHead), C.POINTER(Frame), C.c_size_t, C.POINTER(Candidate),
                                                 C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t]),
+    "adsb_scan_shard_resolved_take": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64,
+                                                C.POINTER(ShardHead), C.POINTER(C.POINTER(Frame)), C.POINTER(C.POINTER(Candidate)),
+                                                C.POINTER(C.c_uint64), C.c_size_t]),
     "adsb_stitch_shards": (C.c_int, [C.POINTER(ShardPart), C.c_int, C.c_uint64, C.POINTER(ShardFix), C.POINTER(Frame),
                                      C.c_size_t, C.POINTER(C.c_size_t)]),
     "adsb_stitch_shards_ex": (C.c_int, [C.POINTER(ShardPart), C.c_int, C.c_uint64, C.POINTER(ShardFix), C.POINTER(Frame),

@@ -1837,6 +1837,44 @@ int adsb_sync(adsb_decoder *d)
     return 0;
 }
 
+int adsb_device_cpulist(int device, char *out, size_t cap)
+{
+    if (!out || cap < 2)
+        return -1;
+    out[0] = 0;
+    char bdf[64];
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess)
+        return -1;
+    for (char *c = bdf; *c; c++) // sysfs spells the address in lower case
+        if (*c >= 'A' && *c <= 'F')
+            *c = (char)(*c - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE *f = fopen(path, "r");
+    int node = -1;
+    if (f) {
+        if (fscanf(f, "%d", &node) != 1)
+            node = -1;
+        fclose(f);
+    }
+    if (node < 0)
+        return 0;
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+    f = fopen(path, "r");
+    if (!f)
+        return 0;
+    const bool got = fgets(out, (int)cap, f) != nullptr;
+    fclose(f);
+    if (!got) {
+        out[0] = 0;
+        return 0;
+    }
+    size_t n = std::strlen(out);
+    while (n && (out[n - 1] == '\n' || out[n - 1] == ' '))
+        out[--n] = 0;
+    return (int)n;
+}
+
 int adsb_host_register(void *p, size_t bytes)
 {
     return (p && bytes && hipHostRegister(p, bytes, hipHostRegisterPortable) == hipSuccess) ? 0 : -1;
@@ -2137,15 +2175,51 @@ int adsb_scan_shard_resolved(adsb_decoder *d, const void *device_samples, uint64
                                          head_cap, nullptr, 0);
 }
 
-int adsb_scan_shard_resolved_walk(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n, uint64_t g_begin,
-                                  uint64_t g_end, uint64_t total_samples, adsb_shard_head *head, adsb_frame *frames,
-                                  size_t frame_cap, adsb_candidate *head_cands, size_t head_cap, uint64_t *bases,
-                                  size_t bases_cap)
+} // extern "C"
+
+namespace {
+
+// what a shard's resolver knows when its chain has reached g_end (chain mode): into the head
+void fill_shard_head(adsb_decoder *d, adsb_shard_head *head, uint64_t g_begin, uint64_t g_end, uint64_t head_end, size_t n_frames,
+                     size_t bases_cap)
 {
-    if (!d || !device_samples || !head || (frame_cap && !frames) || (head_cap && !head_cands))
+    head->g_begin = g_begin;
+    head->g_end = g_end;
+    head->n_frames = n_frames;
+    head->n_head = d->shard_hv.size();
+    head->head_end = head_end;
+    head->skipped = d->res.skipped();
+    if (bases_cap) { // (more bases than the caller's array holds: the stitcher must not use it)
+        head->n_bases = d->res.walk_bases() <= bases_cap ? d->res.walk_bases() : 0;
+        head->walk_final = d->res.walk_final() ? 1 : 0;
+    }
+    const adsb_stats &st = d->res.stats();
+    for (int k = 0; k < 3; k++)
+        head->ok[k] = st.ok[k];
+    head->fixed = st.fixed;
+}
+
+// the shard's own Try count (collect_stats): every try of [g_begin, g_end) against the speculative frames, on the device
+int shard_tries(adsb_decoder *d, adsb_shard_head *head)
+{
+    if (!d->cfg.collect_stats)
+        return 0;
+    if (count_tries_pass(d, nullptr, 0, 0, true) || read_tries(d))
         return -1;
+    head->has_tries = 1;
+    for (int k = 0; k < 3; k++)
+        head->tries[k] = d->res.stats().try_[k];
+    return 0;
+}
+
+// Scan + chain resolution of a shard that is resident in HBM; the results stay in the handle (resolver queue, shard_hv).
+int scan_shard_resolved_core(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n, uint64_t g_begin,
+                             uint64_t g_end, uint64_t total_samples, adsb_shard_head *head, const adsb_frame **fp, uint64_t *bases,
+                             size_t bases_cap)
+{
     std::memset(head, 0, sizeof *head);
     head->status = 1;
+    *fp = nullptr;
     if (d->n_samples != 0 || d->res.pending() != 0) // (it runs this handle's own resolver: a stream in progress would be lost)
         return d->fail("adsb_scan_shard_resolved: the handle holds a stream (adsb_reset it, or use a handle of its own)");
     if (first_sample % 8 || (uintptr_t)device_samples % 16)
@@ -2161,58 +2235,77 @@ int adsb_scan_shard_resolved_walk(adsb_decoder *d, const void *device_samples, u
     HIP_TRY(d, hipSetDevice(d->device));
     if (scan_drain(d))
         return -1;
-    const uint64_t head_span = d->shard_head; // (tests shrink it to reach the stitcher's fallback)
-    std::vector<adsb_candidate> hv;
-    const uint64_t head_end = std::min<uint64_t>(g_end, g_begin + head_span);
+    const uint64_t head_end = std::min<uint64_t>(g_end, g_begin + d->shard_head); // (tests shrink the window to reach the stitcher's fallback)
     d->sink = ScanSink{};
-    d->res.start_chain(g_begin, head_end, &hv);
-    if (bases && bases_cap) // the shard's own walk of the deqframe calls, advanced beside the chain while the kernel runs
-        d->res.start_walk(g_begin, g_end, total_samples, bases, bases_cap);
+    d->shard_hv.clear();
+    d->res.start_chain(g_begin, head_end, &d->shard_hv);
+    const size_t bcap = (bases && bases_cap) ? bases_cap : 0;
+    if (bcap) // the shard's own walk of the deqframe calls, advanced beside the chain while the kernel runs
+        d->res.start_walk(g_begin, g_end, total_samples, bases, bcap);
     d->alt_next = true;
     int rc = scan_submit(d, static_cast<const uint16_t *>(device_samples), first_sample, n, g_begin, g_end);
     d->alt_next = false;
     if (rc == 0)
         rc = scan_drain(d);
-    if (rc == 0)
-        d->res.advance(0, g_end);
-    if (rc == 0 && d->cfg.collect_stats) { // the shard's own Try count: every try of [g_begin, g_end) against the speculative frames
-        rc = count_tries_pass(d, nullptr, 0, 0, true);
-        if (rc == 0)
-            rc = read_tries(d);
-        if (rc == 0) {
-            head->has_tries = 1;
-            for (int k = 0; k < 3; k++)
-                head->tries[k] = d->res.stats().try_[k];
+    if (rc)
+        return -1;
+    d->res.advance(0, g_end);
+    if (shard_tries(d, head))
+        return -1;
+    const size_t nf = d->res.take(fp);
+    fill_shard_head(d, head, g_begin, g_end, head_end, nf, bcap);
+    head->status = 0;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int adsb_scan_shard_resolved_walk(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n, uint64_t g_begin,
+                                  uint64_t g_end, uint64_t total_samples, adsb_shard_head *head, adsb_frame *frames,
+                                  size_t frame_cap, adsb_candidate *head_cands, size_t head_cap, uint64_t *bases,
+                                  size_t bases_cap)
+{
+    if (!d || !device_samples || !head || (frame_cap && !frames) || (head_cap && !head_cands))
+        return -1;
+    const adsb_frame *fp = nullptr;
+    const int rc = scan_shard_resolved_core(d, device_samples, first_sample, n, g_begin, g_end, total_samples, head, &fp, bases, bases_cap);
+    bool fit = false;
+    if (rc == 0) {
+        fit = head->n_frames <= frame_cap && head->n_head <= head_cap;
+        if (fit) {
+            if (head->n_frames)
+                std::memcpy(frames, fp, head->n_frames * sizeof(adsb_frame));
+            if (head->n_head)
+                std::memcpy(head_cands, d->shard_hv.data(), head->n_head * sizeof(adsb_candidate));
+        } else {
+            head->status = 1;
         }
     }
-    const adsb_frame *fp = nullptr;
-    const size_t nf = rc == 0 ? d->res.take(&fp) : 0;
-    head->g_begin = g_begin;
-    head->g_end = g_end;
-    head->n_frames = nf;
-    head->n_head = hv.size();
-    head->head_end = head_end;
-    head->skipped = d->res.skipped();
-    if (bases && bases_cap && rc == 0) {
-        head->n_bases = d->res.walk_bases() <= bases_cap ? d->res.walk_bases() : 0;
-        head->walk_final = d->res.walk_final() ? 1 : 0;
-    }
-    if (rc == 0 && nf <= frame_cap && hv.size() <= head_cap) {
-        if (nf)
-            std::memcpy(frames, fp, nf * sizeof(adsb_frame));
-        if (!hv.empty())
-            std::memcpy(head_cands, hv.data(), hv.size() * sizeof(adsb_candidate));
-        head->status = 0;
-    }
-    const bool fit = head->status == 0;
-    std::string why = d->err;
-    if (adsb_reset(d) != 0) // (the head vector dies with this call; the device's Try accumulators start from zero again)
+    const std::string why = d->err;
+    if (adsb_reset(d) != 0) // (the device's Try accumulators start from zero again; the handle is an ordinary one again)
         return -1;
     if (rc) {
         d->err = why;
         return -1;
     }
     return fit ? 0 : -2;
+}
+
+int adsb_scan_shard_resolved_take(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n, uint64_t g_begin,
+                                  uint64_t g_end, uint64_t total_samples, adsb_shard_head *head, const adsb_frame **frames,
+                                  const adsb_candidate **head_cands, uint64_t *bases, size_t bases_cap)
+{
+    if (!d || !device_samples || !head || !frames || !head_cands)
+        return -1;
+    *head_cands = nullptr;
+    if (adsb_reset(d) != 0) // what the previous call left in the handle (its frames, the Try accumulators) goes now
+        return -1;
+    if (scan_shard_resolved_core(d, device_samples, first_sample, n, g_begin, g_end, total_samples, head, frames, bases, bases_cap))
+        return -1;
+    *head_cands = d->shard_hv.empty() ? nullptr : d->shard_hv.data();
+    return 0;
 }
 
 // ---- a shard fed piecewise: the same chain-mode resolution, driven by the handle's ordinary stream machinery --------------
@@ -2264,28 +2357,14 @@ int adsb_shard_end(adsb_decoder *d, adsb_shard_head *head, const adsb_frame **fr
         return -1;
     if (d->g_scanned < g_end)
         return d->fail("internal: shard scanned to %llu of %llu", (unsigned long long)d->g_scanned, (unsigned long long)g_end);
-    if (d->cfg.collect_stats) {
-        if (count_tries_pass(d, nullptr, 0, 0, true) || read_tries(d))
-            return -1;
-        head->has_tries = 1;
-        for (int k = 0; k < 3; k++)
-            head->tries[k] = d->res.stats().try_[k];
-    }
+    if (shard_tries(d, head))
+        return -1;
     if (wait_last_copy(d)) // every borrowed buffer is free again
         return -1;
     d->finished = true; // (no further push: the next stream or shard starts with adsb_reset / adsb_shard_begin)
     const size_t nf = d->res.take(frames);
     *head_cands = d->shard_hv.empty() ? nullptr : d->shard_hv.data();
-    head->g_begin = g_begin;
-    head->g_end = g_end;
-    head->n_frames = nf;
-    head->n_head = d->shard_hv.size();
-    head->head_end = std::min<uint64_t>(g_end, g_begin + d->shard_head);
-    head->skipped = d->res.skipped();
-    if (d->shard_bases_cap) { // (more bases than the caller's array holds: the stitcher must not use it)
-        head->n_bases = d->res.walk_bases() <= d->shard_bases_cap ? d->res.walk_bases() : 0;
-        head->walk_final = d->res.walk_final() ? 1 : 0;
-    }
+    fill_shard_head(d, head, g_begin, g_end, std::min<uint64_t>(g_end, g_begin + d->shard_head), nf, d->shard_bases_cap);
     head->status = 0;
     return 0;
 }

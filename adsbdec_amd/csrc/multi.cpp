@@ -19,14 +19,18 @@
 // Host-only code on purpose: nothing but the public C-ABI of the library is called from here (no HIP), so the threading
 // can be built against a fake backend and run under ThreadSanitizer (tests/cpp/multi_tsan.cpp).
 #include <fcntl.h>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -49,7 +53,26 @@ constexpr uint64_t kMinShardOffsets = 1ull << 17; // smaller shards are not wort
                                                   // last ADSB_TAIL_OFFSETS offsets and a head window inside ONE shard)
 constexpr uint64_t kHeadTryReach = 1200;          // a frame that starts inside the head window ends at most this far behind it
 
-enum class JobKind { None, Shard, Stream, Quit };
+enum class JobKind { None, Shard, Gather, Stream, Quit };
+
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+// A worker spins for a short while for its next job before it goes to sleep (a decode of slices that are resident in HBM takes
+// a millisecond per call: a futex wake-up would be 5 % of it), in bursts of `pause` so that an SMT sibling keeps the core.
+// The CALLER only ever spins for the short gather jobs: measured, a caller spinning through a shard job sat on the SMT
+// sibling of the worker it had just woken (the scheduler's wake-affine choice) and made that worker 2.6 x slower.
+constexpr double kWorkerSpinMs = 0.3, kGatherSpinMs = 0.3;
+inline void relax_burst()
+{
+    for (int k = 0; k < 32; k++)
+        cpu_relax();
+}
 
 struct Source { // where the samples of a job come from: exactly one of the three
     const uint16_t *mem = nullptr; // host memory, mem[0] = stream sample 0
@@ -77,6 +100,12 @@ struct Job {
     const uint64_t *stream_n = nullptr;
     int n_streams = 0, stream_lo = 0, stream_step = 1;
     StreamResult *results = nullptr;
+    // Gather: this worker's final frames (`n_new` accepted by the seam repair, then `keep` speculative ones from `drop`
+    // on, ts - ts_sub) into dst
+    adsb_frame *dst = nullptr;
+    const adsb_frame *new_src = nullptr;
+    uint64_t n_new = 0, drop = 0, keep = 0;
+    int64_t ts_sub = 0;
 };
 
 struct Worker {
@@ -87,18 +116,19 @@ struct Worker {
     std::mutex mu;
     std::condition_variable cv;
     uint64_t posted = 0, done = 0; // jobs posted / finished (under mu)
+    std::atomic<uint64_t> posted_a{0}, done_a{0}; // the same, for the spinning side of each hand-over
     Job job;
     // result of the last job
     int rc = 0;
     std::string err;
     double ms = 0, create_ms = 0;
+    bool bound = false; // the thread runs on the CPUs of its device's NUMA node
     adsb_shard_head head{};
     const adsb_frame *frames = nullptr;
     const adsb_candidate *head_cands = nullptr;
     std::vector<uint64_t> bases, head_tries, tail_tries;
     uint64_t head_tries_end = 0, tail_from = ~0ull;
-    std::vector<adsb_candidate> scratch_cands, head_buf; // head_buf / frames_buf: results of a device-resident slice
-    std::vector<adsb_frame> frames_buf;
+    std::vector<adsb_candidate> scratch_cands;
     uint16_t *ring[2] = {nullptr, nullptr}; // page-locked pieces of a file source
     uint64_t ring_samples = 0, piece = kPieceSamples;
 
@@ -259,31 +289,14 @@ void run_shard(Worker &w, const Job &j, uint64_t piece)
     if (w.bases.size() < calls)
         w.bases.resize(calls);
     if (j.src.dev) {
-        // resident in this device's HBM: one call, one launch per 128 Mi offsets, resolved while the kernel runs
-        if (w.frames_buf.empty())
-            w.frames_buf.resize(65536 + (size_t)(j.n / 8000)); // ~1 frame per 20 k samples at 1 k frames/s
-        if (w.head_buf.empty())
-            w.head_buf.resize(4096);
-        if (adsb_reset(w.dec)) { // (the handle may hold the stream of an earlier job)
-            w.fail_dec("adsb_reset");
+        // resident in this device's HBM: one call, one launch per 128 Mi offsets, resolved while the kernels run; the frames
+        // stay in the handle's queue until this worker's next job
+        if (adsb_scan_shard_resolved_take(w.dec, j.src.dev, j.first, (size_t)j.n, j.g_begin, j.g_end, j.total, &w.head, &w.frames,
+                                          &w.head_cands, w.bases.data(), w.bases.size())) {
+            w.head.status = 1;
+            w.fail_dec("adsb_scan_shard_resolved_take");
             return;
         }
-        for (int attempt = 0;; attempt++) {
-            const int rc = adsb_scan_shard_resolved_walk(w.dec, j.src.dev, j.first, (size_t)j.n, j.g_begin, j.g_end, j.total, &w.head,
-                                                         w.frames_buf.data(), w.frames_buf.size(), w.head_buf.data(), w.head_buf.size(),
-                                                         w.bases.data(), w.bases.size());
-            if (rc == 0)
-                break;
-            if (rc != -2 || attempt == 2) {
-                w.head.status = 1;
-                w.fail_dec("adsb_scan_shard_resolved_walk");
-                return;
-            }
-            w.frames_buf.resize(std::max<size_t>(w.frames_buf.size(), (size_t)w.head.n_frames + 64));
-            w.head_buf.resize(std::max<size_t>(w.head_buf.size(), (size_t)w.head.n_head + 64));
-        }
-        w.frames = w.frames_buf.data();
-        w.head_cands = w.head_buf.data();
     } else {
     if (adsb_shard_begin(w.dec, j.first, j.g_begin, j.g_end, j.total, w.bases.data(), w.bases.size())) {
         w.fail_dec("adsb_shard_begin");
@@ -302,6 +315,23 @@ void run_shard(Worker &w, const Job &j, uint64_t piece)
         if (window_tries(w, j, w.tail_from, j.g_end, w.tail_tries))
             w.head.status = 1;
     }
+}
+
+// demod.c:86,99: ts counts loop passes from the stream's start; a shard's frames carry the count from the shard's start
+inline void copy_frames_fix_ts(adsb_frame *dst, const adsb_frame *src, uint64_t n, int64_t ts_sub)
+{
+    for (uint64_t k = 0; k < n; k++) {
+        dst[k] = src[k];
+        dst[k].ts = (uint64_t)((int64_t)src[k].ts - ts_sub);
+    }
+}
+
+void run_gather(Worker &w, const Job &j)
+{
+    if (j.n_new)
+        std::memcpy(j.dst, j.new_src, j.n_new * sizeof(adsb_frame));
+    if (j.keep)
+        copy_frames_fix_ts(j.dst + j.n_new, w.frames + j.drop, j.keep, j.ts_sub);
 }
 
 void run_streams(Worker &w, const Job &j, uint64_t piece)
@@ -332,6 +362,40 @@ void run_streams(Worker &w, const Job &j, uint64_t piece)
     }
 }
 
+// The worker consumes its handle's hand-off stream: memory the device writes, polled and resolved while the kernel runs
+// (DESIGN.md section 4).  From a core on the other socket that work was measured 3 x slower (1.90 against 0.61 ms of host
+// time per 1 Gi samples: profiles/r4_ab_runs.txt) and the worker, not the kernel, bounded the step.  So every worker
+// moves to the CPUs of its device's NUMA node -- those of them the process is allowed to use.  Best effort.
+bool bind_near_device(int device)
+{
+    char list[1024];
+    if (adsb_device_cpulist(device, list, sizeof list) <= 0)
+        return false;
+    cpu_set_t allowed, want;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0)
+        return false;
+    CPU_ZERO(&want);
+    int n = 0;
+    for (const char *p = list; *p;) { // "a-b,c,d-e"
+        char *e;
+        const long a = strtol(p, &e, 10);
+        if (e == p)
+            return false;
+        long b = a;
+        if (*e == '-')
+            b = strtol(e + 1, &e, 10);
+        for (long k = a; k <= b && k < CPU_SETSIZE; k++)
+            if (CPU_ISSET((int)k, &allowed)) {
+                CPU_SET((int)k, &want);
+                n++;
+            }
+        p = (*e == ',') ? e + 1 : e;
+        if (*e && *e != ',')
+            break;
+    }
+    return n > 0 && pthread_setaffinity_np(pthread_self(), sizeof want, &want) == 0;
+}
+
 void worker_main(Worker *w, uint64_t piece)
 {
     {   // the handle is created here, on the worker's own thread: the devices' runtimes come up side by side
@@ -342,14 +406,19 @@ void worker_main(Worker *w, uint64_t piece)
         w->dec = adsb_create(&cfg);
         if (!w->dec)
             w->fail_dec("adsb_create");
+        else
+            w->bound = bind_near_device(w->device); // (before the first launch allocates the handle's pinned buffers)
         w->create_ms = ms_since(t0);
         std::lock_guard<std::mutex> lk(w->mu);
         w->done = 1; // "job" 1 is the start-up
+        w->done_a.store(1, std::memory_order_release);
         w->cv.notify_all();
     }
     uint64_t seen = 1;
     for (;;) {
         Job j;
+        for (const auto t0 = clk::now(); w->posted_a.load(std::memory_order_acquire) <= seen && ms_since(t0) < kWorkerSpinMs;)
+            relax_burst();
         {
             std::unique_lock<std::mutex> lk(w->mu);
             w->cv.wait(lk, [&] { return w->posted > seen; });
@@ -366,14 +435,18 @@ void worker_main(Worker *w, uint64_t piece)
                 w->fail("device %d (worker %d): no decoder handle (adsb_create failed at start-up)", w->device, w->index);
             else if (j.kind == JobKind::Shard)
                 run_shard(*w, j, piece);
+            else if (j.kind == JobKind::Gather)
+                run_gather(*w, j);
             else if (j.kind == JobKind::Stream)
                 run_streams(*w, j, piece);
         } catch (const std::exception &e) { // (bad_alloc of a result vector: the job fails, the thread lives)
             w->fail("device %d (worker %d): %s", w->device, w->index, e.what());
         }
-        w->ms = ms_since(t0);
+        if (j.kind != JobKind::Gather)
+            w->ms = ms_since(t0);
         std::lock_guard<std::mutex> lk(w->mu);
         w->done = seen;
+        w->done_a.store(seen, std::memory_order_release);
         w->cv.notify_all();
     }
     if (w->dec)
@@ -388,11 +461,18 @@ void post(Worker &w, const Job &j)
     std::lock_guard<std::mutex> lk(w.mu);
     w.job = j;
     w.posted++;
+    w.posted_a.store(w.posted, std::memory_order_release);
     w.cv.notify_all();
 }
 
-void wait_done(Worker &w)
+void wait_done(Worker &w, double spin_ms = 0)
 {
+    const uint64_t want = w.posted_a.load(std::memory_order_relaxed); // (this thread posted it)
+    for (const auto t0 = clk::now(); spin_ms > 0 && ms_since(t0) < spin_ms;) {
+        if (w.done_a.load(std::memory_order_acquire) == want)
+            return;
+        relax_burst();
+    }
     std::unique_lock<std::mutex> lk(w.mu);
     w.cv.wait(lk, [&] { return w.done == w.posted; });
 }
@@ -508,6 +588,8 @@ long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices,
         m->new_frames.resize(m->new_frames.size() * 8); // (-1 is also "new_cap too small": seams that accept many frames)
     }
     m->info.shards = n;
+    for (int i = 0; i < n; i++)
+        m->info.workers_bound += m->w[i]->bound ? 1 : 0;
     m->info.calls_walked = ws[0];
     m->info.calls_jumped = ws[1];
     m->info.workers_ms = worker_ms;
@@ -530,16 +612,31 @@ long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices,
         count += (size_t)(fix[i].n_new + fix[i].keep);
     m->out.resize(count);
     adsb_frame *o = m->out.data();
+    // The gather: shard i's final frames are new_frames[new_first ..] and its speculative frames from drop_front on, with
+    // the shard's ts offset taken off.  Every worker copies its own share (it is awake: it has just finished), also when
+    // there is only one: the frames lie in the worker's handle, whose resolver rewrites that memory during the next call --
+    // read from the calling thread, on another core or socket, every line of it had to be fetched back first (measured: the
+    // worker's host time per 1 Gi samples went from 0.55 to 1.9 ms, and it, not the kernel, bounded the step).  Only a
+    // handful of frames is not worth a hand-over.
+    const bool spread = count >= 2048;
     for (int i = 0; i < n; i++) {
-        if (fix[i].n_new)
-            std::memcpy(o, m->new_frames.data() + fix[i].new_first, fix[i].n_new * sizeof(adsb_frame));
-        o += fix[i].n_new;
-        if (fix[i].keep) {
-            std::memcpy(o, m->w[i]->frames + fix[i].drop_front, fix[i].keep * sizeof(adsb_frame));
-            adsb_shard_apply_fix(o, (size_t)fix[i].keep, fix[i].ts_sub); // demod.c:86,99: ts counts from the stream's start
-        }
-        o += fix[i].keep;
+        Job g;
+        g.kind = JobKind::Gather;
+        g.dst = o;
+        g.new_src = m->new_frames.data() + fix[i].new_first;
+        g.n_new = fix[i].n_new;
+        g.drop = fix[i].drop_front;
+        g.keep = fix[i].keep;
+        g.ts_sub = fix[i].ts_sub;
+        if (spread)
+            post(*m->w[i], g);
+        else
+            run_gather(*m->w[i], g);
+        o += fix[i].n_new + fix[i].keep;
     }
+    if (spread)
+        for (int i = 0; i < n; i++)
+            wait_done(*m->w[i], kGatherSpinMs);
     m->have_stats = stats;
     m->info.stitch_us = stitch_us;
     m->info.serial_us = 1e3 * ms_since(t_serial);
@@ -621,6 +718,7 @@ adsb_multi *adsb_multi_create(const adsb_config *cfg_in, int n_devices, const in
         std::unique_lock<std::mutex> lk(w->mu);
         w->cv.wait(lk, [&] { return w->done >= 1; });
         w->posted = 1;
+        w->posted_a.store(1, std::memory_order_release);
         if (!w->dec && ok) {
             g_multi_create_error = w->err;
             ok = false;

@@ -76,7 +76,12 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
 {
     if (!parts || n_parts <= 0 || !fix || !n_new_total || (new_cap && !new_frames))
         return -1;
-    int64_t tries[3] = {0, 0, 0};
+    int64_t tries[3] = {0, 0, 0}, oks[3] = {0, 0, 0}, fixed = 0; // (oks / fixed: valid.c:53,75 over the final frames)
+    auto count_ok = [&](const adsb_frame &f, int sign) {
+        const unsigned df = f.frame[0] >> 3;
+        oks[df == 11 ? 0 : df == 17 ? 1 : 2] += sign;
+        fixed += sign * (int)(f.reserved & 1u);
+    };
     std::vector<uint64_t> entry(stats ? (size_t)n_parts : 0); // per shard: offsets below are jumped by a frame of an earlier shard
     size_t n_new = 0;
     uint64_t skipped_global = 0; // offsets jumped by all final frames before the current shard
@@ -134,8 +139,15 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
         if (stats) {
             if (!h.has_tries)
                 return -1;
-            for (int k = 0; k < 3; k++)
+            for (int k = 0; k < 3; k++) {
                 tries[k] += (int64_t)h.tries[k];
+                oks[k] += (int64_t)h.ok[k];
+            }
+            fixed += (int64_t)h.fixed;
+            for (uint64_t q = 0; q < drop; q++) // the shard counted its speculative frames: the repair's verdict
+                count_ok(F[q], -1);
+            for (size_t q = new_first; q < n_new; q++)
+                count_ok(new_frames[q], +1);
             entry[i] = e_prev > h.g_begin ? e_prev : h.g_begin;
             if (e_prev > h.g_begin) {
                 // The shard counted its tries against its speculative frames.  From e_prev on the true chain is the frames
@@ -286,12 +298,18 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
     for (int p = n_parts - 1; p >= 0; p--) {
         adsb_shard_fix &x = fix[p];
         const adsb_frame *F = parts[p].frames + x.drop_front;
-        while (x.keep && F[x.keep - 1].g >= horizon)
+        while (x.keep && F[x.keep - 1].g >= horizon) {
+            if (stats)
+                count_ok(F[x.keep - 1], -1);
             x.keep--;
+        }
         if (x.keep)
             break;
-        while (x.n_new && new_frames[x.new_first + x.n_new - 1].g >= horizon)
+        while (x.n_new && new_frames[x.new_first + x.n_new - 1].g >= horizon) {
+            if (stats)
+                count_ok(new_frames[x.new_first + x.n_new - 1], -1);
             x.n_new--;
+        }
         if (x.n_new)
             break;
     }
@@ -299,17 +317,12 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         for (int k = 0; k < 3; k++) {
-            if (tries[k] < 0)
+            if (tries[k] < 0 || oks[k] < 0)
                 return -1;
             stats->try_[k] = (uint64_t)tries[k];
+            stats->ok[k] = (uint64_t)oks[k];
         }
-        for (int p = 0; p < n_parts; p++)
-            for (uint64_t q = 0; q < fix[p].n_new + fix[p].keep; q++) { // valid.c:53,75
-                const adsb_frame &f = frame_at(p, q);
-                const unsigned df = f.frame[0] >> 3;
-                stats->ok[df == 11 ? 0 : df == 17 ? 1 : 2]++;
-                stats->fixed += f.reserved & 1u;
-            }
+        stats->fixed = (uint64_t)(fixed < 0 ? 0 : fixed);
     }
     return 0;
 }

@@ -305,6 +305,8 @@ typedef struct adsb_shard_head {
     uint64_t tries[3];       /* valid.c:46,68 for the offsets of this shard as the SPECULATIVE chain visits them: DF-gate
                                 passes in [g_begin, g_end) that lie in no speculative frame, per DF (11, 17, 18); counted
                                 on the device.  adsb_stitch_shards_stats turns the sum into the stream's Try row. */
+    uint64_t ok[3];          /* valid.c:53,75 for the speculative frames, per DF; the stitcher corrects the sum for the   */
+    uint64_t fixed;          /* frames a seam repair or the horizon drops and adds (fixed: of them, 1-bit repaired)       */
 } adsb_shard_head;
 
 typedef struct adsb_shard_part { /* one shard as the stitcher sees it (plain host pointers, e.g. into shared memory) */
@@ -342,6 +344,12 @@ int adsb_scan_shard_resolved_walk(adsb_decoder *d, const void *device_samples, u
                                   uint64_t g_begin, uint64_t g_end, uint64_t total_samples, adsb_shard_head *head,
                                   adsb_frame *frames, size_t frame_cap, adsb_candidate *head_cands, size_t head_cap,
                                   uint64_t *bases, size_t bases_cap);
+/* adsb_scan_shard_resolved_walk without the copies: the shard's speculative frames and head candidates are handed out IN
+ * PLACE (like adsb_shard_end does for a shard fed piecewise) and stay valid until the next call on the handle that scans,
+ * pushes or resets.  The call resets the handle first (a stream it held is dropped). */
+int adsb_scan_shard_resolved_take(adsb_decoder *d, const void *device_samples, uint64_t first_sample, size_t n,
+                                  uint64_t g_begin, uint64_t g_end, uint64_t total_samples, adsb_shard_head *head,
+                                  const adsb_frame **frames, const adsb_candidate **head_cands, uint64_t *bases, size_t bases_cap);
 /* A shard's own walk of the deqframe call chain over its speculative frames (each rank, in parallel, after its scan):
  * fills bases[0 .. min(cap, n)) and head->n_bases / walk_final; returns n (> cap: too small, n_bases is left 0). */
 size_t adsb_shard_walk(adsb_shard_head *head, const adsb_frame *frames, uint64_t total_samples, uint64_t *bases, size_t cap);
@@ -388,6 +396,14 @@ size_t adsb_resolver_walk_result(const adsb_resolver *r, int *final);
 long adsb_resolver_head(adsb_resolver *r, adsb_candidate *out, size_t cap);
 uint64_t adsb_resolver_skipped(const adsb_resolver *r);
 
+/* The CPUs that are local to HIP device `device` (the GPU's NUMA node), as the kernel prints them
+ * (/sys/bus/pci/devices/<bdf>/local_cpulist, e.g. "0-63,128-191"), into out.  Why a host wants it: the thread that feeds a
+ * handle polls memory the device writes (the hand-off stream); on the far socket of a two-socket
+ * host that thread was measured 2.5-3 x slower.  adsb_multi_create binds its workers with it; a host with threads of its
+ * own does the same for the thread that calls adsb_push*.  Returns the string's length, 0 when the platform does not say
+ * (numa_node = -1), -1 on error. */
+int adsb_device_cpulist(int device, char *out, size_t cap);
+
 /* ---- ONE process, several GPUs (csrc/multi.cpp) ---------------------------------------------------------------
  * The host of BASELINE configs[3] / configs[4]: a worker thread and a decoder handle per device; no collective on the
  * data path.  Stands where fileInput's loop (air.c:217-246) hands its buffers to decodeiq and the frames
@@ -405,6 +421,8 @@ typedef struct adsb_multi_info { /* of the last adsb_multi_decode_* call */
     double stitch_us;      /* adsb_stitch_shards[_stats] on the calling thread                                        */
     double serial_us;      /* everything behind the last worker: stitch + gather into one array                       */
     double total_ms;
+    int32_t workers_bound; /* workers whose thread runs on the CPUs of its device's NUMA node (adsb_device_cpulist)       */
+    int32_t reserved;
 } adsb_multi_info;
 
 /* n_devices workers; devices[i] = HIP ordinal of worker i (NULL: 0 .. n_devices-1).  An ordinal may repeat: several

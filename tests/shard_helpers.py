@@ -115,6 +115,8 @@ def from_candidates(capi, cands, total, n_shards, head_span=16384, tries=None, w
             fin = C.c_int(0)
             nb = int(L.adsb_resolver_walk_result(r._h, C.byref(fin)))
             hd.n_bases, hd.walk_final = (nb if nb <= cap else 0), fin.value
+        ok = r.stats()["ok"]
+        hd.ok[0], hd.ok[1], hd.ok[2] = ok[11], ok[17], ok[18]
         if tr is not None:
             st = r.stats()["try"]
             hd.has_tries = 1

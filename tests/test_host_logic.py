@@ -26,8 +26,8 @@ def test_struct_layouts_match_header(capi):
     import ctypes as C
     assert C.sizeof(capi.Frame) == 40 and C.sizeof(capi.Candidate) == 32
     assert C.sizeof(capi.Stats) == 56
-    assert C.sizeof(capi.ShardHead) == 13 * 8 and C.sizeof(capi.ShardPart) == 10 * 8 and C.sizeof(capi.ShardFix) == 40
-    assert C.sizeof(capi.MultiInfo) == 64
+    assert C.sizeof(capi.ShardHead) == 17 * 8 and C.sizeof(capi.ShardPart) == 10 * 8 and C.sizeof(capi.ShardFix) == 40
+    assert C.sizeof(capi.MultiInfo) == 72
     assert capi.Frame.frame.offset == 21 and capi.Candidate.frame.offset == 13
 
 
