@@ -403,11 +403,10 @@ void worker_main(Worker *w, uint64_t piece)
         adsb_config cfg = w->cfg;
         cfg.device = w->device;
         cfg.stream = nullptr;
+        w->bound = bind_near_device(w->device); // first: the handle's page-locked buffers are then allocated from this thread's node
         w->dec = adsb_create(&cfg);
         if (!w->dec)
             w->fail_dec("adsb_create");
-        else
-            w->bound = bind_near_device(w->device); // (before the first launch allocates the handle's pinned buffers)
         w->create_ms = ms_since(t0);
         std::lock_guard<std::mutex> lk(w->mu);
         w->done = 1; // "job" 1 is the start-up

@@ -281,7 +281,17 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
                 (parts[p].n_tail_tries && !parts[p].tail_tries))
                 return -3;
             const uint64_t n_here = fix[p].n_new + fix[p].keep;
-            uint64_t q = 0;
+            // the first frame that can still cover an offset at or beyond the horizon starts above horizon - 1200: seek it
+            // (the frames lie in another thread's memory: walking all of them from here is what must not happen)
+            uint64_t q = 0, hi_q = n_here;
+            const uint64_t from = horizon >= ADSB_DECOFFSET ? horizon - ADSB_DECOFFSET : 0;
+            while (q < hi_q) {
+                const uint64_t mid = (q + hi_q) / 2;
+                if (frame_at(p, mid).g < from)
+                    q = mid + 1;
+                else
+                    hi_q = mid;
+            }
             for (uint64_t t = 0; t < parts[p].n_tail_tries; t++) {
                 const uint64_t g = parts[p].tail_tries[t] >> 2;
                 if (g < horizon)
