@@ -445,40 +445,88 @@ def preamble_pass_fraction(x_host: np.ndarray, n=4 << 20):
     return float(np.mean((p1 > 2 * s1) & (p2 > 2 * s2)))
 
 
-def cli_whole_process(x_host: np.ndarray, capi, df18: bool):
-    """The C host program (the actual drop-in: reader thread, async pushes, AVR to stdout, Try/Ok table) on the
-    capture as a file: wall time of the whole process, exec to exit, and its own clock's split."""
+def cli_whole_process(x_host: np.ndarray, capi, df18: bool, sizes=(16 << 20, 64 << 20, 256 << 20)):
+    """The C host program (the actual drop-in: reader thread, async pushes, AVR to stdout, Try/Ok table) on files of three
+    sizes: wall time of the whole process, exec to exit, with the reference's own wall time on the same file beside it
+    (oracle/_ref/ref_adsbdec, one core) -- and from the two, the file size below which the CPU finishes first."""
     import subprocess
     if not os.path.exists(capi.CLI_PATH):
         return None
+    from oracle import oracle as O
+    have_ref = O.ref_available()
     path = ("/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp") + f"/adsb_bench_cli_{os.getpid()}.u16"
-    x_host.tofile(path)
-    try:
+    flags = ["-a"] if df18 else []
+
+    def run_cli(extra_args, env_extra=None):
         walls, inits, decodes, frames = [], [], [], None
         for _ in range(3):
             t0 = time.perf_counter()
-            p = subprocess.run([capi.CLI_PATH] + (["-a"] if df18 else []) + ["-f", path], capture_output=True,
-                               env=dict(os.environ, ADSB_CLI_TIMING="1"))
+            p = subprocess.run([capi.CLI_PATH] + flags + extra_args + ["-f", path], capture_output=True,
+                               env=dict(os.environ, ADSB_CLI_TIMING="1", **(env_extra or {})))
             walls.append(time.perf_counter() - t0)
             if p.returncode != 0:
-                return {"error": p.stderr.decode()[-300:]}
+                raise RuntimeError(p.stderr.decode()[-300:])
             frames = p.stdout.count(b"\n")
             for ln in p.stderr.decode().splitlines():
                 if ln.startswith("timing:"):
                     f = ln.replace(",", " ").split()
                     inits.append(float(f[3]))
                     decodes.append(float(f[6]))
-        wall = sorted(walls)[1]
-        return {"what": "adsbdec_amd_cli -f <capture as a tmpfs file>: whole process, exec to exit, median of 3 (AVR lines to a "
-                        "pipe, Try/Ok table on stderr)", "samples": int(x_host.size), "frames": frames,
-                "wall_ms": round(wall * 1e3, 1), "value": round(x_host.size / wall / 1e6, 1), "unit": "Msamples/s",
-                "runtime_init_ms": round(sorted(inits)[len(inits) // 2], 1) if inits else None,
-                "decode_ms": round(sorted(decodes)[len(decodes) // 2], 1) if decodes else None,
-                "init_share": "the dynamic loader + the GPU runtime's start (runtime_init_ms, measured from main(); the loader "
-                              "adds ~0.1 s in front of it) are most of the wall time; decode_ms is reading, copying, scanning "
-                              "and writing the whole capture once the runtime is up"}
+        med = lambda v: round(sorted(v)[len(v) // 2], 1) if v else None
+        return {"wall_ms": round(sorted(walls)[1] * 1e3, 1), "runtime_init_ms": med(inits), "decode_ms": med(decodes), "frames": frames}
+
+    out = {"what": "adsbdec_amd_cli -f <capture as a tmpfs file>: whole process, exec to exit, median of 3 (AVR lines to a pipe, "
+                   "Try/Ok table on stderr); reference_wall_ms: oracle/_ref/ref_adsbdec (the real chain, one core) on the same file, "
+                   "once", "unit": "Msamples/s", "files": {}}
+    try:
+        pts = []
+        for n in sizes:
+            n = min(n, x_host.size)
+            n -= n % 4
+            x_host[:n].tofile(path)
+            rec = run_cli([])
+            rec["value"] = round(n / rec["wall_ms"] / 1e3, 1)
+            if have_ref:
+                t0 = time.perf_counter()
+                p = subprocess.run([O.REF_ADSBDEC] + flags + [path], capture_output=True)
+                rec["reference_wall_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+                if p.stdout.count(b"\n") != rec["frames"]:
+                    raise SystemExit(f"PARITY FAILURE: the C host program printed {rec['frames']} frames, the reference {p.stdout.count(chr(10).encode())}")
+                rec["speedup_vs_reference"] = round(rec["reference_wall_ms"] / rec["wall_ms"], 2)
+            out["files"][f"{n >> 20}Mi"] = rec
+            pts.append((n, rec["wall_ms"], rec.get("reference_wall_ms")))
+            if n == x_host.size:
+                break
+        big_n = pts[-1][0]
+        last = out["files"][f"{big_n >> 20}Mi"]
+        # the largest file again with every device of the node visible to the runtime (what round 3's program did), and through
+        # the multi-GPU driver with two handles on this device (-G 0,0): same bytes, the driver's start-up beside the plain one
+        out["largest_file_all_devices_visible"] = run_cli([], {"ADSB_CLI_ALL_DEVICES": "1"})
+        out["largest_file_G_0_0"] = run_cli(["-G", "0,0"])
+        out.update({"samples": big_n, "frames": last["frames"], "wall_ms": last["wall_ms"], "value": last["value"],
+                    "runtime_init_ms": last["runtime_init_ms"], "decode_ms": last["decode_ms"]})
+        if have_ref and len(pts) >= 2:
+            (n0, g0, c0), (n1, g1, c1) = pts[0], pts[-1]
+            b = (g1 - g0) / (n1 - n0)            # ms per sample once the process is up
+            a = g0 - b * n0                      # what it costs to get there: loader + GPU runtime
+            c = c1 / n1                          # the reference: proportional to the file
+            if c > b:
+                n_star = a / (c - b)
+                out["crossover"] = {"samples": int(n_star), "file_MB": round(2 * n_star / 1e6), "seconds_of_signal": round(n_star / 20e6, 1),
+                                    "startup_ms": round(a, 1), "gpu_ms_per_Mi_samples": round(b * (1 << 20), 4),
+                                    "reference_ms_per_Mi_samples": round(c * (1 << 20), 4),
+                                    "what": "below this file size the reference's single CPU thread finishes before this program: "
+                                            "wall = startup + samples x rate for this program (fitted to the smallest and largest file), "
+                                            "samples x rate for the reference"}
+        out["init_share"] = ("the dynamic loader + the GPU runtime's start (runtime_init_ms, measured from main(); the loader adds "
+                             "~0.1 s in front of it) are most of the wall time; decode_ms is reading, copying, scanning and writing "
+                             "the whole capture once the runtime is up")
+        return out
+    except RuntimeError as e:
+        return {"error": str(e)}
     finally:
-        os.unlink(path)
+        if os.path.exists(path):
+            os.unlink(path)
 
 
 def multi_stream_host_fed(torch, capi, x_dev, df18, counts=(1, 2, 4)):
@@ -644,6 +692,8 @@ def main():
     ap.add_argument("--bind-cpu", choices=["on", "off"], default="on",
                     help="bind this rank's host threads to the CPUs of its GPU's NUMA node (on a two-socket host an unbound "
                          "run is sometimes 20 %% slower: profiles/r3_ab_runs.txt)")
+    ap.add_argument("--die-rank", type=int, default=-1, help=argparse.SUPPRESS)   # test hook: that rank vanishes (os._exit) in front of
+    #                                                                                the timed region; the job must end non-zero, not hang
     ap.add_argument("--one-device-test", action="store_true",
                     help="plumbing test only: every rank uses GPU 0 and gloo (numbers are meaningless)")
     args = ap.parse_args()
@@ -752,6 +802,8 @@ def main():
         i += 1
     for i in range(args.warmup):
         step(i)
+    if args.die_rank == rank and world > 1:
+        os._exit(9)
 
     fence()
     p0 = dec.profile()  # counters accumulate over the handle's life: take differences
@@ -765,6 +817,21 @@ def main():
     frames = capi._frames_to_dicts(raw[0], raw[1])
     p1 = dec.profile()
     roofline, roofline_valu = roofline_objects(p0, p1, args.steps, "r3_dense" if args.dense else "r3", clock, dt / args.steps * 1e3)
+
+    # ---- the same step 1000 more times (the driver's default is 20 steps = 3 ms of measurement; box-to-box the kernel
+    # spreads by 7 %): a sturdier sample of the same quantity, every rank, same fences
+    steady = None
+    if not args.no_extras:
+        q0 = dec.profile()
+        with ClockSampler(local_rank) as sampler2:
+            dt2, _ = timed_steps(step, 1000, fence, torch.cuda.synchronize)
+        dt2 = max_over_ranks(dt2)
+        q1 = dec.profile()
+        roof2, _ = roofline_objects(q0, q1, 1000, "r3_dense" if args.dense else "r3", sampler2.ghz(), dt2 / 1000 * 1e3)
+        steady = {"steps": 1000, "value": round(world * n * 1000 / dt2 / 1e6, 1), "unit": "Msamples/s",
+                  "ms_per_step": round(dt2 / 1000 * 1e3, 4), "launch_ms": roof2["launch_ms"], "roofline_frac": roof2["frac"],
+                  "what": "the timed region repeated with 1000 steps right behind the K steps of `value` (same captures in rotation, "
+                          "same fences): 0.15 s of measurement instead of 3 ms"}
 
     # every capture of the rotation, decoded once more and kept for the gate
     per_capture = []
@@ -905,7 +972,7 @@ def main():
                 "what": "the like-for-like figure of the drop-in: the same step with collect_stats=1, which is what the C host "
                         "program and the INTEGRATION.md patch run (the reference always keeps and prints valid.c's Try/Ok table); "
                         "`value` is the step without that table"},
-            "value_cold": value_cold, "with_stats": with_stats, "dense": dense, "e2e_host_fed": e2e,
+            "value_cold": value_cold, "value_1000_steps": steady, "with_stats": with_stats, "dense": dense, "e2e_host_fed": e2e,
             "multi_stream_host_fed": multi, "e2e_host_fed_sharded": sharded, "cli_whole_process": cli,
         }
         emit_line(line)

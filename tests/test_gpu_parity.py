@@ -882,6 +882,35 @@ def test_two_rank_independent_streams_are_gated_on_every_rank():
 
 
 # ------------------------------------------------------------------ size-independent properties
+def test_eight_ranks_on_one_device(capi):
+    """The driver's command shape at N = 8 (`python bench.py --gpus 8`: eight processes, one stream and one handle each, gloo
+    for the barriers / the max of the times / the AND of the parity flags), with every rank on this box's one GPU: the
+    plumbing an 8-GPU node runs, minus the other seven devices.  Every rank gates its captures against the oracle."""
+    line = _bench_line(["--gpus", "8", "--one-device-test", "--samples", str(8 << 20), "--steps", "3", "--warmup", "1",
+                        "--preroll-ms", "0", "--no-extras"], timeout=1200)
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert line["config"]["parity_vs_cpu"] is True and line["config"]["ranks_gated"] == 8
+    assert line["cpu_baseline"]["value"] > 0
+
+
+def test_a_rank_that_dies_ends_the_job(capi):
+    """Rank 1 of 3 vanishes (os._exit, no goodbye -- what an OOM kill looks like) right in front of the timed region.  The job
+    must end non-zero within the deadline instead of hanging in a barrier, and the report must name the rank."""
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--one-device-test", "--samples", str(8 << 20), "--steps", "3",
+                        "--warmup", "1", "--preroll-ms", "0", "--no-extras", "--die-rank", "1"], cwd=root, capture_output=True,
+                       timeout=600, env=env)
+    assert p.returncode != 0
+    assert time.time() - t0 < 300
+    err = p.stderr.decode()
+    assert ("rank      : 1" in err or "rank: 1" in err or "local_rank: 1" in err) and "exitcode  : 9" in err.replace("exitcode: 9", "exitcode  : 9"), err[-2500:]
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.strip().startswith("{")], "no JSON line may come out of a failed job"
+
+
 def test_round_trip_at_scale(dec_factory, torch_cuda):
     """64 Mi samples generated on the device: every injected, well-separated frame
     must come back exactly once, in order, with ts == g+1-skipped (a checksum of the
