@@ -10,7 +10,7 @@ CSRC     := adsbdec_amd/csrc
 LIBDIR   := adsbdec_amd/lib
 LIB      := $(LIBDIR)/libadsbdec_amd.so
 CLI      := $(LIBDIR)/adsbdec_amd_cli
-HDRS     := $(CSRC)/scan_kernel.h $(CSRC)/resolver.hpp $(CSRC)/stitch.hpp include/adsbdec_amd.h
+HDRS     := $(CSRC)/scan_kernel.h $(CSRC)/scan_kernel_format.h $(CSRC)/handoff.hpp $(CSRC)/resolver.hpp $(CSRC)/stitch.hpp include/adsbdec_amd.h
 
 all: $(LIB) $(CLI)
 
@@ -22,11 +22,11 @@ $(LIBDIR)/format.c.o: $(CSRC)/format.c $(HDRS)
 	@mkdir -p $(LIBDIR)
 	$(CC) -O2 -fPIC -Wall -c $< -o $@
 
-$(LIBDIR)/multi.cpp.o: $(CSRC)/multi.cpp $(HDRS)
+$(LIBDIR)/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(LIBDIR)
 	g++ -O2 -fPIC -std=c++17 -Wall -Wextra -pthread -c $< -o $@
 
-$(LIB): $(LIBDIR)/scan_kernel.hip.o $(LIBDIR)/decoder.hip.o $(LIBDIR)/format.c.o $(LIBDIR)/multi.cpp.o
+$(LIB): $(LIBDIR)/scan_kernel.hip.o $(LIBDIR)/decoder.hip.o $(LIBDIR)/format.c.o $(LIBDIR)/multi.cpp.o $(LIBDIR)/host_abi.cpp.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm -lpthread
 
 $(CLI): $(CSRC)/cli/adsbdec_amd_cli.c $(LIB) include/adsbdec_amd.h

@@ -384,8 +384,11 @@ int main(int argc, char **argv)
     if (rg.fd >= 0) { /* an unopenable file ends the run silently (air.c:225-228) */
         struct stat sb;
         unsigned long long size = (fstat(rg.fd, &sb) == 0 && sb.st_size > 0) ? (unsigned long long)sb.st_size : 0;
-        if (size > RING_MAX_BYTES || size == 0)
-            size = RING_MAX_BYTES; /* pipes and huge files: a bounded ring, the reader waits for free buffers */
+        unsigned long long ring_max = RING_MAX_BYTES;
+        if (getenv("ADSB_CLI_RING_MB") && atoll(getenv("ADSB_CLI_RING_MB")) >= 96) /* (measurement knob of this program, not of the library) */
+            ring_max = (unsigned long long)atoll(getenv("ADSB_CLI_RING_MB")) << 20;
+        if (size > ring_max || size == 0)
+            size = ring_max; /* pipes and large files: a bounded ring, the reader waits for free buffers */
         rg.nbuf = (int)(size / ((unsigned long long)BUF_SAMPLES * 2)) + 2;
         if (rg.nbuf < 3)
             rg.nbuf = 3;

@@ -44,6 +44,7 @@
 #include <sched.h>
 
 #include "../../include/adsbdec_amd.h"
+#include "handoff.hpp"
 #include "resolver.hpp"
 #include "scan_kernel.h"
 #include "stitch.hpp"
@@ -127,9 +128,6 @@ struct ScanSink { // where collected records go: a caller's vectors, or (null) t
     std::vector<uint64_t> *tries = nullptr;
 };
 
-namespace {
-struct StreamReader;
-}
 
 struct adsb_decoder {
     adsb_config cfg{};
@@ -170,7 +168,7 @@ struct adsb_decoder {
     adsb_profile prof{};
     adsb::Resolver res;
     std::vector<uint32_t> order, scratch_a, scratch_b, gather, tile_start, tile_count;
-    StreamReader *reader = nullptr;    // cfg.host_threads = 2: the thread that reads the hand-off stream (slot_collect_streaming)
+    adsb::StreamReader *reader = nullptr;    // cfg.host_threads = 2: the thread that reads the hand-off stream (slot_collect_streaming)
     uint32_t reader_min_tiles = 1024; // launches below this many tiles are collected by the calling thread alone
     bool no_streaming = false; // cfg.debug_no_streaming: always collect after completion
     uint64_t shard_head = 16384; // offsets of a resolved shard whose candidates are ALL kept for the stitcher (cfg.debug_shard_head)
@@ -543,279 +541,26 @@ void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uin
     }
 }
 
-// The reading side of the streaming collect: where the host stands in a launch's hand-off stream.
-struct HandCursor {
-    using clk = std::chrono::steady_clock;
-    struct View { // the launch's stream: where it lies, how many tiles write into it, the launch's tag, its size in granules
-        const uint32_t *hand;
-        uint32_t ntiles;
-        hipEvent_t ev_ready; // behind the launch (null: nothing will ever complete these bytes -- adsb_handoff_walk)
-    } s;
-    uint32_t *t_start, *t_count; // per tile: granule index of its first record, and its record count (~0u: not in yet)
-    const uint32_t gen, cap;
-    uint32_t pos = 0;      // granules of the stream consumed
-    uint32_t frontier = 0; // every tile below is in
-    uint32_t tile = 0, nf = 0; // the marker tile_in() accepted last
-    double wait_ms = 0;
-    clk::time_point t_last_wait;
+// (the reading side of the hand-off stream -- HandCursor, StreamReader, the two consumer loops -- is host-only code:
+// handoff.hpp)
 
-    HandCursor(const ScanSlot &slot, uint32_t *ts, uint32_t *tc)
-        : s{slot.hand, slot.ntiles, slot.ev_ready[slot.ev_cur]}, t_start(ts), t_count(tc), gen(slot.args.gen),
-          cap(slot.args.hand_cap), t_last_wait(clk::now())
-    {
-    }
-    HandCursor(const uint32_t *stream, uint32_t granules, uint32_t ntiles, uint32_t gen_, uint32_t *ts, uint32_t *tc)
-        : s{stream, ntiles, nullptr}, t_start(ts), t_count(tc), gen(gen_), cap(granules), t_last_wait(clk::now())
-    {
-    }
-    // marker {tile, n | flags, check}: valid once it and the XOR of the 2n granules
-    // behind it agree (16-byte loads; the bytes are re-read on every poll)
-    bool tile_in()
-    {
-        const __m128i *gp = reinterpret_cast<const __m128i *>(s.hand) + pos;
-        std::atomic_signal_fence(std::memory_order_seq_cst); // compiler: re-read the bytes on every poll
-        const __m128i mk = _mm_load_si128(gp);
-        alignas(16) uint32_t mw[4], a[4];
-        _mm_store_si128(reinterpret_cast<__m128i *>(mw), mk);
-        tile = mw[0], nf = mw[1];
-        const uint32_t n = nf & 0xFFFFu;
-        const bool fits = !(nf & adsb::kMarkNoFit);
-        if (tile >= s.ntiles || (fits && (uint64_t)pos + 1 + 2ull * n > cap))
-            return false; // not a marker of this launch (yet)
-        __m128i acc = _mm_setzero_si128();
-        if (fits)
-            for (uint32_t k = 1; k <= 2 * n; k++)
-                acc = _mm_xor_si128(acc, _mm_load_si128(gp + k));
-        _mm_store_si128(reinterpret_cast<__m128i *>(a), acc);
-        uint32_t lo, hi;
-        adsb::marker_check(tile, nf, gen, a[0], a[1], a[2], a[3], lo, hi);
-        return mw[2] == lo && mw[3] == hi;
-    }
-    // spin until tile_in(); gives up (false) once the kernel has long finished
-    bool wait_tile()
-    {
-        constexpr int kPollPause = 4; // measured: 0..256 make no difference to the kernel or the step
-        if (tile_in())
-            return true;
-        if (!s.ev_ready)
-            return false;
-        const auto t_w = clk::now();
-        bool ok = false;
-        uint64_t after_done = 0;
-        for (uint64_t spins = 1;; spins++) {
-            if (tile_in()) {
-                ok = true;
-                break;
-            }
-            // a few pauses between polls: the line being re-read has to be pulled out of this
-            // core's cache by the very device write that is awaited
-            for (int k = 0; k < kPollPause; k++)
-                __builtin_ia32_pause();
-            if ((spins & 0x3F) == 0) {
-                const hipError_t q = hipEventQuery(s.ev_ready);
-                if (q != hipErrorNotReady && (q != hipSuccess || ++after_done > 2000))
-                    break; // the launch failed, or it completed long ago: the bytes will not come
-            }
-        }
-        t_last_wait = clk::now();
-        wait_ms += std::chrono::duration<double, std::milli>(t_last_wait - t_w).count();
-        return ok;
-    }
-    // Take the tile whose marker tile_in() just accepted.  0: taken; 1: it (or the stream) says "finish after
-    // completion"; -1: the stream is corrupt.
-    int take()
-    {
-        const uint32_t n = nf & 0xFFFFu;
-        if (t_count[tile] != ~0u)
-            return -1;
-        if (nf & (adsb::kMarkOver | adsb::kMarkNoFit))
-            return 1;
-        t_start[tile] = pos + 1;
-        t_count[tile] = n;
-        pos += std::max(adsb::marker_granules(nf), adsb::stream_granules(n)); // what the tile reserved (it may have kept fewer records than it reserved for)
-        while (frontier < s.ntiles && t_count[frontier] != ~0u)
-            frontier++;
-        return 0;
-    }
-};
-
-// A decoder's second host thread (cfg.host_threads = 2): it reads and checks the hand-off stream of the launch being
-// collected and publishes how far the stream is complete, while the calling thread resolves behind it.  One thread
-// doing both has ~125 us of work per 256 Mi-sample launch inside the ~105 us between the first tile's end and the
-// last one's, and ends 15-20 us behind the kernel; split, neither side is the bottleneck.  The thread spins for a
-// short while after a job (so that back-to-back launches find it awake), then sleeps.
-struct StreamReader {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::atomic<bool> sleeping{false}, quit{false};
-    std::atomic<uint32_t> job_seq{0};
-    int device = 0;
-    bool place = false; // keep the thread on the caller's L3 (place_reader_thread)
-    int placed_l3 = -1;
-    // the job (written by the caller before job_seq)
-    const ScanSlot *slot = nullptr;
-    uint32_t *t_start = nullptr, *t_count = nullptr;
-    // progress and result (written by the reader)
-    alignas(64) std::atomic<uint32_t> frontier{0};
-    alignas(64) std::atomic<uint32_t> done_seq{0};
-    int status = 0; // 0: every tile is in; 1: finish after completion; -1: stream corrupt; -2: the bytes never came
-    uint32_t pos = 0, stop_tile = 0;
-    double wait_ms = 0, busy_ms = 0;
-
-    static constexpr uint32_t kPublishEvery = 32; // tiles between two stores of `frontier` while the device is ahead
-
-    void run_job()
-    {
-        using clk = std::chrono::steady_clock;
-        const auto t0 = clk::now();
-        HandCursor cur(*slot, t_start, t_count);
-        uint32_t published = 0;
-        status = 0;
-        while (cur.frontier < slot->ntiles) {
-            if (cur.pos >= cur.cap) {
-                status = 1;
-                break;
-            }
-            if (!cur.tile_in()) {
-                if (cur.frontier != published) // the device is behind: hand over what is in before waiting
-                    frontier.store(published = cur.frontier, std::memory_order_release);
-                if (!cur.wait_tile()) {
-                    status = -2;
-                    break;
-                }
-            }
-            const int rc = cur.take();
-            if (rc != 0) {
-                status = rc;
-                break;
-            }
-            if (cur.frontier - published >= kPublishEvery)
-                frontier.store(published = cur.frontier, std::memory_order_release);
-        }
-        pos = cur.pos;
-        stop_tile = cur.tile;
-        wait_ms = cur.wait_ms;
-        busy_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count() - cur.wait_ms;
-        frontier.store(cur.frontier, std::memory_order_release);
-    }
-    void loop()
-    {
-        (void)hipSetDevice(device); // hipEventQuery in wait_tile()
-        uint32_t seen = 0;
-        for (;;) {
-            // spin for a while, then sleep
-            const auto t_idle = std::chrono::steady_clock::now();
-            for (uint32_t spins = 1; job_seq.load(std::memory_order_acquire) == seen && !quit.load(std::memory_order_relaxed); spins++) {
-                __builtin_ia32_pause();
-                if ((spins & 0xFF) == 0 && std::chrono::steady_clock::now() - t_idle > std::chrono::microseconds(kSpinUs)) {
-                    std::unique_lock<std::mutex> lk(mu);
-                    sleeping.store(true);
-                    cv.wait(lk, [&] { return quit.load() || job_seq.load() != seen; });
-                    sleeping.store(false);
-                }
-            }
-            if (quit.load())
-                return;
-            seen = job_seq.load(std::memory_order_acquire);
-            run_job();
-            done_seq.store(seen, std::memory_order_release);
-        }
-    }
-    static constexpr int kSpinUs = 400;
-    void post(const ScanSlot &s, uint32_t *ts, uint32_t *tc)
-    {
-        slot = &s, t_start = ts, t_count = tc;
-        frontier.store(0, std::memory_order_relaxed);
-        job_seq.fetch_add(1); // seq_cst, against `sleeping`
-        if (sleeping.load()) {
-            std::lock_guard<std::mutex> lk(mu);
-            cv.notify_one();
-        }
-    }
-    void stop()
-    {
-        if (!th.joinable())
-            return;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            quit.store(true);
-            cv.notify_one();
-        }
-        th.join();
-    }
-};
-
-// The reader thread is kept near the caller: on a core that shares the caller's L3 (the records it has checked are
-// read again by the resolver), but neither the caller's own core nor its SMT sibling.  Checked again at every job
-// (sched_getcpu is a vDSO call): a caller that has moved to another L3 takes the thread along -- left behind, on the
-// other socket of a two-socket host, the pair is 2.5 x slower than one thread.  Best effort; silent on failure.
-static bool read_cpu_list(const char *fmt, int c, cpu_set_t *out)
+// "has the launch behind these bytes ended?" for handoff.hpp: ctx is the launch's completion event
+int launch_done(void *ctx)
 {
-    char path[160], buf[1024];
-    snprintf(path, sizeof path, fmt, c);
-    FILE *f = fopen(path, "r");
-    if (!f)
-        return false;
-    const bool got = fgets(buf, sizeof buf, f) != nullptr;
-    fclose(f);
-    if (!got)
-        return false;
-    CPU_ZERO(out);
-    for (char *p = buf; *p && *p != '\n';) { // "a-b,c,d-e"
-        char *e;
-        const long a = strtol(p, &e, 10);
-        if (e == p)
-            return false;
-        long b = a;
-        if (*e == '-')
-            b = strtol(e + 1, &e, 10);
-        for (long k = a; k <= b && k < CPU_SETSIZE; k++)
-            CPU_SET((int)k, out);
-        p = (*e == ',') ? e + 1 : e;
-    }
-    return true;
+    const hipError_t q = hipEventQuery(static_cast<hipEvent_t>(ctx));
+    return q == hipErrorNotReady ? 0 : q == hipSuccess ? 1 : -1;
 }
 
-// the L3 a CPU belongs to, named by the lowest CPU that shares it (-1: unknown); sysfs is read once per CPU
-static int l3_of_cpu(int cpu)
+adsb::HandJob hand_job(const ScanSlot &s)
 {
-    static std::atomic<int> cache[CPU_SETSIZE]; // 0: not looked up yet; else id + 2
-    if (cpu < 0 || cpu >= CPU_SETSIZE)
-        return -1;
-    const int c = cache[cpu].load(std::memory_order_relaxed);
-    if (c != 0)
-        return c - 2;
-    cpu_set_t l3;
-    int id = -1;
-    if (read_cpu_list("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu, &l3))
-        for (int k = 0; k < CPU_SETSIZE; k++)
-            if (CPU_ISSET(k, &l3)) {
-                id = k;
-                break;
-            }
-    cache[cpu].store(id + 2, std::memory_order_relaxed);
-    return id;
-}
-
-// returns the L3 the thread was placed on (-1: not placed)
-static int place_reader_thread(std::thread &th, int cpu)
-{
-    if (cpu < 0)
-        return -1;
-    cpu_set_t l3, smt, allowed, want;
-    if (!read_cpu_list("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu, &l3) ||
-        !read_cpu_list("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu, &smt) ||
-        sched_getaffinity(0, sizeof allowed, &allowed) != 0)
-        return -1;
-    CPU_ZERO(&want);
-    int n = 0;
-    for (int k = 0; k < CPU_SETSIZE; k++)
-        if (CPU_ISSET(k, &l3) && CPU_ISSET(k, &allowed) && !CPU_ISSET(k, &smt))
-            CPU_SET(k, &want), n++;
-    if (n == 0 || pthread_setaffinity_np(th.native_handle(), sizeof want, &want) != 0)
-        return -1;
-    return l3_of_cpu(cpu);
+    adsb::HandJob j;
+    j.hand = s.hand;
+    j.ntiles = s.ntiles;
+    j.gen = s.args.gen;
+    j.cap = s.args.hand_cap;
+    j.done = launch_done;
+    j.ctx = s.ev_ready[s.ev_cur];
+    return j;
 }
 
 // Streaming collect: consume the oldest scan WHILE its kernel is still running, so
@@ -834,7 +579,6 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
 
-    constexpr uint32_t kGroup = 512; // tiles resolved per batch while the host is behind the device
     std::vector<uint32_t> &order = d->order;     // a batch's records in ascending g (granule indices)
     std::vector<uint32_t> &t_start = d->tile_start; // per tile: granule index of its first record ...
     std::vector<uint32_t> &t_count = d->tile_count; // ... and its record count (~0u: not in yet)
@@ -878,76 +622,27 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
                         std::chrono::duration<double, std::micro>(clk::now() - t_begin).count(), upto, nc, wait_ms * 1e3);
         }
     };
-    // the tiles of the last resident round finish in a burst at the kernel's end: take
-    // them in small batches, so that little is left to do once the last one is in
-    constexpr uint32_t kTailTiles = 768, kTailGroup = 64;
+    const adsb::HandJob job = hand_job(s);
+    adsb::CollectEnd end;
     if (d->reader && s.ntiles >= d->reader_min_tiles) {
-        // two threads: the reader publishes its frontier, this one resolves behind it
-        StreamReader &rd = *d->reader;
+        adsb::StreamReader &rd = *d->reader;
         if (rd.place) { // the caller may have moved since the thread was placed
             const int cpu = sched_getcpu();
-            const int l3 = l3_of_cpu(cpu);
+            const int l3 = adsb::l3_of_cpu(cpu);
             if (l3 >= 0 && l3 != rd.placed_l3)
-                rd.placed_l3 = place_reader_thread(rd.th, cpu);
+                rd.placed_l3 = adsb::place_reader_thread(rd.th, cpu);
         }
-        rd.post(s, t_start.data(), t_count.data());
-        const uint32_t seq = rd.job_seq.load(std::memory_order_relaxed);
-        for (;;) {
-            const bool fin = rd.done_seq.load(std::memory_order_acquire) == seq; // read BEFORE the frontier: a finished reader's is final
-            const uint32_t f = rd.frontier.load(std::memory_order_acquire);
-            if (f > delivered && (fin || f - delivered >= kTailGroup)) {
-                flush(f);
-                continue;
-            }
-            if (fin)
-                break;
-            const auto t_w = clk::now();
-            while (rd.frontier.load(std::memory_order_relaxed) == f && rd.done_seq.load(std::memory_order_relaxed) != seq)
-                for (int k = 0; k < 32; k++) // poll gently: every look takes the line away from the thread that writes it
-                    __builtin_ia32_pause();
-            t_last_wait = clk::now();
-            wait_ms += std::chrono::duration<double, std::milli>(t_last_wait - t_w).count();
-        }
-        if (rd.status == -1)
-            return d->fail("hand-off stream corrupt at granule %u (tile %u twice)", rd.pos, rd.stop_tile);
-        if (rd.status == -2)
-            return d->fail("scan kernel finished without publishing granule %u (tile %u of %u pending)", rd.pos, delivered,
-                           s.ntiles);
-        overflowed = rd.status == 1;
+        end = adsb::collect_behind_reader(rd, job, t_start.data(), t_count.data(), delivered, flush, wait_ms, t_last_wait);
         if (dbg_on)
             fprintf(stderr, "stream reader thread: busy %.1f us, waits %.1f us\n", rd.busy_ms * 1e3, rd.wait_ms * 1e3);
     } else {
-        HandCursor cur(s, t_start.data(), t_count.data());
-        while (cur.frontier < s.ntiles) {
-            if (cur.pos >= cur.cap) { // the stream is full: the rest of the launch is on the loose list
-                overflowed = true;
-                break;
-            }
-            if (!cur.tile_in()) {
-                // the device is behind: use the time to resolve what is complete, then wait
-                if (cur.frontier > delivered) {
-                    flush(cur.frontier);
-                    continue;
-                }
-                if (!cur.wait_tile())
-                    return d->fail("scan kernel finished without publishing granule %u (tile %u of %u pending)", cur.pos,
-                                   cur.frontier, s.ntiles);
-            }
-            const int rc = cur.take();
-            if (rc < 0)
-                return d->fail("hand-off stream corrupt at granule %u (tile %u twice)", cur.pos, cur.tile);
-            if (rc == 1) { // finish after completion
-                overflowed = true;
-                break;
-            }
-            if (cur.frontier - delivered >= (s.ntiles - delivered > kTailTiles ? kGroup : kTailGroup))
-                flush(cur.frontier);
-        }
-        if (cur.frontier > delivered)
-            flush(cur.frontier);
-        wait_ms = cur.wait_ms;
-        t_last_wait = cur.t_last_wait;
+        end = adsb::collect_alone(job, t_start.data(), t_count.data(), delivered, flush, wait_ms, t_last_wait);
     }
+    if (end.status == -1)
+        return d->fail("hand-off stream corrupt at granule %u (tile %u twice)", end.pos, end.tile);
+    if (end.status == -2)
+        return d->fail("scan kernel finished without publishing granule %u (tile %u of %u pending)", end.pos, end.tile, s.ntiles);
+    overflowed = end.status == 1;
     if (dbg_on)
         fprintf(stderr,
                 "stream collect: %.1f us in all, resolve %.1f us in %d batches, waits %.1f us; %.1f us after the last wait\n",
@@ -1210,10 +905,12 @@ int slot_collect(adsb_decoder *d)
             const uint32_t tile = m[0], nf = m[1], n = nf & 0xFFFFu;
             if (tile >= s.ntiles || (nf & adsb::kMarkNoFit) || (uint64_t)pos + 1 + 2ull * n > lim)
                 break;
-            uint32_t a[4] = {0, 0, 0, 0}, lo, hi;
+            uint32_t a[4] = {0, 0, 0, 0}, sum = 0, lo, hi;
             for (uint32_t k = 0; k < 8 * n; k++)
                 a[k & 3] ^= m[4 + k];
-            adsb::marker_check(tile, nf, s.args.gen, a[0], a[1], a[2], a[3], lo, hi);
+            for (uint32_t r = 0; r < n; r++)
+                sum += adsb::record_term(r, m[4 + 8 * r], m[5 + 8 * r]);
+            adsb::marker_check(tile, nf, s.args.gen, a[0], a[1], a[2], a[3], sum, lo, hi);
             if (m[2] != lo || m[3] != hi)
                 break;
             if (tile >= resume_tile)
@@ -1464,23 +1161,6 @@ int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind, bo
 
 extern "C" {
 
-int adsb_abi_version(void) { return ADSB_ABI_VERSION; }
-
-void adsb_config_init(adsb_config *cfg, size_t struct_size)
-{
-    if (!cfg || struct_size < offsetof(adsb_config, device) + sizeof(int32_t))
-        return;
-    if (struct_size > sizeof *cfg) // a caller from the future: this library fills what it knows, adsb_create refuses the rest
-        struct_size = sizeof *cfg;
-    std::memset(cfg, 0, struct_size);
-    cfg->struct_size = (uint32_t)struct_size;
-    cfg->device = -1;
-}
-
-// The symbol binaries built against ABI <= 3 call: their adsb_config ended behind host_threads (72 bytes); writing this
-// library's longer struct into it would run over the caller's stack (found in round 4 by a stale test binary).
-void (adsb_config_default)(adsb_config *cfg) { adsb_config_init(cfg, offsetof(adsb_config, host_threads) + 2 * sizeof(int32_t)); }
-
 adsb_decoder *adsb_create(const adsb_config *cfg_in)
 {
     adsb_config cfg;
@@ -1617,11 +1297,12 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         if (cfg.debug_reader_min_tiles > 0)
             d->reader_min_tiles = (uint32_t)cfg.debug_reader_min_tiles;
         if (d->cfg.host_threads == 2) {
-            d->reader = new (std::nothrow) StreamReader;
+            d->reader = new (std::nothrow) adsb::StreamReader;
             if (d->reader) {
-                d->reader->device = d->device;
+                d->reader->on_start = [](void *ctx) { (void)hipSetDevice(static_cast<adsb_decoder *>(ctx)->device); }; // launch_done()
+                d->reader->on_start_ctx = d;
                 try {
-                    d->reader->th = std::thread([r = d->reader] { r->loop(); });
+                    d->reader->start();
                 } catch (...) { // no thread to be had: the calling thread consumes the stream alone, as without the option
                     delete d->reader;
                     d->reader = nullptr;
@@ -1629,7 +1310,7 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
                 if (d->reader) {
                     d->reader->place = true;
                     if (d->reader->place)
-                        d->reader->placed_l3 = place_reader_thread(d->reader->th, sched_getcpu());
+                        d->reader->placed_l3 = adsb::place_reader_thread(d->reader->th, sched_getcpu());
                 }
             }
         }
@@ -2367,188 +2048,6 @@ int adsb_shard_end(adsb_decoder *d, adsb_shard_head *head, const adsb_frame **fr
     fill_shard_head(d, head, g_begin, g_end, std::min<uint64_t>(g_end, g_begin + d->shard_head), nf, d->shard_bases_cap);
     head->status = 0;
     return 0;
-}
-
-int adsb_stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
-                       adsb_frame *new_frames, size_t new_cap, size_t *n_new_total)
-{
-    return adsb::stitch_shards(parts, n_parts, total_samples, fix, new_frames, new_cap, n_new_total);
-}
-
-int adsb_stitch_shards_ex(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
-                          adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t walk_stats[2])
-{
-    return adsb::stitch_shards(parts, n_parts, total_samples, fix, new_frames, new_cap, n_new_total, walk_stats);
-}
-
-int adsb_stitch_shards_stats(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
-                             adsb_frame *new_frames, size_t new_cap, size_t *n_new_total, uint64_t walk_stats[2], adsb_stats *stats)
-{
-    if (!stats)
-        return -1;
-    return adsb::stitch_shards(parts, n_parts, total_samples, fix, new_frames, new_cap, n_new_total, walk_stats, stats);
-}
-
-size_t adsb_shard_walk(adsb_shard_head *head, const adsb_frame *frames, uint64_t total_samples, uint64_t *bases, size_t cap)
-{
-    if (!head || (head->n_frames && !frames) || (cap && !bases))
-        return 0;
-    int final = 0;
-    const size_t n = adsb::walk_shard_calls(frames, head->n_frames, head->g_begin, head->g_end, total_samples, bases, cap, &final);
-    head->n_bases = n <= cap ? n : 0;
-    head->walk_final = final;
-    return n;
-}
-
-void adsb_shard_apply_fix(adsb_frame *frames, size_t n, int64_t ts_sub)
-{
-    for (size_t i = 0; i < n; i++)
-        frames[i].ts = (uint64_t)((int64_t)frames[i].ts - ts_sub);
-}
-
-int adsb_plan_shards(uint64_t total_samples, int n_shards, uint64_t *g_begin, uint64_t *g_end,
-                     uint64_t *first_sample, uint64_t *n_samples)
-{
-    if (n_shards <= 0 || !g_begin || !g_end || !first_sample || !n_samples)
-        return -1;
-    const uint64_t m = 2 * (total_samples / 4);
-    const uint64_t n_off = m >= ADSB_WINDOW ? m - ADSB_WINDOW + 1 : 0;
-    for (int i = 0; i < n_shards; i++) {
-        const uint64_t lo = round_down((uint64_t)((__uint128_t)n_off * (unsigned)i / (unsigned)n_shards), 28);
-        const uint64_t hi = (i == n_shards - 1)
-                                ? n_off
-                                : round_down((uint64_t)((__uint128_t)n_off * (unsigned)(i + 1) / (unsigned)n_shards), 28);
-        g_begin[i] = lo;
-        g_end[i] = hi;
-        // pre-halo: 8 pairs (6 needed; 8 keeps 16-byte alignment); post-halo: one window
-        const uint64_t s0 = lo >= 8 ? 2 * (lo - 8) : 0;
-        uint64_t s1 = hi > lo ? 2 * (hi - 1 + ADSB_WINDOW) : s0;
-        if (s1 > total_samples)
-            s1 = total_samples;
-        first_sample[i] = s0;
-        n_samples[i] = s1 > s0 ? s1 - s0 : 0;
-    }
-    return 0;
-}
-
-// ---- resolver handle ----------------------------------------------------------
-struct adsb_resolver {
-    adsb::Resolver r;
-    std::vector<adsb_candidate> head;
-};
-
-adsb_resolver *adsb_resolver_create(void)
-{
-    adsb_resolver *r = new (std::nothrow) adsb_resolver();
-    if (r)
-        r->r.reset();
-    return r;
-}
-
-void adsb_resolver_destroy(adsb_resolver *r) { delete r; }
-
-int adsb_resolver_feed(adsb_resolver *r, const adsb_candidate *cands, size_t n_cands,
-                       const uint64_t *tries, size_t n_tries)
-{
-    if (!r || (n_cands && !cands) || (n_tries && !tries))
-        return -1;
-    r->r.feed(cands, n_cands, tries, n_tries);
-    return 0;
-}
-
-int adsb_resolver_advance(adsb_resolver *r, uint64_t power_samples, uint64_t g_complete)
-{
-    if (!r)
-        return -1;
-    r->r.advance(power_samples, g_complete);
-    return 0;
-}
-
-long adsb_resolver_drain(adsb_resolver *r, adsb_frame *out, size_t cap)
-{
-    if (!r || (!out && cap))
-        return -1;
-    return (long)r->r.drain(out, cap);
-}
-
-int adsb_resolver_start_chain(adsb_resolver *r, uint64_t g_begin, uint64_t head_end)
-{
-    if (!r)
-        return -1;
-    r->head.clear();
-    r->r.start_chain(g_begin, head_end, &r->head);
-    return 0;
-}
-
-int adsb_resolver_start_walk(adsb_resolver *r, uint64_t g_begin, uint64_t g_end, uint64_t total_samples, uint64_t *bases, size_t cap)
-{
-    if (!r || (cap && !bases))
-        return -1;
-    r->r.start_walk(g_begin, g_end, total_samples, bases, cap);
-    return 0;
-}
-
-size_t adsb_resolver_walk_result(const adsb_resolver *r, int *final)
-{
-    if (!r)
-        return 0;
-    if (final)
-        *final = r->r.walk_final() ? 1 : 0;
-    return r->r.walk_bases();
-}
-
-long adsb_resolver_head(adsb_resolver *r, adsb_candidate *out, size_t cap)
-{
-    if (!r || (!out && cap))
-        return -1;
-    const size_t n = std::min(cap, r->head.size());
-    if (n)
-        std::memcpy(out, r->head.data(), n * sizeof(adsb_candidate));
-    return (long)r->head.size();
-}
-
-uint64_t adsb_resolver_skipped(const adsb_resolver *r) { return r ? r->r.skipped() : 0; }
-
-int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out)
-{
-    if (!r || !out)
-        return -1;
-    *out = r->r.stats();
-    return 0;
-}
-
-long adsb_handoff_walk(const void *stream, size_t granules, uint32_t n_tiles, uint32_t gen, uint32_t *tile_start,
-                       uint32_t *tile_count, int *status)
-{
-    if (!stream || !tile_start || !tile_count || !status || granules > 0xFFFFFFFFull)
-        return -1;
-    // the checks read 16-byte granules with aligned loads: walk a 64-byte-aligned copy
-    const size_t bytes = granules * adsb::kGranuleWords * sizeof(uint32_t);
-    void *copy = nullptr;
-    if (posix_memalign(&copy, 64, bytes ? bytes : 64) != 0)
-        return -1;
-    std::memcpy(copy, stream, bytes);
-    for (uint32_t t = 0; t < n_tiles; t++)
-        tile_start[t] = 0, tile_count[t] = ~0u;
-    HandCursor cur(static_cast<const uint32_t *>(copy), (uint32_t)granules, n_tiles, gen, tile_start, tile_count);
-    *status = 0;
-    while (cur.frontier < n_tiles) {
-        if (cur.pos >= cur.cap) {
-            *status = 1;
-            break;
-        }
-        if (!cur.wait_tile()) { // (no launch behind these bytes: one look)
-            *status = 2;
-            break;
-        }
-        const int rc = cur.take();
-        if (rc != 0) {
-            *status = rc < 0 ? -1 : 1;
-            break;
-        }
-    }
-    free(copy);
-    return (long)cur.frontier;
 }
 
 } // extern "C"

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "scan_kernel_format.h" // the hand-off stream's format: shared with host-only code
+
 namespace adsb {
 
 // Launch shape (what every measurement of DESIGN.md was taken with; the experiments that set other values are history)
@@ -25,23 +27,11 @@ constexpr int ADSB_DECOFFSET_K = 1200; // longest span an accepted frame jumps (
 constexpr int kCandWords = 6;   // {g_rel, pw, frame[0..13] | len<<16 in the last word}
 constexpr int kSyndWords = 14 * 256;
 constexpr int kFixSlots = 512;
-// hand-off stream (ScanArgs::hand): 16-byte granules
-constexpr int kGranuleWords = 4;
 constexpr int kCounterWords = 8; // the launch counters as the host sees them (ScanArgs::report)
 // On the device every counter has a 128-byte line of its own (ScanArgs::counters[i * kCounterPad]; the two
 // 64-bit profile maxima are counters 4 and 5).  All of a launch's tiles hit them with device-scope atomics.
 constexpr int kCounterPad = 32;
 constexpr int kDevCounterWords = 6 * kCounterPad;
-constexpr uint32_t kMarkOver = 0x10000u;  // marker flag: some records of the tile are on the loose list
-constexpr uint32_t kMarkNoFit = 0x20000u; // marker flag: the tile's range ran past the array (records are loose)
-constexpr int kMarkLinesShift = 18;       // marker word 1, bits 18..31: 64-byte lines the tile reserved (it may keep fewer records
-                                          // than it reserved for: the host skips to the next tile's marker by this)
-__host__ __device__ constexpr uint32_t marker_granules(uint32_t nf) { return (nf >> kMarkLinesShift) * 4u; }
-// Granules a tile with n records reserves: marker + 2 n, rounded up to whole 64-byte lines, so
-// that the host never reads (and caches) a line the device has yet to write another tile into
-// -- every later device write to such a line has to pull it out of the CPU's cache first.
-__host__ __device__ constexpr uint32_t stream_granules(uint32_t n) { return (1u + 2u * n + 3u) & ~3u; }
-
 constexpr int owned_runs(int passes) { return kPassRuns * passes - kReachRuns; }
 constexpr int tile_offsets(int passes) { return kRun * owned_runs(passes); }
 constexpr size_t lds_bytes(int passes)
@@ -78,18 +68,6 @@ inline uint32_t tile_count(uint64_t n_offsets, uint32_t stagger, int k)
 }
 
 constexpr uint64_t kMaxLaunchOffsets = (1ull << 30) - tile_offsets(kMaxPasses); // g_rel must fit 30 bits
-
-// Check words of a tile marker (device writes them, host checks them): a0..a3 = XOR,
-// word by word, of the 2n record granules that follow the marker.  gen differs
-// between any two launches that can touch the same bytes, so a marker written by an
-// earlier launch never validates, and a range in which some granule has not landed yet
-// (stale bytes) passes with probability 2^-64.
-__host__ __device__ inline void marker_check(uint32_t tile, uint32_t nf, uint32_t gen, uint32_t a0, uint32_t a1, uint32_t a2,
-                                             uint32_t a3, uint32_t &lo, uint32_t &hi)
-{
-    lo = a0 ^ (a2 << 16 | a2 >> 16) ^ gen ^ tile ^ (nf << 11 | nf >> 21);
-    hi = a1 ^ (a3 << 16 | a3 >> 16) ^ ~gen ^ (tile << 7 | tile >> 25) ^ nf;
-}
 
 struct ScanArgs {
     const uint32_t *x;   // (I,Q) pairs; x[0] is stream pair index pbuf0 (16-byte aligned, pbuf0 % 4 == 0)

@@ -469,8 +469,8 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
 // ------------------------------ Stage B ------------------------------
 // Everything behind a tile's planes: gate, survivor queue, slicer + CRC, never-visited filter, ranking, finishing and
 // the hand-off, by the tile's four waves between workgroup barriers.
-// LDS of Stage B: queue[queue_cap], ctl[32] (qcount, qover, cl_n, cl_over, tile_n, tile_over, tile_base, try_base,
-// tile_res, tile_fit, tile_chk[4]; the rest is the kernel's), cl_rec[clist_cap * kCandWords].
+// LDS of Stage B: queue[queue_cap], ctl[16] (qcount, qover, cl_n, cl_over, tile_n, tile_over, tile_base, try_base,
+// tile_res, tile_fit, tile_chk[4], tile_lines, tile_sum), cl_rec[clist_cap * kCandWords].
 template <bool kStats>
 __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t tile, const int K, const int64_t t0, const int tid,
                                         const uint32_t *pl_d, const uint32_t *pl_e1, const uint32_t *pl_e2, uint32_t *queue,
@@ -489,6 +489,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     uint32_t *tile_fit = qcount + 9;  // ... and the whole range lies inside the array
     uint32_t *tile_chk = qcount + 10; // [4]: XOR of the granules the tile wrote there, word by word
     uint32_t *tile_lines = qcount + 14; // 64-byte lines of args.hand the tile has reserved (its marker says so: kMarkLinesShift)
+    uint32_t *tile_sum = qcount + 15;   // rank-weighted sum over the records it wrote there (record_term: the marker's second summary)
     if (tid == 0) { // (the first barrier of the round loop below orders these)
         *tile_n = 0;
         *tile_over = 0;
@@ -496,6 +497,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         *tile_res = 0;
         *tile_fit = 0;
         *tile_lines = 0;
+        *tile_sum = 0;
         tile_chk[0] = tile_chk[1] = tile_chk[2] = tile_chk[3] = 0;
     }
     // A finished record that cannot go through the hand-off stream (hand-off disabled,
@@ -848,6 +850,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                     atomicXor(&tile_chk[1], fin[1] ^ fin[5]);
                     atomicXor(&tile_chk[2], fin[2]);
                     atomicXor(&tile_chk[3], fin[3]);
+                    atomicAdd(tile_sum, record_term(rank, fin[0], fin[1]));
                 } else {
                     const uint32_t wds[4] = {fin[2], fin[3], fin[4], fin[5]};
                     emit_loose(fin[0], fin[1], wds);
@@ -866,7 +869,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                             continue;
                         const uint32_t nf = nk | (*tile_over ? kMarkOver : 0u) | (*tile_lines << kMarkLinesShift);
                         uint32_t lo, hi;
-                        marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
+                        marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], *tile_sum, lo, hi);
                         gv = u32x4{tile, nf, lo, hi};
                         *tile_res = 2; // marker written
                     } else {
@@ -914,7 +917,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             if (b < args.hand_cap) {
                 const uint32_t nf = *tile_n | (*tile_over ? kMarkOver : 0u) | (fit ? 0u : kMarkNoFit) | (lines << kMarkLinesShift);
                 uint32_t lo, hi;
-                marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], lo, hi);
+                marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], *tile_sum, lo, hi);
                 store_granule_through(args.hand, b, u32x4{tile, nf, lo, hi});
             }
         }

@@ -18,13 +18,18 @@ def rotl(x, k):
 
 
 def check_words(tile, nf, gen, recs):
-    """scan_kernel.h marker_check: XOR of the record granules, mixed with the launch's gen, the tile and nf."""
+    """scan_kernel_format.h marker_check: the XOR of the record granules and the rank-weighted sum over {g_rel, pw} of the
+    records, mixed with the launch's gen, the tile and nf."""
     a = [0, 0, 0, 0]
-    for g in np.asarray(recs, np.uint32).reshape(-1, 4):
+    grans = np.asarray(recs, np.uint32).reshape(-1, 4)
+    for g in grans:
         for k in range(4):
             a[k] ^= int(g[k])
-    lo = a[0] ^ rotl(a[2], 16) ^ gen ^ tile ^ rotl(nf, 11)
-    hi = a[1] ^ rotl(a[3], 16) ^ (~gen & M32) ^ rotl(tile, 7) ^ nf
+    s = 0
+    for r, g in enumerate(grans[0::2]):
+        s = (s + (2 * r + 1) * (int(g[0]) ^ rotl(int(g[1]), 13))) & M32
+    lo = a[0] ^ rotl(a[2], 16) ^ gen ^ tile ^ rotl(nf, 11) ^ s
+    hi = a[1] ^ rotl(a[3], 16) ^ (~gen & M32) ^ rotl(tile, 7) ^ nf ^ rotl(s, 16)
     return lo & M32, hi & M32
 
 
@@ -172,3 +177,27 @@ def test_many_random_streams(capi):
                 assert (ts[t], tc[t]) == img.where[t]
             else:
                 assert tc[t] == M32
+
+
+def test_stale_records_whose_differences_cancel_in_the_xor_do_not_validate(capi):
+    """The marker carries two summaries of the records: their XOR, and a rank-weighted sum over {g_rel, pw}.  The case the
+    second one exists for: the bytes behind a (new) marker are still the previous launch's records of the SAME frames at
+    other offsets -- same frame words, g_rel differing alike in two records.  In the XOR the two differences cancel; the tile
+    must stay out all the same (a round-4 harness with regular records found the XOR alone accepting such ranges)."""
+    gen = 0x1234ABCD
+    for d in (28, 0x100, 0x55AA, 1 << 29):
+        img = Image(64, gen)
+        recs = img.tile(0, 4)
+        assert walk(capi, img, 1)[:2] == (1, 0)
+        p = img.where[0][0]
+        for r in (1, 3):                       # records 1 and 3: g_rel ^= d  ->  the XOR over the range is unchanged
+            img.w[4 * (p + 2 * r)] ^= d
+        f, st, _, tc = walk(capi, img, 1)
+        assert (f, st) == (0, 2), (d, f, st)
+        for r in (1, 3):                       # ... and the same for pw
+            img.w[4 * (p + 2 * r)] ^= d
+            img.w[4 * (p + 2 * r) + 1] ^= d
+        assert walk(capi, img, 1)[:2] == (0, 2), d
+        for r in (1, 3):
+            img.w[4 * (p + 2 * r) + 1] ^= d
+        assert walk(capi, img, 1)[:2] == (1, 0)
