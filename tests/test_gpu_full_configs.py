@@ -100,6 +100,35 @@ def test_config2_256Mi_dense_noise(capi, oracle, torch_cuda):
         d.close()
 
 
+def test_config2_256Mi_at_ten_percent_density_and_the_gate_storm(capi, oracle, torch_cuda):
+    """BASELINE configs[2] at the density it states (~10 % of the offsets pass the preamble test: 112-bit frames packed back to
+    back in sigma = 300 noise + slots of frame starts), and the adversarial capture made of frame starts only (7 % of ALL offsets
+    pass the DF gate: every tile overflows its survivor queue into the fallback rounds, the launch-wide try list is regrown):
+    frames, ts, pw and the Try/Ok table equal to the oracle's on the full 256 Mi samples."""
+    from bench import make_dense10, make_gate_storm, preamble_pass_fraction
+    n = (256 << 20) - (256 << 20) % 28
+    for make, seed, lo, hi, min_frames in ((make_dense10, 101, 0.095, 0.108, 80_000), (make_gate_storm, 102, 0.25, 0.35, 0)):
+        t = make(torch_cuda, n, seed)
+        x = _host(t)
+        assert lo < preamble_pass_fraction(x) < hi
+        want, wstats = oracle.decode(x, df18=True)
+        assert len(want) >= min_frames
+        for stats in (False, True):
+            d = capi.Decoder(df18=True, collect_stats=stats, profile=True)
+            try:
+                d.push_device_final(t.data_ptr(), t.numel())
+                got = d.drain()
+                assert records(got) == records(want)
+                if stats:
+                    assert d.stats() == wstats
+                if make is make_gate_storm:
+                    assert sum(wstats["try"].values()) > 0.05 * (n // 2)
+            finally:
+                d.close()
+        del t
+        torch_cuda.cuda.empty_cache()
+
+
 def test_config4_2Gi_one_stream_in_8_shards(capi, oracle, torch_cuda):
     """contiguous shards starting on multiples of 28 offsets, halo = 8 pairs
     before + one 1196-sample window after (adsb_plan_shards), stateless per-shard scans
