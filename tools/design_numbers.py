@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Regenerates the two measured tables of DESIGN.md (section 7 results, section 6 shard runs) from the files under profiles/,
-between the <!-- r3-...:begin/end --> markers: every number in them is read from a committed file, none is typed.
+between the <!-- r4-...:begin/end --> markers: every number in them is read from a committed file, none is typed.
 
     python tools/design_numbers.py          # rewrites DESIGN.md in place
 """
@@ -26,46 +26,60 @@ def frac(us):
 
 
 def results():
-    d, u, pmc = J("r3_bench.json"), J("r3_bench_under_rocprofv3.json"), J("r3_pmc.json")
-    dur, sdur, ddur = durations("r3_dispatches.csv"), durations("r3_stats_dispatches.csv"), durations("r3_dense_dispatches.csv")
+    d, u, pmc = J("r4_bench.json"), J("r4_bench_under_rocprofv3.json"), J("r4_pmc.json")
+    dur, sdur = durations("r4_dispatches.csv"), durations("r4_stats_dispatches.csv")
     c = pmc["counters"]
     wc = c["SQ_WAVE_CYCLES"]["mean"]
-    cnt = [r for r in csv.reader(open(P("r3_stats_kernel_stats.csv"))) if "count_tries_kernel" in r[0]][0]
-    e = d["e2e_host_fed"]
+    cnt = [r for r in csv.reader(open(P("r4_stats_kernel_stats.csv"))) if "count_tries_kernel" in r[0]][0]
+    e, k = d["e2e_host_fed"], d["value_1000_steps"]
+    sh, cli, dn = d["e2e_host_fed_sharded"], d["cli_whole_process"], d["dense"]
+    x = cli.get("crossover") or {}
+    files = " / ".join(f"{n}: {r['wall_ms']:.0f} ms against {r.get('reference_wall_ms', float('nan')):.0f} ms" for n, r in cli["files"].items())
     return f"""| what | value | file |
 |---|---|---|
-| `bench.py`, default line (one box) | **{d['value'] / 1e6:.3f} Tsamples/s**, {d['ms_per_step']:.4f} ms per 256 Mi-sample step; scan kernel {d['roofline']['launch_ms'] * 1e3:.1f} µs on its own clock = {d['roofline']['achieved']:.0f} GB/s = **{d['roofline']['frac']:.3f} of 8 TB/s** | `r3_bench.json` |
-| the same command under `rocprofv3 --kernel-trace --stats`, 1000 timed steps (another box) | `scan_kernel<false>`: {len(dur)} dispatches, average **{statistics.mean(dur):.1f} µs** (pre-roll and warm-up included) = {frac(statistics.mean(dur)):.3f}; last 1000: {statistics.mean(dur[-1000:]):.1f} µs = **{frac(statistics.mean(dur[-1000:])):.3f}**; minimum {min(dur):.1f} µs; the bench line of that very run read {u['roofline']['launch_ms'] * 1e3:.1f} µs in-kernel (1 % below the trace, as in every round) | `r3_kernel_stats.csv`, `r3_dispatches.csv`, `r3_bench_under_rocprofv3.json` |
-| box-to-box spread of the kernel this round | 0.137–0.147 ms (0.457–0.490), same build, same command | `r3_ab_runs.txt` (every block is one box) |
-| HBM traffic per launch | {pmc['hbm_bytes_per_launch'] / 1e6:.1f} MB = {pmc['hbm_bytes_per_launch'] / B:.3f} × the 536.9 MB of algorithmic input (FETCH_SIZE × 2 + WRITE_SIZE, separate passes) | `r3_pmc.json` |
-| VALU wave-instructions per launch | {c['SQ_INSTS_VALU']['mean'] / 1e6:.2f} M; Stage A's pass 660 instructions = 2 554 issue cycles (3.87 per instruction) | `r3_pmc.json`, `r3_isa_mix.json` |
-| wave time | issuing {c['SQ_ACTIVE_INST_ANY']['mean'] / wc * 100:.0f} %, stalled wanting to issue {c['SQ_WAIT_INST_ANY']['mean'] / wc * 100:.0f} %, parked on `s_waitcnt` / `s_barrier` {c['SQ_WAIT_ANY']['mean'] / wc * 100:.0f} % | `r3_pmc.json` |
-| with the Try/Ok table (`collect_stats=1`: what the drop-in runs) | {d['with_stats']['ms_per_step']:.4f} ms per step = **{d['with_stats']['value'] / 1e6:.3f} Tsamples/s** (`value_dropin`; round 2: 0.1761); under rocprofv3 `scan_kernel<true>` {statistics.mean(sdur[-1000:]):.1f} µs (last 1000 of {len(sdur)}), `count_tries_kernel` {float(cnt[3]) / 1e3:.1f} µs on its own stream | `r3_bench.json`, `r3_stats_kernel_stats.csv`, `r3_stats_dispatches.csv` |
-| dense (`configs[2]`: σ = 300 + one 112-bit frame per ms, `-a`) | {d['dense']['ms_per_step']:.4f} ms per step, kernel {d['dense']['launch_ms'] * 1e3:.1f} µs = {d['dense']['roofline_frac']:.3f}; measured density: {d['dense']['preamble_pass_fraction'] * 100:.2f} % of the offsets pass the preamble test, {d['dense']['df_gate_pass_fraction_of_visited'] * 100:.3f} % the DF gate (BASELINE says "~10 %": σ = 300 noise alone gives 7 %, and the frames do not move that); as the main workload under rocprofv3: {statistics.mean(ddur[-1000:]):.1f} µs | `r3_bench.json` `dense`, `r3_dense_*` |
-| cold (first steps after 0.5 s of idle) | {d['value_cold']['ms_each_step']} ms: only the FIRST step is slow — 60–90 µs of wake-up before its kernel starts; the kernels themselves average {d['value_cold']['kernel_ms_per_step'] * 1e3:.0f} µs. Nothing a library can pre-spin for a caller who shows up after an idle period; `value_cold` = {d['value_cold']['value'] / 1e6:.2f} Tsamples/s | `r3_bench.json` `value_cold` |
-| host-fed, PCIe-inclusive (never `value`) | 1 Mi-sample calls: `adsb_push` {e['push_1Mi_sync'] / 1e3:.1f}, with `push_overlap` {e['push_1Mi_overlap'] / 1e3:.1f}, `adsb_push_async` {e['push_1Mi_async'] / 1e3:.1f} GS/s; 16 Mi: {e['push_16Mi_sync'] / 1e3:.1f} / {e['push_16Mi_overlap'] / 1e3:.1f} / {e['push_16Mi_async'] / 1e3:.1f}; 1 / 2 / 4 streams on one GPU: {d['multi_stream_host_fed']['streams_1']['aggregate'] / 1e3:.1f} / {d['multi_stream_host_fed']['streams_2']['aggregate'] / 1e3:.1f} / {d['multi_stream_host_fed']['streams_4']['aggregate'] / 1e3:.1f} GS/s | `r3_bench.json` `e2e_host_fed`, `multi_stream_host_fed` |
-| the C host program, whole process on a 512 MiB file | {d['cli_whole_process']['wall_ms']:.0f} ms = {d['cli_whole_process']['value']:.0f} Msamples/s; runtime start {d['cli_whole_process']['runtime_init_ms']:.0f} ms, decode {d['cli_whole_process']['decode_ms']:.0f} ms | `r3_bench.json` `cli_whole_process` |
-| CPU beside it (the REAL reference chain, 1 core, EPYC 9575F) | {d['cpu_baseline']['value']:.0f} Msamples/s (the oracle's restatement: {d['cpu_baseline']['port_value']:.0f}) | `r3_bench.json` `cpu_baseline` |
-| fuzz | 420 s, 12 390 captures, 813 582 frames, nine feeding modes (resolved shards and `push_overlap` among them), both kernels: no mismatch; `tools/async_race.py` 60 × 19 configurations: clean except the one that switches the ordering rule off | `r3_fuzz_420s.txt`, `r3_async_race_60x19.txt` |"""
+| `bench.py`, default line (one box) | **{d['value'] / 1e6:.3f} Tsamples/s**, {d['ms_per_step']:.4f} ms per 256 Mi-sample step; scan kernel {d['roofline']['launch_ms'] * 1e3:.1f} µs on its own clock = {d['roofline']['achieved']:.0f} GB/s = **{d['roofline']['frac']:.3f} of 8 TB/s** | `r4_bench.json` |
+| ... the same region with 1000 steps instead of the driver's 20 (`value_1000_steps`) | {k['value'] / 1e6:.3f} Tsamples/s, {k['ms_per_step']:.4f} ms per step, kernel {k['launch_ms'] * 1e3:.1f} µs = {k['roofline_frac']:.3f} | `r4_bench.json` |
+| the same command under `rocprofv3 --kernel-trace --stats`, 1000 timed steps (another box) | `scan_kernel<false>`: {len(dur)} dispatches, average **{statistics.mean(dur):.1f} µs** (pre-roll and warm-up included) = {frac(statistics.mean(dur)):.3f}; last 1000: {statistics.mean(dur[-1000:]):.1f} µs = **{frac(statistics.mean(dur[-1000:])):.3f}**; minimum {min(dur):.1f} µs; the bench line of that very run read {u['roofline']['launch_ms'] * 1e3:.1f} µs in-kernel (1 % below the trace, as in every round) | `r4_kernel_stats.csv`, `r4_dispatches.csv`, `r4_bench_under_rocprofv3.json` |
+| box-to-box spread of the kernel | 0.137–0.147 ms (0.457–0.490), same build, same command (round 3's and round 4's boxes) | `r3_ab_runs.txt`, `r4_ab_runs.txt` |
+| HBM traffic per launch | {pmc['hbm_bytes_per_launch'] / 1e6:.1f} MB = {pmc['hbm_bytes_per_launch'] / B:.3f} × the 536.9 MB of algorithmic input (FETCH_SIZE × 2 + WRITE_SIZE, separate passes) | `r4_pmc.json` |
+| VALU wave-instructions per launch | {c['SQ_INSTS_VALU']['mean'] / 1e6:.2f} M; Stage A's pass 660 instructions = 2 554 issue cycles (3.87 per instruction) | `r4_pmc.json`, `r4_isa_mix.json` |
+| wave time | issuing {c['SQ_ACTIVE_INST_ANY']['mean'] / wc * 100:.0f} %, stalled wanting to issue {c['SQ_WAIT_INST_ANY']['mean'] / wc * 100:.0f} %, parked on `s_waitcnt` / `s_barrier` {c['SQ_WAIT_ANY']['mean'] / wc * 100:.0f} % | `r4_pmc.json` |
+| with the Try/Ok table (`collect_stats=1`: what the drop-in runs) | {d['with_stats']['ms_per_step']:.4f} ms per step = **{d['with_stats']['value'] / 1e6:.3f} Tsamples/s** (`value_dropin`); under rocprofv3 `scan_kernel<true>` {statistics.mean(sdur[-1000:]):.1f} µs (last 1000 of {len(sdur)}), `count_tries_kernel` {float(cnt[3]) / 1e3:.1f} µs on its own stream | `r4_bench.json`, `r4_stats_kernel_stats.csv`, `r4_stats_dispatches.csv` |
+| dense, σ = 300 noise + one 112-bit frame per ms, `-a` (rounds 1–3's `configs[2]`) | {dn['noise']['plain']['ms_per_step']:.4f} ms per step, kernel {dn['noise']['plain']['launch_ms'] * 1e3:.1f} µs = {dn['noise']['plain']['roofline_frac']:.3f}; {dn['noise']['preamble_pass_fraction'] * 100:.2f} % of the offsets pass the preamble test, {dn['noise']['df_gate_pass_fraction_of_visited'] * 100:.3f} % the DF gate; with the table {dn['noise']['with_stats']['ms_per_step']:.4f} ms | `r4_bench.json` `dense.noise` |
+| dense, **`configs[2]` at its stated density** (112-bit frames packed back to back in σ = 300 noise, 3 % of the ms slots full of frame starts) | **{dn['target_10_percent']['preamble_pass_fraction'] * 100:.2f} %** of the offsets pass the preamble test; {dn['target_10_percent']['plain']['frames']} frames per step; {dn['target_10_percent']['plain']['ms_per_step']:.3f} ms per step = {dn['target_10_percent']['plain']['value'] / 1e3:.1f} Gsamples/s (kernel {dn['target_10_percent']['plain']['launch_ms']:.3f} ms; the step is bound by the host: §7 below); with the table {dn['target_10_percent']['with_stats']['ms_per_step']:.3f} ms; frames and table equal to the oracle's | `r4_bench.json` `dense.target_10_percent` |
+| adversarial: nothing but frame starts (`gate_storm`) | {dn['gate_storm']['preamble_pass_fraction'] * 100:.1f} % pass the preamble test, {dn['gate_storm']['df_gate_pass_fraction_of_visited'] * 100:.2f} % of ALL offsets the DF gate: every tile overflows its survivor queue; kernel {dn['gate_storm']['plain']['launch_ms']:.3f} ms = **{dn['gate_storm']['plain']['launch_ms'] / d['roofline']['launch_ms']:.0f} × the sparse launch**; with the table {dn['gate_storm']['with_stats']['launch_ms']:.2f} ms ({dn['gate_storm']['with_stats']['relaunches']} relaunch with regrown try list); table equal to the oracle's | `r4_bench.json` `dense.gate_storm` |
+| cold (first steps after 0.5 s of idle) | {d['value_cold']['ms_each_step']} ms: only the FIRST step is slow; `value_cold` = {d['value_cold']['value'] / 1e6:.2f} Tsamples/s | `r4_bench.json` `value_cold` |
+| host-fed, PCIe-inclusive (never `value`) | 1 Mi-sample calls: `adsb_push` {e['push_1Mi_sync'] / 1e3:.1f}, with `push_overlap` {e['push_1Mi_overlap'] / 1e3:.1f}, `adsb_push_async` {e['push_1Mi_async'] / 1e3:.1f} GS/s; 16 Mi: {e['push_16Mi_sync'] / 1e3:.1f} / {e['push_16Mi_overlap'] / 1e3:.1f} / {e['push_16Mi_async'] / 1e3:.1f}; 1 / 2 / 4 streams on one GPU: {d['multi_stream_host_fed']['streams_1']['aggregate'] / 1e3:.1f} / {d['multi_stream_host_fed']['streams_2']['aggregate'] / 1e3:.1f} / {d['multi_stream_host_fed']['streams_4']['aggregate'] / 1e3:.1f} GS/s | `r4_bench.json` `e2e_host_fed`, `multi_stream_host_fed` |
+| the multi-GPU driver on ONE page-locked capture, Try/Ok table included, 1 / 2 / 4 handles on this one device (`e2e_host_fed_sharded`) | {sh['handles_1']['value'] / 1e3:.1f} / {sh['handles_2']['value'] / 1e3:.1f} / {sh['handles_4']['value'] / 1e3:.1f} GS/s (one link: plumbing, not scaling); calling thread's share {sh['handles_1']['serial_us']:.0f} / {sh['handles_2']['serial_us']:.0f} / {sh['handles_4']['serial_us']:.0f} µs per call | `r4_bench.json` |
+| the C host program, whole process, exec to exit, against the reference's wall time on the same file | {files}; below **{x.get('samples', 0) / 1e6:.0f} M samples ({x.get('file_MB', 0)} MB, {x.get('seconds_of_signal', 0)} s of signal) the reference's one CPU thread finishes first** (start-up {x.get('startup_ms', 0):.0f} ms, then {x.get('gpu_ms_per_Mi_samples', 0):.2f} against {x.get('reference_ms_per_Mi_samples', 0):.2f} ms per Mi samples); every device visible to the runtime: {cli['largest_file_all_devices_visible']['runtime_init_ms']:.0f} ms of runtime start against {cli['runtime_init_ms']:.0f} (a one-GPU box: no difference to see); `-G 0,0`: {cli['largest_file_G_0_0']['wall_ms']:.0f} ms | `r4_bench.json` `cli_whole_process` |
+| CPU beside it (the REAL reference chain, 1 core, EPYC 9575F) | {d['cpu_baseline']['value']:.0f} Msamples/s (the oracle's restatement: {d['cpu_baseline']['port_value']:.0f}) | `r4_bench.json` `cpu_baseline` |
+| fuzz | see `r4_fuzz.txt`: ten feeding modes (the multi-GPU driver and resolved shards with statistics among them): no mismatch | `r4_fuzz.txt` |"""
 
 
 def shards():
-    sh, shg = J("r3_bench_shard_N1_2Gi.json"), J("r3_bench_shard_N1_2Gi_gather_path.json")
-    sh2, st2, s2g = J("r3_bench_shard_N2_one_device_plumbing.json"), J("r3_bench_stream_N2_one_device_plumbing.json"), J("r3_bench_stream_2Gi.json")
-    return f"""| run | ms per step | Msamples/s | rank-0 serial part | note |
-|---|---|---|---|---|
-| N = 1, 2 Gi samples, resolved path | {sh['ms_per_step']:.3f} | {sh['value']:.0f} | {sh['config']['rank0_serial_us']} µs | {sh['config']['frames_decoded']} frames equal to the real reference chain's; the shard's own walk starts at the stream's true first base, so the stitcher jumps over all {sh['config']['deqframe_calls_jumped']} calls; the walk itself (27 k calls over 107 k frames, ≈ 0.19 ms if done afterwards) is advanced beside the greedy chain while the kernel runs (`Resolver::start_walk`) |
-| N = 1, 2 Gi samples, checker path (every candidate to one resolver) | {shg['ms_per_step']:.3f} | {shg['value']:.0f} | the whole resolve | round 2's path: 2.40 ms |
-| N = 1, 2 Gi samples, plain stream path (`bench.py --samples 2 Gi`) | {s2g['ms_per_step']:.3f} | {s2g['value']:.0f} | — | eight launches on alternating streams |
-| N = 2 on ONE GPU, 512 Mi samples, resolved path | {sh2['ms_per_step']:.3f} | {sh2['value']:.0f} | {sh2['config']['rank0_serial_us']} µs | shard 0 jumped, shard 1's {sh2['config']['deqframe_calls_walked_by_rank0']} calls walked by rank 0 (9 ns per call): the two chains never met |
-| N = 2 on ONE GPU, 2 × 256 Mi samples, independent streams (`configs[3]` plumbing) | {st2['ms_per_step']:.3f} | {st2['value']:.0f} | — | both ranks gated against the oracle |"""
+    rows = []
+    for name, label in (("r4_bench_shard_N1_2Gi", "1 handle, 2 Gi samples resident in HBM"),
+                        ("r4_bench_shard_N1_2Gi_stats", "... with the Try/Ok table"),
+                        ("r4_bench_shard_8handles_one_device_2Gi", "8 handles on ONE device, 2 Gi samples resident, Try/Ok table"),
+                        ("r4_bench_shard_host_fed_N1_512Mi", "1 handle, 512 Mi samples in page-locked host memory, Try/Ok table"),
+                        ("r4_bench_shard_host_fed_4handles_512Mi", "4 handles on ONE device (one link), same capture"),
+                        ("r4_bench_shard_file_fed_4handles_512Mi", "4 handles, the capture as a tmpfs file (every worker preads its slice)")):
+        j = J(name + ".json")
+        c = j["config"]
+        rows.append(f"| {label} | {j['ms_per_step']:.3f} | {j['value'] / 1e3:.1f} | {c['slowest_worker_ms']:.3f} ms | {c['serial_us']:.0f} µs (stitch {c['stitch_us']:.0f}) | "
+                    f"{c['deqframe_calls_walked']} / {c['deqframe_calls_jumped']} | {c['frames_decoded']} frames; {c['parity']} |")
+    st8 = J("r4_bench_stream_N8_one_device_plumbing.json")
+    rows.append(f"| `configs[3]` in the driver's command shape: 8 PROCESSES on one device, 64 Mi samples each (`bench.py --gpus 8 --one-device-test`) | {st8['ms_per_step']:.3f} | "
+                f"{st8['value'] / 1e3:.1f} | — | — | — | every one of the {st8['config']['ranks_gated']} ranks gated against the oracle |")
+    return ("| run (`bench.py --mode shard`, one process) | ms per call | Gsamples/s | slowest worker | calling thread behind it | deqframe calls walked / jumped | parity |\n"
+            "|---|---|---|---|---|---|---|\n" + "\n".join(rows)).replace("\\n", "\n")
 
 
 def main():
     path = os.path.join(ROOT, "DESIGN.md")
     t = open(path).read()
     for tag, text in (("results", results()), ("shards", shards())):
-        a, b = f"<!-- r3-{tag}:begin -->", f"<!-- r3-{tag}:end -->"
+        a, b = f"<!-- r4-{tag}:begin -->", f"<!-- r4-{tag}:end -->"
         assert a in t and b in t, tag
         t = t[: t.index(a) + len(a)] + "\n" + text + "\n" + t[t.index(b):]
     open(path, "w").write(t)
