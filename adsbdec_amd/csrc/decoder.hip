@@ -563,6 +563,33 @@ adsb::HandJob hand_job(const ScanSlot &s)
     return j;
 }
 
+// Tiles [from, upto) of the launch's hand-off stream (d->tile_start / d->tile_count say where each one's records lie) go to
+// the sink: a caller's vectors, or the stream's resolver, which walks the ranges where they lie.  Returns the records handed on.
+size_t deliver_tiles(adsb_decoder *d, ScanSlot &s, uint32_t from, uint32_t upto)
+{
+    const uint32_t *t_start = d->tile_start.data(), *t_count = d->tile_count.data();
+    const uint64_t g_complete = std::min<uint64_t>(
+        s.args.g_end, s.args.g_begin + adsb::kRun * adsb::tile_first_run(upto, s.args.stagger, s.args.passes));
+    size_t nc = 0;
+    if (d->sink.cands) { // per-shard scan: the caller's vectors
+        std::vector<uint32_t> &order = d->order; // the records in ascending g (granule indices)
+        order.clear();
+        for (uint32_t u = from; u < upto; u++)
+            for (uint32_t i = 0, b = t_start[u], n = t_count[u]; i < n; i++)
+                order.push_back(b + 2 * i);
+        nc = order.size();
+        deliver(d, s, s.hand, order.data(), nc, adsb::kGranuleWords, 0, nullptr, 0, g_complete);
+    } else { // the stream's resolver walks the tile ranges where they lie
+        for (uint32_t u = from; u < upto; u++)
+            nc += t_count[u];
+        d->prof.candidates += nc;
+        if (d->res.head_wanted(s.args.g_begin + adsb::kRun * adsb::tile_first_run(from, s.args.stagger, s.args.passes)))
+            d->res.capture_head_tiles(s.hand, t_start, t_count, from, upto, s.args.g_begin);
+        d->res.advance_tiles(s.hand, t_start, t_count, from, upto, 0, s.args.g_begin, power_samples_produced(d->n_samples), g_complete);
+    }
+    return nc;
+}
+
 // Streaming collect: consume the oldest scan WHILE its kernel is still running, so
 // that resolving overlaps the scan.  The hand-off stream (scan_kernel.h) is read strictly
 // sequentially -- one prefetchable stream of device-written lines, no directory to poll:
@@ -574,12 +601,11 @@ adsb::HandJob hand_job(const ScanSlot &s)
 // Returns 1 if a tile reported records on the loose list (or the stream is full): the
 // caller then finishes the launch through the collect-after-completion path, from tile
 // *resume_tile on.
-int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
+int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, uint32_t *tiles_in)
 {
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
 
-    std::vector<uint32_t> &order = d->order;     // a batch's records in ascending g (granule indices)
     std::vector<uint32_t> &t_start = d->tile_start; // per tile: granule index of its first record ...
     std::vector<uint32_t> &t_count = d->tile_count; // ... and its record count (~0u: not in yet)
     t_start.assign(s.ntiles, 0u);
@@ -594,25 +620,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
         clk::time_point tp;
         if (dbg_on)
             tp = clk::now();
-        const uint64_t g_complete = std::min<uint64_t>(
-            s.args.g_end, s.args.g_begin + adsb::kRun * adsb::tile_first_run(upto, s.args.stagger, s.args.passes));
-        size_t nc = 0;
-        if (d->sink.cands) { // per-shard scan: the caller's vectors
-            order.clear();
-            for (uint32_t u = delivered; u < upto; u++)
-                for (uint32_t i = 0, b = t_start[u], n = t_count[u]; i < n; i++)
-                    order.push_back(b + 2 * i);
-            nc = order.size();
-            deliver(d, s, s.hand, order.data(), nc, adsb::kGranuleWords, 0, nullptr, 0, g_complete);
-        } else { // the stream's resolver walks the tile ranges where they lie
-            for (uint32_t u = delivered; u < upto; u++)
-                nc += t_count[u];
-            d->prof.candidates += nc;
-            if (d->res.head_wanted(s.args.g_begin + adsb::kRun * adsb::tile_first_run(delivered, s.args.stagger, s.args.passes)))
-                d->res.capture_head_tiles(s.hand, t_start.data(), t_count.data(), delivered, upto, s.args.g_begin);
-            d->res.advance_tiles(s.hand, t_start.data(), t_count.data(), delivered, upto, 0, s.args.g_begin,
-                                 power_samples_produced(d->n_samples), g_complete);
-        }
+        const size_t nc = deliver_tiles(d, s, delivered, upto);
         delivered = upto;
         if (dbg_on) {
             dbg[1] += std::chrono::duration<double, std::micro>(clk::now() - tp).count();
@@ -652,6 +660,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile)
     d->prof.wait_ms += wait_ms;
     d->prof.host_ms += total_ms - wait_ms;
     *resume_tile = delivered;
+    *tiles_in = end.frontier;
     return overflowed ? 1 : 0;
 }
 
@@ -815,10 +824,11 @@ int slot_collect(adsb_decoder *d)
 {
     ScanSlot &s = d->slots[d->slot_head];
     using clk = std::chrono::steady_clock;
-    uint32_t resume_tile = 0;
+    uint32_t resume_tile = 0, tiles_in = 0;
     bool partial = false; // tiles below resume_tile were already delivered
+    bool relaunched = false;
     if (s.streaming) {
-        const int rc = slot_collect_streaming(d, s, &resume_tile);
+        const int rc = slot_collect_streaming(d, s, &resume_tile, &tiles_in);
         if (rc < 0)
             return -1;
         partial = rc == 1;
@@ -872,6 +882,7 @@ int slot_collect(adsb_decoder *d)
         if (attempt >= 2)
             return d->fail("record buffers overflowed repeatedly (%zu candidates, %zu tries)", nc, nt);
         d->prof.relaunches++;
+        relaunched = true;
         HIP_TRY(d, hipStreamSynchronize(s.launch_stream ? s.launch_stream : d->stream));
         if (slot_reserve(d, s, std::max(s.cand_cap, nc + nc / 8 + 64),
                          s.tries_on_device ? s.try_cap : std::max(s.try_cap, nt + nt / 8 + 64)))
@@ -894,16 +905,26 @@ int slot_collect(adsb_decoder *d)
         const size_t nt_host = s.tries_on_device ? 0 : nt;
         deliver(d, s, s.cands, d->order.data(), nc, adsb::kCandWords, 0, s.tries, nt_host, s.args.g_end);
     } else if (partial) {
-        // Some records are on the loose list: gather what is left -- the hand-off stream's
-        // tiles not yet delivered (the kernel has completed: every granule that was ever
-        // written is in; a missing or non-fitting marker ends the stream) + the loose list
-        // -- and sort it like the path above.
-        d->gather.clear();
-        const uint32_t lim = (uint32_t)std::min<size_t>(s.hc()[2], s.args.hand_cap);
+        // Some tile could not put all its records into the hand-off stream (staged list or survivor queue overflowed, its
+        // range did not fit): those records are on the loose list, which is only complete now that the kernel has ended.
+        // Every granule that was ever written is in: walk the stream again from its start (a missing or non-fitting marker
+        // ends it), note where each tile's records lie, sort the LOOSE records (few) and hand the tiles on in order -- runs of
+        // tiles that are whole in the stream where they lie, like the streaming collect does; a tile with loose records, or
+        // none in the stream at all, merged on the way.  (Round 3 gathered and sorted everything that was left: 4 ms for
+        // the 311 k records of a dense launch in which ONE early tile had overflowed.)
+        std::vector<uint32_t> &t_start = d->tile_start, &t_count = d->tile_count;
+        // (the streaming collect went on reading and checking behind the first tile that held it up: when it got to the end
+        // of the launch, where every tile's records lie is known already)
+        const bool walked = tiles_in == s.ntiles && !relaunched;
+        if (!walked) {
+            t_start.assign(s.ntiles, 0u);
+            t_count.assign(s.ntiles, ~0u);
+        }
+        const uint32_t lim = walked ? 0u : (uint32_t)std::min<size_t>(s.hc()[2], s.args.hand_cap);
         for (uint32_t pos = 0; pos < lim;) {
             const uint32_t *m = s.hand + (size_t)pos * adsb::kGranuleWords;
             const uint32_t tile = m[0], nf = m[1], n = nf & 0xFFFFu;
-            if (tile >= s.ntiles || (nf & adsb::kMarkNoFit) || (uint64_t)pos + 1 + 2ull * n > lim)
+            if (tile >= s.ntiles || (nf & adsb::kMarkNoFit) || (uint64_t)pos + 1 + 2ull * n > lim || t_count[tile] != ~0u)
                 break;
             uint32_t a[4] = {0, 0, 0, 0}, sum = 0, lo, hi;
             for (uint32_t k = 0; k < 8 * n; k++)
@@ -913,25 +934,61 @@ int slot_collect(adsb_decoder *d)
             adsb::marker_check(tile, nf, s.args.gen, a[0], a[1], a[2], a[3], sum, lo, hi);
             if (m[2] != lo || m[3] != hi)
                 break;
-            if (tile >= resume_tile)
-                for (uint32_t i = 0; i < n; i++) {
-                    const uint32_t *w = m + (size_t)(1 + 2 * i) * adsb::kGranuleWords;
-                    d->gather.insert(d->gather.end(), w, w + 6); // {g_rel, pw, w0..w3}
-                }
+            t_start[tile] = pos + 1;
+            t_count[tile] = n;
             pos += std::max(adsb::marker_granules(nf), adsb::stream_granules(n));
         }
-        // The loose list may also hold records of tiles the streamed part has already
-        // delivered: after a relaunch (record buffers regrown) every tile runs again, and
-        // whether a tile's range fits the hand-off stream depends on completion order.
+        // The loose list may also hold records of tiles the streamed part has already delivered: after a relaunch (record
+        // buffers regrown) every tile runs again, and whether a tile's range fits the stream depends on completion order.
         const uint64_t resume_rel = (uint64_t)adsb::kRun * adsb::tile_first_run(resume_tile, s.args.stagger, s.args.passes);
+        d->gather.clear();
         for (size_t i = 0; i < nc; i++) {
             const uint32_t *w = s.cands + i * adsb::kCandWords;
             if (w[0] >= resume_rel)
                 d->gather.insert(d->gather.end(), w, w + adsb::kCandWords);
         }
-        const size_t total = d->gather.size() / adsb::kCandWords;
-        sort_order(d, d->gather.data(), total);
-        deliver(d, s, d->gather.data(), d->order.data(), total, adsb::kCandWords, 0, nullptr, 0, s.args.g_end);
+        const size_t n_loose = d->gather.size() / adsb::kCandWords;
+        sort_order(d, d->gather.data(), n_loose);
+        const std::vector<uint32_t> loose_order(d->order.begin(), d->order.begin() + (ptrdiff_t)n_loose); // (deliver() reuses d->order)
+        std::vector<uint32_t> &merged = d->scratch_b; // one tile's records, kCandWords each, ascending
+        std::vector<uint32_t> iota;
+        size_t li = 0;
+        uint32_t run_from = resume_tile;
+        for (uint32_t u = resume_tile; u < s.ntiles; u++) {
+            const uint64_t hi_rel = (uint64_t)adsb::kRun * adsb::tile_first_run(u + 1, s.args.stagger, s.args.passes);
+            size_t lj = li;
+            while (lj < n_loose && d->gather[(size_t)loose_order[lj] * adsb::kCandWords] < hi_rel)
+                lj++;
+            if (t_count[u] != ~0u && lj == li)
+                continue; // whole in the stream: part of the current run
+            if (u > run_from)
+                deliver_tiles(d, s, run_from, u);
+            // this tile: its records in the stream (if it got that far) merged with its loose ones, both ascending
+            merged.clear();
+            const uint32_t ns = t_count[u] == ~0u ? 0u : t_count[u];
+            const uint32_t *sr = s.hand + (size_t)t_start[u] * adsb::kGranuleWords;
+            uint32_t si = 0;
+            while (si < ns || li < lj) {
+                const uint32_t *lw = li < lj ? d->gather.data() + (size_t)loose_order[li] * adsb::kCandWords : nullptr;
+                const uint32_t *sw = si < ns ? sr + (size_t)si * 2 * adsb::kGranuleWords : nullptr;
+                if (sw && (!lw || sw[0] <= lw[0])) {
+                    merged.insert(merged.end(), sw, sw + adsb::kCandWords); // {g_rel, pw, w0, w1}{w2, w3, ..}: the first six words
+                    si++;
+                } else {
+                    merged.insert(merged.end(), lw, lw + adsb::kCandWords);
+                    li++;
+                }
+            }
+            const size_t nm = merged.size() / adsb::kCandWords;
+            iota.resize(nm);
+            for (size_t i = 0; i < nm; i++)
+                iota[i] = (uint32_t)i;
+            const uint64_t g_complete = std::min<uint64_t>(s.args.g_end, s.args.g_begin + hi_rel);
+            deliver(d, s, merged.data(), iota.data(), nm, adsb::kCandWords, 0, nullptr, 0, g_complete);
+            run_from = u + 1;
+        }
+        if (s.ntiles > run_from)
+            deliver_tiles(d, s, run_from, s.ntiles);
     } else if (nc != 0) {
         return d->fail("internal: %zu loose records without a tile overflow flag", nc);
     }

@@ -50,6 +50,8 @@ struct HandCursor {
     const uint32_t gen, cap;
     uint32_t pos = 0;      // granules of the stream consumed
     uint32_t frontier = 0; // every tile below is in
+    uint32_t hold = ~0u;   // the lowest tile that says "some of my records are on the loose list": it, and every tile behind
+                           // it, can only be handed on once the launch has ended -- but they are READ (and checked) meanwhile
     uint32_t tile = 0, nf = 0; // the marker tile_in() accepted last
     double wait_ms = 0;
     clk::time_point t_last_wait;
@@ -121,14 +123,18 @@ struct HandCursor {
         wait_ms += std::chrono::duration<double, std::milli>(t_last_wait - t_w).count();
         return ok;
     }
-    // Take the tile whose marker tile_in() just accepted.  0: taken; 1: it (or the stream) says "finish after
-    // completion"; -1: the stream is corrupt.
+    uint32_t deliverable() const { return std::min(frontier, hold); } // tiles below may go to the resolver now
+    // Take the tile whose marker tile_in() just accepted.  0: taken (a tile that also has loose records lowers `hold`);
+    // 1: its range ran past the array -- nothing of it, and no marker behind it, is in the stream: the stream ends here;
+    // -1: the stream is corrupt.
     int take()
     {
         const uint32_t n = nf & 0xFFFFu;
         if (t_count[tile] != ~0u)
             return -1;
         if (nf & (kMarkOver | kMarkNoFit))
+            hold = std::min(hold, tile);
+        if (nf & kMarkNoFit)
             return 1;
         t_start[tile] = pos + 1;
         t_count[tile] = n;
@@ -139,11 +145,13 @@ struct HandCursor {
     }
 };
 
-// How a collect ended: 0 every tile is in; 1 finish after completion (a tile says so, or the stream is full); -1 the stream
-// is corrupt (a tile twice); -2 the launch ended and the bytes never came.  pos / tile: where the cursor stood.
+// How a collect ended: 0 every tile is in and has been handed on; 1 finish after completion (a tile has records on the loose
+// list, or the stream is full: tiles from `delivered` on wait for the launch's end); -1 the stream is corrupt (a tile twice);
+// -2 the launch ended and the bytes never came.  pos / tile: where the cursor stood; frontier: every tile below is in the
+// stream and checked (t_start / t_count say where), whether or not it could be handed on yet.
 struct CollectEnd {
     int status = 0;
-    uint32_t pos = 0, tile = 0;
+    uint32_t pos = 0, tile = 0, frontier = 0;
 };
 
 // A decoder's second host thread (cfg.host_threads = 2): it reads and checks the hand-off stream of the launch being
@@ -192,8 +200,8 @@ struct StreamReader {
                 break;
             }
             if (!cur.tile_in()) {
-                if (cur.frontier != published) // the device is behind: hand over what is in before waiting
-                    frontier.store(published = cur.frontier, std::memory_order_release);
+                if (cur.deliverable() != published) // the device is behind: hand over what is in before waiting
+                    frontier.store(published = cur.deliverable(), std::memory_order_release);
                 if (!cur.wait_tile()) {
                     status = -2;
                     break;
@@ -204,15 +212,18 @@ struct StreamReader {
                 status = rc;
                 break;
             }
-            if (cur.frontier - published >= kPublishEvery)
-                frontier.store(published = cur.frontier, std::memory_order_release);
+            if (cur.deliverable() - published >= kPublishEvery)
+                frontier.store(published = cur.deliverable(), std::memory_order_release);
         }
+        if (status == 0 && cur.hold != ~0u)
+            status = 1;
         end.status = status;
         end.pos = cur.pos;
         end.tile = cur.tile;
+        end.frontier = cur.frontier;
         wait_ms = cur.wait_ms;
         busy_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count() - cur.wait_ms;
-        frontier.store(cur.frontier, std::memory_order_release);
+        frontier.store(cur.deliverable(), std::memory_order_release); // (what the caller may hand on: tiles below the first that holds)
     }
     void loop()
     {
@@ -353,8 +364,8 @@ CollectEnd collect_alone(const HandJob &job, uint32_t *t_start, uint32_t *t_coun
         }
         if (!cur.tile_in()) {
             // the device is behind: use the time to resolve what is complete, then wait
-            if (cur.frontier > delivered) {
-                flush(cur.frontier);
+            if (cur.deliverable() > delivered) {
+                flush(cur.deliverable());
                 continue;
             }
             if (!cur.wait_tile()) {
@@ -367,12 +378,16 @@ CollectEnd collect_alone(const HandJob &job, uint32_t *t_start, uint32_t *t_coun
             end.status = rc;
             break;
         }
-        if (cur.frontier - delivered >= (job.ntiles - delivered > kCollectTailTiles ? kCollectGroup : kCollectTailGroup))
-            flush(cur.frontier);
+        if (cur.deliverable() > delivered &&
+            cur.deliverable() - delivered >= (job.ntiles - delivered > kCollectTailTiles ? kCollectGroup : kCollectTailGroup))
+            flush(cur.deliverable());
     }
-    if (end.status >= 0 && cur.frontier > delivered)
-        flush(cur.frontier);
+    if (end.status >= 0 && cur.deliverable() > delivered)
+        flush(cur.deliverable());
+    if (end.status == 0 && cur.hold != ~0u)
+        end.status = 1;
     end.pos = cur.pos;
+    end.frontier = cur.frontier;
     end.tile = end.status == -2 ? cur.frontier : cur.tile;
     wait_ms = cur.wait_ms;
     t_last_wait = cur.t_last_wait;

@@ -220,8 +220,10 @@ long adsb_handoff_walk(const void *stream, size_t granules, uint32_t n_tiles, ui
             break;
         }
     }
+    if (*status == 0 && cur.hold != ~0u)
+        *status = 1; // every tile is in, but from the one that holds on they wait for the launch's end
     free(copy);
-    return (long)cur.frontier;
+    return (long)cur.deliverable();
 }
 
 } // extern "C"

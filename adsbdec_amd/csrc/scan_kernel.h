@@ -22,7 +22,8 @@ constexpr int kReachRuns = 44;  // runs of bit planes one long-frame evaluation 
 constexpr int kMaxPasses = 32;
 constexpr int kQueueCap = 4 * kThreads; // survivors compacted per round
 constexpr int kPlanePad = 8;
-constexpr int kClistCap = 192;  // CRC-valid candidates staged per tile for the never-visited filter
+constexpr int kClistCap = 256;  // CRC-valid candidates staged per tile for the never-visited filter: one per thread (a tile of 48 k
+                                // offsets full of 112-bit frames packed back to back decodes at ~130-190 offsets: BASELINE configs[2])
 constexpr int ADSB_DECOFFSET_K = 1200; // longest span an accepted frame jumps (adsbdec.h:3)
 constexpr int kCandWords = 6;   // {g_rel, pw, frame[0..13] | len<<16 in the last word}
 constexpr int kSyndWords = 14 * 256;

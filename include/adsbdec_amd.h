@@ -99,7 +99,7 @@ typedef struct adsb_config {
      * that tests can force every overflow path (relaunch with regrown buffers, loose list) */
     int32_t debug_cand_cap;    /* loose-list records per launch slot                         */
     int32_t debug_try_cap;     /* try words per launch slot (collect_stats)                  */
-    int32_t debug_clist_cap;   /* CRC-valid candidates staged per tile (1..192)              */
+    int32_t debug_clist_cap;   /* CRC-valid candidates staged per tile (1..256)              */
     int32_t push_overlap;      /* 1: adsb_push() returns as soon as `samples` has been COPIED to the device (the buffer
                                   is free again, which is all decodeiq's callers need: air.c:230-239, 173-177) and
                                   leaves the scan in flight; the frames of a call become drainable during the NEXT
@@ -254,10 +254,12 @@ int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out);
  * adsb_handoff_walk applies exactly the rules the streaming collect applies (the same code) to an
  * image of such a stream in ordinary memory: tile_start[t] / tile_count[t] (n_tiles entries each)
  * receive the granule index of tile t's first record and its record count (~0u: not in), the
- * return value is the number of leading tiles that are all in, and *status says why the walk
- * ended: 0 every tile is in; 1 a tile asks to be finished after completion (flag 0x10000 /
- * 0x20000) or the stream is full; 2 the bytes at the cursor are not (yet) a valid marker of this
- * launch; -1 a tile appears twice.  No GPU is needed: this is how the host logic is tested. */
+ * return value is the number of leading tiles that may be handed on (all in, none of them holding),
+ * and *status says why the walk ended: 0 every tile is in; 1 a tile holds -- it has records on the
+ * loose list (flag 0x10000: the tiles behind it are still read, and wait with it for the launch's end)
+ * or its range ran past the array (flag 0x20000: the stream ends there) -- or the stream is full;
+ * 2 the bytes at the cursor are not (yet) a valid marker of this launch; -1 a tile appears twice.
+ * No GPU is needed: this is how the host logic is tested. */
 long adsb_handoff_walk(const void *stream, size_t granules, uint32_t n_tiles, uint32_t gen,
                        uint32_t *tile_start, uint32_t *tile_count, int *status);
 

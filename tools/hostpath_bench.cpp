@@ -1,87 +1,86 @@
-// hostpath_bench.cpp -- CPU-only timing of the host side of the streaming hand-off
-// (stream validation + in-place resolve) on a synthetic stream shaped like the bench
-// capture: 3941 tiles, ~15k records.  Tuning aid, not part of the library.
-//   g++ -O2 -std=c++17 -I adsbdec_amd/csrc tools/hostpath_bench.cpp -o tools/bin/hostpath_bench
+// hostpath_bench.cpp -- CPU-only timing of the host side of the streaming hand-off (handoff.hpp's collect_alone: marker
+// check + tile bookkeeping; resolver.hpp's advance_tiles: the greedy replay) on two synthetic launches shaped like the
+// bench's: sparse (2 786 tiles, ~17 k records, 13 k frames) and dense10 (BASELINE configs[2] at its stated density: ~110
+// records per tile, 311 k records, 106 k frames).  The stream is complete before the host starts (what the host sees when it
+// is the bottleneck) and lies in ordinary cached memory (the real one is device-written: every line is a miss the first time).
+//   g++ -O2 -std=c++17 tools/hostpath_bench.cpp -o tools/bin/hostpath_bench && tools/bin/hostpath_bench
 #include <chrono>
 #include <cstdio>
-#include <emmintrin.h>
+#include <cstring>
 #include <random>
 #include <vector>
-#include "resolver.hpp"
-static inline uint32_t rotl(uint32_t v, int s) { return v << s | v >> (32 - s); }
+
+#include "../adsbdec_amd/csrc/handoff.hpp"
+#include "../adsbdec_amd/csrc/resolver.hpp"
+using namespace adsb;
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-int main()
+
+static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_gap, int copies)
 {
-    const uint32_t ntiles = 3941, per = 34048, gen = 0x1234567u;
+    const uint32_t gen = 0x1234567u;
     std::mt19937 rng(1);
-    std::vector<uint32_t> hand_v;
+    std::vector<uint32_t> hv;
     uint64_t nrec = 0;
+    uint64_t next_frame = 500;
     for (uint32_t t = 0; t < ntiles; t++) {
         std::vector<uint32_t> gs;
-        for (uint32_t g = rng() % 9000; g < per; g += 7000 + rng() % 6000) {
-            gs.push_back(g);
-            if (rng() % 8 == 0 && g + 1 < per) gs.push_back(g + 1);
+        while (next_frame < (uint64_t)(t + 1) * per) {
+            for (int c = 0; c < copies; c++)
+                if (next_frame + c < (uint64_t)(t + 1) * per)
+                    gs.push_back((uint32_t)(next_frame + c));
+            next_frame += frame_gap + (frame_gap > 2000 ? rng() % frame_gap : 0);
         }
-        const uint32_t n = gs.size();
-        uint32_t acc[4] = {0, 0, 0, 0};
-        const size_t mpos = hand_v.size();
-        hand_v.insert(hand_v.end(), 4, 0u);
-        for (uint32_t g : gs) {
-            uint32_t r[8] = {t * per + g, 1000 + g % 77, (17u << 3) | (uint32_t)(rng() << 8), (uint32_t)rng(), (uint32_t)rng(),
+        const uint32_t n = (uint32_t)gs.size(), reserve = stream_granules(n);
+        uint32_t a[4] = {0, 0, 0, 0}, sum = 0;
+        const size_t mpos = hv.size();
+        hv.insert(hv.end(), 4 * reserve, 0u);
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t r[8] = {gs[i], 1000 + gs[i] % 77, (17u << 3) | (uint32_t)(rng() << 8), (uint32_t)rng(), (uint32_t)rng(),
                              ((uint32_t)rng() & 0xFFFFu) | (14u << 16), 0, 0};
-            for (int k = 0; k < 8; k++) acc[k & 3] ^= r[k];
-            hand_v.insert(hand_v.end(), r, r + 8);
+            for (int k = 0; k < 8; k++) a[k & 3] ^= r[k];
+            sum += record_term(i, r[0], r[1]);
+            std::memcpy(hv.data() + mpos + 4 + 8 * i, r, 32);
             nrec++;
         }
-        uint32_t *m = hand_v.data() + mpos;
-        m[0] = t, m[1] = n;
-        m[2] = acc[0] ^ rotl(acc[2], 16) ^ gen ^ t ^ rotl(n, 11);
-        m[3] = acc[1] ^ rotl(acc[3], 16) ^ ~gen ^ rotl(t, 7) ^ n;
+        const uint32_t nf = n | ((reserve >> 2) << kMarkLinesShift);
+        uint32_t lo, hi;
+        marker_check(t, nf, gen, a[0], a[1], a[2], a[3], sum, lo, hi);
+        uint32_t m[4] = {t, nf, lo, hi};
+        std::memcpy(hv.data() + mpos, m, 16);
     }
-    // 16-byte aligned copy
-    std::vector<__m128i> store(hand_v.size() / 4 + 1);
+    std::vector<__m128i> store(hv.size() / 4 + 1);
     uint32_t *hand = reinterpret_cast<uint32_t *>(store.data());
-    std::copy(hand_v.begin(), hand_v.end(), hand);
-    printf("%u tiles, %llu records, %zu KiB stream\n", ntiles, (unsigned long long)nrec, hand_v.size() * 4 / 1024);
-    adsb::Resolver res;
-    std::vector<uint32_t> order, t_start(ntiles), t_count(ntiles);
-    std::vector<adsb_frame> out(nrec);
-    for (int rep = 0; rep < 8; rep++) {
+    std::memcpy(hand, hv.data(), hv.size() * 4);
+    printf("%s: %u tiles, %llu records, %zu KiB stream\n", name, ntiles, (unsigned long long)nrec, hv.size() * 4 / 1024);
+    Resolver res;
+    std::vector<uint32_t> t_start(ntiles), t_count(ntiles);
+    for (int rep = 0; rep < 6; rep++) {
         res.reset();
-        double tr = 0;
-        const double t0 = now();
-        uint32_t pos = 0, frontier = 0, delivered = 0;
         std::fill(t_count.begin(), t_count.end(), ~0u);
-        while (frontier < ntiles) {
-            const __m128i *gp = reinterpret_cast<const __m128i *>(hand) + pos;
-            const __m128i mk = _mm_load_si128(gp);
-            const uint32_t tile = (uint32_t)_mm_cvtsi128_si32(mk), nf = (uint32_t)_mm_cvtsi128_si32(_mm_srli_si128(mk, 4));
-            const uint32_t n = nf & 0xFFFFu;
-            if (tile >= ntiles || n > 4096) return 1;
-            __m128i acc = _mm_setzero_si128();
-            for (uint32_t k = 0; k < 2 * n; k++) acc = _mm_xor_si128(acc, _mm_load_si128(gp + 1 + k));
-            alignas(16) uint32_t a[4], mw[4];
-            _mm_store_si128((__m128i *)a, acc);
-            _mm_store_si128((__m128i *)mw, mk);
-            if (mw[2] != (a[0] ^ rotl(a[2], 16) ^ gen ^ tile ^ rotl(nf, 11)) || mw[3] != (a[1] ^ rotl(a[3], 16) ^ ~gen ^ rotl(tile, 7) ^ nf))
-                return 2;
-            t_start[tile] = pos + 1;
-            t_count[tile] = n;
-            pos += 1 + 2 * n;
-            while (frontier < ntiles && t_count[frontier] != ~0u) frontier++;
-            if (frontier - delivered >= 512 || frontier == ntiles) {
-                const double ta = now();
-                res.advance_tiles(hand, t_start.data(), t_count.data(), delivered, frontier, 0, 0, (uint64_t)ntiles * per + 100000,
-                                  (uint64_t)frontier * per);
-                delivered = frontier;
-                tr += now() - ta;
-            }
-        }
+        HandJob job;
+        job.hand = hand, job.ntiles = ntiles, job.gen = gen, job.cap = (uint32_t)(hv.size() / 4);
+        double tr = 0, wait_ms = 0;
+        auto tl = HandCursor::clk::now();
+        uint32_t delivered = 0;
+        const double t0 = now();
+        auto flush = [&](uint32_t upto) {
+            const double ta = now();
+            res.advance_tiles(hand, t_start.data(), t_count.data(), delivered, upto, 0, 0, (uint64_t)ntiles * per + 100000, (uint64_t)upto * per);
+            delivered = upto;
+            tr += now() - ta;
+        };
+        const CollectEnd end = collect_alone(job, t_start.data(), t_count.data(), delivered, flush, wait_ms, tl);
         const double t1 = now();
-        const size_t nf = res.drain(out.data(), out.size());
-        const double t2 = now();
-        printf("rep %d: parse+validate %.1f us, resolve %.1f us, total %.1f us, drain %.1f us, %zu frames\n", rep, t1 - t0 - tr, tr,
-               t1 - t0, t2 - t1, nf);
+        const adsb_frame *fp;
+        const size_t nf = res.take(&fp);
+        printf("  rep %d: status %d, check + bookkeeping %.1f us, resolve %.1f us, total %.1f us = %.1f ns per record, %zu frames\n", rep, end.status,
+               t1 - t0 - tr, tr, t1 - t0, (t1 - t0) * 1e3 / nrec, nf);
     }
+}
+
+int main()
+{
+    run("sparse", 2786, 48188, 10000, 1);
+    run("dense10", 2786, 48188, 1200, 3);
     return 0;
 }
