@@ -29,8 +29,8 @@ $(LIBDIR)/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
 $(LIB): $(LIBDIR)/scan_kernel.hip.o $(LIBDIR)/decoder.hip.o $(LIBDIR)/format.c.o $(LIBDIR)/multi.cpp.o $(LIBDIR)/host_abi.cpp.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm -lpthread
 
-$(CLI): $(CSRC)/cli/adsbdec_amd_cli.c $(LIB) include/adsbdec_amd.h
-	$(CC) -O2 -Wall -o $@ $< -Iinclude -L$(LIBDIR) -ladsbdec_amd -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+$(CLI): $(CSRC)/cli/adsbdec_amd_cli.c $(CSRC)/cli/sink.c $(CSRC)/cli/sink.h $(LIB) include/adsbdec_amd.h
+	$(CC) -O2 -Wall -o $@ $(CSRC)/cli/adsbdec_amd_cli.c $(CSRC)/cli/sink.c -Iinclude -L$(LIBDIR) -ladsbdec_amd -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 # test infrastructure (never linked into the library): the CPU oracle, and the reference
 # objects it is pinned against when /root/reference is present

@@ -76,8 +76,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force or _newer(LIB, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lm", "-lpthread"])
     cli_src = os.path.join(CSRC, "cli", "adsbdec_amd_cli.c")
-    if os.path.exists(cli_src) and (force or _newer(CLI, [cli_src, LIB] + hdrs)):
-        _run(["gcc", "-O2", "-Wall", "-o", CLI, cli_src, "-I", os.path.join(ROOT, "include"),
+    sink_src = os.path.join(CSRC, "cli", "sink.c")
+    if os.path.exists(cli_src) and (force or _newer(CLI, [cli_src, sink_src, os.path.join(CSRC, "cli", "sink.h"), LIB] + hdrs)):
+        _run(["gcc", "-O2", "-Wall", "-o", CLI, cli_src, sink_src, "-I", os.path.join(ROOT, "include"),
               "-L", LIBDIR, "-ladsbdec_amd", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 

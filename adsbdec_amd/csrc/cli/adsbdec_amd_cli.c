@@ -18,8 +18,10 @@
  *                   capture k's packets go to <file k>.avr / .mlat / .beast instead of stdout.
  * The GPU runtime initialises every device it can see, which takes longer the more there are: before its first call
  * this program narrows ROCR_VISIBLE_DEVICES to the devices it is going to use (unless the variable is already set).
- * -s / -l (TCP sinks), the live Airspy input and anything else print the usage
- * text and exit 1, like the reference's default: branch (main.c:85-87).
+ *     -s addr[:port]  send the packets to a TCP peer instead of stdout (main.c:65-68; default port 30001)
+ *     -l addr[:port]  listen, accept ONE peer and send the packets to it (main.c:69-72; default port 30002); sink.c
+ * The live Airspy input and anything else print the usage text and exit 1, like the reference's default: branch
+ * (main.c:85-87).
  *
  * Differences from the reference, on purpose (DESIGN.md "CLI"):
  *   - every accepted frame is written: the reference drops frames still queued
@@ -39,6 +41,7 @@
 #include <unistd.h>
 
 #include "adsbdec_amd.h"
+#include "sink.h"
 
 /* fileInput (air.c:217-246) reads 2 MiB at a time into one buffer and decodes it before the
  * next read().  Here a reader thread fills a ring of 32 MiB buffers from the moment the
@@ -139,10 +142,12 @@ static void *locker_main(void *arg)
 static void usage(void)
 {
     printf("adsbdec_amd : MI355X offline ADS-B decoder (adsbdec -f compatible)\n\n");
-    printf("usage : adsbdec_amd_cli [-a] [-m] [-b] [-d gpu | -G gpus] -f filename [-f filename ...]\n\n");
+    printf("usage : adsbdec_amd_cli [-a] [-m] [-b] [-s addr[:port] | -l addr[:port]] [-d gpu | -G gpus] -f filename [-f filename ...]\n\n");
     printf("\t-a : decode DF18 too\n");
     printf("\t-m : output avrmlat format (ie : with 12Mhz timestamp)\n");
     printf("\t-b : output binary beast format\n");
+    printf("\t-s addr[:port] : send ouput via TCP to addr:port (default port 30001)\n");
+    printf("\t-l addr[:port] : listen to addr:port (default port 30002) and send ouput to the peer that connects\n");
     printf("\t-x : (extension) repair 1-bit CRC errors in DF17/18 frames\n");
     printf("\t-d k : (extension) use GPU k\n");
     printf("\t-G n | a,b,.. : (extension) shard the file over n GPUs / the GPUs listed; several -f: one capture per GPU,\n");
@@ -151,17 +156,34 @@ static void usage(void)
     printf("\t     bit-identical to adsbdec for codes 0..4095, see adsbdec_amd.h for the wider domain)\n");
 }
 
+static sink out_sink; /* stdout unless -s / -l */
+
+/* Packets leave in batches of up to 64 KiB: one fwrite / send per batch. */
+static int write_frames(sink *out, const adsb_frame *fr, long n, int outformat)
+{
+    static char batch[65536 + 256];
+    size_t fill = 0;
+    unsigned long packets = 0;
+    for (long i = 0; i < n; i++) {
+        fill += (size_t)adsb_format_frame(&fr[i], outformat, batch + fill);
+        packets++;
+        if (fill >= 65536 || i + 1 == n) {
+            const int rc = sink_write(out, batch, fill, packets);
+            if (rc < 0)
+                return -1;
+            fill = 0, packets = 0; /* (rc == 1: the peer went away and the batch with it, output.c:321-327) */
+        }
+    }
+    return 0;
+}
+
 static int flush_frames(adsb_decoder *dec, int outformat)
 {
     const adsb_frame *fr; /* the handle's own queue: formatted where it lies */
-    char pkt[256];
     const long n = adsb_take(dec, &fr);
-    for (long i = 0; i < n; i++) {
-        int len = adsb_format_frame(&fr[i], outformat, pkt);
-        if (fwrite(pkt, 1, (size_t)len, stdout) != (size_t)len)
-            return -1;
-    }
-    return n < 0 ? -1 : 0;
+    if (n < 0)
+        return -1;
+    return write_frames(&out_sink, fr, n, outformat);
 }
 
 static void print_stats(const adsb_stats *st) /* valid.c:84-100 */
@@ -175,7 +197,7 @@ static void print_stats(const adsb_stats *st) /* valid.c:84-100 */
     fprintf(stderr, "Total :\t%10llu\n", tot); /* tot_fi is uninitialised there */
 }
 
-static int write_frames(FILE *out, const adsb_frame *fr, long n, int outformat)
+static int write_frames_file(FILE *out, const adsb_frame *fr, long n, int outformat)
 {
     char pkt[256];
     for (long i = 0; i < n; i++) {
@@ -258,9 +280,9 @@ static int run_multi(const adsb_config *cfg, int *devs, int ndev, char **files, 
             fprintf(stderr, "adsb_multi_decode_file() failed: %s\n", adsb_multi_last_error(m));
             rc = 255;
         } else {
-            if (write_frames(stdout, fr, n, outformat) != 0)
+            if (write_frames(&out_sink, fr, n, outformat) != 0)
                 rc = 1;
-            fflush(stdout);
+            sink_close(&out_sink);
             if (timing) {
                 adsb_multi_info inf;
                 adsb_multi_get_info(m, &inf);
@@ -283,7 +305,7 @@ static int run_multi(const adsb_config *cfg, int *devs, int ndev, char **files, 
             char path[4096];
             snprintf(path, sizeof path, "%s.%s", files[k], ext[outformat]);
             FILE *out = n >= 0 ? fopen(path, "wb") : NULL;
-            if (!out || write_frames(out, fr, n, outformat) != 0 || fclose(out) != 0) {
+            if (!out || write_frames_file(out, fr, n, outformat) != 0 || fclose(out) != 0) {
                 fprintf(stderr, "%s: cannot write\n", path);
                 rc = 1;
                 break;
@@ -307,8 +329,10 @@ int main(int argc, char **argv)
     char *files[MAX_FILES];
     int nfiles = 0, devs[MAX_GPUS], ndev = 0, device = -1;
     int outformat = 0, df18 = 0, fix1 = 0, c;
+    int outmode = SINK_STDOUT;
+    const char *rawaddr = NULL;
 
-    while ((c = getopt(argc, argv, "f:g:ambxd:G:")) != EOF) {
+    while ((c = getopt(argc, argv, "f:g:ambxd:G:s:l:")) != EOF) {
         switch (c) {
         case 'f':
             filename = optarg;
@@ -332,6 +356,14 @@ int main(int argc, char **argv)
                 return 1;
             }
             break;
+        case 's':
+            rawaddr = optarg;
+            outmode = SINK_CONNECT;
+            break;
+        case 'l':
+            rawaddr = optarg;
+            outmode = SINK_LISTEN;
+            break;
         case 'g':
             break;
         case 'a':
@@ -351,10 +383,14 @@ int main(int argc, char **argv)
             return 1;
         }
     }
-    if (!filename || (nfiles > 1 && ndev == 0) || (ndev && device >= 0)) { /* several captures need -G; -d and -G exclude each other */
+    /* several captures need -G and go to files; -d and -G exclude each other */
+    if (!filename || (nfiles > 1 && (ndev == 0 || outmode != SINK_STDOUT)) || (ndev && device >= 0)) {
         usage();
         return 1;
     }
+    sink_init(&out_sink, outmode, rawaddr);
+    if (getenv("ADSB_CLI_RETRY_S")) /* (a test's knob: the reference waits 3 s between attempts, output.c:282) */
+        out_sink.retry_s = (unsigned)atoi(getenv("ADSB_CLI_RETRY_S"));
 
     const int timing = getenv("ADSB_CLI_TIMING") != NULL;
     if (ndev) {
@@ -364,6 +400,8 @@ int main(int argc, char **argv)
         mcfg.fix_1bit = fix1;
         mcfg.collect_stats = 1; /* the reference always prints Try/Ok */
         restrict_visible_devices(devs, ndev);
+        if (sink_wait_peer(&out_sink) != 0)
+            return 255; /* unusable address: runOutput() == -1 (output.c:278-279) */
         return run_multi(&mcfg, devs, ndev, files, nfiles, outformat, timing);
     }
     if (device >= 0) {
@@ -397,6 +435,11 @@ int main(int argc, char **argv)
         pthread_cond_init(&rg.cv, NULL);
         have_reader = rg.slot && pthread_create(&reader, NULL, reader_main, &rg) == 0;
     }
+
+    /* -s / -l: the peer first (output.c:277-285: no peer, no packets; an unusable address ends the run with
+     * runOutput() == -1).  The file is being read meanwhile. */
+    if (sink_wait_peer(&out_sink) != 0)
+        return 255;
 
     adsb_config cfg;
     adsb_config_default(&cfg);
@@ -459,8 +502,9 @@ int main(int argc, char **argv)
             fprintf(stderr, "adsb_finish() failed: %s\n", adsb_last_error(dec));
             rc = 255;
         }
-        flush_frames(dec, outformat);
-        fflush(stdout);
+        if (flush_frames(dec, outformat) != 0 && rc == 0)
+            rc = 1;
+        sink_close(&out_sink);
         if (rc != 0) { /* let the reader run out: hand every buffer back */
             pthread_mutex_lock(&rg.mu);
             for (int i = 0; i < rg.nbuf; i++)

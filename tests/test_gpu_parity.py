@@ -568,6 +568,36 @@ def test_survivor_queue_overflow_fallback(oracle, dec_factory):
     assert sum(wstats["try"].values()) > 5000
 
 
+def test_overflow_rounds_ranges_and_bit_positions(oracle, dec_factory, torch_cuda):
+    """A capture whose survivors are dense AND uneven -- a stretch of nothing but frame starts (7 % of the offsets pass
+    the DF gate: ~500 per chunk of 256 runs), then frames packed back to back, then a stretch of both -- against queues of
+    256, 512 and 1 024 entries: tiles are redone in ranges of chunks sized from the failed round's count, single chunks
+    that still do not fit go bit position by bit position, every round's candidates are staged in the tile's one list.
+    Frames and the Try/Ok table must not change, with the list at its normal size and shrunk (candidates go loose)."""
+    import bench
+    from oracle import gen_signal as G
+    rng = np.random.default_rng(77)
+    storm = np.tile(bench._frame_start_wave(), 1 + 300_000 // 260)[:300_000]
+    placed = [(10_000 + 2_400 * i, G.make_frame([17, 18, 17, 11][i % 4], rng), float(rng.uniform(500, 1500)), float(i))
+              for i in range(250)]
+    back = G.synth(10_000 + 2_400 * 250 + 30_000, placed, 6.0, 5).astype(np.float32) - 2048.0
+    sig = np.concatenate([storm, back, storm[:150_000] * 0.5 + back[:150_000], rng.normal(0, 300, 200_000)]).astype(np.float32)
+    sig += rng.normal(0, 30, sig.size).astype(np.float32)
+    x = np.clip(np.rint(sig + 2048.0), 0, 4095).astype(np.uint16)
+    want, wstats = oracle.decode(x, df18=True)
+    assert len(want) > 200 and sum(wstats["try"].values()) > 10_000
+    t = _dev(torch_cuda, x)
+    for qcap in (256, 512, 1024):
+        for kw in (dict(), dict(collect_stats=True), dict(collect_stats=True, debug_clist_cap=3), dict(all_candidates=True)):
+            d = dec_factory(df18=True, debug_queue_cap=qcap, **kw)
+            for _ in range(2):
+                d.reset()
+                d.push_device_final(t.data_ptr(), t.numel())
+                assert records(d.drain()) == records(want), (qcap, kw)
+                if kw.get("collect_stats"):
+                    assert d.stats() == wstats, (qcap, kw)
+
+
 def test_one_bit_repair_extension_vs_oracle(oracle, dec_factory):
     """cfg.fix_1bit (EXTENSION: the reference has no error correction; no
     reference parity exists) against the oracle's restatement of the same rule; with
@@ -958,6 +988,77 @@ def test_cli_matches_golden_avr_mlat_beast(capi, tmp_path):
         assert [int(v) for v in err[2].split(":")[1].split()] == [rec["stats"]["ok"][k] for k in (11, 17, 18)]
     # unknown flags print the usage text and exit 1 (main.c:85-87)
     assert subprocess.run([capi.CLI_PATH, "-e"], capture_output=True).returncode == 1
+
+
+def test_cli_tcp_sinks_carry_the_same_packets(capi, tmp_path):
+    """-s (connect) and -l (listen), the reference's outmode 1 / 2 (main.c:65-72, output.c:59-157): the packets a loopback
+    peer receives are the golden capture's AVR / MLAT / Beast bytes (minted through the reference's own formatpkt: over a
+    socket the reference writes Beast with its real length, output.c:318-320), stdout stays empty, stderr says
+    "connected" ("listening" first with -l) and then prints the Try/Ok table; one device and sharded over two handles."""
+    import socket
+    import threading
+    x, rec = load_golden("mixed_df_a_384Ki")
+    path = tmp_path / "in.bin"
+    x.tofile(path)
+
+    def want_bytes(key):
+        if key == "beast":
+            return b"".join(bytes.fromhex(f["beast"]) for f in rec["frames"])
+        return "".join(f[key] for f in rec["frames"]).encode()
+
+    def table_ok(lines):
+        assert [int(v) for v in lines[1].split(":")[1].split()] == [rec["stats"]["try"][k] for k in (11, 17, 18)]
+        assert [int(v) for v in lines[2].split(":")[1].split()] == [rec["stats"]["ok"][k] for k in (11, 17, 18)]
+
+    for flag, key in (([], "avr"), (["-m"], "mlat"), (["-b"], "beast")):
+        for opts in ([], ["-G", "0,0"]):
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.bind(("127.0.0.1", 0))
+            srv.listen(1)
+            got = []
+
+            def serve():
+                c, _ = srv.accept()
+                with c:
+                    while True:
+                        b = c.recv(1 << 16)
+                        if not b:
+                            break
+                        got.append(b)
+            t = threading.Thread(target=serve, daemon=True)
+            t.start()
+            p = subprocess.run([capi.CLI_PATH, "-a"] + flag + opts + ["-s", f"127.0.0.1:{srv.getsockname()[1]}", "-f", str(path)],
+                               capture_output=True, timeout=300)
+            t.join(30)
+            srv.close()
+            assert p.returncode == 0, p.stderr
+            assert p.stdout == b"" and b"".join(got) == want_bytes(key), (key, opts)
+            err = p.stderr.decode().splitlines()
+            assert err[0] == "connected"
+            table_ok(err[1:])
+    # -l: the program listens, this test is the peer
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = subprocess.Popen([capi.CLI_PATH, "-a", "-m", "-l", f"127.0.0.1:{port}", "-f", str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.stderr.readline() == b"listening\n"
+    c = socket.create_connection(("127.0.0.1", port), timeout=30)
+    data = b""
+    while True:
+        b = c.recv(1 << 16)
+        if not b:
+            break
+        data += b
+    c.close()
+    out, err = p.communicate(timeout=120)
+    assert p.returncode == 0 and out == b"" and data == want_bytes("mlat")
+    err = err.decode().splitlines()
+    assert err[0] == "connected"
+    table_ok(err[1:])
+    # an unusable address ends the run before anything is decoded (runOutput() == -1 -> 255); -s with several captures is a usage error
+    p = subprocess.run([capi.CLI_PATH, "-s", "[::1", "-f", str(path)], capture_output=True, timeout=60)
+    assert p.returncode == 255 and p.stderr == b"Invalid IPV6 address\n" and p.stdout == b""
+    assert subprocess.run([capi.CLI_PATH, "-G", "0,0", "-s", "127.0.0.1:9", "-f", str(path), "-f", str(path)], capture_output=True).returncode == 1
 
 
 def test_staggered_tile_sizes(oracle, dec_factory, torch_cuda):
