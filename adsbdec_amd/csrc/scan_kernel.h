@@ -11,7 +11,7 @@ namespace adsb {
 // Launch shape (what every measurement of DESIGN.md was taken with; the experiments that set other values are history)
 constexpr int kFirGroup = 4;       // FIR outputs advanced together (independent accumulation chains interleaved)
 constexpr int kSleepStagger = 90;  // s_sleep units (64 cycles) between the starts of a CU's first four workgroups
-constexpr int kMinWaves = 4;       // __launch_bounds__ second argument: waves per SIMD (100 VGPRs)
+constexpr int kMinWaves = 5;       // __launch_bounds__ second argument: waves per SIMD (96 VGPRs; 5 workgroups' LDS fit a CU)
 
 constexpr int kRun = 28;        // power samples per thread run (4 x 7: see scan_kernel.hip)
 constexpr int kThreads = 256;   // 4 wavefronts

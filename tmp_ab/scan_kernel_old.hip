@@ -499,12 +499,10 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         *tile_lines = 0;
         *tile_sum = 0;
         tile_chk[0] = tile_chk[1] = tile_chk[2] = tile_chk[3] = 0;
-        qcount[2] = 0; // cl_n, cl_over: the staged list is the TILE's, whatever the number of rounds
-        qcount[3] = 0;
     }
     // A finished record that cannot go through the hand-off stream (hand-off disabled,
-    // staged list full, stream full) goes to the launch-wide loose list; the tile's marker
-    // then tells the host to collect after completion.
+    // record emitted outside the whole-tile round, stream full) goes to the launch-wide
+    // loose list; the tile's marker then tells the host to collect after completion.
     auto emit_loose = [&](uint32_t g_rel, uint32_t pw, const uint32_t (&wds)[4]) {
         if (args.hand)
             *tile_over = 1;
@@ -524,27 +522,28 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     const uint32_t df18_mask = args.df18 ? ~0u : 0u;
     const int nchunks = (own + NT - 1) / NT;
     uint32_t *qover = qcount + 1;
-    uint32_t *cl_n = qcount + 2;    // CRC-valid candidates of the tile staged in LDS
+    uint32_t *cl_n = qcount + 2;    // CRC-valid candidates staged in LDS this round
     uint32_t *cl_over = qcount + 3; // some were emitted directly: the staged list is incomplete
     const uint32_t qcap = (uint32_t)args.queue_cap;
     const uint32_t tile_rel = (uint32_t)(t0 - (int64_t)args.g_begin);
 
-    // Normally ONE round: the survivors of the whole tile (~0.5 % of its offsets) fit the queue and all four waves
-    // slice with dense lanes.  If they do not fit, the tile is redone in ranges of chunks [ch_lo, ch_hi) sized from
-    // the count the failed round left in *qcount (a failed round costs its gate words only: ~3 us for a whole
-    // tile); a single chunk that does not fit goes bit position by bit position (offset within the run): <= 256
-    // entries per round, which cannot overflow (queue_cap >= 256).  The CRC-valid candidates of every round are
-    // staged in the same list, which the filter behind the loop sees whole.
+    // Normally ONE round: the survivors of the whole tile (~0.5 % of its offsets)
+    // fit the queue and all four waves slice with dense lanes.  If they do not fit,
+    // the tile is redone chunk by chunk, one bit position (offset within the run)
+    // per round: <= 256 entries, which cannot overflow (queue_cap >= 256).
     constexpr int kGateBatch = 4; // chunks whose gate words are computed together
-    int ch_lo = 0, ch_hi = nchunks, grp = -1, width = nchunks;
-    bool first = true;
-    const bool stage_cands = !args.all_candidates;
+    int ch_lo = 0, ch_hi = nchunks, grp = -1;
     for (;;) {
         if (tid == 0) {
             *qcount = 0;
             *qover = 0;
+            *cl_n = 0;
+            *cl_over = 0;
         }
         __syncthreads();
+        // Whole-tile rounds see every CRC-valid candidate of the tile, which is what
+        // the never-visited filter below needs; fallback rounds emit directly.
+        const bool stage_cands = (grp < 0) && !args.all_candidates;
 
 #pragma unroll 1
         for (int base = ch_lo; base < ch_hi; base += kGateBatch) {
@@ -614,21 +613,20 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         }
         __syncthreads();
         const bool over = *qover != 0;
-        const int qtotal = (int)*qcount; // every survivor of the range, queued or not
-        const int qn = over ? 0 : qtotal;
+        const int qn = over ? 0 : (int)*qcount;
         // valid.c:46,68: every DF-gate pass that is visited is a Try -- the queue entries ARE the tries.  A
         // whole-tile round puts them into the tile's own region of args.tries (kTryRegion words; the count goes
         // to args.try_counts[tile]): no launch-wide reservation -- one more device-scope atomic per tile, awaited
-        // by the wave that issued it at its next load, cost 22 % of the kernel (0.174 against 0.142 ms).  The rounds
-        // behind a queue overflow, and launches without regions (per-shard scans hand a dense list to the host),
+        // by the wave that issued it at its next load, cost 22 % of the kernel (0.174 against 0.142 ms).  Fallback
+        // rounds (queue overflow), and launches without regions (per-shard scans hand a dense list to the host),
         // reserve a range of the launch-wide list behind the regions; that round trip runs under the slicer.
-        const bool try_region = kStats && args.try_counts && first; // workgroup-uniform
+        const bool try_region = kStats && args.try_counts && grp < 0; // workgroup-uniform
         uint32_t try_res = 0;
         if (kStats && tid == 0) {
             if (over && args.hand)
                 *tile_over = 1; // the launch-wide try list is in use: the host must wait for the launch's counters
             if (try_region)
-                args.try_counts[tile] = (uint32_t)qn; // 0 when the queue overflowed: the rounds that follow list them
+                args.try_counts[tile] = (uint32_t)qn; // 0 when the queue overflowed: the fallback rounds list them
             else if (qn)
                 try_res = atomicAdd(&args.counters[1 * kCounterPad], (uint32_t)qn);
         }
@@ -714,196 +712,190 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                     dst[q] = ((tile_rel + (uint32_t)kRun * (ent >> 7) + ((ent >> 2) & 31u)) << 2) | (ent & 3u);
             }
         }
-        // next round (all of this is workgroup-uniform)
-        first = false;
-        if (grp >= 0) {
-            if (++grp == kRun) { // chunk ch_lo is done bit by bit: on with the rest
-                grp = -1;
-                ch_lo = ch_hi;
-                ch_hi = min(ch_lo + width, nchunks);
-            }
-        } else if (over) {
-            // the same range again, cut to what the count says fits (and at least one chunk shorter)
-            const int w = ch_hi - ch_lo;
-            width = max(1, min(w - 1, (int)((uint32_t)w * qcap / (uint32_t)qtotal)));
-            if (w == 1)
-                grp = 0;
-            else
-                ch_hi = ch_lo + width;
-        } else {
-            if (2 * qn <= (int)qcap)
-                width = min(2 * width, nchunks);
-            ch_lo = ch_hi;
-            ch_hi = min(ch_lo + width, nchunks);
-        }
-        if (ch_lo >= nchunks)
-            break;
-        __syncthreads(); // queue is rewritten
-    }
-
-    if (stage_cands) {
-        // Drop candidates the greedy scan (demod.c:89,128,134,141) can never visit.
-        // Let c' be the closest candidate before c, with c inside c' (c.g < c'.g +
-        // span').  The scan reaches c only by landing in (c'.g, c.g]: it cannot
-        // walk there (it would visit c' first and jump past c), so some candidate
-        // frame must END in (c'.g, c.g].  If the tile knows every candidate that
-        // could (they start at >= c'.g - 1199, i.e. inside this tile, and the staged
-        // list is complete), and none does, c is unreachable.  These are the +-1/2
-        // sample shifted copies of every real frame: 3 of 4 records.
-        __syncthreads();
-        const int ncl = min((int)*cl_n, clist_cap); // <= kClistCap <= NT: one entry per thread
-        const bool complete = *cl_over == 0;
-        // The tile reserves its range of the hand-off stream -- one marker granule plus two per record, in whole
-        // 64-byte lines -- with one device-scope atomic whose answer takes ~2 us under the scan's traffic.  How many
-        // records it KEEPS is only known behind the filter below; it reserves for the staged ones now (an upper
-        // bound, ~4x: the marker tells the host how many lines to skip), so that the round trip runs beside the
-        // filter and the finishing instead of behind the filter.
-        uint32_t res_need = 0, res_base = 0;
-        const bool reserves = tid == 0 && args.hand;
-        bool keep = false;
-        uint32_t rank = 0; // kept entries with a smaller offset: the record's place behind the tile's marker
-        const uint32_t *ri = cl_rec + tid * kCandWords;
-        const bool one_wave = ncl <= 64; // workgroup-uniform; the usual case (a tile stages ~20 candidates)
-        if (one_wave) {
-            // Every entry sits in a lane of wave 0 and the all-pairs comparisons run on lane broadcasts
-            // (v_readlane: the loop index is wave-uniform) instead of dependent LDS reads: measured with
-            // per-phase stamps, the LDS loops below took 3.2 us of a 50 us tile, this takes 0.3.
-            if (tid < 64) {
-                const bool has = tid < ncl;
-                const int gi = has ? (int)(ri[0] - tile_rel) : 0x3fffffff; // tile-local offset
-                const bool lng = has && (ri[1] & 0xFFu) != 0;
-                // key = 2 g + (long frame): ordered like g, and the closest predecessor's span comes with its key
-                const int key = 2 * gi + (lng ? 1 : 0), g2 = 2 * gi;
-                const int ei = has ? gi + (lng ? 1200 : 640) : 0x7fffffff; // where the candidate's frame ends
-                // pk = the largest key below this one's = the closest candidate before it (with its length);
-                // emax = the latest frame END that is not beyond this candidate: some frame ends in (pg, gi] <=> emax > pg.
-                // Four entries per round, every round's broadcasts and compares independent of each other (lanes
-                // beyond ncl hold neutral values): the lane -> scalar -> vector round trips overlap.
-                int pk = -1, emax = -1;
-                for (int j = 0; j < ncl; j += 4) {
-                    int kj[4], ej[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        kj[u] = __builtin_amdgcn_readlane(key, j + u);
-                        ej[u] = __builtin_amdgcn_readlane(ei, j + u);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        kj[u] = kj[u] < g2 ? kj[u] : -1;
-                        ej[u] = ej[u] <= gi ? ej[u] : -1;
-                    }
-                    pk = max(max(pk, kj[0]), max(max(kj[1], kj[2]), kj[3]));
-                    emax = max(max(emax, ej[0]), max(max(ej[1], ej[2]), ej[3]));
-                }
-                const int pg = pk >> 1, pspan = (pk & 1) ? 1200 : 640; // pk == -1: pg == -1, nothing precedes
-                const bool drop = complete && pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan && !(emax > pg);
-                keep = has && !drop;
-                const unsigned long long kept = __ballot(keep);
-                const int kk = keep ? key : 0x7fffffff; // the entries that stay, as keys; the others never count
-                for (int j = 0; j < ncl; j += 4) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        rank += (uint32_t)(__builtin_amdgcn_readlane(kk, j + u) < g2);
-                }
-                if (tid == 0)
-                    *tile_n = (uint32_t)__popcll(kept);
-            }
-        } else if (tid < ncl) {
-            const int gi = (int)(ri[0] - tile_rel); // tile-local offset
-            bool drop = false;
-            if (complete) {
-                int pg = -1, pspan = 0;
-                for (int j = 0; j < ncl; j++) {
-                    const int gj = (int)(cl_rec[j * kCandWords] - tile_rel);
-                    if (gj < gi && gj > pg) {
-                        pg = gj;
-                        pspan = (cl_rec[j * kCandWords + 1] & 0xFFu) == 0 ? 640 : 1200; // staged word 1 = code
-                    }
-                }
-                if (pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan) {
-                    bool lands = false;
-                    for (int j = 0; j < ncl; j++) {
-                        const int ej = (int)(cl_rec[j * kCandWords] - tile_rel) +
-                                       ((cl_rec[j * kCandWords + 1] & 0xFFu) == 0 ? 640 : 1200);
-                        lands |= (ej > pg && ej <= gi);
-                    }
-                    drop = !lands;
-                }
-            }
-            keep = !drop;
-            // the tile reserves one marker granule plus two per kept record of the hand-off
-            // stream; the records follow the marker in ascending g (rank = kept entries
-            // with a smaller offset), so that the host can take the range as it is
-            if (keep) {
-                atomicAdd(tile_n, 1u);
-                cl_rec[tid * kCandWords + 1] |= 0x10000u; // staged word 1, bit 16: kept
-            }
-        }
-        __syncthreads();
-        if (reserves) { // the result is not looked at before this thread's own record is finished
-            res_need = stream_granules(*tile_n);
-            res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
-        }
-        if (keep && !one_wave) {
-            const uint32_t gi = ri[0];
-            for (int j = 0; j < ncl; j++)
-                rank += ((cl_rec[j * kCandWords + 1] >> 16) & 1u) & (uint32_t)(cl_rec[j * kCandWords] < gi);
-        }
-        // finish the record: bytes in order, pw (demod.c:127,133).  The loads of pw_at
-        // run while thread 0's reservation above is still on its way back.
-        uint32_t fin[6];
-        if (keep) {
-            const uint32_t cw[4] = {ri[2], ri[3], ri[4], ri[5]};
-            uint32_t wds[4];
-            columns_to_bytes(cw, (ri[1] & 0xFFu) == 0, wds);
-            wds[3] |= ((ri[1] >> 8) & 1u) << 24; // repaired-by-extension flag
-            const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + ri[0]);
-            fin[0] = ri[0], fin[1] = pw, fin[2] = wds[0], fin[3] = wds[1], fin[4] = wds[2], fin[5] = wds[3];
-        }
-        if (reserves) {
-            *tile_base = res_base;
-            *tile_fit = (res_base < args.hand_cap && res_need <= args.hand_cap - res_base) ? 1u : 0u;
-            *tile_lines = res_need >> 2;
-            *tile_res = 1;
-        }
-        __syncthreads(); // tile_base / tile_fit are in, and every staged entry has been read
-        const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
-        if (keep) {
-            if (to_stream) {
-                // the finished records replace the staged list, in rank order
-                uint32_t *o = cl_rec + rank * kCandWords;
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    o[k] = fin[k];
-                atomicXor(&tile_chk[0], fin[0] ^ fin[4]); // word-wise XOR of its two granules
-                atomicXor(&tile_chk[1], fin[1] ^ fin[5]);
-                atomicXor(&tile_chk[2], fin[2]);
-                atomicXor(&tile_chk[3], fin[3]);
-                atomicAdd(tile_sum, record_term(rank, fin[0], fin[1]));
-            } else {
-                const uint32_t wds[4] = {fin[2], fin[3], fin[4], fin[5]};
-                emit_loose(fin[0], fin[1], wds);
-            }
-        }
-        if (to_stream) {
-            // the tile's range {marker, records} leaves as one store of adjacent lanes
+        if (stage_cands) {
+            // Drop candidates the greedy scan (demod.c:89,128,134,141) can never visit.
+            // Let c' be the closest candidate before c, with c inside c' (c.g < c'.g +
+            // span').  The scan reaches c only by landing in (c'.g, c.g]: it cannot
+            // walk there (it would visit c' first and jump past c), so some candidate
+            // frame must END in (c'.g, c.g].  If the tile knows every candidate that
+            // could (they start at >= c'.g - 1199, i.e. inside this tile, and the staged
+            // list is complete), and none does, c is unreachable.  These are the +-1/2
+            // sample shifted copies of every real frame: 3 of 4 records.
             __syncthreads();
-            const uint32_t nk = *tile_n;
-            for (uint32_t L = tid; L < 1u + 2u * nk; L += NT) {
-                u32x4 gv;
-                if (L == 0) {
-                    const uint32_t nf = nk | (*tile_over ? kMarkOver : 0u) | (*tile_lines << kMarkLinesShift);
-                    uint32_t lo, hi;
-                    marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], *tile_sum, lo, hi);
-                    gv = u32x4{tile, nf, lo, hi};
-                    *tile_res = 2; // marker written
-                } else {
-                    const uint32_t *r = cl_rec + ((L - 1u) >> 1) * kCandWords;
-                    gv = ((L - 1u) & 1u) ? u32x4{r[4], r[5], 0u, 0u} : u32x4{r[0], r[1], r[2], r[3]};
+            const int ncl = min((int)*cl_n, clist_cap); // <= kClistCap <= NT: one entry per thread
+            const bool complete = *cl_over == 0;
+            // The tile reserves its range of the hand-off stream -- one marker granule plus two per record, in whole
+            // 64-byte lines -- with one device-scope atomic whose answer takes ~2 us under the scan's traffic.  How many
+            // records it KEEPS is only known behind the filter below; it reserves for the staged ones now (an upper
+            // bound, ~4x: the marker tells the host how many lines to skip), so that the round trip runs beside the
+            // filter and the finishing instead of behind the filter.
+            uint32_t res_need = 0, res_base = 0;
+            const bool reserves = tid == 0 && args.hand;
+            bool keep = false;
+            uint32_t rank = 0; // kept entries with a smaller offset: the record's place behind the tile's marker
+            const uint32_t *ri = cl_rec + tid * kCandWords;
+            const bool one_wave = ncl <= 64; // workgroup-uniform; the usual case (a tile stages ~20 candidates)
+            if (one_wave) {
+                // Every entry sits in a lane of wave 0 and the all-pairs comparisons run on lane broadcasts
+                // (v_readlane: the loop index is wave-uniform) instead of dependent LDS reads: measured with
+                // per-phase stamps, the LDS loops below took 3.2 us of a 50 us tile, this takes 0.3.
+                if (tid < 64) {
+                    const bool has = tid < ncl;
+                    const int gi = has ? (int)(ri[0] - tile_rel) : 0x3fffffff; // tile-local offset
+                    const bool lng = has && (ri[1] & 0xFFu) != 0;
+                    // key = 2 g + (long frame): ordered like g, and the closest predecessor's span comes with its key
+                    const int key = 2 * gi + (lng ? 1 : 0), g2 = 2 * gi;
+                    const int ei = has ? gi + (lng ? 1200 : 640) : 0x7fffffff; // where the candidate's frame ends
+                    // pk = the largest key below this one's = the closest candidate before it (with its length);
+                    // emax = the latest frame END that is not beyond this candidate: some frame ends in (pg, gi] <=> emax > pg.
+                    // Four entries per round, every round's broadcasts and compares independent of each other (lanes
+                    // beyond ncl hold neutral values): the lane -> scalar -> vector round trips overlap.
+                    int pk = -1, emax = -1;
+                    for (int j = 0; j < ncl; j += 4) {
+                        int kj[4], ej[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            kj[u] = __builtin_amdgcn_readlane(key, j + u);
+                            ej[u] = __builtin_amdgcn_readlane(ei, j + u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            kj[u] = kj[u] < g2 ? kj[u] : -1;
+                            ej[u] = ej[u] <= gi ? ej[u] : -1;
+                        }
+                        pk = max(max(pk, kj[0]), max(max(kj[1], kj[2]), kj[3]));
+                        emax = max(max(emax, ej[0]), max(max(ej[1], ej[2]), ej[3]));
+                    }
+                    const int pg = pk >> 1, pspan = (pk & 1) ? 1200 : 640; // pk == -1: pg == -1, nothing precedes
+                    const bool drop = complete && pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan && !(emax > pg);
+                    keep = has && !drop;
+                    const unsigned long long kept = __ballot(keep);
+                    const int kk = keep ? key : 0x7fffffff; // the entries that stay, as keys; the others never count
+                    for (int j = 0; j < ncl; j += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            rank += (uint32_t)(__builtin_amdgcn_readlane(kk, j + u) < g2);
+                    }
+                    if (tid == 0)
+                        *tile_n = (uint32_t)__popcll(kept);
                 }
-                store_granule_through(args.hand, *tile_base + L, gv);
+            } else if (tid < ncl) {
+                const int gi = (int)(ri[0] - tile_rel); // tile-local offset
+                bool drop = false;
+                if (complete) {
+                    int pg = -1, pspan = 0;
+                    for (int j = 0; j < ncl; j++) {
+                        const int gj = (int)(cl_rec[j * kCandWords] - tile_rel);
+                        if (gj < gi && gj > pg) {
+                            pg = gj;
+                            pspan = (cl_rec[j * kCandWords + 1] & 0xFFu) == 0 ? 640 : 1200; // staged word 1 = code
+                        }
+                    }
+                    if (pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan) {
+                        bool lands = false;
+                        for (int j = 0; j < ncl; j++) {
+                            const int ej = (int)(cl_rec[j * kCandWords] - tile_rel) +
+                                           ((cl_rec[j * kCandWords + 1] & 0xFFu) == 0 ? 640 : 1200);
+                            lands |= (ej > pg && ej <= gi);
+                        }
+                        drop = !lands;
+                    }
+                }
+                keep = !drop;
+                // the tile reserves one marker granule plus two per kept record of the hand-off
+                // stream; the records follow the marker in ascending g (rank = kept entries
+                // with a smaller offset), so that the host can take the range as it is
+                if (keep) {
+                    atomicAdd(tile_n, 1u);
+                    cl_rec[tid * kCandWords + 1] |= 0x10000u; // staged word 1, bit 16: kept
+                }
+            }
+            __syncthreads();
+            if (reserves) { // the result is not looked at before this thread's own record is finished
+                res_need = stream_granules(*tile_n);
+                res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
+            }
+            if (keep && !one_wave) {
+                const uint32_t gi = ri[0];
+                for (int j = 0; j < ncl; j++)
+                    rank += ((cl_rec[j * kCandWords + 1] >> 16) & 1u) & (uint32_t)(cl_rec[j * kCandWords] < gi);
+            }
+            // finish the record: bytes in order, pw (demod.c:127,133).  The loads of pw_at
+            // run while thread 0's reservation above is still on its way back.
+            uint32_t fin[6];
+            if (keep) {
+                const uint32_t cw[4] = {ri[2], ri[3], ri[4], ri[5]};
+                uint32_t wds[4];
+                columns_to_bytes(cw, (ri[1] & 0xFFu) == 0, wds);
+                wds[3] |= ((ri[1] >> 8) & 1u) << 24; // repaired-by-extension flag
+                const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + ri[0]);
+                fin[0] = ri[0], fin[1] = pw, fin[2] = wds[0], fin[3] = wds[1], fin[4] = wds[2], fin[5] = wds[3];
+            }
+            if (reserves) {
+                *tile_base = res_base;
+                *tile_fit = (res_base < args.hand_cap && res_need <= args.hand_cap - res_base) ? 1u : 0u;
+                *tile_lines = res_need >> 2;
+                *tile_res = 1;
+            }
+            __syncthreads(); // tile_base / tile_fit are in, and every staged entry has been read
+            const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
+            if (keep) {
+                if (to_stream) {
+                    // the finished records replace the staged list, in rank order
+                    uint32_t *o = cl_rec + rank * kCandWords;
+#pragma unroll
+                    for (int k = 0; k < 6; k++)
+                        o[k] = fin[k];
+                    atomicXor(&tile_chk[0], fin[0] ^ fin[4]); // word-wise XOR of its two granules
+                    atomicXor(&tile_chk[1], fin[1] ^ fin[5]);
+                    atomicXor(&tile_chk[2], fin[2]);
+                    atomicXor(&tile_chk[3], fin[3]);
+                    atomicAdd(tile_sum, record_term(rank, fin[0], fin[1]));
+                } else {
+                    const uint32_t wds[4] = {fin[2], fin[3], fin[4], fin[5]};
+                    emit_loose(fin[0], fin[1], wds);
+                }
+            }
+            if (to_stream) {
+                // the tile's range {marker, records} leaves as one store of adjacent lanes
+                __syncthreads();
+                const uint32_t nk = *tile_n;
+                // no fallback rounds will follow (they emit loose records): the marker is final
+                const bool marker_now = !over;
+                for (uint32_t L = tid; L < 1u + 2u * nk; L += NT) {
+                    u32x4 gv;
+                    if (L == 0) {
+                        if (!marker_now)
+                            continue;
+                        const uint32_t nf = nk | (*tile_over ? kMarkOver : 0u) | (*tile_lines << kMarkLinesShift);
+                        uint32_t lo, hi;
+                        marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], *tile_sum, lo, hi);
+                        gv = u32x4{tile, nf, lo, hi};
+                        *tile_res = 2; // marker written
+                    } else {
+                        const uint32_t *r = cl_rec + ((L - 1u) >> 1) * kCandWords;
+                        gv = ((L - 1u) & 1u) ? u32x4{r[4], r[5], 0u, 0u} : u32x4{r[0], r[1], r[2], r[3]};
+                    }
+                    store_granule_through(args.hand, *tile_base + L, gv);
+                }
             }
         }
+
+        // next round (all of this is workgroup-uniform)
+        if (grp < 0) {
+            if (!over)
+                break;
+            ch_lo = 0;
+            ch_hi = kFallbackChunks;
+            grp = 0;
+        } else if (++grp == kRun) {
+            grp = 0;
+            ch_lo += kFallbackChunks;
+            ch_hi += kFallbackChunks;
+            if (ch_lo >= nchunks)
+                break;
+        }
+        __syncthreads(); // queue is rewritten
     }
 
 
@@ -917,7 +909,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         if (tid == 0 && *tile_res != 2) {
             uint32_t b = *tile_base, fit = *tile_fit;
             uint32_t lines = *tile_lines;
-            if (!*tile_res) { // nothing was staged (all_candidates)
+            if (!*tile_res) { // no whole-tile round staged anything (all_candidates, fallback rounds)
                 b = atomicAdd(&args.counters[2 * kCounterPad], stream_granules(0));
                 fit = b < args.hand_cap;
                 lines = stream_granules(0) >> 2;
@@ -948,12 +940,11 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArg
     uint32_t *cl_rec = qcount + 16; // kClistCap records of kCandWords
 
     const int tid = threadIdx.x;
-    // The kMinWaves workgroups that start together on a CU at the head of a large launch (blocks b, b + 256, b + 512,
-    // ... with the observed round-robin placement; nothing depends on it) begin 0, 1, 2, ... x kSleepStagger x 64 cycles
-    // apart (2.6 us steps), so that their load phases do not coincide from the first pass on.  Measured in bench.py
-    // with four per CU: -3.2 .. -4.0 % kernel time on one MI355X box, +-0.5 % on another; steps of 1.2 us did nothing,
-    // steps of 3.7 us and more were worse than 2.6.  With five per CU (96 VGPRs since round 4) and only the first four
-    // staggered the step was 3 % slower than with all five (profiles/r4_ab_runs.txt section 7).
+    // The four workgroups that start together on a CU at the head of a large launch (blocks b, b + 256,
+    // b + 512, b + 768 with the observed round-robin placement; nothing depends on it) begin 0, 1, 2, 3 x
+    // kSleepStagger x 64 cycles apart (2.6 us steps), so that their load phases do not coincide from
+    // the first pass on.  Measured in bench.py: -3.2 .. -4.0 % kernel time on one MI355X box, +-0.5 % on
+    // another; steps of 1.2 us did nothing, steps of 3.7 us and more were worse than 2.6.
     if (gridDim.x >= 256u * kMinWaves * 4 / kWaves && blockIdx.x < 256u * kMinWaves * 4 / kWaves) {
         const uint32_t slot = blockIdx.x >> 8;
         for (uint32_t i = 0; i < slot; i++)
