@@ -78,17 +78,18 @@ struct HandCursor {
         const bool fits = !(nf & kMarkNoFit);
         if (tile >= s.ntiles || (fits && (uint64_t)pos + 1 + 2ull * n > cap))
             return false; // not a marker of this launch (yet)
+        // one pass over the records: the XOR of both granules, and the second summary -- rank-weighted, over {g_rel, pw}
+        // of every record (scan_kernel_format.h) -- from the first granule's low words while it is in a register
         __m128i acc = _mm_setzero_si128();
+        uint32_t sum = 0;
         if (fits)
-            for (uint32_t k = 1; k <= 2 * n; k++)
-                acc = _mm_xor_si128(acc, _mm_load_si128(gp + k));
+            for (uint32_t r = 0; r < n; r++) {
+                const __m128i g0 = _mm_load_si128(gp + 1 + 2 * r), g1 = _mm_load_si128(gp + 2 + 2 * r);
+                acc = _mm_xor_si128(acc, _mm_xor_si128(g0, g1));
+                const uint64_t w01 = (uint64_t)_mm_cvtsi128_si64(g0);
+                sum += record_term(r, (uint32_t)w01, (uint32_t)(w01 >> 32));
+            }
         _mm_store_si128(reinterpret_cast<__m128i *>(a), acc);
-        uint32_t sum = 0; // the second summary: rank-weighted, over {g_rel, pw} of every record (scan_kernel_format.h)
-        if (fits) {
-            const uint32_t *w = s.hand + 4 * ((size_t)pos + 1);
-            for (uint32_t r = 0; r < n; r++, w += 8)
-                sum += record_term(r, w[0], w[1]);
-        }
         uint32_t lo, hi;
         marker_check(tile, nf, gen, a[0], a[1], a[2], a[3], sum, lo, hi);
         return mw[2] == lo && mw[3] == hi;

@@ -47,6 +47,29 @@ def make_capture(rng):
     return G.synth(n, frames, sigma, int(rng.integers(0, 1 << 30)))
 
 
+def add_storm(x, seed):
+    """One capture in seven gets stretches of nothing but frame starts (preamble + DF17's five bits back to back: 7 % of the
+    offsets pass the DF gate there, ~500 survivors per chunk of 256 runs) laid over it: tiles overflow their survivor
+    queues unevenly and are redone in ranges of chunks / bit positions (scan_kernel.hip, stage_b).  Its own generator, so
+    that a seed's capture underneath and its feeding mode stay what they were."""
+    rng = np.random.default_rng(seed ^ 0x53746F726D)
+    if rng.random() >= 1.0 / 7.0 or x.size < 100_000:
+        return x, False
+    env = np.zeros(260, np.float32)
+    for s0 in (0, 20, 70, 90):
+        env[s0:s0 + 10] = 1.0
+    for i, b in enumerate((1, 0, 0, 0, 1)):
+        s0 = 160 + 20 * i + (0 if b else 10)
+        env[s0:s0 + 10] = 1.0
+    wave = env * np.cos(np.pi * np.arange(260) / 2 + 0.7).astype(np.float32)
+    y = x.astype(np.float32)
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(20_000, min(600_000, x.size // 2)))
+        at = 260 * int(rng.integers(0, (x.size - n) // 260))
+        y[at:at + n] += float(rng.uniform(300, 1500)) * np.tile(wave, n // 260 + 1)[:n]
+    return np.clip(np.rint(y), 0, 65535).astype(np.uint16), True
+
+
 def key(fs):
     return [(f["g"], f["ts"], f["pw"], f["frame"]) for f in fs]
 
@@ -62,7 +85,7 @@ def run(seconds: float, seed: int = 1, log=print):
     # a few handles with shrunken record buffers / staged lists (cfg.debug_*): every overflow path --
     # relaunch with regrown buffers, loose list, partial gather -- runs inside the fuzz as well
     tight = [dict(), dict(debug_clist_cap=2), dict(debug_cand_cap=24, debug_clist_cap=3),
-             dict(debug_cand_cap=16, debug_try_cap=128), dict(debug_queue_cap=256, debug_clist_cap=1)]
+             dict(debug_cand_cap=16, debug_try_cap=128), dict(debug_queue_cap=256, debug_clist_cap=1), dict(debug_queue_cap=512)]
 
     def dec(df18, stats, fix, caps=0, overlap=False):
         k = (df18, stats, fix, caps, overlap)
@@ -80,6 +103,7 @@ def run(seconds: float, seed: int = 1, log=print):
     multis, multi_fallbacks = {}, [0]
     stitch_fallbacks = [0]
     reader_runs = 0
+    storms = 0
     pinned = capi.PinnedBuffers(2, 1 << 20)
     bufs = pinned.__enter__()
     first_seed = seed
@@ -87,7 +111,8 @@ def run(seconds: float, seed: int = 1, log=print):
     while time.time() - t0 < seconds:
         t_cap = time.time()
         rng = np.random.default_rng(seed)
-        x = make_capture(rng)
+        x, stormy = add_storm(make_capture(rng), seed)
+        storms += int(stormy)
         df18, stats, fix = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
         want, wstats = O.decode(x, df18=df18, fix1=fix)
         if with_ref and not fix and seed % 4 == 0:   # the restatement itself against the real chain, on this capture
@@ -228,7 +253,7 @@ def run(seconds: float, seed: int = 1, log=print):
                    multi_driver_fallbacks=multi_fallbacks[0],
                    with_the_reader_thread=reader_runs, stitcher_fallbacks=stitch_fallbacks[0],
                    also_checked_against_real_reference_chain=ref_checked,
-                   with_shrunken_record_buffers=tight_runs,
+                   with_shrunken_record_buffers=tight_runs, with_frame_start_storms=storms,
                    relaunches=sum(int(d.profile()["relaunches"]) for d in decs_all))
     for d in decs_all:
         d.close()
