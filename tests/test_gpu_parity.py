@@ -596,6 +596,13 @@ def test_overflow_rounds_ranges_and_bit_positions(oracle, dec_factory, torch_cud
                 assert records(d.drain()) == records(want), (qcap, kw)
                 if kw.get("collect_stats"):
                     assert d.stats() == wstats, (qcap, kw)
+    # tiles of 2 .. 7 passes (2 .. 7 chunks of 256 runs): every shape of the range loop
+    for passes in (2, 3, 5, 7):
+        d = dec_factory(df18=True, collect_stats=True, debug_queue_cap=256, debug_passes=passes, debug_stagger=0)
+        d.reset()
+        d.push_device_final(t.data_ptr(), t.numel())
+        assert records(d.drain()) == records(want), passes
+        assert d.stats() == wstats, passes
 
 
 def test_one_bit_repair_extension_vs_oracle(oracle, dec_factory):
