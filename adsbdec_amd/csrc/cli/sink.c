@@ -125,9 +125,17 @@ int sink_write(sink *s, const char *buf, size_t len, unsigned long packets)
         return fwrite(buf, 1, len, stdout) == len ? 0 : -1;
     if (s->fd < 0) {
         /* Before the first peer: wait for one, however long (output.c:277-285).  Behind a peer that went away: the
-         * reference, reading a file, is at its end by then and exits with its queue unsent; here the input is
-         * decoded faster than a peer comes back, so one attempt per batch, and the batch is dropped without one. */
-        const int rc = s->had_peer ? sink_establish(s) : sink_wait_peer(s);
+         * reference, reading a file, is at its end by then and exits with its queue unsent (a listening one first sits
+         * in accept() until somebody connects); here the input is decoded faster than a peer comes back, so a
+         * connecting sink makes one attempt per batch and drops the batch without a peer, and a listening sink does
+         * not listen again: the rest of the run's packets are dropped. */
+        int rc;
+        if (!s->had_peer)
+            rc = sink_wait_peer(s);
+        else if (s->mode == SINK_CONNECT)
+            rc = sink_establish(s);
+        else
+            rc = 1;
         if (rc < 0)
             return -1;
         if (rc > 0) {

@@ -25,7 +25,8 @@ int sink_establish(sink *s);
 int sink_wait_peer(sink *s);
 /* Write one batch of packets (any bytes).  stdout: 0 / -1 (stdout is gone).  TCP: the first call waits for a peer; a
  * peer that goes away gets "disconnected" on stderr and the rest of the batch is dropped (returns 1); every later batch
- * tries ONCE for a new peer and is dropped without one.  -1: the address is unusable. */
+ * tries ONCE to connect again (-s) and is dropped without a peer; a listening sink (-l) does not listen again.
+ * -1: the address is unusable. */
 int sink_write(sink *s, const char *buf, size_t len, unsigned long packets);
 void sink_close(sink *s);
 #endif

@@ -1,7 +1,7 @@
 """The host program's TCP sinks (-s connect, -l listen: the reference's outmode 1 / 2, main.c:65-72, output.c:59-157,
 318-336) without a GPU: tests/cpp/sink_harness.c drives adsbdec_amd/csrc/cli/sink.c with packets from the library's own
 formatter over loopback sockets.  The end-to-end run (the real program decoding a capture into a socket, compared with
-the oracle's packets and with the reference's own bytes over the same kind of socket) is in tests/test_gpu_cli_sink.py."""
+the golden packets, which were minted through the reference's own formatpkt) is tests/test_gpu_parity.py::test_cli_tcp_sinks_carry_the_same_packets."""
 import os
 import socket
 import subprocess
@@ -171,3 +171,20 @@ def test_a_peer_that_goes_away(harness, tmp_path):
     assert len(got) > 0 and sent[:len(got)] == got[:len(sent)]
     lost = int(lines[-1].split("lost ")[1].split(",")[0])
     assert lost >= 1 and "packets dropped 0" not in lines[-1]
+
+
+def test_a_listening_sink_whose_peer_goes_away_does_not_wait_for_another(harness, tmp_path):
+    """-l: the one accepted peer closes early.  The reference would sit in accept() again (output.c:139) until somebody
+    connects; this program drops the rest of the run's packets and ends."""
+    port = _free_port()
+    copy = str(tmp_path / "copy.bin")
+    p = subprocess.Popen([harness, "2", f"127.0.0.1:{port}", "0", "60000", copy, "30"], stderr=subprocess.PIPE, text=True)
+    assert p.stderr.readline().strip() == "listening"
+    c = socket.create_connection(("127.0.0.1", port), timeout=10)
+    assert p.stderr.readline().strip() == "connected"
+    assert len(c.recv(1)) == 1
+    c.close()
+    assert p.wait(60) == 0
+    rest = p.stderr.read().splitlines()
+    assert "disconnected" in rest and rest.count("listening") == 0
+    assert "packets dropped 0" not in rest[-1]
