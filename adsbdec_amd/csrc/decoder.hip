@@ -168,8 +168,11 @@ struct adsb_decoder {
     adsb_profile prof{};
     adsb::Resolver res;
     std::vector<uint32_t> order, scratch_a, scratch_b, gather, tile_start, tile_count;
-    adsb::StreamReader *reader = nullptr;    // cfg.host_threads = 2: the thread that reads the hand-off stream (slot_collect_streaming)
+    adsb::StreamReader *reader = nullptr;    // the thread that reads the hand-off stream (slot_collect_streaming): cfg.host_threads = 2
+                                             // from the start, 0 (auto) from the first launch that follows a dense one
+    bool reader_failed = false;              // no thread could be had: do not try again
     uint32_t reader_min_tiles = 1024; // launches below this many tiles are collected by the calling thread alone
+    uint64_t last_launch_records = 0; // records the previous launch handed over (auto: the thread pays from kAutoReaderRecords on)
     bool no_streaming = false; // cfg.debug_no_streaming: always collect after completion
     uint64_t shard_head = 16384; // offsets of a resolved shard whose candidates are ALL kept for the stitcher (cfg.debug_shard_head)
     int dbg_async = 0;         // tuning builds only (ADSB_DEBUG_ASYNC, tools/async_race.py): 1 = wait for every async copy,
@@ -601,6 +604,34 @@ size_t deliver_tiles(adsb_decoder *d, ScanSlot &s, uint32_t from, uint32_t upto)
 // Returns 1 if a tile reported records on the loose list (or the stream is full): the
 // caller then finishes the launch through the collect-after-completion path, from tile
 // *resume_tile on.
+// The handle's second host thread (handoff.hpp StreamReader), kept on the caller's L3.  cfg.host_threads = 2 starts it with the
+// handle; 0 (auto) the first time a launch follows one that handed over kAutoReaderRecords or more -- at the channel's
+// capacity one thread needs four times the kernel's time for a launch's records, and reading + checking on one thread while
+// the caller resolves takes a quarter off that; under ordinary traffic the thread never exists.
+constexpr uint64_t kAutoReaderRecords = 65536;
+void start_reader(adsb_decoder *d)
+{
+    if (d->reader || d->reader_failed)
+        return;
+    d->reader = new (std::nothrow) adsb::StreamReader;
+    if (d->reader) {
+        d->reader->on_start = [](void *ctx) { (void)hipSetDevice(static_cast<adsb_decoder *>(ctx)->device); }; // launch_done()
+        d->reader->on_start_ctx = d;
+        try {
+            d->reader->start();
+        } catch (...) { // no thread to be had: the calling thread consumes the stream alone, as without the option
+            delete d->reader;
+            d->reader = nullptr;
+        }
+    }
+    if (d->reader) {
+        d->reader->place = true;
+        d->reader->placed_l3 = adsb::place_reader_thread(d->reader->th, sched_getcpu());
+    } else {
+        d->reader_failed = true;
+    }
+}
+
 int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, uint32_t *tiles_in)
 {
     using clk = std::chrono::steady_clock;
@@ -611,6 +642,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     t_start.assign(s.ntiles, 0u);
     t_count.assign(s.ntiles, ~0u);
     uint32_t delivered = 0; // every tile below has been handed to the resolver
+    uint64_t recs_handed = 0;
     bool overflowed = false;
     double dbg[3] = {0, 0, 0};
     const bool dbg_on = tuning_env("ADSB_DEBUG_HOST") != nullptr;
@@ -622,6 +654,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
             tp = clk::now();
         const size_t nc = deliver_tiles(d, s, delivered, upto);
         delivered = upto;
+        recs_handed += nc;
         if (dbg_on) {
             dbg[1] += std::chrono::duration<double, std::micro>(clk::now() - tp).count();
             dbg[2] += 1;
@@ -632,7 +665,10 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     };
     const adsb::HandJob job = hand_job(s);
     adsb::CollectEnd end;
-    if (d->reader && s.ntiles >= d->reader_min_tiles) {
+    const bool after_dense = d->cfg.host_threads == 0 && d->last_launch_records >= kAutoReaderRecords;
+    if (after_dense)
+        start_reader(d);
+    if (d->reader && s.ntiles >= d->reader_min_tiles && (d->cfg.host_threads == 2 || after_dense)) {
         adsb::StreamReader &rd = *d->reader;
         if (rd.place) { // the caller may have moved since the thread was placed
             const int cpu = sched_getcpu();
@@ -661,6 +697,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     d->prof.host_ms += total_ms - wait_ms;
     *resume_tile = delivered;
     *tiles_in = end.frontier;
+    d->last_launch_records = recs_handed; // (a launch that is finished after completion adds its part there)
     return overflowed ? 1 : 0;
 }
 
@@ -915,6 +952,7 @@ int slot_collect(adsb_decoder *d)
         std::vector<uint32_t> &t_start = d->tile_start, &t_count = d->tile_count;
         // (the streaming collect went on reading and checking behind the first tile that held it up: when it got to the end
         // of the launch, where every tile's records lie is known already)
+        d->last_launch_records = std::max<uint64_t>(d->last_launch_records, s.hc()[2] / 2); // (an estimate from the granules the stream used)
         const bool walked = tiles_in == s.ntiles && !relaunched;
         if (!walked) {
             t_start.assign(s.ntiles, 0u);
@@ -1353,24 +1391,8 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
     {
         if (cfg.debug_reader_min_tiles > 0)
             d->reader_min_tiles = (uint32_t)cfg.debug_reader_min_tiles;
-        if (d->cfg.host_threads == 2) {
-            d->reader = new (std::nothrow) adsb::StreamReader;
-            if (d->reader) {
-                d->reader->on_start = [](void *ctx) { (void)hipSetDevice(static_cast<adsb_decoder *>(ctx)->device); }; // launch_done()
-                d->reader->on_start_ctx = d;
-                try {
-                    d->reader->start();
-                } catch (...) { // no thread to be had: the calling thread consumes the stream alone, as without the option
-                    delete d->reader;
-                    d->reader = nullptr;
-                }
-                if (d->reader) {
-                    d->reader->place = true;
-                    if (d->reader->place)
-                        d->reader->placed_l3 = adsb::place_reader_thread(d->reader->th, sched_getcpu());
-                }
-            }
-        }
+        if (d->cfg.host_threads == 2)
+            start_reader(d);
     }
     d->no_streaming = cfg.debug_no_streaming != 0;
     if (cfg.debug_shard_head > 0)

@@ -250,7 +250,11 @@ struct StreamReader {
             done_seq.store(seen, std::memory_order_release);
         }
     }
-    void start() { th = std::thread([this] { loop(); }); }
+    void start()
+    {
+        th = std::thread([this] { loop(); });
+        pthread_setname_np(th.native_handle(), "adsb-reader"); // (what top -H and /proc/<pid>/task/*/comm show)
+    }
     void post(const HandJob &j, uint32_t *ts, uint32_t *tc)
     {
         job = j, t_start = ts, t_count = tc;

@@ -105,10 +105,13 @@ typedef struct adsb_config {
                                   leaves the scan in flight; the frames of a call become drainable during the NEXT
                                   adsb_push / adsb_finish / adsb_sync instead of during the call itself (same frames,
                                   same order).  0 (default): frames are drainable when the call returns. */
-    int32_t host_threads;      /* 0 / 1 (default): the calling thread alone consumes the device's hand-off stream.
+    int32_t host_threads;      /* 1: the calling thread alone consumes the device's hand-off stream.
                                   2: the handle owns a second thread that reads and checks the stream of large launches
                                   while the caller resolves behind it; same frames, same order.  The thread spins for
-                                  ~0.4 ms after a launch, then sleeps until the next one. */
+                                  ~0.4 ms after a launch, then sleeps until the next one.
+                                  0 (default): 1, until a launch hands over 65 536 records or more (a channel near its
+                                  capacity: ~20 k frames per second of signal); from the next launch on, 2 for every
+                                  launch that follows such a one. */
     /* more test knobs (0 = default).  The library reads no environment variable: whatever a test has to force is here. */
     int32_t debug_no_streaming;     /* 1: every launch is collected after completion (no hand-off stream)              */
     int32_t debug_frames_cap;       /* collect_stats: accepted frames the upload buffers start with (regrow path)      */

@@ -38,6 +38,18 @@ def _host(t):
     return t.cpu().numpy().view(np.uint16)
 
 
+def _reader_threads():
+    """Threads of this process named "adsb-reader" (handoff.hpp StreamReader: a handle's second host thread)."""
+    n = 0
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            with open(f"/proc/self/task/{tid}/comm") as f:
+                n += f.read().strip() == "adsb-reader"
+        except OSError:
+            pass
+    return n
+
+
 def _ts_checksum(frames):
     """ts == g + 1 - sum(span - 1): a checksum of the whole greedy replay (demod.c:86,99,128,134)."""
     skipped = 0
@@ -114,17 +126,28 @@ def test_config2_256Mi_at_ten_percent_density_and_the_gate_storm(capi, oracle, t
         want, wstats = oracle.decode(x, df18=True)
         assert len(want) >= min_frames
         for stats in (False, True):
+            assert _reader_threads() == 0
             d = capi.Decoder(df18=True, collect_stats=stats, profile=True)
             try:
-                d.push_device_final(t.data_ptr(), t.numel())
-                got = d.drain()
-                assert records(got) == records(want)
-                if stats:
-                    assert d.stats() == wstats
+                # three times on one handle: cfg.host_threads = 0 (auto) hands the stream of a launch that FOLLOWS a dense one
+                # (65 536 records or more) to the handle's second host thread, which is started then; same records either way
+                for rep in range(3):
+                    d.reset()
+                    d.push_device_final(t.data_ptr(), t.numel())
+                    got = d.drain()
+                    assert records(got) == records(want), rep
+                    if stats:
+                        assert d.stats() == wstats, rep
+                    extra = _reader_threads()
+                    if make is make_dense10:        # 310 k records per launch
+                        assert extra == (0 if rep == 0 else 1), (rep, extra)
+                    else:                            # one record: the thread never exists
+                        assert extra == 0
                 if make is make_gate_storm:
                     assert sum(wstats["try"].values()) > 0.05 * (n // 2)
             finally:
                 d.close()
+            assert _reader_threads() == 0
         del t
         torch_cuda.cuda.empty_cache()
 
