@@ -41,8 +41,8 @@ def results():
 |---|---|---|
 | `bench.py`, default line (one box) | **{d['value'] / 1e6:.3f} Tsamples/s**, {d['ms_per_step']:.4f} ms per 256 Mi-sample step; scan kernel {d['roofline']['launch_ms'] * 1e3:.1f} µs on its own clock = {d['roofline']['achieved']:.0f} GB/s = **{d['roofline']['frac']:.3f} of 8 TB/s** | `r4_bench.json` |
 | ... the same region with 1000 steps instead of the driver's 20 (`value_1000_steps`) | {k['value'] / 1e6:.3f} Tsamples/s, {k['ms_per_step']:.4f} ms per step, kernel {k['launch_ms'] * 1e3:.1f} µs = {k['roofline_frac']:.3f} | `r4_bench.json` |
-| the same command under `rocprofv3 --kernel-trace --stats`, 1000 timed steps (another box) | `scan_kernel<false>`: {len(dur)} dispatches, average **{statistics.mean(dur):.1f} µs** (pre-roll and warm-up included) = {frac(statistics.mean(dur)):.3f}; last 1000: {statistics.mean(dur[-1000:]):.1f} µs = **{frac(statistics.mean(dur[-1000:])):.3f}**; minimum {min(dur):.1f} µs; the bench line of that very run read {u['roofline']['launch_ms'] * 1e3:.1f} µs in-kernel (1 % below the trace, as in every round) | `r4_kernel_stats.csv`, `r4_dispatches.csv`, `r4_bench_under_rocprofv3.json` |
-| box-to-box spread of the kernel | 0.137–0.147 ms (0.457–0.490), same build, same command (round 3's and round 4's boxes) | `r3_ab_runs.txt`, `r4_ab_runs.txt` |
+| the same command under `rocprofv3 --kernel-trace --stats`, 1000 timed steps (the same box, the same gpurun call) | `scan_kernel<false>`: {len(dur)} dispatches, average **{statistics.mean(dur):.1f} µs** (pre-roll and warm-up included) = {frac(statistics.mean(dur)):.3f}; last 1000: {statistics.mean(dur[-1000:]):.1f} µs = **{frac(statistics.mean(dur[-1000:])):.3f}**; minimum {min(dur):.1f} µs; the bench line of that very run read {u['roofline']['launch_ms'] * 1e3:.1f} µs in-kernel (1 % below the trace, as in every round) | `r4_kernel_stats.csv`, `r4_dispatches.csv`, `r4_bench_under_rocprofv3.json` |
+| spread of the kernel | box to box 0.137–0.148 ms (0.453–0.490), same build, same command (round 3's and round 4's boxes); on one box the 200 default steps read ≈ 3 % longer than 1000 steps right behind them (the clock governor is still ramping: rows 1 and 2) | `r3_ab_runs.txt`, `r4_ab_runs.txt` |
 | HBM traffic per launch | {pmc['hbm_bytes_per_launch'] / 1e6:.1f} MB = {pmc['hbm_bytes_per_launch'] / B:.3f} × the 536.9 MB of algorithmic input (FETCH_SIZE × 2 + WRITE_SIZE, separate passes) | `r4_pmc.json` |
 | VALU wave-instructions per launch | {c['SQ_INSTS_VALU']['mean'] / 1e6:.2f} M; Stage A's pass 660 instructions = 2 554 issue cycles (3.87 per instruction) | `r4_pmc.json`, `r4_isa_mix.json` |
 | wave time | issuing {c['SQ_ACTIVE_INST_ANY']['mean'] / wc * 100:.0f} %, stalled wanting to issue {c['SQ_WAIT_INST_ANY']['mean'] / wc * 100:.0f} %, parked on `s_waitcnt` / `s_barrier` {c['SQ_WAIT_ANY']['mean'] / wc * 100:.0f} % | `r4_pmc.json` |
