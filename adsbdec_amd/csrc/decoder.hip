@@ -1920,8 +1920,11 @@ int adsb_scan_shard_host(adsb_decoder *d, const uint16_t *host_samples, uint64_t
         HIP_TRY(d, hipMalloc(&d->win_buf, cap * sizeof(uint16_t)));
         d->win_cap = cap;
     }
-    // (a plain copy: the scan's launches may go to either compute stream, and a window is a few hundred KB)
-    HIP_TRY(d, hipMemcpy(d->win_buf, host_samples, n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    // (copied and waited for: the scan's launches may go to either compute stream, and a window is a few hundred KB.  On a
+    // copy stream of the handle's: the synchronous hipMemcpy was seen to cost the process ~1 KB of host memory per call
+    // that never came back -- tools/soak_probe.py)
+    HIP_TRY(d, hipMemcpyAsync(d->win_buf, host_samples, n * sizeof(uint16_t), hipMemcpyHostToDevice, d->copy_stream[0]));
+    HIP_TRY(d, hipStreamSynchronize(d->copy_stream[0]));
     return adsb_scan_shard(d, d->win_buf, first_sample, n, g_begin, g_end, cands, cand_cap, n_cands, tries, try_cap, n_tries);
 }
 
