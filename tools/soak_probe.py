@@ -55,8 +55,24 @@ def main():
         r1, b1 = rss_mb()
         legs.append((name, it, r1 - r0, (f0 - torch.cuda.mem_get_info()[0]) / 2 ** 20, b1 - b0))
         d.close()
-    md = sharding.MultiDecoder(4, [0, 0, 0, 0], collect_stats=True)
     x = sparse.cpu().numpy().view("uint16")
+    # host pushes at the reference's call size (1 Mi samples, air.c:218): from pageable memory (adsb_push), with cfg.push_overlap,
+    # and from two page-locked buffers in turn (adsb_push_async)
+    for name, kw, mode in (("adsb_push, pageable memory, 1 Mi samples per call", dict(collect_stats=True), "sync"),
+                           ("adsb_push with push_overlap", dict(collect_stats=True, push_overlap=True), "overlap"),
+                           ("adsb_push_async, two page-locked buffers", dict(collect_stats=True), "async")):
+        d = capi.Decoder(**kw)
+        part = x[: 16 << 20]
+        for _ in range(3):
+            d.decode(part, chunk=1 << 20, mode=mode)
+        (r0, b0), f0, t0, it = rss_mb(), torch.cuda.mem_get_info()[0], time.time(), 0
+        while time.time() - t0 < a.seconds:
+            d.decode(part, chunk=1 << 20, mode=mode)
+            it += 16
+        r1, b1 = rss_mb()
+        legs.append((name + " (calls)", it, r1 - r0, (f0 - torch.cuda.mem_get_info()[0]) / 2 ** 20, b1 - b0))
+        d.close()
+    md = sharding.MultiDecoder(4, [0, 0, 0, 0], collect_stats=True)
     with capi.PinnedBuffers(1, n) as bufs:
         bufs[0][:] = x
         for _ in range(10):
