@@ -188,3 +188,22 @@ def test_a_listening_sink_whose_peer_goes_away_does_not_wait_for_another(harness
     rest = p.stderr.read().splitlines()
     assert "disconnected" in rest and rest.count("listening") == 0
     assert "packets dropped 0" not in rest[-1]
+
+
+def test_the_host_program_refuses_unusable_addresses_before_it_touches_the_gpu(tmp_path):
+    """adsbdec_amd_cli itself (built by __graft_entry__.build()): -s / -l with an address that cannot be used end the run with
+    status 255 and the reference's message before adsb_create is reached -- so this runs on a box without a GPU; -s together
+    with several captures, and unknown options, print the usage text and exit 1 (main.c:85-87)."""
+    from adsbdec_amd import capi
+    if not os.path.exists(capi.CLI_PATH):
+        pytest.skip("the host program is not built")
+    f = tmp_path / "z.u16"
+    f.write_bytes(b"\0" * 4096)
+    p = subprocess.run([capi.CLI_PATH, "-s", "[::1", "-f", str(f)], capture_output=True, timeout=60)
+    assert p.returncode == 255 and p.stderr == b"Invalid IPV6 address\n" and p.stdout == b""
+    p = subprocess.run([capi.CLI_PATH, "-l", "no.such.host.invalid:1", "-f", str(f)], capture_output=True, timeout=60)
+    assert p.returncode == 255 and p.stderr == b"Invalid/unknown address no.such.host.invalid\n"
+    p = subprocess.run([capi.CLI_PATH, "-G", "0,0", "-s", "127.0.0.1:9", "-f", str(f), "-f", str(f)], capture_output=True, timeout=60)
+    assert p.returncode == 1 and b"usage" in p.stdout
+    p = subprocess.run([capi.CLI_PATH, "-s"], capture_output=True, timeout=60)      # option without its argument
+    assert p.returncode == 1
