@@ -115,7 +115,7 @@ def test_config2_256Mi_dense_noise(capi, oracle, torch_cuda):
 def test_config2_256Mi_at_ten_percent_density_and_the_gate_storm(capi, oracle, torch_cuda):
     """BASELINE configs[2] at the density it states (~10 % of the offsets pass the preamble test: 112-bit frames packed back to
     back in sigma = 300 noise + slots of frame starts), and the adversarial capture made of frame starts only (7 % of ALL offsets
-    pass the DF gate: every tile overflows its survivor queue into the fallback rounds, the launch-wide try list is regrown):
+    pass the DF gate: every tile overflows its survivor queue and is redone in ranges of chunks, the launch-wide try list is regrown):
     frames, ts, pw and the Try/Ok table equal to the oracle's on the full 256 Mi samples."""
     from bench import make_dense10, make_gate_storm, preamble_pass_fraction
     n = (256 << 20) - (256 << 20) % 28

@@ -557,8 +557,8 @@ def test_staged_list_overflow_and_partial_relaunch(oracle, dec_factory, torch_cu
 
 def test_survivor_queue_overflow_fallback(oracle, dec_factory):
     """With the per-workgroup survivor queue shrunk to 256 entries about half the
-    tiles of a noise capture overflow it and take the bit-position-by-bit-position
-    fallback; results must not change."""
+    tiles of a noise capture overflow it and are redone in ranges of chunks (a chunk
+    that still does not fit: bit position by bit position); results must not change."""
     rng = np.random.default_rng(31)
     x = rng.integers(0, 4096, 1 << 21, dtype=np.uint16)
     want, wstats = oracle.decode(x, df18=True)
