@@ -632,7 +632,7 @@ void start_reader(adsb_decoder *d)
     }
 }
 
-int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, uint32_t *tiles_in)
+int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, uint32_t *tiles_in, bool *tries_listed)
 {
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
@@ -697,6 +697,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     d->prof.host_ms += total_ms - wait_ms;
     *resume_tile = delivered;
     *tiles_in = end.frontier;
+    *tries_listed = end.tries_listed;
     d->last_launch_records = recs_handed; // (a launch that is finished after completion adds its part there)
     return overflowed ? 1 : 0;
 }
@@ -864,16 +865,18 @@ int slot_collect(adsb_decoder *d)
     uint32_t resume_tile = 0, tiles_in = 0;
     bool partial = false; // tiles below resume_tile were already delivered
     bool relaunched = false;
+    bool tries_listed = false; // (statistics runs) some tile's tries are on the launch-wide list: its length comes with the counters
     if (s.streaming) {
-        const int rc = slot_collect_streaming(d, s, &resume_tile, &tiles_in);
+        const int rc = slot_collect_streaming(d, s, &resume_tile, &tiles_in, &tries_listed);
         if (rc < 0)
             return -1;
         partial = rc == 1;
     }
-    if (s.streaming && !partial && (!s.tries_on_device || s.try_regions)) {
+    if (s.streaming && !partial && !tries_listed && (!s.tries_on_device || s.try_regions)) {
         // Every tile has been published and consumed and none used the loose list -- nor, in a statistics
-        // run, the launch-wide try list: a tile that falls back to overflow rounds flags its marker, and
-        // the tries of all others are in their regions.  The launch-wide counters have nothing to add, so
+        // run, the launch-wide try list: a tile that overflows its survivor queue says so in its marker (kMarkTries:
+        // its records are in the stream and have been handed on like any other's), and the tries of all others are
+        // in their regions.  The launch-wide counters have nothing to add, so
         // do not wait for them (nor for the kernel's end event -- the profile reads that later).
         s.prof_pending[s.ev_cur] = d->cfg.profile != 0;
         d->prof.launches++;

@@ -50,6 +50,7 @@ struct HandCursor {
     const uint32_t gen, cap;
     uint32_t pos = 0;      // granules of the stream consumed
     uint32_t frontier = 0; // every tile below is in
+    bool tries_listed = false; // some tile of a statistics run sent its tries through the launch-wide list (kMarkTries)
     uint32_t hold = ~0u;   // the lowest tile that says "some of my records are on the loose list": it, and every tile behind
                            // it, can only be handed on once the launch has ended -- but they are READ (and checked) meanwhile
     uint32_t tile = 0, nf = 0; // the marker tile_in() accepted last
@@ -135,6 +136,8 @@ struct HandCursor {
             return -1;
         if (nf & (kMarkOver | kMarkNoFit))
             hold = std::min(hold, tile);
+        if (nf & kMarkTries)
+            tries_listed = true;
         if (nf & kMarkNoFit)
             return 1;
         t_start[tile] = pos + 1;
@@ -153,6 +156,7 @@ struct HandCursor {
 struct CollectEnd {
     int status = 0;
     uint32_t pos = 0, tile = 0, frontier = 0;
+    bool tries_listed = false; // kMarkTries seen: the launch-wide try list is in use, its length comes with the launch's counters
 };
 
 // A decoder's second host thread (cfg.host_threads = 2): it reads and checks the hand-off stream of the launch being
@@ -222,6 +226,7 @@ struct StreamReader {
         end.pos = cur.pos;
         end.tile = cur.tile;
         end.frontier = cur.frontier;
+        end.tries_listed = cur.tries_listed;
         wait_ms = cur.wait_ms;
         busy_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count() - cur.wait_ms;
         frontier.store(cur.deliverable(), std::memory_order_release); // (what the caller may hand on: tiles below the first that holds)
@@ -393,6 +398,7 @@ CollectEnd collect_alone(const HandJob &job, uint32_t *t_start, uint32_t *t_coun
         end.status = 1;
     end.pos = cur.pos;
     end.frontier = cur.frontier;
+    end.tries_listed = cur.tries_listed;
     end.tile = end.status == -2 ? cur.frontier : cur.tile;
     wait_ms = cur.wait_ms;
     t_last_wait = cur.t_last_wait;

@@ -482,7 +482,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     const int64_t pbuf0 = args.pbuf0, p_lo = args.p_lo, p_hi = args.p_hi;
     const int own = kPassRuns * K - kReachRuns;
     uint32_t *tile_n = qcount + 4;    // records this tile keeps (ranked into its hand-off range)
-    uint32_t *tile_over = qcount + 5; // some records had to go to the loose list
+    uint32_t *tile_over = qcount + 5; // bit 0: some records had to go to the loose list; bit 1: tries went to the launch-wide list
     uint32_t *tile_base = qcount + 6; // granule index of the tile's marker in args.hand
     uint32_t *try_base = qcount + 7;  // first index of the round's range in args.tries (kStats)
     uint32_t *tile_res = qcount + 8;  // the tile has reserved its range of args.hand
@@ -507,7 +507,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     // then tells the host to collect after completion.
     auto emit_loose = [&](uint32_t g_rel, uint32_t pw, const uint32_t (&wds)[4]) {
         if (args.hand)
-            *tile_over = 1;
+            atomicOr(tile_over, 1u);
         const uint32_t slot = atomicAdd(&args.counters[0 * kCounterPad], 1u);
         if (slot < args.cand_cap) {
             uint32_t *rec = args.cands + (size_t)slot * kCandWords;
@@ -626,7 +626,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         uint32_t try_res = 0;
         if (kStats && tid == 0) {
             if (over && args.hand)
-                *tile_over = 1; // the launch-wide try list is in use: the host must wait for the launch's counters
+                atomicOr(tile_over, 2u); // the launch-wide try list is in use: the count pass needs the launch's counters (kMarkTries)
             if (try_region)
                 args.try_counts[tile] = (uint32_t)qn; // 0 when the queue overflowed: the rounds that follow list them
             else if (qn)
@@ -892,7 +892,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             for (uint32_t L = tid; L < 1u + 2u * nk; L += NT) {
                 u32x4 gv;
                 if (L == 0) {
-                    const uint32_t nf = nk | (*tile_over ? kMarkOver : 0u) | (*tile_lines << kMarkLinesShift);
+                    const uint32_t nf = nk | ((*tile_over & 1u) ? kMarkOver : 0u) | ((*tile_over & 2u) ? kMarkTries : 0u) | (*tile_lines << kMarkLinesShift);
                     uint32_t lo, hi;
                     marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], *tile_sum, lo, hi);
                     gv = u32x4{tile, nf, lo, hi};
@@ -923,7 +923,8 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                 lines = stream_granules(0) >> 2;
             }
             if (b < args.hand_cap) {
-                const uint32_t nf = *tile_n | (*tile_over ? kMarkOver : 0u) | (fit ? 0u : kMarkNoFit) | (lines << kMarkLinesShift);
+                const uint32_t nf = *tile_n | ((*tile_over & 1u) ? kMarkOver : 0u) | ((*tile_over & 2u) ? kMarkTries : 0u) | (fit ? 0u : kMarkNoFit) |
+                                    (lines << kMarkLinesShift);
                 uint32_t lo, hi;
                 marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], *tile_sum, lo, hi);
                 store_granule_through(args.hand, b, u32x4{tile, nf, lo, hi});

@@ -18,7 +18,9 @@ namespace adsb {
 constexpr int kGranuleWords = 4;
 constexpr uint32_t kMarkOver = 0x10000u;  // marker flag: some records of the tile are on the loose list
 constexpr uint32_t kMarkNoFit = 0x20000u; // marker flag: the tile's range ran past the array (records are loose)
-constexpr int kMarkLinesShift = 18;       // marker word 1, bits 18..31: 64-byte lines the tile reserved (it may keep fewer records
+constexpr uint32_t kMarkTries = 0x40000u; // marker flag (statistics runs): the tile's tries went through the launch-wide list -- its
+                                          // records are all here, but the count pass needs the launch's counters (nothing is held up)
+constexpr int kMarkLinesShift = 19;       // marker word 1, bits 19..31: 64-byte lines the tile reserved (it may keep fewer records
                                           // than it reserved for: the host skips to the next tile's marker by this)
 ADSB_HD constexpr uint32_t marker_granules(uint32_t nf) { return (nf >> kMarkLinesShift) * 4u; }
 // Granules a tile with n records reserves: marker + 2 n, rounded up to whole 64-byte lines, so

@@ -251,7 +251,7 @@ int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out);
 
 /* ---- diagnostics: the device -> host hand-off stream, walked without a device -------------
  * The scan kernel hands its records to the host through ONE stream of 16-byte granules in pinned
- * host memory: per tile a marker {tile, n | flags | lines reserved << 18,
+ * host memory: per tile a marker {tile, n | flags | lines reserved << 19,
  * check_lo, check_hi} followed by n records of two granules; a tile counts only once its marker's
  * check words agree with the XOR of its record granules, mixed with the launch's `gen`.
  * adsb_handoff_walk applies exactly the rules the streaming collect applies (the same code) to an
@@ -260,7 +260,8 @@ int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out);
  * return value is the number of leading tiles that may be handed on (all in, none of them holding),
  * and *status says why the walk ended: 0 every tile is in; 1 a tile holds -- it has records on the
  * loose list (flag 0x10000: the tiles behind it are still read, and wait with it for the launch's end)
- * or its range ran past the array (flag 0x20000: the stream ends there) -- or the stream is full;
+ * or its range ran past the array (flag 0x20000: the stream ends there) -- or the stream is full (flag 0x40000, a statistics
+ * run's "my tries are on the launch-wide list", holds nothing up);
  * 2 the bytes at the cursor are not (yet) a valid marker of this launch; -1 a tile appears twice.
  * No GPU is needed: this is how the host logic is tested. */
 long adsb_handoff_walk(const void *stream, size_t granules, uint32_t n_tiles, uint32_t gen,

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 M32 = 0xFFFFFFFF
-OVER, NOFIT, LINES_SHIFT = 0x10000, 0x20000, 18
+OVER, NOFIT, TRIES, LINES_SHIFT = 0x10000, 0x20000, 0x40000, 19
 
 
 def rotl(x, k):
@@ -128,6 +128,22 @@ def test_tiles_that_ask_to_be_finished_after_completion(capi, flag):
         assert tc == [2, 5, 1]                   # ... but a tile with loose records, and the tiles behind it, are read meanwhile
     else:
         assert tc[1] == M32 and tc[2] == M32     # a range past the array ends the stream: nothing behind it can be in it
+
+
+def test_a_tile_whose_tries_went_through_the_launch_wide_list_holds_nothing_up(capi):
+    """kMarkTries (statistics runs, a tile that overflowed its survivor queue): the tile's records are all in the stream; only
+    the count pass has to wait for the launch's counters.  Every tile may be handed on, status 0; the flag is covered by the
+    marker's check words like everything else in nf."""
+    img = Image(1024, gen=77)
+    img.tile(0, 2)
+    img.tile(1, 5, flags=TRIES)
+    img.tile(2, 1, flags=TRIES, lines=3)
+    f, st, ts, tc = walk(capi, img, 3)
+    assert (f, st) == (3, 0) and tc == [2, 5, 1]
+    assert [ts[t] for t in range(3)] == [img.where[t][0] for t in range(3)]
+    img.w[4 * (img.where[1][0] - 1) + 1] ^= TRIES            # the flag flipped on its way: not the marker that was written
+    f, st, _, tc = walk(capi, img, 3)
+    assert st == 2 and f == 1
 
 
 def test_a_tile_that_reserved_more_lines_than_it_kept_records_for(capi):
