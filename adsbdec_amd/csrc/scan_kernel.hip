@@ -1032,6 +1032,11 @@ __device__ __forceinline__ bool try_shadowed(const TryCountArgs &a, uint64_t g)
 // 34 us per 256 Mi samples with 8 192 resident waves, and slowed the scan kernel running beside it by as much.
 // The remaining blocks: the launch-wide list and the carry of earlier passes, grid-stride.
 constexpr int kCountThreads = 256;
+// Blocks that walk the tile regions, four tiles at a time each (grid-stride).  The pass runs beside the NEXT launch's scan, which
+// is bound by VALU issue: with one block per four tiles (697 for a 256 Mi-sample launch) that scan took 0.156 ms, with 256 or 64
+// blocks 0.149 ms and the statistics step 2 % less; with 16 the pass itself (0.33 ms) became the step
+// (profiles/r4_ab_runs.txt section 8).
+constexpr int kCountRegionGrid = 64;
 __global__ __launch_bounds__(kCountThreads) void count_tries_kernel(const TryCountArgs a)
 {
     uint32_t cnt[3] = {0, 0, 0};
@@ -1045,8 +1050,10 @@ __global__ __launch_bounds__(kCountThreads) void count_tries_kernel(const TryCou
         else
             a.acc[3] = 1; // reported when the statistics are read
     };
-    if (blockIdx.x < region_blocks) {
-        const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t region_grid = min(region_blocks, (uint32_t)kCountRegionGrid);
+    if (blockIdx.x < region_grid) {
+      for (uint32_t rb = blockIdx.x; rb < region_blocks; rb += region_grid) {
+        const uint32_t tile = rb * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
         const uint32_t n = tile < a.n_tiles ? min(a.region_counts[tile], (uint32_t)kTryRegion) : 0u;
         if (n) { // wave-uniform
             const uint64_t t0 = a.g_base + (uint64_t)kRun * tile_first_run(tile, a.stagger, a.passes);
@@ -1096,13 +1103,14 @@ __global__ __launch_bounds__(kCountThreads) void count_tries_kernel(const TryCou
                     cnt[code < 3 ? code : 2]++;
             }
         }
+      }
     } else {
         const uint32_t n_carry = min(*a.n_carry, a.carry_cap);
-        if (blockIdx.x == region_blocks && threadIdx.x == 0)
+        if (blockIdx.x == region_grid && threadIdx.x == 0)
             *a.n_carry_next = 0; // three counts in rotation: nobody reads or appends to this one during this pass
         const uint32_t total = a.n_tries + n_carry;
-        const uint32_t nb = gridDim.x - region_blocks;
-        for (uint32_t i = (blockIdx.x - region_blocks) * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
+        const uint32_t nb = gridDim.x - region_grid;
+        for (uint32_t i = (blockIdx.x - region_grid) * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
             uint64_t g;
             uint32_t code;
             if (i < a.n_tries) {
@@ -1146,7 +1154,8 @@ hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream)
     const uint32_t region_blocks = args.regions ? (args.n_tiles + 3u) / 4u : 0u;
     const uint32_t guess = args.n_tries + 65536u;
     const unsigned list_blocks = (unsigned)std::min<uint32_t>((guess + kCountThreads - 1u) / kCountThreads, args.regions ? 64u : 2048u);
-    hipLaunchKernelGGL(count_tries_kernel, dim3(region_blocks + list_blocks), dim3(kCountThreads), 0, stream, args);
+    const uint32_t region_grid = std::min<uint32_t>(region_blocks, (uint32_t)kCountRegionGrid);
+    hipLaunchKernelGGL(count_tries_kernel, dim3(region_grid + list_blocks), dim3(kCountThreads), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -2,7 +2,7 @@
 # Same-box A/B of whole source trees: tools/ab_sources.sh [--rounds N] name=csrc_dir [name=csrc_dir ...]
 # Builds every directory (a copy of adsbdec_amd/csrc, e.g. `git show <rev>:adsbdec_amd/csrc/scan_kernel.hip` over a copy, made
 # BEFORE the gpurun call: the GPU box has no .git) into adsbdec_amd/lib_var/<name>/ and runs bench.py --steps 300 --no-extras on
-# each, N rounds, order reversed every other round.  The directories must lie two levels below a directory that holds include/
+# each (plus $BENCH_FLAGS, e.g. --stats), N rounds, order reversed every other round.  The directories must lie two levels below a directory that holds include/
 # (the sources include "../../include/adsbdec_amd.h").  profiles/r4_ab_runs.txt section 7 was made with it.
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
@@ -21,7 +21,7 @@ for round in $(seq 1 "$rounds"); do
   order=("${names[@]}")
   if [ $((round % 2)) = 0 ]; then order=(); for ((i=${#names[@]}-1; i>=0; i--)); do order+=("${names[i]}"); done; fi
   for v in "${order[@]}"; do
-    ADSB_LIB_PATH=$PWD/adsbdec_amd/lib_var/$v/libadsbdec_amd.so timeout 300 python bench.py --steps 300 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+    ADSB_LIB_PATH=$PWD/adsbdec_amd/lib_var/$v/libadsbdec_amd.so timeout 300 python bench.py --steps 300 --no-cpu-baseline --no-extras $BENCH_FLAGS 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('round $round $v: ms_per_step', d['ms_per_step'], 'launch_ms', r['launch_ms'], 'frac', r['frac'])"
   done
 done
