@@ -702,10 +702,13 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         }
 
         if (kStats && qn) { // (qn is workgroup-uniform)
-            if (tid == 0)
-                *try_base = try_res;
-            __syncthreads(); // (the slicer only reads the queue)
-            const uint32_t tb = *try_base;
+            uint32_t tb = 0;
+            if (!try_region) { // (workgroup-uniform) the range of the launch-wide list that thread 0 reserved
+                if (tid == 0)
+                    *try_base = try_res;
+                __syncthreads(); // (the slicer only reads the queue)
+                tb = *try_base;
+            }
             uint32_t *dst = args.tries + (try_region ? (size_t)tile * kTryRegion : (size_t)args.try_list_first + tb);
             const uint32_t room = try_region ? (uint32_t)kTryRegion : (tb < args.try_cap ? args.try_cap - tb : 0u);
             for (int q = tid; q < qn; q += NT) { // adjacent lanes, adjacent words
