@@ -1037,9 +1037,9 @@ __device__ __forceinline__ bool try_shadowed(const TryCountArgs &a, uint64_t g)
 constexpr int kCountThreads = 256;
 // Blocks that walk the tile regions, four tiles at a time each (grid-stride).  The pass runs beside the NEXT launch's scan, which
 // is bound by VALU issue: with one block per four tiles (697 for a 256 Mi-sample launch) that scan took 0.156 ms, with 256 or 64
-// blocks 0.149 ms and the statistics step 2 % less; with 16 the pass itself (0.33 ms) became the step
-// (profiles/r4_ab_runs.txt section 8).
-constexpr int kCountRegionGrid = 64;
+// blocks 0.149 ms and the statistics step 2 % less; with 16 the pass itself (0.33 ms) became the step, and with 64 a stream of
+// eight launches (2 Gi samples) ended 0.3 ms later, its passes queued up behind the scans (profiles/r4_ab_runs.txt section 8).
+constexpr int kCountRegionGrid = 256;
 __global__ __launch_bounds__(kCountThreads) void count_tries_kernel(const TryCountArgs a)
 {
     uint32_t cnt[3] = {0, 0, 0};
