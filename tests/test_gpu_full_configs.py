@@ -201,3 +201,48 @@ def test_config4_2Gi_one_stream_in_8_shards(capi, oracle, torch_cuda):
         finally:
             d.close()
             r.close()
+
+
+def test_a_stream_just_below_the_sample_counter_limit(capi, torch_cuda):
+    """The longest stream there is: 2^32 - 4 samples (3.6 minutes of signal, 8 GiB resident in HBM; the reference's sample
+    counter wraps at 2^32, air.c:34, and the library refuses a stream that would reach it).  No CPU oracle at this size: the
+    size-independent properties instead -- ts is the checksum of the whole greedy replay (demod.c:86,99,128,134), every decoded
+    frame is one that was sent, in order -- and two independent paths through the library against each other, frame for frame
+    and Try/Ok table for table: one handle decoding the stream in one pass (32 launches), and the multi-GPU driver with eight
+    handles on this device (eight shards, each resolved on its own, seams and horizon stitched)."""
+    from adsbdec_amd import sharding
+    from bench import make_workload
+    n = ((1 << 32) - 1) // 28 * 28
+    assert (1 << 32) - n == 4
+    t, truth = make_workload(torch_cuda, n, seed=21)
+    d = capi.Decoder(df18=False, collect_stats=True)
+    try:
+        d.push_device_final(t.data_ptr(), t.numel())
+        raw = d.take_raw()
+        got, gstats = capi._frames_to_dicts(*raw), d.stats()
+        assert len(got) > 0.9 * len(truth) and len(truth) > 200_000
+        _ts_checksum(got)
+        assert got[-1]["g"] > (n // 2) - 40_980 - 1200 - 30_000          # frames right up to the end-of-file horizon
+        sent = iter(fr for _, fr in truth)
+        assert all(any(f["frame"] == s for s in sent) for f in got)
+        md = sharding.MultiDecoder(8, [0] * 8, df18=False, collect_stats=True)
+        try:
+            plan = md.plan(n)
+            assert len(plan) == 8
+            other = capi._frames_to_dicts(*md.decode_device(n, [t.data_ptr() + 2 * p["first_sample"] for p in plan]))
+            assert records(other) == records(got)
+            assert md.stats() == gstats
+            assert md.info()["fallback"] == 0
+        finally:
+            md.close()
+        # one sample more than the reference can count: refused, before anything is read
+        d.reset()
+        d.push_device(t.data_ptr(), 1 << 20)
+        with pytest.raises(capi.AdsbError, match="2\\^32"):
+            d.push_device(t.data_ptr(), (1 << 32) - (1 << 20))
+        d.push_device_final(t.data_ptr() + 2 * (1 << 20), n - (1 << 20))   # ... and one that just fits still goes
+        assert records(capi._frames_to_dicts(*d.take_raw())) == records(got)
+    finally:
+        d.close()
+    del t
+    torch_cuda.cuda.empty_cache()
