@@ -31,7 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import gen_signal as G  # noqa: E402
+from tools import gen_signal as G  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")

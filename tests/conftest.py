@@ -1,7 +1,10 @@
 """pytest configuration: the `gpu` marker, repo-root imports, build-once fixtures."""
+import faulthandler
 import json
 import os
+import signal
 import sys
+import threading
 
 import numpy as np
 import pytest
@@ -15,8 +18,86 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def pytest_configure(config):
-    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+def pytest_addoption(parser):
+    parser.addoption("--gpu-big", action="store_true", default=False,
+                     help="also run the opt-in gpu_big tests (many GiB of HBM, minutes of wall time)")
+
+
+# Order of the -m gpu run: cheap and most diagnostic first, the heavy full-size configurations last, so that a run cut short
+# (the driver's limit, -x) has seen every golden fixture, configs[3] and the multi-process shape before anything large.
+_ORDER = (
+    ("golden", 0),                                   # the committed fixtures, 0.1 s each (all files)
+    ("test_gpu_parity.py::test_seeded", 1),
+    ("test_generator_digests_on_the_device", 1),
+    ("test_multi_independent_streams", 2),           # configs[3]: one capture per handle ...
+    ("test_two_rank_independent_streams", 2),        # ... and one PROCESS per device, the driver's command shape
+    ("test_eight_ranks_on_one_device", 2),
+    ("test_a_rank_that_dies_ends_the_job", 2),
+    ("test_cli_", 4),                                # the C host program
+    ("test_fuzz_30s", 8),
+    ("test_round_trip_at_scale", 8),
+    ("test_gpu_parity.py", 3),
+    ("test_gpu_dropin.py", 5),                       # the reference's own harness with INTEGRATION.md's patch
+    ("test_gpu_multi.py::test_bench_shard_mode", 8),
+    ("test_gpu_multi.py", 6),
+    ("test_gpu_full_configs.py", 9),                 # BASELINE's configurations at their stated sizes
+)
+
+
+def _rank(item):
+    for key, r in _ORDER:
+        if key in item.nodeid:
+            return r
+    return 3
+
+
+def pytest_collection_modifyitems(config, items):
+    if not config.getoption("--gpu-big"):
+        big = [it for it in items if it.get_closest_marker("gpu_big")]
+        if big:
+            config.hook.pytest_deselected(items=big)
+            items[:] = [it for it in items if not it.get_closest_marker("gpu_big")]
+    gpu = [it for it in items if it.get_closest_marker("gpu")]
+    if gpu:
+        rest = [it for it in items if not it.get_closest_marker("gpu")]
+        gpu.sort(key=_rank)          # stable: the files' own order inside a rank
+        items[:] = rest + gpu
+
+
+class TestTimeLimit(Exception):
+    pass
+
+
+def _dump_all_stacks(what):
+    sys.stderr.write(f"\n===== {what}: stacks of every thread =====\n")
+    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+    sys.stderr.flush()
+
+
+@pytest.fixture(autouse=True)
+def _per_test_time_limit(request):
+    """No test may hang the run.  At the limit SIGALRM fails the test with every thread's stack; if the main thread sits in a C
+    call that never returns (the signal handler only runs between bytecodes), a watchdog of faulthandler's own (a C thread:
+    it needs no GIL) dumps the stacks 45 s later and ENDS the process -- a red run with a cause instead of a killed one."""
+    m = request.node.get_closest_marker("limit")
+    limit = float(m.args[0]) if m else (150.0 if request.node.get_closest_marker("gpu") else 300.0)
+    if threading.current_thread() is not threading.main_thread() or not hasattr(signal, "SIGALRM"):
+        yield
+        return
+
+    def on_alarm(signum, frame):
+        _dump_all_stacks(f"{request.node.nodeid} exceeded its limit of {limit:.0f} s")
+        raise TestTimeLimit(f"{request.node.nodeid} exceeded its limit of {limit:.0f} s (stacks on stderr)")
+
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    signal.setitimer(signal.ITIMER_REAL, limit)
+    faulthandler.dump_traceback_later(limit + 45.0, exit=True, file=sys.stderr)
+    try:
+        yield
+    finally:
+        signal.setitimer(signal.ITIMER_REAL, 0)
+        signal.signal(signal.SIGALRM, old)
+        faulthandler.cancel_dump_traceback_later()
 
 
 @pytest.fixture(scope="session")
@@ -68,3 +149,15 @@ def shard_power(oracle, x, shard):
     pad = s0 % 28
     xs = np.concatenate([np.full(pad, 2048, np.uint16), x[s0: s0 + shard["n_samples"]]])
     return oracle.power(xs), (s0 - pad) // 2
+
+
+def preamble_pass_fraction(x_host, n=4 << 20):
+    """Share of the preamble offsets of a prefix that pass demod.c:102-107 (p1 > 2 s1 && p2 > 2 s2), from the oracle's
+    power samples: the density figure BASELINE configs[2] quotes ("~10 % of offsets above preamble threshold")."""
+    from oracle import oracle as O
+    O.build()
+    a = O.power(np.ascontiguousarray(x_host[:n]))
+    m = a.size - 1196
+    c = np.trunc(a[:-10] + a[10:]).astype(np.int64)   # c[k] = (int)(a[k] + a[k+10]): all four sums have this form
+    p1, s1, s2, p2 = c[0:m], c[5:m + 5], c[30:m + 30], c[35:m + 35]
+    return float(np.mean((p1 > 2 * s1) & (p2 > 2 * s2)))

@@ -28,7 +28,7 @@ def _free_port():
 
 
 def _stream_of(rank):
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     return G.dense_capture((1 << 19) + 4 * rank, seed=44 + rank, sigma=50.0, n_frames=150 + 20 * rank)[0]
 
 

@@ -58,7 +58,7 @@ def test_dropin_binary_fails_loudly_without_a_gpu(tmp_path):
 ])
 def test_patched_reference_equals_the_reference(tmp_path, seed, n, sigma, nfr, df18, chunk):
     _need_binaries()
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(n, seed=seed, sigma=sigma, n_frames=nfr, amp=(150, 1900))
     f = tmp_path / "capture.u16"
     x.tofile(f)

@@ -59,7 +59,7 @@ def _ts_checksum(frames):
 
 
 def test_config1_256Mi_sparse(capi, oracle, torch_cuda):
-    from bench import make_workload
+    from tools.gen_signal import make_workload
     n = (256 << 20) - (256 << 20) % 28
     t, truth = make_workload(torch_cuda, n, seed=1)
     d = capi.Decoder(df18=False, collect_stats=True)
@@ -95,7 +95,7 @@ def test_config1_256Mi_sparse(capi, oracle, torch_cuda):
 
 
 def test_config2_256Mi_dense_noise(capi, oracle, torch_cuda):
-    from bench import make_dense
+    from tools.gen_signal import make_dense
     n = (256 << 20) - (256 << 20) % 28
     t = make_dense(torch_cuda, n, 100)   # sigma = 300 noise + one strong 112-bit frame per ms
     d = capi.Decoder(df18=True, collect_stats=True)
@@ -117,7 +117,8 @@ def test_config2_256Mi_at_ten_percent_density_and_the_gate_storm(capi, oracle, t
     back in sigma = 300 noise + slots of frame starts), and the adversarial capture made of frame starts only (7 % of ALL offsets
     pass the DF gate: every tile overflows its survivor queue and is redone in ranges of chunks, the launch-wide try list is regrown):
     frames, ts, pw and the Try/Ok table equal to the oracle's on the full 256 Mi samples."""
-    from bench import make_dense10, make_gate_storm, preamble_pass_fraction
+    from conftest import preamble_pass_fraction
+    from tools.gen_signal import make_dense10, make_gate_storm
     n = (256 << 20) - (256 << 20) % 28
     for make, seed, lo, hi, min_frames in ((make_dense10, 101, 0.095, 0.108, 80_000), (make_gate_storm, 102, 0.25, 0.35, 0)):
         t = make(torch_cuda, n, seed)
@@ -158,7 +159,7 @@ def test_config4_2Gi_one_stream_in_8_shards(capi, oracle, torch_cuda):
     (adsb_scan_shard), candidates gathered in shard order into ONE resolver that replays
     the sequential rules (greedy skip demod.c:128,134; ts demod.c:86,99; deqframe call
     pattern and EOF horizon air.c:94-99).  Here all eight shards run on this GPU."""
-    from bench import make_workload
+    from tools.gen_signal import make_workload
     n = (2 << 30) - (2 << 30) % 28
     t, _ = make_workload(torch_cuda, n, seed=9, damage_share=0.2)
     x = _host(t)
@@ -201,8 +202,12 @@ def test_config4_2Gi_one_stream_in_8_shards(capi, oracle, torch_cuda):
         finally:
             d.close()
             r.close()
+    del t, x, want
+    torch_cuda.cuda.empty_cache()
 
 
+@pytest.mark.gpu_big          # opt-in (--gpu-big): 8 GiB of HBM, 215 k frames synthesised on the host, minutes of wall time
+@pytest.mark.limit(1500)
 def test_a_stream_just_below_the_sample_counter_limit(capi, torch_cuda):
     """The longest stream there is: 2^32 - 4 samples (3.6 minutes of signal, 8 GiB resident in HBM; the reference's sample
     counter wraps at 2^32, air.c:34, and the library refuses a stream that would reach it).  No CPU oracle at this size: the
@@ -211,7 +216,7 @@ def test_a_stream_just_below_the_sample_counter_limit(capi, torch_cuda):
     and Try/Ok table for table: one handle decoding the stream in one pass (32 launches), and the multi-GPU driver with eight
     handles on this device (eight shards, each resolved on its own, seams and horizon stitched)."""
     from adsbdec_amd import sharding
-    from bench import make_workload
+    from tools.gen_signal import make_workload
     n = ((1 << 32) - 1) // 28 * 28
     assert (1 << 32) - n == 4
     t, truth = make_workload(torch_cuda, n, seed=21)

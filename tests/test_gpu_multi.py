@@ -29,7 +29,7 @@ def _dev(torch, x):
 
 
 def _back_to_back(n_frames, seed):
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(seed)
     placed = [(10_000 + 2_400 * i, G.make_frame([17, 18, 17, 11][i % 4], rng), float(rng.uniform(500, 1500)), float(i))
               for i in range(n_frames)]
@@ -44,7 +44,7 @@ def _recs(capi, raw):
 def captures(oracle):
     """(name, capture, frames, Try/Ok) of: overlapping frames in noise; frames packed back to back, so that EVERY seam cuts
     through one and the last call's horizon lands inside a run of them; dense noise (thousands of tries per window)."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     out = []
     for name, x in (("noisy", G.dense_capture((3 << 20) + 4, seed=91, sigma=40.0, n_frames=1500, amp=(200, 1800))[0]),
                     ("back_to_back", _back_to_back(1300, 45)),
@@ -119,7 +119,7 @@ def test_multi_short_captures(capi, oracle, torch_cuda, n):
     """Captures shorter than one window, than the first deqframe call (81 960 samples: nothing is ever visited), than one
     shard's worth: the plan falls back to fewer shards and the answer stays the reference's (frames AND Try/Ok)."""
     from adsbdec_amd import sharding
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x = G.dense_capture(max(n, 4), seed=7 + n, sigma=60.0, n_frames=max(1, n // 6000), amp=(300, 1800))[0][:n] if n else np.zeros(0, np.uint16)
     want, wstats = oracle.decode(x, df18=True) if n else ([], {"try": {11: 0, 17: 0, 18: 0}, "ok": {11: 0, 17: 0, 18: 0}})
     md = sharding.MultiDecoder(4, [0] * 4, df18=True, collect_stats=True)
@@ -152,7 +152,7 @@ def test_multi_independent_streams(capi, oracle, torch_cuda, tmp_path):
     """BASELINE configs[3] in one process: N different captures, stream s on worker s mod K, each with its own ts and Try/Ok
     table; more streams than workers too."""
     from adsbdec_amd import sharding
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     xs = [G.dense_capture((1 << 20) + 4 * s, seed=300 + s, sigma=[8.0, 40.0, 300.0][s % 3], n_frames=300 + 50 * s, amp=(300, 1800))[0]
           for s in range(5)]
     wants = [oracle.decode(x, df18=True) for x in xs]
@@ -178,7 +178,7 @@ def test_multi_one_bit_repair_extension(capi, oracle, torch_cuda):
     """cfg.fix_1bit through the sharded path == the oracle's own rule on the whole stream (no reference parity exists for the
     extension); `fixed` is counted from the final frames."""
     from adsbdec_amd import sharding
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(17)
     placed = []
     for i in range(500):
@@ -284,7 +284,7 @@ def test_cli_sharded_equals_the_real_reference_chain(capi, oracle, tmp_path):
     table byte-identical to the unpatched reference chain (oracle/_ref/ref_adsbdec), with and without -a, AVR and MLAT; -d,
     and files shorter than one window per shard.  `-G 4` on a box with fewer than four GPUs fails and names the device."""
     _ref_or_skip(oracle)
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture((64 << 20) + 6, seed=411, sigma=30.0, n_frames=9000, amp=(150, 1800))
     big = str(tmp_path / "big.u16")
     x.tofile(big)
@@ -314,7 +314,7 @@ def test_cli_several_captures_one_per_handle(capi, oracle, tmp_path):
     """`-G 0,0,0 -f a -f b -f c -f d`: configs[3] from the C host program; capture k's packets in <file k>.avr, its table on
     stderr -- each equal to what the reference prints for that file alone."""
     _ref_or_skip(oracle)
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     paths = []
     for s in range(4):
         x, _ = G.dense_capture((2 << 20) + 8 * s, seed=500 + s, sigma=20.0 + 90 * s, n_frames=600, amp=(200, 1800))

@@ -80,7 +80,7 @@ def test_golden_device_final_one_pass(capi, dec_factory, torch_cuda, name):
 
 
 def test_device_final_after_earlier_pushes(oracle, dec_factory, torch_cuda):
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture((1 << 20) + 6, seed=19, sigma=45.0, n_frames=250)
     want, wstats = oracle.decode(x, df18=True)
     t = _dev(torch_cuda, x)
@@ -97,7 +97,7 @@ def test_device_final_after_earlier_pushes(oracle, dec_factory, torch_cuda):
 @pytest.mark.parametrize("seed,sigma,nfr,df18", [(101, 8.0, 80, False), (102, 40.0, 300, True),
                                                  (103, 300.0, 60, True), (104, 120.0, 500, False)])
 def test_seeded_vs_oracle(oracle, dec_factory, seed, sigma, nfr, df18):
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture((1 << 20) + 4 * seed, seed=seed, sigma=sigma, n_frames=nfr, amp=(150, 1900))
     want, wstats = oracle.decode(x, df18=df18)
     d = dec_factory(df18=df18, collect_stats=True)
@@ -123,7 +123,7 @@ def test_beyond_12_bit_codes_vs_oracle(oracle, dec_factory, hi):
     """uint16 codes far outside the ADC's 12 bits (|x-2048| up to ~22 k): power sums
     exceed 2^24 (so float truncation is the identity and pair sums round), yet stay
     below 2^31 where the reference's float->int conversion is defined."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(hi)
     x = rng.integers(0, hi, 1 << 20, dtype=np.uint16)
     fr = [G.make_frame(17, rng) for _ in range(40)]
@@ -150,7 +150,7 @@ def test_chunked_pushes_equal_one_shot(oracle, dec_factory, chunk, mode):
     with adsb_push, with the overlapped adsb_push_async (copy of chunk k+1 beside the
     scan of chunk k, frames one call later) and with cfg.push_overlap (adsb_push returns when the
     copy is done; ONE buffer, scribbled over right after every call) alike."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     n = 200_000 if chunk < 1000 else 600_000
     x, _ = G.dense_capture(n, seed=5, sigma=35.0, n_frames=100)
     want, wstats = oracle.decode(x, df18=True)
@@ -163,7 +163,7 @@ def test_chunked_pushes_equal_one_shot(oracle, dec_factory, chunk, mode):
 def test_push_overlap_at_the_reference_call_size(capi, oracle, dec_factory, torch_cuda, stage):
     """cfg.push_overlap at IQBUFFSZ = 1 Mi samples per call (air.c:218) from one reused buffer, then mixed with
     adsb_push_async, device pushes and an adsb_sync; odd sizes and a small staging buffer (a compaction per piece)."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture((5 << 20) + 6, seed=62, sigma=30.0, n_frames=1200, amp=(150, 1800))
     want, wstats = oracle.decode(x, df18=True)
     d = dec_factory(df18=True, collect_stats=True, stage_samples=stage, push_overlap=True)
@@ -202,7 +202,7 @@ def test_async_pushes_reference_call_size_and_mixed_calls(capi, oracle, dec_fact
     air.c:218) from two alternating page-locked buffers; then the same stream with
     async, sync and device pushes mixed and an adsb_sync in the middle.  A small staging
     buffer makes every push several pieces."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture((5 << 20) + 6, seed=61, sigma=30.0, n_frames=1200, amp=(150, 1800))
     want, wstats = oracle.decode(x, df18=True)
     d = dec_factory(df18=True, collect_stats=True, stage_samples=stage)
@@ -240,7 +240,7 @@ def test_statistics_read_patterns(capi, oracle, dec_factory, torch_cuda):
     clearing behind a pass that is still pending.  Every order of reading, not reading, resetting and destroying
     must give the table of the stream that was decoded last -- here 60 steps over three captures with the table
     read never, once or twice per step, between pushes of one stream too, and handles closed with a pass pending."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(77)
     caps = []
     for k in range(3):
@@ -283,7 +283,7 @@ def test_accepted_frame_log_regrows(capi, oracle, torch_cuda):
     from; when a pass has more frames than the array holds, the rest goes to a vector and the arrays are regrown.  Start
     with room for 8 frames (cfg.debug_frames_cap) and decode streams with hundreds of frames per
     launch, several streams on one handle, chunked and in one piece: the Try/Ok table must equal the oracle's every time."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     d = capi.Decoder(df18=True, collect_stats=True, debug_frames_cap=8)
     try:
         for seed, n, nfr in ((41, 3 << 20, 900), (42, 1 << 20, 300), (43, (2 << 20) + 6, 1500)):
@@ -300,7 +300,7 @@ def test_accepted_frame_log_regrows(capi, oracle, torch_cuda):
 
 def test_decode_device_is_reset_push_final_take(capi, oracle, dec_factory, torch_cuda):
     """adsb_decode_device: one call per device-resident capture, several captures on one handle (statistics too)."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     d = dec_factory(df18=True, collect_stats=True)
     for seed, n in ((11, 1 << 21), (12, (1 << 20) + 6), (13, 90_000), (14, 3 << 20)):
         x, _ = G.dense_capture(n, seed=seed, sigma=30.0, n_frames=n // 5000, amp=(200, 1800))
@@ -334,7 +334,7 @@ def test_try_counting_with_more_than_64_frames_per_tile(oracle, dec_factory, pas
     apart: the greedy scan lands exactly on the next preamble, demod.c:128) put 75+ accepted frames into the
     window of a 7-pass tile, more than a wave holds: the per-try binary search takes over.  Tile size forced
     through cfg.debug_passes (launches this small would take 2..6 passes)."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(11)
     n = 3 << 19
     frames = [(5_000 + 1_280 * i, G.make_frame(11, rng), float(rng.uniform(600, 1500)), float(rng.uniform(0, 6.28)))
@@ -360,7 +360,7 @@ def test_async_small_staging_seam_is_ordered(capi, dec_factory, stats):
     compaction's tail copy (scan stream) -- inside one cache line.  Unordered, one of the two writes was lost in
     5-35 % of the runs and a frame straddling the seam disappeared (tools/async_race.py reproduces it on a
     -DADSB_TUNING build with the ordering rule switched off).  The copy streams now wait for the tail copy; 150 decodes, odd push sizes included."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture((5 << 20) + 6, seed=61, sigma=30.0, n_frames=1200, amp=(150, 1800))
     ref = dec_factory(df18=True, collect_stats=stats)
     want = ref.decode(x)
@@ -376,7 +376,7 @@ def test_async_small_staging_seam_is_ordered(capi, dec_factory, stats):
 def test_async_pushes_from_pageable_memory(oracle, dec_factory):
     """adsb_push_async does not require page-locked buffers (the runtime then stages the copy itself and
     the overlap is lost, not the result): plain numpy arrays, each kept alive until the next call returned."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture((3 << 20) + 2, seed=81, sigma=30.0, n_frames=700, amp=(150, 1800))
     want, wstats = oracle.decode(x, df18=True)
     d = dec_factory(df18=True, collect_stats=True)
@@ -397,7 +397,7 @@ def test_async_pushes_from_pageable_memory(oracle, dec_factory):
 def test_reset_with_launches_in_flight(oracle, dec_factory, capi):
     """adsb_reset right after adsb_push_async (scans and copies still running): the old
     stream's records are dropped and the next stream decodes cleanly on the same slots."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     xa, _ = G.dense_capture(3 << 20, seed=71, sigma=30.0, n_frames=700)
     xb, _ = G.dense_capture((1 << 20) + 4, seed=72, sigma=50.0, n_frames=300)
     want, wstats = oracle.decode(xb, df18=True)
@@ -415,7 +415,7 @@ def test_reset_with_launches_in_flight(oracle, dec_factory, capi):
 def test_streaming_frames_available_before_eof(oracle, dec_factory):
     """Frames come out as soon as the reference would have emitted them (each
     deqframe call), not only at adsb_finish."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.sparse_capture(1 << 20, 100, seed=1)
     want, _ = oracle.decode(x)
     d = dec_factory()
@@ -432,7 +432,7 @@ def test_streaming_frames_available_before_eof(oracle, dec_factory):
 def test_device_pushes_in_place_and_staged(oracle, dec_factory, torch_cuda, split):
     """Two device-resident pushes: an aligned split is scanned in place (seam through
     the staging buffer), an unaligned one is staged; both must equal the oracle."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(1 << 20, seed=9, sigma=45.0, n_frames=250)
     want, wstats = oracle.decode(x, df18=True)
     t = _dev(torch_cuda, x)
@@ -448,7 +448,7 @@ def test_device_pushes_in_place_and_staged(oracle, dec_factory, torch_cuda, spli
 def test_small_staging_buffer_many_pieces(oracle, dec_factory, torch_cuda):
     """A 64 Ki-sample staging buffer forces every push through many stage/scan/carry
     cycles (host pushes and unaligned device pushes alike)."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(700_001, seed=23, sigma=40.0, n_frames=150)
     want, wstats = oracle.decode(x, df18=True)
     d = dec_factory(df18=True, collect_stats=True, stage_samples=1 << 16)
@@ -469,7 +469,7 @@ def test_small_staging_buffer_many_pieces(oracle, dec_factory, torch_cuda):
 def test_tiny_and_threshold_lengths(oracle, dec_factory, n):
     """Empty / tiny inputs and lengths around the first deqframe call
     (40980 power samples = 81960 input samples, air.c:94)."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(n)
     fr = G.make_frame(17, rng)
     x = G.synth(n, [(1000, fr, 800.0, 1.0)] if n > 4000 else [], 10.0, n) if n else np.empty(0, np.uint16)
@@ -484,7 +484,7 @@ def test_tiny_and_threshold_lengths(oracle, dec_factory, n):
 def test_back_to_back_and_overlapping_frames(oracle, dec_factory):
     """Greedy skip (demod.c:128,134): a frame starting inside an accepted one is never
     reported; one starting right at its end is."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(2)
     frs = [G.make_frame(df, rng) for df in (17, 17, 11, 18, 17)]
     s0 = 30_000
@@ -524,7 +524,7 @@ def test_record_buffer_overflow_is_regrown(oracle, dec_factory):
     assert d.stats() == wstats
     assert d.profile()["relaunches"] >= 1
     # (b) the loose list overflows: all_candidates sends every record there
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     xb = _back_to_back(600, 43)
     wb, wbstats = oracle.decode(xb, df18=True)
     d = dec_factory(df18=True, all_candidates=True, debug_cand_cap=64)
@@ -574,10 +574,9 @@ def test_overflow_rounds_ranges_and_bit_positions(oracle, dec_factory, torch_cud
     256, 512 and 1 024 entries: tiles are redone in ranges of chunks sized from the failed round's count, single chunks
     that still do not fit go bit position by bit position, every round's candidates are staged in the tile's one list.
     Frames and the Try/Ok table must not change, with the list at its normal size and shrunk (candidates go loose)."""
-    import bench
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(77)
-    storm = np.tile(bench._frame_start_wave(), 1 + 300_000 // 260)[:300_000]
+    storm = np.tile(G._frame_start_wave(), 1 + 300_000 // 260)[:300_000]
     placed = [(10_000 + 2_400 * i, G.make_frame([17, 18, 17, 11][i % 4], rng), float(rng.uniform(500, 1500)), float(i))
               for i in range(250)]
     back = G.synth(10_000 + 2_400 * 250 + 30_000, placed, 6.0, 5).astype(np.float32) - 2048.0
@@ -609,7 +608,7 @@ def test_one_bit_repair_extension_vs_oracle(oracle, dec_factory):
     """cfg.fix_1bit (EXTENSION: the reference has no error correction; no
     reference parity exists) against the oracle's restatement of the same rule; with
     the flag off the very same capture decodes exactly like the reference."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(3)
     placed = []
     for i in range(120):
@@ -632,7 +631,7 @@ def test_one_bit_repair_extension_vs_oracle(oracle, dec_factory):
 
 
 def _back_to_back(n_frames, seed):
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(seed)
     placed = [(10_000 + 2_400 * i, G.make_frame([17, 18, 17, 11][i % 4], rng), float(rng.uniform(500, 1500)), float(i))
               for i in range(n_frames)]
@@ -669,7 +668,7 @@ def test_streaming_handoff_is_stable_over_many_launches(oracle, dec_factory, tor
     buffers are rewritten with different records at different positions every launch, so
     a marker or a granule left over from the previous launch is a wrong record here, not
     the same one -- and compares every record of every launch."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     caps = []
     for seed, n, nfr in ((55, 1 << 22, 1500), (56, (1 << 22) - 300_000, 900), (57, (1 << 21) + 4096, 1100)):
         x, _ = G.dense_capture(n, seed=seed, sigma=30.0, n_frames=nfr, amp=(150, 1800))
@@ -687,7 +686,7 @@ def test_reader_thread_consumes_the_handoff_stream(capi, oracle, dec_factory, to
     it (decoder.hip StreamReader).  Same frames, same statistics, on every path a launch's collect can take: rotating
     captures on one handle (stale bytes of the previous launch must not be taken), chunked pushes, a statistics run,
     tiles that flag "finish after completion" (staged-list overflow, loose list, relaunch)."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rd = dict(host_threads=2, debug_reader_min_tiles=1)   # also the small launches of this test go through the thread
     caps = []
     for seed, n, nfr in ((61, 1 << 22, 1500), (62, (1 << 22) - 300_000, 900), (63, (1 << 21) + 4096, 1100)):
@@ -744,7 +743,7 @@ def test_golden_without_streaming_handoff(capi, dec_factory, torch_cuda, name):
 
 @pytest.mark.parametrize("seed,sigma,nfr,df18", [(111, 8.0, 80, False), (112, 300.0, 60, True)])
 def test_seeded_without_streaming_handoff(oracle, dec_factory, seed, sigma, nfr, df18):
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture((3 << 20) + 4 * seed, seed=seed, sigma=sigma, n_frames=nfr, amp=(150, 1900))
     want, wstats = oracle.decode(x, df18=df18)
     d = dec_factory(df18=df18, collect_stats=True, debug_no_streaming=True)
@@ -767,7 +766,7 @@ def test_hip_equals_real_reference_chain(capi, oracle, dec_factory, seed, n, sig
     from /root/reference in the build container (the binary travels, the sources do not).
     No restatement in between: ts, pw, frame bytes, Try/Ok and all three output formats."""
     _ref_or_skip(oracle)
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(n, seed=seed, sigma=sigma, n_frames=nfr, amp=(150, 1900))
     rf, rstats = oracle.ref_decode(x, df18)
     d = dec_factory(df18=df18, collect_stats=True)
@@ -785,7 +784,7 @@ def test_cli_equals_real_reference_chain_on_a_file(capi, oracle, tmp_path):
     """The C host program on a file against the real chain on the same file: stdout bytes
     (AVR, AVR-MLAT) and the stderr Try/Ok table."""
     _ref_or_skip(oracle)
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture((40 << 20) + 2, seed=207, sigma=25.0, n_frames=4000, amp=(150, 1800))  # > 2 ring buffers
     path = str(tmp_path / "capture.u16")
     x.tofile(path)
@@ -822,7 +821,7 @@ def test_fuzz_30s(oracle):
 def test_shard_scan_and_host_gather(capi, oracle, dec_factory, torch_cuda):
     """SURVEY 8e with every shard on this one GPU: per-shard stateless scans over the
     planner's halo'd ranges + one host resolver == the sequential reference."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(1 << 21, seed=77, sigma=50.0, n_frames=500)
     want, wstats = oracle.decode(x, df18=True)
     t = _dev(torch_cuda, x)
@@ -842,7 +841,7 @@ def test_shard_scan_and_host_gather(capi, oracle, dec_factory, torch_cuda):
 def test_shard_candidates_equal_oracle_exhaustive(capi, oracle, dec_factory, torch_cuda):
     """Candidate-level parity (before resolution): every CRC-valid offset and every
     DF-gate pass the kernel reports equals the oracle's exhaustive evaluation."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(1 << 19, seed=78, sigma=200.0, n_frames=80)
     a = oracle.power(x)
     g_end = a.size - 1195
@@ -875,7 +874,7 @@ def test_resolved_shards_equal_the_sequential_decode(capi, oracle, dec_factory, 
     frames packed back to back so that every seam cuts through one; with a head window too small to decide such a seam
     the stitcher must say so (-3) rather than guess.  (The product's driver of these calls is adsb_multi_*: test_gpu_multi.py.)"""
     import shard_helpers
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     xa, _ = G.dense_capture((3 << 20) + 4, seed=91, sigma=40.0, n_frames=1500, amp=(200, 1800))
     xb = _back_to_back(1100, 45)
     for x in (xa, xb):
@@ -954,7 +953,7 @@ def test_round_trip_at_scale(dec_factory, torch_cuda):
     whole greedy replay), independent of any oracle."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import make_workload
+    from tools.gen_signal import make_workload
     torch = torch_cuda
     n = 64 << 20
     t, truth = make_workload(torch, n, n_frames=3000, seed=5, sigma=8.0)
@@ -1072,7 +1071,7 @@ def test_staggered_tile_sizes(oracle, dec_factory, torch_cuda):
     """Staggered tile sizes (the first tiles of a launch take K-3..K passes in turn, scan_kernel.h tile_passes)
     were an experiment that did not pay and are off; the tile geometry functions stay covered by forcing it on a
     small capture (cfg.debug_passes / cfg.debug_stagger) and comparing with the oracle, statistics included."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(1 << 22, seed=77, sigma=25.0, n_frames=1200, amp=(150, 1800))
     want, wstats = oracle.decode(x, df18=True)
     t = _dev(torch_cuda, x)
@@ -1092,7 +1091,7 @@ def test_two_streams_interleaved_on_one_gpu(oracle, dec_factory, torch_cuda):
     interleaved pushes of unequal sizes -- host pushes into one, device pushes into the
     other -- and each must equal its own stream decoded alone; then both are reset and
     swap captures."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     xa, _ = G.dense_capture(1 << 21, seed=201, sigma=20.0, n_frames=500, amp=(150, 1800))
     xb, _ = G.dense_capture((1 << 21) + 4096, seed=202, sigma=60.0, n_frames=300, amp=(200, 1500))
     wa, sa = oracle.decode(xa, df18=True)
@@ -1133,7 +1132,7 @@ def capi_frames(p, n):
 def test_take_is_drain_without_the_copy(oracle, dec_factory):
     """adsb_take hands out the queued frames in place; mixing it with adsb_drain and with
     further pushes must neither lose nor repeat a frame."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(1 << 21, seed=303, sigma=20.0, n_frames=400, amp=(150, 1800))
     want, _ = oracle.decode(x, df18=True)
     d = dec_factory(df18=True)

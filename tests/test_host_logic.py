@@ -108,7 +108,7 @@ def test_resolver_replays_reference_order_on_golden(capi, oracle, name):
 
 def test_resolver_streaming_equals_one_shot(capi, oracle):
     """Feeding candidates piecewise as the stream grows gives the same frames."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(1 << 19, seed=21, sigma=60.0, n_frames=200)
     a = oracle.power(x)
     g_end = a.size - 1195
@@ -166,7 +166,7 @@ def test_sharded_candidates_resolve_like_one_stream(capi, oracle):
     """SURVEY 8e on CPU: per-shard exhaustive scans (oracle standing in for the device,
     tests only) over the planner's halo'd sample ranges + one host resolver == the
     sequential reference."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(1 << 20, seed=33, sigma=45.0, n_frames=300)
     want, wstats = oracle.decode(x, df18=True)
     for n_shards in (2, 5):
@@ -247,7 +247,7 @@ def test_stitched_shards_equal_the_sequential_decode(capi, kind):
     adsb_stitch_shards: seam repair from the head candidates, per-shard ts offsets, end-of-file horizon.  Equal to the
     oracle's sequential decode (demod.c:86-143 + air.c:94-99) whatever the cut -- with frames packed back to back across
     every seam too -- or, when the head window is too small to decide a seam, an honest -3."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     from oracle import oracle as O
     O.build()
     rng = np.random.default_rng(5)

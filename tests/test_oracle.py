@@ -59,7 +59,7 @@ needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(G
 @needs_ref
 @pytest.mark.parametrize("seed,df18", [(1, False), (2, True), (3, True)])
 def test_oracle_vs_real_reference_on_signals(oracle, seed, df18):
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     x, _ = G.dense_capture(3 << 17, seed=seed, sigma=30.0 * seed, n_frames=150)
     a = oracle.power(x)
     rf, rstats = oracle.ref_demod(a, df18)
@@ -90,7 +90,7 @@ def test_oracle_demod_vs_real_reference_on_random_power(oracle):
     """Fuzzes getdf / getabyte / greedy skip / ts on synthetic POWER (no front end):
     exponential noise makes ~8 % of offsets pass the preamble test and planted
     frames (some overlapping, some straddling a deqframe call boundary) are accepted."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(5)
     a = rng.exponential(1000.0, 400_000).astype(np.float32)
     for k in range(150):
@@ -169,7 +169,7 @@ def test_front_end_fs4_carrier_gives_flat_power(oracle):
 
 def test_eof_tail_is_never_decoded(oracle):
     """a frame in the last ~41k power samples is not reported."""
-    from oracle import gen_signal as G
+    from tools import gen_signal as G
     rng = np.random.default_rng(9)
     fr = G.make_frame(17, rng)
     n = 1 << 18

@@ -23,7 +23,7 @@ They are skipped where oracle/_ref is absent (it is built only where
 import numpy as np
 import pytest
 
-from oracle import gen_signal as G
+from tools import gen_signal as G
 from oracle import oracle as O
 
 pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch  # noqa: E402
 
 from adsbdec_amd import capi, sharding  # noqa: E402
-from oracle import gen_signal as G  # noqa: E402
+from tools import gen_signal as G  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
