@@ -114,6 +114,8 @@ SYMBOLS = {
     "adsb_resolver_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "adsb_handoff_walk": (C.c_long, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "adsb_resolver_advance_stream": (C.c_long, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64,
+                                                C.c_uint64, C.c_uint64, C.c_int]),
     "adsb_scan_shard_resolved": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64, C.c_uint64,
                                            C.POINTER(ShardHead), C.POINTER(Frame), C.c_size_t, C.POINTER(Candidate),
                                            C.c_size_t]),

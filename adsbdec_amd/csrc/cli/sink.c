@@ -94,8 +94,10 @@ int sink_establish(sink *s)
             fprintf(stderr, "listening\n");
             fflush(stderr);
             got = accept(sock, NULL, NULL); /* ONE peer; the listening socket goes away with it (output.c:139-146) */
+            close(sock);                    /* ... BEFORE the word on stderr: whoever reads "connected" finds the port closed */
             if (got >= 0)
                 fprintf(stderr, "connected\n");
+            continue;
         }
         close(sock);
     }

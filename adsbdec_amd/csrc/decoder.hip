@@ -525,12 +525,15 @@ void deliver(adsb_decoder *d, const ScanSlot &s, const uint32_t *recs, const uin
             const uint32_t *r = recs + (size_t)order[i] * words + off;
             adsb_candidate c;
             std::memset(&c, 0, sizeof c);
-            c.g = s.args.g_begin + r[0];
-            c.pw = r[1];
             std::memcpy(c.frame, &r[2], 14);
             c.len = (uint8_t)((r[5] >> 16) & 0xFF);
             c.reserved = (uint8_t)((r[5] >> 24) & 1u);
-            d->sink.cands->push_back(c);
+            // (a stream record may stand for the same frame at up to three consecutive offsets: scan_kernel_format.h)
+            for (uint32_t k = 0, nk = words == adsb::kGranuleWords ? adsb::rec_copies(r) : 1u; k < nk; k++) {
+                c.g = s.args.g_begin + r[0] + k;
+                c.pw = k ? r[5 + k] : r[1];
+                d->sink.cands->push_back(c);
+            }
         }
         for (size_t i = 0; i < nt; i++)
             d->sink.tries->push_back((((uint64_t)(tries[i] >> 2) + s.args.g_begin) << 2) | (tries[i] & 3u));
@@ -1013,7 +1016,15 @@ int slot_collect(adsb_decoder *d)
                 const uint32_t *lw = li < lj ? d->gather.data() + (size_t)loose_order[li] * adsb::kCandWords : nullptr;
                 const uint32_t *sw = si < ns ? sr + (size_t)si * 2 * adsb::kGranuleWords : nullptr;
                 if (sw && (!lw || sw[0] <= lw[0])) {
-                    merged.insert(merged.end(), sw, sw + adsb::kCandWords); // {g_rel, pw, w0, w1}{w2, w3, ..}: the first six words
+                    // {g_rel, pw, w0, w1}{w2, w3, pw', pw''}: the first six words, once per offset the record stands for (a run
+                    // of copies is never interleaved with a loose record: the offsets are consecutive and every offset yields
+                    // at most one candidate -- but a loose one may lie INSIDE the run only if it is one of its offsets, which
+                    // the tile would have staged with the others; so the run goes in whole)
+                    for (uint32_t k = 0, nk = adsb::rec_copies(sw); k < nk; k++) {
+                        const uint32_t one[adsb::kCandWords] = {sw[0] + k, k ? sw[5 + k] : sw[1], sw[2], sw[3], sw[4],
+                                                                 sw[5] & ~(3u << adsb::kRecCopiesShift)};
+                        merged.insert(merged.end(), one, one + adsb::kCandWords);
+                    }
                     si++;
                 } else {
                     merged.insert(merged.end(), lw, lw + adsb::kCandWords);

@@ -226,4 +226,46 @@ long adsb_handoff_walk(const void *stream, size_t granules, uint32_t n_tiles, ui
     return (long)cur.deliverable();
 }
 
+// The streaming collect's hand-over to the resolver, over an image of a stream: every tile must be in (adsb_handoff_walk's
+// rules); the resolver then walks the tiles' records where they lie -- the same Resolver::advance_tiles the decoder calls --
+// so that the RECORD format (a record that stands for the same frame at up to three consecutive offsets) is tested without
+// a device.  Returns the tiles handed on (n_tiles), or -1.
+long adsb_resolver_advance_stream(adsb_resolver *r, const void *stream, size_t granules, uint32_t n_tiles, uint32_t gen,
+                                  uint64_t g_base, uint64_t power_samples, uint64_t g_complete, int with_head)
+{
+    if (!r || !stream || granules > 0xFFFFFFFFull || n_tiles == 0)
+        return -1;
+    const size_t bytes = granules * adsb::kGranuleWords * sizeof(uint32_t);
+    void *copy = nullptr;
+    if (posix_memalign(&copy, 64, bytes ? bytes : 64) != 0)
+        return -1;
+    std::memcpy(copy, stream, bytes);
+    std::vector<uint32_t> ts(n_tiles, 0u), tc(n_tiles, ~0u);
+    adsb::HandJob job;
+    job.hand = static_cast<const uint32_t *>(copy);
+    job.ntiles = n_tiles;
+    job.gen = gen;
+    job.cap = (uint32_t)granules;
+    HandCursor cur(job, ts.data(), tc.data());
+    long rc = (long)n_tiles;
+    while (cur.frontier < n_tiles)
+        if (cur.pos >= cur.cap || !cur.wait_tile() || cur.take() != 0) {
+            rc = -1;
+            break;
+        }
+    if (rc >= 0 && cur.hold != ~0u)
+        rc = -1;
+    if (rc >= 0) {
+        try {
+            if (with_head)
+                r->r.capture_head_tiles(job.hand, ts.data(), tc.data(), 0, n_tiles, g_base);
+            r->r.advance_tiles(job.hand, ts.data(), tc.data(), 0, n_tiles, 0, g_base, power_samples, g_complete);
+        } catch (const std::exception &) {
+            rc = -1;
+        }
+    }
+    free(copy);
+    return rc;
+}
+
 } // extern "C"

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/adsbdec_amd.h"
+#include "scan_kernel_format.h"
 
 namespace adsb {
 
@@ -180,9 +181,11 @@ public:
         for (uint32_t u = t0; u < t1; u++)
             for (uint32_t i = 0; i < counts[u]; i++) {
                 const uint32_t *r = stream + ((size_t)starts[u] + 2 * (size_t)i) * 4;
-                if (g_base + r[0] >= head_end_)
-                    return;
-                push_head(r, g_base);
+                for (uint32_t k = 0, nk = rec_copies(r); k < nk; k++) {
+                    if (g_base + r[0] + k >= head_end_)
+                        return;
+                    push_head(r, g_base, k);
+                }
             }
     }
     bool head_wanted(uint64_t g_from) const { return head_ && g_from < head_end_; }
@@ -315,12 +318,12 @@ private:
         }
     }
 
-    void push_head(const uint32_t *r, uint64_t g_base)
+    void push_head(const uint32_t *r, uint64_t g_base, uint32_t copy = 0)
     {
         head_->emplace_back();
         adsb_candidate &c = head_->back();
-        c.g = g_base + r[0];
-        c.pw = r[1];
+        c.g = g_base + r[0] + copy;
+        c.pw = copy ? r[5 + copy] : r[1];
         std::memcpy(c.frame, &r[2], 14);
         c.len = (uint8_t)((r[5] >> 16) & 0xFF);
         c.reserved = (uint8_t)((r[5] >> 24) & 1u);
@@ -371,26 +374,53 @@ private:
         // or: tile ranges of a granule stream
         const uint32_t *starts = nullptr, *counts = nullptr;
         uint32_t u = 0, u_end = 0, left = 0;
+        // a stream record stands for `copies` candidates at consecutive offsets (scan_kernel_format.h); `sub` is the one `cur`
+        // means at the moment.  Index-list records (6 words) are always single.
+        uint32_t sub = 0, copies = 1;
 
+        uint64_t g() const { return g_base + cur[0] + sub; }
+        uint32_t pw() const { return sub ? cur[5 + sub] : cur[1]; }
         void seek_tile(uint32_t t)
         {
+            sub = 0;
             for (u = t; u < u_end; u++)
                 if (counts[u]) {
                     left = counts[u];
                     cur = recs + (size_t)starts[u] * 4;
+                    copies = rec_copies(cur);
                     return;
                 }
             cur = nullptr;
         }
-        void next()
+        void next_record()
         {
+            sub = 0;
             if (order) {
                 pos++;
                 cur = pos < n ? recs + (size_t)order[pos] * words : nullptr;
             } else if (--left) {
                 cur += 8; // two granules per record
+                copies = rec_copies(cur);
             } else {
                 seek_tile(u + 1);
+            }
+        }
+        void next()
+        {
+            if (++sub >= copies)
+                next_record();
+        }
+        // the first candidate at or beyond idx
+        void skip_below(uint64_t idx)
+        {
+            while (cur) {
+                const uint64_t g0 = g_base + cur[0];
+                if (g0 + copies > idx) { // the record's last copy is at g0 + copies - 1
+                    if (g0 + sub < idx)
+                        sub = (uint32_t)(idx - g0);
+                    return;
+                }
+                next_record();
             }
         }
     };
@@ -401,8 +431,8 @@ private:
             const uint32_t *r = batch_.cur;
             cands_.emplace_back();
             adsb_candidate &c = cands_.back();
-            c.g = batch_.g_base + r[0];
-            c.pw = r[1];
+            c.g = batch_.g();
+            c.pw = batch_.pw();
             std::memcpy(c.frame, &r[2], 14);
             c.len = (uint8_t)((r[5] >> 16) & 0xFF);
             c.reserved = (uint8_t)((r[5] >> 24) & 1u);
@@ -423,10 +453,9 @@ private:
             if (from_queue) {
                 g = cands_[chead_].g;
             } else {
-                while (batch_.cur && batch_.g_base + batch_.cur[0] < idx)
-                    batch_.next();
+                batch_.skip_below(idx);
                 if (batch_.cur)
-                    g = batch_.g_base + batch_.cur[0];
+                    g = batch_.g();
             }
             if (g >= limit) { // also: no candidate left
                 count_tries(idx, limit - 1);
@@ -446,8 +475,8 @@ private:
                 f.reserved = c.reserved;
             } else { // straight from the device record {g_rel, pw, frame[14] | len << 16 | flags << 24}
                 const uint32_t *r = batch_.cur;
+                f.pw = batch_.pw();
                 batch_.next();
-                f.pw = r[1];
                 std::memcpy(f.frame, &r[2], 14);
                 f.len = (uint8_t)((r[5] >> 16) & 0xFF);
                 f.reserved = (uint8_t)((r[5] >> 24) & 1u);

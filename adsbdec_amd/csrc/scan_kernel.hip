@@ -811,46 +811,53 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                 if (tid == 0)
                     *tile_n = (uint32_t)__popcll(kept);
             }
-        } else if (tid < ncl) {
-            const int gi = (int)(ri[0] - tile_rel); // tile-local offset
-            bool drop = false;
-            if (complete) {
-                int pg = -1, pspan = 0;
-                for (int j = 0; j < ncl; j++) {
-                    const int gj = (int)(cl_rec[j * kCandWords] - tile_rel);
-                    if (gj < gi && gj > pg) {
-                        pg = gj;
-                        pspan = (cl_rec[j * kCandWords + 1] & 0xFFu) == 0 ? 640 : 1200; // staged word 1 = code
+        } else {
+            // More than a wave of entries (a tile of 48 k offsets full of 112-bit frames back to back stages ~150: BASELINE
+            // configs[2]): the same all-pairs rule, the keys and frame ends laid out as two arrays in the survivor queue's LDS
+            // (free behind the rounds) and read four to a broadcast load -- 2 x ncl / 4 LDS reads per entry and pass.  (Until
+            // round 5 this path read the staged records themselves, 2 dependent words per pair: 4 x ncl reads per entry and
+            // three passes -- ~15 us of such a tile's life.)
+            uint32_t *fk = queue, *fe = queue + kClistCap, *kkv = queue + 2 * kClistCap;
+            const bool has = tid < ncl;
+            const int gi = has ? (int)(ri[0] - tile_rel) : 0x3fffffff; // tile-local offset
+            const bool lng = has && (ri[1] & 0xFFu) != 0;
+            const int key = 2 * gi + (lng ? 1 : 0), g2 = 2 * gi;
+            fk[tid] = (uint32_t)key;                                          // (NT == kClistCap: one slot per thread)
+            fe[tid] = (uint32_t)(has ? gi + (lng ? 1200 : 640) : 0x7fffffff); // where the candidate's frame ends
+            __syncthreads();
+            const int n4 = (ncl + 3) & ~3;
+            int pk = -1, emax = -1;
+            if (has) {
+                for (int j = 0; j < n4; j += 4) {
+                    const u32x4 k4 = *reinterpret_cast<const u32x4 *>(fk + j), e4 = *reinterpret_cast<const u32x4 *>(fe + j);
+                    int kj[4] = {(int)k4.x, (int)k4.y, (int)k4.z, (int)k4.w}, ej[4] = {(int)e4.x, (int)e4.y, (int)e4.z, (int)e4.w};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        kj[u] = kj[u] < g2 ? kj[u] : -1;
+                        ej[u] = ej[u] <= gi ? ej[u] : -1;
                     }
-                }
-                if (pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan) {
-                    bool lands = false;
-                    for (int j = 0; j < ncl; j++) {
-                        const int ej = (int)(cl_rec[j * kCandWords] - tile_rel) +
-                                       ((cl_rec[j * kCandWords + 1] & 0xFFu) == 0 ? 640 : 1200);
-                        lands |= (ej > pg && ej <= gi);
-                    }
-                    drop = !lands;
+                    pk = max(max(pk, kj[0]), max(max(kj[1], kj[2]), kj[3]));
+                    emax = max(max(emax, ej[0]), max(max(ej[1], ej[2]), ej[3]));
                 }
             }
-            keep = !drop;
-            // the tile reserves one marker granule plus two per kept record of the hand-off
-            // stream; the records follow the marker in ascending g (rank = kept entries
-            // with a smaller offset), so that the host can take the range as it is
-            if (keep) {
-                atomicAdd(tile_n, 1u);
-                cl_rec[tid * kCandWords + 1] |= 0x10000u; // staged word 1, bit 16: kept
-            }
+            const int pg = pk >> 1, pspan = (pk & 1) ? 1200 : 640; // pk == -1: pg == -1, nothing precedes
+            const bool drop = complete && pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan && !(emax > pg);
+            keep = has && !drop;
+            kkv[tid] = keep ? (uint32_t)key : 0x7fffffffu; // the entries that stay, as keys; the others never count
+            const unsigned long long kept = __ballot(keep);
+            if ((tid & 63) == 0 && kept)
+                atomicAdd(tile_n, (uint32_t)__popcll(kept));
+            __syncthreads();
+            if (keep)
+                for (int j = 0; j < n4; j += 4) {
+                    const u32x4 k4 = *reinterpret_cast<const u32x4 *>(kkv + j);
+                    rank += (uint32_t)((int)k4.x < g2) + (uint32_t)((int)k4.y < g2) + (uint32_t)((int)k4.z < g2) + (uint32_t)((int)k4.w < g2);
+                }
         }
         __syncthreads();
         if (reserves) { // the result is not looked at before this thread's own record is finished
             res_need = stream_granules(*tile_n);
             res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
-        }
-        if (keep && !one_wave) {
-            const uint32_t gi = ri[0];
-            for (int j = 0; j < ncl; j++)
-                rank += ((cl_rec[j * kCandWords + 1] >> 16) & 1u) & (uint32_t)(cl_rec[j * kCandWords] < gi);
         }
         // finish the record: bytes in order, pw (demod.c:127,133).  The loads of pw_at
         // run while thread 0's reservation above is still on its way back.
@@ -878,31 +885,86 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
 #pragma unroll
                 for (int k = 0; k < 6; k++)
                     o[k] = fin[k];
-                atomicXor(&tile_chk[0], fin[0] ^ fin[4]); // word-wise XOR of its two granules
-                atomicXor(&tile_chk[1], fin[1] ^ fin[5]);
-                atomicXor(&tile_chk[2], fin[2]);
-                atomicXor(&tile_chk[3], fin[3]);
-                atomicAdd(tile_sum, record_term(rank, fin[0], fin[1]));
             } else {
                 const uint32_t wds[4] = {fin[2], fin[3], fin[4], fin[5]};
                 emit_loose(fin[0], fin[1], wds);
             }
         }
         if (to_stream) {
+            // One record per RUN OF COPIES.  A frame decodes at two or three neighbouring offsets (the half-sample shifts); an
+            // isolated frame's extra copies went with the filter above, but where frames stand back to back every copy is
+            // reachable -- which one the scan lands on is decided by where the previous frame ended (demod.c:125-141) -- and a
+            // full channel would cost three records per frame (310 k per 256 Mi samples at BASELINE configs[2]'s density, which
+            // the host then has to read, check and walk: 3 x the kernel's time).  Records r-1 and r are LINKED when r's offset is
+            // the next one and its four frame words (bytes, length, repair flag) are the same; a chain of links is cut into
+            // records of up to three offsets: the first one's {g_rel, pw}, the others' pw in the second granule's spare words,
+            // their number in flags bits 1..2 (scan_kernel_format.h).  The host expands them where the greedy rule needs them.
+            __syncthreads();
+            const uint32_t nk = *tile_n; // ranked records in cl_rec
+            uint32_t *ext = queue, *wl = queue + kQueueCap - 4; // the copies' pw (two per record); leaders per wave
+            bool lead = false;
+            uint32_t out[8];
+            if ((uint32_t)tid < nk) {
+                auto linked = [&](uint32_t a) { // is record a the previous record's frame, one offset on?
+                    if (a == 0 || a >= nk)
+                        return false;
+                    const uint32_t *p = cl_rec + (a - 1) * kCandWords, *q = p + kCandWords;
+                    return q[0] == p[0] + 1u && q[2] == p[2] && q[3] == p[3] && q[4] == p[4] && q[5] == p[5];
+                };
+                uint32_t back = 0; // links behind this record
+                while (linked((uint32_t)tid - back))
+                    back++;
+                lead = back % 3u == 0;
+                if (lead) {
+                    const uint32_t *r = cl_rec + tid * kCandWords;
+                    const bool c1 = linked((uint32_t)tid + 1), c2 = c1 && linked((uint32_t)tid + 2);
+#pragma unroll
+                    for (int k = 0; k < 6; k++)
+                        out[k] = r[k];
+                    out[5] |= ((c1 ? 1u : 0u) + (c2 ? 1u : 0u)) << kRecCopiesShift;
+                    out[6] = c1 ? r[kCandWords + 1] : 0u;
+                    out[7] = c2 ? r[2 * kCandWords + 1] : 0u;
+                }
+            }
+            const unsigned long long leaders = __ballot(lead);
+            if ((tid & 63) == 0)
+                wl[tid >> 6] = (uint32_t)__popcll(leaders);
+            __syncthreads(); // every record has been read: the leaders' records go back into the list, compacted
+            uint32_t nrec = 0, r2 = (uint32_t)__popcll(leaders & ((1ull << (tid & 63)) - 1ull));
+#pragma unroll
+            for (int w = 0; w < kWaves; w++) {
+                r2 += w < (tid >> 6) ? wl[w] : 0u;
+                nrec += wl[w];
+            }
+            if (lead) {
+                uint32_t *o = cl_rec + r2 * kCandWords;
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+                    o[k] = out[k];
+                ext[2 * r2] = out[6];
+                ext[2 * r2 + 1] = out[7];
+                atomicXor(&tile_chk[0], out[0] ^ out[4]); // word-wise XOR of its two granules
+                atomicXor(&tile_chk[1], out[1] ^ out[5]);
+                atomicXor(&tile_chk[2], out[2] ^ out[6]);
+                atomicXor(&tile_chk[3], out[3] ^ out[7]);
+                atomicAdd(tile_sum, record_term(r2, out[0], out[1]));
+            }
+            if (tid == 0)
+                *tile_n = nrec; // (the marker's count; the lines the tile reserved stay what they were)
             // the tile's range {marker, records} leaves as one store of adjacent lanes
             __syncthreads();
-            const uint32_t nk = *tile_n;
-            for (uint32_t L = tid; L < 1u + 2u * nk; L += NT) {
+            for (uint32_t L = tid; L < 1u + 2u * nrec; L += NT) {
                 u32x4 gv;
                 if (L == 0) {
-                    const uint32_t nf = nk | ((*tile_over & 1u) ? kMarkOver : 0u) | ((*tile_over & 2u) ? kMarkTries : 0u) | (*tile_lines << kMarkLinesShift);
+                    const uint32_t nf = nrec | ((*tile_over & 1u) ? kMarkOver : 0u) | ((*tile_over & 2u) ? kMarkTries : 0u) | (*tile_lines << kMarkLinesShift);
                     uint32_t lo, hi;
                     marker_check(tile, nf, args.gen, tile_chk[0], tile_chk[1], tile_chk[2], tile_chk[3], *tile_sum, lo, hi);
                     gv = u32x4{tile, nf, lo, hi};
                     *tile_res = 2; // marker written
                 } else {
-                    const uint32_t *r = cl_rec + ((L - 1u) >> 1) * kCandWords;
-                    gv = ((L - 1u) & 1u) ? u32x4{r[4], r[5], 0u, 0u} : u32x4{r[0], r[1], r[2], r[3]};
+                    const uint32_t ri2 = (L - 1u) >> 1;
+                    const uint32_t *r = cl_rec + ri2 * kCandWords;
+                    gv = ((L - 1u) & 1u) ? u32x4{r[4], r[5], ext[2 * ri2], ext[2 * ri2 + 1]} : u32x4{r[0], r[1], r[2], r[3]};
                 }
                 store_granule_through(args.hand, *tile_base + L, gv);
             }

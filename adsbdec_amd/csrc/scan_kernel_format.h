@@ -28,6 +28,15 @@ ADSB_HD constexpr uint32_t marker_granules(uint32_t nf) { return (nf >> kMarkLin
 // -- every later device write to such a line has to pull it out of the CPU's cache first.
 ADSB_HD constexpr uint32_t stream_granules(uint32_t n) { return (1u + 2u * n + 3u) & ~3u; }
 
+// A record of the stream is two granules {g_rel, pw, w0, w1}{w2, w3 | len << 16 | flags << 24, pw', pw''}.  flags bit 0: repaired by
+// the 1-bit extension.  flags bits 1..2: the record stands for 1 + that many candidates -- the SAME frame bytes decoded at
+// the consecutive offsets g_rel, g_rel + 1 (pw'), g_rel + 2 (pw''): the half-sample shifted copies of one frame, which the
+// tile cannot prove unreachable when frames stand back to back (demod.c:125-141 decides which copy the scan lands on) and
+// which would otherwise cost three records per frame on a full channel.  Records of the loose list (6 words) never carry copies.
+constexpr int kRecCopiesShift = 25;
+ADSB_HD inline uint32_t rec_copies(const uint32_t *r) { return 1u + ((r[5] >> kRecCopiesShift) & 3u); }
+ADSB_HD inline uint32_t rec_pw(const uint32_t *r, uint32_t k) { return k ? r[5 + k] : r[1]; }
+
 // Check words of a tile marker (device writes them, host checks them).  Two independent summaries of the records behind
 // the marker go in:
 //   a0..a3  the XOR, word by word, of the 2n record granules;

@@ -266,6 +266,17 @@ int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out);
  * No GPU is needed: this is how the host logic is tested. */
 long adsb_handoff_walk(const void *stream, size_t granules, uint32_t n_tiles, uint32_t gen,
                        uint32_t *tile_start, uint32_t *tile_count, int *status);
+/* A record of that stream is two granules {g_rel, pw, w0, w1}{w2, w3 | len << 16 | flags << 24, pw', pw''}: the frame's
+ * 14 bytes in w0..w3, flags bit 0 = repaired by the 1-bit extension, flags bits 1..2 = the record stands for 1 + that many
+ * candidates -- the same bytes decoded at the consecutive offsets g_rel, g_rel + 1 (power pw'), g_rel + 2 (pw''): the
+ * half-sample shifted copies of one frame, which stay reachable when frames stand back to back (demod.c:125-141 decides
+ * which copy the scan lands on) and would otherwise cost three records per frame on a full channel.
+ * adsb_resolver_advance_stream: the streaming collect's hand-over to the resolver over such an image -- every tile must be in
+ * (the rules above); the resolver (adsb_resolver_*, in stream or chain mode) then walks the tiles' records where they lie
+ * (offsets = g_base + g_rel), like adsb_resolver_feed + adsb_resolver_advance(power_samples, g_complete) would on the
+ * expanded candidates; with_head != 0 also copies the head candidates of a chain (adsb_resolver_head).  Returns n_tiles or -1. */
+long adsb_resolver_advance_stream(adsb_resolver *r, const void *stream, size_t granules, uint32_t n_tiles, uint32_t gen,
+                                  uint64_t g_base, uint64_t power_samples, uint64_t g_complete, int with_head);
 
 /* ---- shard planning -------------------------------------------
  * Splits the offsets [0, power_samples-ADSB_WINDOW] of one stream over n_shards

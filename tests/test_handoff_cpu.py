@@ -220,3 +220,100 @@ def test_stale_records_whose_differences_cancel_in_the_xor_do_not_validate(capi)
         for r in (1, 3):
             img.w[4 * (p + 2 * r) + 1] ^= d
         assert walk(capi, img, 1)[:2] == (1, 0)
+
+
+# ---- records that stand for a run of copies (scan_kernel_format.h kRecCopiesShift) ----------------------------------------
+def _frame_words(frame: bytes):
+    """w0..w3 of a record: the 14 bytes, the length in bits 16..23 of w3."""
+    b = frame + bytes(14 - len(frame))
+    w = [int.from_bytes(b[4 * k:4 * k + 4], "little") for k in range(3)] + [int.from_bytes(b[12:14], "little")]
+    w[3] |= len(frame) << 16
+    return w
+
+
+def _stream_of(tiles, gen, collapse, tile_offsets=48_160):
+    """tiles: per tile a list of candidates (g_rel, pw, frame) in ascending g_rel.  collapse: runs of the same frame at
+    consecutive offsets become one record of up to three (what the kernel writes since round 5); else one record each."""
+    img = Image(16 + sum(4 + 2 * len(t) for t in tiles) * 2, gen)
+    for ti, cands in enumerate(tiles):
+        recs, i = [], 0
+        while i < len(cands):
+            g, pw, fr = cands[i]
+            run = 1
+            if collapse:
+                while run < 3 and i + run < len(cands) and cands[i + run][0] == g + run and cands[i + run][2] == fr:
+                    run += 1
+            w = _frame_words(fr)
+            pws = [cands[i + k][1] for k in range(run)] + [0, 0]
+            recs.append([g, pw, w[0], w[1]])
+            recs.append([w[2], w[3] | ((run - 1) << 25), pws[1] if run > 1 else 0, pws[2] if run > 2 else 0])
+            i += run
+        n = len(recs) // 2
+        nf = n | (((len(cands) * 2 + 1 + 3) // 4) << LINES_SHIFT)          # the tile reserved for its candidates, kept fewer records
+        lo, hi = check_words(ti, nf, gen, recs)
+        p = img.pos
+        img.w[4 * p:4 * p + 4] = (ti, nf, lo, hi)
+        if n:
+            img.w[4 * (p + 1):4 * (p + 1 + 2 * n)] = np.asarray(recs, np.uint32).reshape(-1)
+        img.pos += max(((len(cands) * 2 + 1 + 3) // 4) * 4, stream_granules(n))
+        img.where[ti] = (p + 1, n)
+    return img
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_records_that_stand_for_copies_resolve_like_their_expansion(capi, seed):
+    """A full channel: 112-bit frames back to back, every one decoded at 1-4 neighbouring offsets (which copy the greedy scan
+    lands on depends on where the previous frame ended: demod.c:125-141), some short frames and gaps in between.  The stream
+    with one record per run of copies must resolve to the frames -- g, ts, pw, bytes -- of the stream with one record per
+    candidate, and of the plain candidate list through adsb_resolver_feed; head candidates of a chain likewise."""
+    rng = np.random.default_rng(100 + seed)
+    tile_offsets, n_tiles = 48_160, 5
+    cands, g = [], int(rng.integers(0, 300))
+    while g < n_tiles * tile_offsets - 1300:
+        long = rng.random() < 0.85
+        fr = bytes(rng.integers(0, 256, 14 if long else 7, dtype=np.uint8).tolist())
+        ncopy = int(rng.integers(1, 5))
+        first = g - int(rng.integers(0, 2))
+        for k in range(ncopy):
+            if rng.random() < 0.9 and (not cands or first + k > cands[-1][0]):
+                cands.append((first + k, int(rng.integers(1, 1 << 20)), fr))
+        g += (1200 if long else 640) + (0 if rng.random() < 0.8 else int(rng.integers(1, 3000)))
+    tiles = [[(c[0] - t * tile_offsets, c[1], c[2]) for c in cands if t * tile_offsets <= c[0] < (t + 1) * tile_offsets]
+             for t in range(n_tiles)]
+    # (tile-relative g_rel here: the records carry launch-relative offsets, so give every tile its base back)
+    tiles = [[(g + t * tile_offsets, pw, fr) for g, pw, fr in tl] for t, tl in enumerate(tiles)]
+    L = capi.load()
+    g_base, total = 1_000_000 * 28, 4 * (n_tiles * tile_offsets + 1_000_000 * 28)
+    m = 2 * (total // 4)
+    results, heads = [], []
+    for mode in ("list", "expanded", "collapsed"):
+        for chain in (False, True):
+            r = capi.Resolver()
+            if chain:
+                assert L.adsb_resolver_start_chain(r._h, g_base, g_base + 16_384) == 0
+            if mode == "list":
+                r.feed([(g_base + g, pw, fr) for g, pw, fr in cands])
+                r.advance(m, g_base + n_tiles * tile_offsets)
+            else:
+                img = _stream_of(tiles, 0xABCD + seed, mode == "collapsed")
+                buf = np.ascontiguousarray(img.w)
+                assert L.adsb_resolver_advance_stream(r._h, buf.ctypes.data, buf.size // 4, n_tiles, img.gen, g_base, m,
+                                                      g_base + n_tiles * tile_offsets, 1) == n_tiles
+            got = [(f["g"], f["ts"], f["pw"], bytes(f["frame"])) for f in r.drain()]
+            results.append((mode, chain, got))
+            if chain:
+                hb = (capi.Candidate * 4096)()
+                nh = L.adsb_resolver_head(r._h, hb, 4096)
+                heads.append([(hb[i].g, hb[i].pw, bytes(hb[i].frame[:hb[i].len])) for i in range(nh)])
+            r.close()
+    n_exp = sum(n for _, n in _stream_of(tiles, 1, False).where.values())
+    n_col = sum(n for _, n in _stream_of(tiles, 1, True).where.values())
+    assert n_exp == len(cands) and n_col < 0.6 * n_exp          # most frames have two or more copies
+    ref = {False: results[0][2], True: results[1][2]}
+    assert len(ref[False]) > 100
+    for mode, chain, got in results:
+        assert got == ref[chain], (mode, chain)
+    assert heads[0] == heads[1] == heads[2] and len(heads[0]) > 5
+    # the greedy rule really does land on later copies here: not every accepted frame is a run's first offset
+    firsts = {c[0] for i, c in enumerate(cands) if i == 0 or not (cands[i - 1][0] == c[0] - 1 and cands[i - 1][2] == c[2])}
+    assert any(g - g_base not in firsts for g, *_ in ref[False])

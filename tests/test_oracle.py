@@ -31,7 +31,7 @@ def test_crc_known_answers(oracle):
 
 
 def test_crc_matches_bitwise_definition(oracle):
-    from oracle.gen_signal import crc24
+    from tools.gen_signal import crc24
     rng = np.random.default_rng(0)
     for n in (7, 14):
         for _ in range(200):
