@@ -62,7 +62,7 @@ class Config(C.Structure):
                 ("debug_clist_cap", C.c_int32), ("push_overlap", C.c_int32),
                 ("host_threads", C.c_int32), ("debug_no_streaming", C.c_int32), ("debug_frames_cap", C.c_int32),
                 ("debug_reader_min_tiles", C.c_int32), ("debug_shard_head", C.c_int32), ("debug_passes", C.c_int32),
-                ("debug_stagger", C.c_int32)]
+                ("debug_stagger", C.c_int32), ("wait_timeout_s", C.c_int32)]
 
 
 class MultiInfo(C.Structure):
@@ -183,7 +183,12 @@ def load():
                             "(there is no fallback implementation)")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                if os.environ.get("ADSB_LIB_PATH"):  # an A/B run against an older build of the library: it has what it has
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L
@@ -217,7 +222,8 @@ def make_config(df18: bool = False, device: int = -1, collect_stats: bool = Fals
                 debug_queue_cap: int = 0, all_candidates: bool = False, fix_1bit: bool = False,
                 debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0, push_overlap: bool = False,
                 host_threads: int = 0, debug_no_streaming: bool = False, debug_frames_cap: int = 0,
-                debug_reader_min_tiles: int = 0, debug_shard_head: int = 0, debug_passes: int = 0, debug_stagger: int = 0):
+                debug_reader_min_tiles: int = 0, debug_shard_head: int = 0, debug_passes: int = 0, debug_stagger: int = 0,
+                wait_timeout_s: int = 0):
     """adsb_config from keywords (adsb_config_default + the members named)."""
     cfg = Config()
     load().adsb_config_init(C.byref(cfg), C.sizeof(cfg))
@@ -241,6 +247,8 @@ def make_config(df18: bool = False, device: int = -1, collect_stats: bool = Fals
     cfg.debug_shard_head = debug_shard_head
     cfg.debug_passes = debug_passes
     cfg.debug_stagger = debug_stagger
+    if cfg.struct_size >= Config.wait_timeout_s.offset + 4:   # (an older library in an A/B run fills, and accepts, a shorter struct)
+        cfg.wait_timeout_s = wait_timeout_s
     return cfg
 
 

@@ -39,6 +39,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include <emmintrin.h>
 #include <pthread.h>
 #include <sched.h>
@@ -259,6 +261,55 @@ struct adsb_decoder {
 
 namespace {
 
+// Every wait for the device inside the library has a deadline (cfg.wait_timeout_s, default 120 s): a kernel or copy that never
+// completes -- a wedged queue, a device that has gone away -- ends the call with -1 and a message that says what was waited
+// for, instead of a host thread that never returns (the reference's counterpart is a read() that cannot hang).  Polls with
+// pauses for the first ~200 us (the usual case: the work is microseconds from its end), then sleeps between looks.
+template <class Query>
+int wait_until_done(adsb_decoder *d, Query &&query, const char *what)
+{
+    using clk = std::chrono::steady_clock;
+    hipError_t q;
+    for (int spin = 0; spin < 4096; spin++) {
+        if ((q = query()) != hipErrorNotReady)
+            goto out;
+        __builtin_ia32_pause();
+    }
+    {
+        const auto t0 = clk::now();
+        const auto limit = std::chrono::seconds(d->cfg.wait_timeout_s > 0 ? d->cfg.wait_timeout_s : 120);
+        unsigned nap_us = 20;
+        for (;;) {
+            for (int spin = 0; spin < 256; spin++) {
+                if ((q = query()) != hipErrorNotReady)
+                    goto out;
+                __builtin_ia32_pause();
+            }
+            if (clk::now() - t0 > limit)
+                return d->fail("the device did not finish %s within %lld s (wedged queue or lost device?): giving up", what,
+                               (long long)limit.count());
+            if (clk::now() - t0 > std::chrono::milliseconds(2)) { // long waits (copies of GiBs, first-touch page faults) sleep between looks
+                usleep(nap_us);
+                nap_us = std::min(nap_us * 2, 200u);
+            }
+        }
+    }
+out:
+    if (q != hipSuccess)
+        return d->fail("waiting for %s failed: %s", what, hipGetErrorString(q));
+    return 0;
+}
+inline int wait_event(adsb_decoder *d, hipEvent_t ev, const char *what)
+{
+    return wait_until_done(d, [ev] { return hipEventQuery(ev); }, what);
+}
+inline int wait_stream(adsb_decoder *d, hipStream_t st, const char *what)
+{
+    return wait_until_done(d, [st] { return hipStreamQuery(st); }, what);
+}
+#define WAIT_EVENT(d, ev, what)   do { if (wait_event((d), (ev), (what))) return -1; } while (0)
+#define WAIT_STREAM(d, st, what)  do { if (wait_stream((d), (st), (what))) return -1; } while (0)
+
 inline uint64_t power_samples_produced(uint64_t n_samples)
 {
     return 2 * (n_samples / 4); // air.c:59-92: two power samples per four input samples
@@ -292,7 +343,7 @@ int wait_last_copy(adsb_decoder *d)
     if (d->piece == 0 || d->dbg_async == 2)
         return 0;
     HIP_TRY(d, hipSetDevice(d->device));
-    HIP_TRY(d, hipEventSynchronize(d->ev_copy[d->piece % adsb_decoder::kCopyStreams]));
+    WAIT_EVENT(d, d->ev_copy[d->piece % adsb_decoder::kCopyStreams], "the host-to-device copy of the previous piece");
     return 0;
 }
 
@@ -315,7 +366,7 @@ int slot_reserve_device_tries(adsb_decoder *d, ScanSlot &s, size_t want_list, si
         if (d->count_stream) { // a count pass may still be reading the old arrays
             if (count_flush(d))
                 return -1;
-            HIP_TRY(d, hipStreamSynchronize(d->count_stream));
+            WAIT_STREAM(d, d->count_stream, "the try-count stream");
         }
         if (s.d_tries)
             HIP_TRY(d, hipFree(s.d_tries));
@@ -378,7 +429,7 @@ int slot_settle_profile(adsb_decoder *d, ScanSlot &s, int copy)
     if (!s.prof_pending[copy])
         return 0;
     s.prof_pending[copy] = false;
-    HIP_TRY(d, hipEventSynchronize(s.ev_ready[copy]));
+    WAIT_EVENT(d, s.ev_ready[copy], "a scan launch");
     const uint32_t *c = s.h_counters + copy * adsb::kCounterWords;
     const uint64_t t_begin = ~((uint64_t)c[5] << 32 | c[4]), t_end = (uint64_t)c[7] << 32 | c[6];
     const double ms = t_end > t_begin ? (double)(t_end - t_begin) * 1e-5 : 0.0; // 10 ns ticks
@@ -772,7 +823,7 @@ int count_tries_pass(adsb_decoder *d, ScanSlot *slot, uint32_t n_tries, uint64_t
         return 0;
     }
     if (!over.empty() || nf > d->frames_cap) { // rare: grow the frame arrays (passes in flight use them: drain the stream first)
-        HIP_TRY(d, hipStreamSynchronize(cs));
+        WAIT_STREAM(d, cs, "the try-count stream");
         const size_t cap = std::max<size_t>(nf + nf / 4 + 1, 2 * d->frames_cap);
         adsb::TryFrame *nh[adsb_decoder::kFrameBufs] = {nullptr, nullptr, nullptr};
         for (int i = 0; i < adsb_decoder::kFrameBufs; i++)
@@ -800,7 +851,7 @@ int count_tries_pass(adsb_decoder *d, ScanSlot *slot, uint32_t n_tries, uint64_t
     {   // the resolver goes on logging into the buffer of the pass before last
         const int nb = (b + 1) % adsb_decoder::kFrameBufs;
         if (d->frames_pending[nb]) {
-            HIP_TRY(d, hipEventSynchronize(d->ev_frames[nb]));
+            WAIT_EVENT(d, d->ev_frames[nb], "the upload of the accepted frames");
             d->frames_pending[nb] = false;
         }
         d->log_buf = nb;
@@ -852,7 +903,7 @@ int read_tries(adsb_decoder *d)
         return -1;
     unsigned long long acc[4];
     HIP_TRY(d, hipMemcpyAsync(acc, d->d_try_acc, sizeof acc, hipMemcpyDeviceToHost, d->count_stream));
-    HIP_TRY(d, hipStreamSynchronize(d->count_stream));
+    WAIT_STREAM(d, d->count_stream, "the try-count stream");
     d->tries_unread = false;
     if (acc[3])
         return d->fail("undecided tries exceeded the carry buffer (%u entries)", kCarryCap);
@@ -904,12 +955,9 @@ int slot_collect(adsb_decoder *d)
         if (s.streaming && !partial) {
             // every tile has been consumed: the kernel is ending and its report is microseconds
             // away -- poll for it instead of going to sleep in hipEventSynchronize
-            hipError_t q;
-            while ((q = hipEventQuery(s.ev_ready[s.ev_cur])) == hipErrorNotReady)
-                __builtin_ia32_pause();
-            HIP_TRY(d, q);
+            WAIT_EVENT(d, s.ev_ready[s.ev_cur], "the end of a scan launch whose every tile has been consumed");
         } else {
-            HIP_TRY(d, hipEventSynchronize(s.ev_ready[s.ev_cur]));
+            WAIT_EVENT(d, s.ev_ready[s.ev_cur], "a scan launch");
         }
         s.prof_pending[s.ev_cur] = d->cfg.profile != 0;
         if (slot_settle_profile(d, s, s.ev_cur))
@@ -926,7 +974,7 @@ int slot_collect(adsb_decoder *d)
             return d->fail("record buffers overflowed repeatedly (%zu candidates, %zu tries)", nc, nt);
         d->prof.relaunches++;
         relaunched = true;
-        HIP_TRY(d, hipStreamSynchronize(s.launch_stream ? s.launch_stream : d->stream));
+        WAIT_STREAM(d, s.launch_stream ? s.launch_stream : d->stream, "the launch's stream");
         if (slot_reserve(d, s, std::max(s.cand_cap, nc + nc / 8 + 64),
                          s.tries_on_device ? s.try_cap : std::max(s.try_cap, nt + nt / 8 + 64)))
             return -1;
@@ -1245,7 +1293,7 @@ int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind, bo
             if (d->dbg_async != 2)
                 HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_copy[cs], 0));
             if (d->dbg_async == 1)
-                HIP_TRY(d, hipStreamSynchronize(cstream));
+                WAIT_STREAM(d, cstream, "a copy stream");
         } else {
             HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur] + d->stage_fill, p, take * sizeof(uint16_t), kind, d->stream));
             d->copy_unconfirmed = true;
@@ -1260,7 +1308,7 @@ int push_copy(adsb_decoder *d, const void *src, size_t n, hipMemcpyKind kind, bo
             // adsb_push_async's contract: the buffer of the PREVIOUS piece is free when this call
             // returns.  Collecting that piece's scan implies it; a piece too small to launch a
             // scan leaves only its copy to wait for (already complete in every other case).
-            HIP_TRY(d, hipEventSynchronize(d->ev_copy[(d->piece - 1) % adsb_decoder::kCopyStreams]));
+            WAIT_EVENT(d, d->ev_copy[(d->piece - 1) % adsb_decoder::kCopyStreams], "the host-to-device copy of the previous piece");
         }
     }
     return 0;
@@ -1427,15 +1475,15 @@ void adsb_destroy(adsb_decoder *d)
     }
     for (hipStream_t cs : d->copy_stream)
         if (cs)
-            (void)hipStreamSynchronize(cs);
+            (void)wait_stream(d, cs, "a copy stream (adsb_destroy)");
     if (d->stream)
-        (void)hipStreamSynchronize(d->stream);
+        (void)wait_stream(d, d->stream, "the scan stream (adsb_destroy)");
     if (d->stream2) {
-        (void)hipStreamSynchronize(d->stream2);
+        (void)wait_stream(d, d->stream2, "the second scan stream (adsb_destroy)");
         (void)hipStreamDestroy(d->stream2);
     }
     if (d->count_stream) {
-        (void)hipStreamSynchronize(d->count_stream);
+        (void)wait_stream(d, d->count_stream, "the try-count stream (adsb_destroy)");
         (void)hipStreamDestroy(d->count_stream);
     }
     for (int i = 0; i < adsb_decoder::kCopyStreams; i++) {
@@ -1486,14 +1534,14 @@ int adsb_reset(adsb_decoder *d)
         // let them end before their slots are reused -- their records are dropped with the stream
         HIP_TRY(d, hipSetDevice(d->device));
         for (hipStream_t cs : d->copy_stream)
-            HIP_TRY(d, hipStreamSynchronize(cs));
-        HIP_TRY(d, hipStreamSynchronize(d->stream));
+            WAIT_STREAM(d, cs, "a copy stream");
+        WAIT_STREAM(d, d->stream, "the scan stream");
         if (d->stream2)
-            HIP_TRY(d, hipStreamSynchronize(d->stream2));
+            WAIT_STREAM(d, d->stream2, "the second scan stream");
         if (d->count_stream) {
             if (count_flush(d))
                 return -1;
-            HIP_TRY(d, hipStreamSynchronize(d->count_stream));
+            WAIT_STREAM(d, d->count_stream, "the try-count stream");
         }
         for (ScanSlot &sl : d->slots) {
             // normally the report kernel behind each scan has left the counters zero; after a failed launch it may not have
@@ -1505,7 +1553,7 @@ int adsb_reset(adsb_decoder *d)
         }
         // ... except these fills: the slot's next launch may go to the second scan stream, which nothing orders behind
         // d->stream -- a late fill would zero the counters of a running scan
-        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        WAIT_STREAM(d, d->stream, "the scan stream");
     }
     else if (wait_last_copy(d)) // a late asynchronous copy must not land in stage[0] beside the next stream's
         return -1;
@@ -1572,7 +1620,7 @@ int adsb_push(adsb_decoder *d, const uint16_t *samples, size_t n)
     if (push_copy(d, samples, n, hipMemcpyHostToDevice))
         return -1;
     if (d->copy_unconfirmed) { // `samples` is only borrowed for the call: no scan behind the last copy has confirmed it
-        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        WAIT_STREAM(d, d->stream, "the scan stream");
         d->copy_unconfirmed = false;
     }
     return 0;
@@ -1604,10 +1652,10 @@ int adsb_sync(adsb_decoder *d)
     if (!d->finished)
         d->res.advance(power_samples_produced(d->n_samples), d->g_scanned);
     for (hipStream_t cs : d->copy_stream)
-        HIP_TRY(d, hipStreamSynchronize(cs));
-    HIP_TRY(d, hipStreamSynchronize(d->stream)); // tail copies: every borrowed buffer is free
+        WAIT_STREAM(d, cs, "a copy stream");
+    WAIT_STREAM(d, d->stream, "the scan stream"); // tail copies: every borrowed buffer is free
     if (d->stream2)
-        HIP_TRY(d, hipStreamSynchronize(d->stream2));
+        WAIT_STREAM(d, d->stream2, "the second scan stream");
     return 0;
 }
 
@@ -1703,7 +1751,7 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
         // the staging copy may still be queued when no scan was launched behind it (and
         // collected): the caller is free to reuse or free the buffer on return
         if (d->copy_unconfirmed) {
-            HIP_TRY(d, hipStreamSynchronize(d->stream));
+            WAIT_STREAM(d, d->stream, "the scan stream");
             d->copy_unconfirmed = false;
         }
         return 0;
@@ -1773,12 +1821,12 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
             return -1;
         d->g_scanned = g_end;
     } else {
-        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        WAIT_STREAM(d, d->stream, "the scan stream");
     }
     if (scan_drain(d))
         return -1;
     if (d->stream2) // the launches may all have gone to the second stream: the tail copy is not implied by their end
-        HIP_TRY(d, hipStreamSynchronize(d->stream));
+        WAIT_STREAM(d, d->stream, "the scan stream");
     d->res.advance(m_real, d->g_scanned);
     return 0;
 }
@@ -1938,7 +1986,7 @@ int adsb_scan_shard_host(adsb_decoder *d, const uint16_t *host_samples, uint64_t
     // copy stream of the handle's: the synchronous hipMemcpy was seen to cost the process ~1 KB of host memory per call
     // that never came back -- tools/soak_probe.py)
     HIP_TRY(d, hipMemcpyAsync(d->win_buf, host_samples, n * sizeof(uint16_t), hipMemcpyHostToDevice, d->copy_stream[0]));
-    HIP_TRY(d, hipStreamSynchronize(d->copy_stream[0]));
+    WAIT_STREAM(d, d->copy_stream[0], "a copy stream");
     return adsb_scan_shard(d, d->win_buf, first_sample, n, g_begin, g_end, cands, cand_cap, n_cands, tries, try_cap, n_tries);
 }
 

@@ -117,6 +117,9 @@ struct Worker {
     std::condition_variable cv;
     uint64_t posted = 0, done = 0; // jobs posted / finished (under mu)
     std::atomic<uint64_t> posted_a{0}, done_a{0}; // the same, for the spinning side of each hand-over
+    std::atomic<uint64_t> beat{0}; // signs of life inside a job (one per piece pushed, window scanned, stream ended): what the
+                                   // caller's deadline watches (wait_done)
+    bool orphaned = false;         // (under mu) the driver gave this worker up: it cleans up after itself and ends
     Job job;
     // result of the last job
     int rc = 0;
@@ -149,6 +152,13 @@ struct Worker {
     }
 };
 
+// how long the driver waits for a worker that shows no sign of life (wait_done)
+inline double worker_limit_s(const adsb_config &cfg)
+{
+    const double t = cfg.wait_timeout_s > 0 ? cfg.wait_timeout_s : 120;
+    return t + std::max(5.0, t / 4);
+}
+
 } // namespace
 
 struct adsb_multi {
@@ -162,7 +172,15 @@ struct adsb_multi {
     adsb_multi_info info{};
     double create_ms = 0;
     uint64_t piece_samples = kPieceSamples;
+    bool broken = false; // a worker stopped answering (gave_up): every later call fails at once
 
+    long gave_up(const Worker &w)
+    {
+        broken = true;
+        return fail("device %d (worker %d) has shown no sign of life for %.0f s (adsb_config.wait_timeout_s + margin): giving up; "
+                    "this adsb_multi handle is unusable now -- destroy it",
+                    w.device, w.index, worker_limit_s(cfg));
+    }
     long fail(const char *fmt, ...)
     {
         char buf[768];
@@ -234,6 +252,7 @@ int window_tries(Worker &w, const Job &j, uint64_t g_lo, uint64_t g_hi, std::vec
             rc = adsb_scan_shard_host(w.dec, p, s0, (size_t)(s1 - s0), g_lo, g_hi, w.scratch_cands.data(), cap_c, &nc, out.data(),
                                       cap_t, &nt);
         }
+        w.beat.fetch_add(1, std::memory_order_relaxed);
         if (rc == 0) {
             out.resize(nt);
             return 0;
@@ -256,6 +275,7 @@ int feed(Worker &w, const Source &src, uint64_t first, uint64_t n, uint64_t piec
             return -1;
         if (adsb_push_async(w.dec, p, (size_t)len))
             return w.fail_dec("adsb_push_async");
+        w.beat.fetch_add(1, std::memory_order_relaxed);
     }
     return 0;
 }
@@ -359,6 +379,7 @@ void run_streams(Worker &w, const Job &j, uint64_t piece)
         r.rc = w.rc;
         r.err = w.err;
         r.ms = ms_since(t0);
+        w.beat.fetch_add(1, std::memory_order_relaxed);
     }
 }
 
@@ -418,11 +439,22 @@ void worker_main(Worker *w, uint64_t piece)
         Job j;
         for (const auto t0 = clk::now(); w->posted_a.load(std::memory_order_acquire) <= seen && ms_since(t0) < kWorkerSpinMs;)
             relax_burst();
+        bool orphan = false;
         {
             std::unique_lock<std::mutex> lk(w->mu);
-            w->cv.wait(lk, [&] { return w->posted > seen; });
+            w->cv.wait(lk, [&] { return w->posted > seen || w->orphaned; });
+            orphan = w->orphaned;
             seen = w->posted;
             j = w->job;
+        }
+        if (orphan) { // the driver stopped waiting for this worker (wait_done's deadline) and is gone: nobody joins, nobody frees
+            if (w->dec)
+                adsb_destroy(w->dec);
+            for (uint16_t *b : w->ring)
+                if (b)
+                    adsb_host_free(b);
+            delete w;
+            return;
         }
         if (j.kind == JobKind::Quit)
             break;
@@ -464,16 +496,34 @@ void post(Worker &w, const Job &j)
     w.cv.notify_all();
 }
 
-void wait_done(Worker &w, double spin_ms = 0)
+// Wait for the job just posted to worker w.  A worker's own waits for its device are bounded (adsb_config.wait_timeout_s); the
+// caller's wait for the worker is bounded too: if the worker shows no sign of life (Worker::beat) for that limit plus a
+// margin, the wait ends with false and the driver marks itself broken -- it answers -1 from then on, naming the worker,
+// instead of sleeping on a condition variable for ever.
+bool wait_done(Worker &w, double spin_ms = 0)
 {
     const uint64_t want = w.posted_a.load(std::memory_order_relaxed); // (this thread posted it)
     for (const auto t0 = clk::now(); spin_ms > 0 && ms_since(t0) < spin_ms;) {
         if (w.done_a.load(std::memory_order_acquire) == want)
-            return;
+            return true;
         relax_burst();
     }
+    const double limit_ms = 1e3 * worker_limit_s(w.cfg);
+    uint64_t beat = w.beat.load(std::memory_order_relaxed);
+    auto t_beat = clk::now();
     std::unique_lock<std::mutex> lk(w.mu);
-    w.cv.wait(lk, [&] { return w.done == w.posted; });
+    // (wait_until on the system clock = pthread_cond_timedwait; wait_for would be pthread_cond_clockwait, which gcc 11's
+    // ThreadSanitizer does not intercept and then reports as a double lock.  A clock step only moves one 250 ms tick.)
+    while (!w.cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(250), [&] { return w.done == w.posted; })) {
+        const uint64_t b = w.beat.load(std::memory_order_relaxed);
+        if (b != beat) {
+            beat = b;
+            t_beat = clk::now();
+        } else if (ms_since(t_beat) > limit_ms) {
+            return false;
+        }
+    }
+    return true;
 }
 
 // How many shards a stream of `total` samples is cut into on n workers, and the plan.
@@ -499,7 +549,8 @@ long whole_stream(adsb_multi *m, const Source &src, uint64_t total)
     j.n_streams = 1;
     j.results = m->streams.data();
     post(*m->w[0], j);
-    wait_done(*m->w[0]);
+    if (!wait_done(*m->w[0]))
+        return m->gave_up(*m->w[0]);
     StreamResult &r = m->streams[0];
     if (r.rc)
         return m->fail("fallback decode on one device failed: %s", r.err.c_str());
@@ -512,6 +563,8 @@ long whole_stream(adsb_multi *m, const Source &src, uint64_t total)
 long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices, int n_slices, uint64_t total,
                     const adsb_frame **frames)
 {
+    if (m->broken)
+        return m->fail("this adsb_multi handle is unusable: a worker stopped answering earlier (destroy it)");
     if (!m || !frames)
         return -1;
     *frames = nullptr;
@@ -545,7 +598,8 @@ long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices,
     }
     double worker_ms = 0;
     for (int i = 0; i < n; i++) {
-        wait_done(*m->w[i]);
+        if (!wait_done(*m->w[i]))
+            return m->gave_up(*m->w[i]);
         worker_ms = std::max(worker_ms, m->w[i]->ms);
     }
     for (int i = 0; i < n; i++)
@@ -635,7 +689,8 @@ long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices,
     }
     if (spread)
         for (int i = 0; i < n; i++)
-            wait_done(*m->w[i], kGatherSpinMs);
+            if (!wait_done(*m->w[i], kGatherSpinMs))
+                return m->gave_up(*m->w[i]);
     m->have_stats = stats;
     m->info.stitch_us = stitch_us;
     m->info.serial_us = 1e3 * ms_since(t_serial);
@@ -646,6 +701,8 @@ long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices,
 
 int decode_streams(adsb_multi *m, const std::vector<Source> &src, const std::vector<uint64_t> &n)
 {
+    if (m->broken)
+        return (int)m->fail("this adsb_multi handle is unusable: a worker stopped answering earlier (destroy it)");
     m->err.clear();
     m->info = adsb_multi_info{};
     const auto t0 = clk::now();
@@ -664,7 +721,8 @@ int decode_streams(adsb_multi *m, const std::vector<Source> &src, const std::vec
         post(*m->w[i], j);
     }
     for (int i = 0; i < used; i++) {
-        wait_done(*m->w[i]);
+        if (!wait_done(*m->w[i]))
+            return (int)m->gave_up(*m->w[i]);
         m->info.workers_ms = std::max(m->info.workers_ms, m->w[i]->ms);
     }
     m->info.shards = used;
@@ -715,7 +773,19 @@ adsb_multi *adsb_multi_create(const adsb_config *cfg_in, int n_devices, const in
     bool ok = true;
     for (auto &w : m->w) {
         std::unique_lock<std::mutex> lk(w->mu);
-        w->cv.wait(lk, [&] { return w->done >= 1; });
+        if (!w->cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::seconds((long)worker_limit_s(m->cfg) + 60),
+                              [&] { return w->done >= 1; })) {
+            // (the runtime's start is the one wait the handle's own deadline cannot cover: hipSetDevice / hipStreamCreate block)
+            if (ok) {
+                char buf[256];
+                snprintf(buf, sizeof buf, "device %d (worker %d): the runtime did not come up within %.0f s", w->device, w->index,
+                         worker_limit_s(m->cfg) + 60);
+                g_multi_create_error = buf;
+            }
+            ok = false;
+            m->broken = true;
+            continue;
+        }
         w->posted = 1;
         w->posted_a.store(1, std::memory_order_release);
         if (!w->dec && ok) {
@@ -735,6 +805,26 @@ void adsb_multi_destroy(adsb_multi *m)
 {
     if (!m)
         return;
+    if (m->broken) {
+        // some worker never answered: nobody can join it.  Every worker is cut loose instead -- it frees its handle and itself
+        // when (if) it comes back -- and the driver's own memory goes now; the workers hold no pointer into it ... except
+        // the source and result arrays of the job they may still be running, which stay the CALLER's to keep alive.
+        for (auto &w : m->w) {
+            Worker *p = w.release();
+            if (!p->th.joinable()) {
+                delete p;
+                continue;
+            }
+            {
+                std::lock_guard<std::mutex> lk(p->mu);
+                p->orphaned = true;
+            }
+            p->cv.notify_all();
+            p->th.detach();
+        }
+        delete m;
+        return;
+    }
     Job q;
     q.kind = JobKind::Quit;
     for (auto &w : m->w)

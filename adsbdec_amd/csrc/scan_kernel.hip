@@ -756,12 +756,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         __syncthreads();
         const int ncl = min((int)*cl_n, clist_cap); // <= kClistCap <= NT: one entry per thread
         const bool complete = *cl_over == 0;
-        // The tile reserves its range of the hand-off stream -- one marker granule plus two per record, in whole
-        // 64-byte lines -- with one device-scope atomic whose answer takes ~2 us under the scan's traffic.  How many
-        // records it KEEPS is only known behind the filter below; it reserves for the staged ones now (an upper
-        // bound, ~4x: the marker tells the host how many lines to skip), so that the round trip runs beside the
-        // filter and the finishing instead of behind the filter.
-        uint32_t res_need = 0, res_base = 0;
+        uint32_t res_need = 0, res_base = 0; // (the tile's reservation in the hand-off stream: below, once its records are counted)
         const bool reserves = tid == 0 && args.hand;
         bool keep = false;
         uint32_t rank = 0; // kept entries with a smaller offset: the record's place behind the tile's marker
@@ -854,21 +849,77 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                     rank += (uint32_t)((int)k4.x < g2) + (uint32_t)((int)k4.y < g2) + (uint32_t)((int)k4.z < g2) + (uint32_t)((int)k4.w < g2);
                 }
         }
+        // ---- from the staged entries that stay to the tile's records in the stream.
+        // One record per RUN OF COPIES.  A frame decodes at two or three neighbouring offsets (the half-sample shifts); an
+        // isolated frame's extra copies went with the filter above, but where frames stand back to back every copy is
+        // reachable -- which one the scan lands on is decided by where the previous frame ended (demod.c:125-141) -- and a full
+        // channel would cost three records per frame (310 k per 256 Mi samples at BASELINE configs[2]'s density, which the host
+        // then has to read, check and walk: 3 x the kernel's time).  Entries r-1 and r (in ascending offset) are LINKED when
+        // r's offset is the next one and code, repair flag and the four column words are the same; a chain of links is cut
+        // into records of up to three offsets: the first one's {g_rel, pw}, the others' pw in the second granule's spare words,
+        // their number in flags bits 1..2 (scan_kernel_format.h).  The host expands them where the greedy rule needs them.
+        uint32_t st[kCandWords];
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < kCandWords; k++)
+                st[k] = ri[k];
+            st[1] &= 0xFFFFu; // (the multi-wave filter's "kept" bit never existed here, but a link compares the whole word)
+        }
+        __syncthreads(); // every thread has read what it needs of the staged list (the filter's loops included)
+        if (keep) {      // the entries that stay replace the list, in ascending offset
+            uint32_t *o = cl_rec + rank * kCandWords;
+#pragma unroll
+            for (int k = 0; k < kCandWords; k++)
+                o[k] = st[k];
+        }
         __syncthreads();
+        const uint32_t nk = *tile_n; // entries in cl_rec now; thread r < nk takes entry r from here on
+        uint32_t *pwbuf = queue, *ext = queue + kClistCap, *wl = queue + kQueueCap - 4; // every entry's pw; the copies' pw (two per record); leaders per wave
+        const uint32_t *my = cl_rec + tid * kCandWords;
+        bool lead = false, c1 = false, c2 = false;
+        if ((uint32_t)tid < nk) {
+            auto linked = [&](uint32_t a) { // is entry a the previous entry's frame, one offset on?
+                if (a == 0 || a >= nk)
+                    return false;
+                const uint32_t *p = cl_rec + (a - 1) * kCandWords, *q = p + kCandWords;
+                return q[0] == p[0] + 1u && q[1] == p[1] && q[2] == p[2] && q[3] == p[3] && q[4] == p[4] && q[5] == p[5];
+            };
+            uint32_t back = 0; // links behind this entry
+            while (linked((uint32_t)tid - back))
+                back++;
+            lead = back % 3u == 0;
+            c1 = lead && linked((uint32_t)tid + 1);
+            c2 = c1 && linked((uint32_t)tid + 2);
+        }
+        const unsigned long long leaders = __ballot(lead);
+        if ((tid & 63) == 0)
+            wl[tid >> 6] = (uint32_t)__popcll(leaders);
+        __syncthreads();
+        uint32_t nrec = 0, r2 = (uint32_t)__popcll(leaders & ((1ull << (tid & 63)) - 1ull)); // records; this leader's place among them
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) {
+            r2 += w < (tid >> 6) ? wl[w] : 0u;
+            nrec += wl[w];
+        }
+        // The tile reserves its range of the hand-off stream -- one marker granule plus two per record, in whole 64-byte
+        // lines -- with one device-scope atomic whose answer takes ~2 us under the scan's traffic: the round trip runs beside
+        // the finishing below.  (Until round 5 the tile reserved for every entry that stayed, BEFORE it knew its records:
+        // with runs of copies that left two thirds of every range unwritten, and the host, which reads the stream
+        // sequentially, lost its prefetcher at every tile: 1.0 ms per 2 800 tiles.)
         if (reserves) { // the result is not looked at before this thread's own record is finished
-            res_need = stream_granules(*tile_n);
+            res_need = stream_granules(nrec);
             res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
         }
-        // finish the record: bytes in order, pw (demod.c:127,133).  The loads of pw_at
-        // run while thread 0's reservation above is still on its way back.
-        uint32_t fin[6];
-        if (keep) {
-            const uint32_t cw[4] = {ri[2], ri[3], ri[4], ri[5]};
+        // finish the entry: bytes in order, pw (demod.c:127,133) -- every offset has a pw of its own
+        uint32_t fin[6] = {0, 0, 0, 0, 0, 0};
+        if ((uint32_t)tid < nk) {
+            const uint32_t cw[4] = {my[2], my[3], my[4], my[5]};
             uint32_t wds[4];
-            columns_to_bytes(cw, (ri[1] & 0xFFu) == 0, wds);
-            wds[3] |= ((ri[1] >> 8) & 1u) << 24; // repaired-by-extension flag
-            const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + ri[0]);
-            fin[0] = ri[0], fin[1] = pw, fin[2] = wds[0], fin[3] = wds[1], fin[4] = wds[2], fin[5] = wds[3];
+            columns_to_bytes(cw, (my[1] & 0xFFu) == 0, wds);
+            wds[3] |= ((my[1] >> 8) & 1u) << 24; // repaired-by-extension flag
+            const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + my[0]);
+            fin[0] = my[0], fin[1] = pw, fin[2] = wds[0], fin[3] = wds[1], fin[4] = wds[2], fin[5] = wds[3];
+            pwbuf[tid] = pw;
         }
         if (reserves) {
             *tile_base = res_base;
@@ -876,81 +927,34 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             *tile_lines = res_need >> 2;
             *tile_res = 1;
         }
-        __syncthreads(); // tile_base / tile_fit are in, and every staged entry has been read
+        __syncthreads(); // tile_base / tile_fit are in, every entry has been read, every pw is known
         const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
-        if (keep) {
-            if (to_stream) {
-                // the finished records replace the staged list, in rank order
-                uint32_t *o = cl_rec + rank * kCandWords;
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    o[k] = fin[k];
-            } else {
+        if ((uint32_t)tid < nk) {
+            if (!to_stream) {
                 const uint32_t wds[4] = {fin[2], fin[3], fin[4], fin[5]};
-                emit_loose(fin[0], fin[1], wds);
+                emit_loose(fin[0], fin[1], wds); // (one by one: records of the loose list never carry copies)
+            } else if (lead) {
+                fin[5] |= ((c1 ? 1u : 0u) + (c2 ? 1u : 0u)) << kRecCopiesShift;
+                const uint32_t pw1 = c1 ? pwbuf[tid + 1] : 0u, pw2 = c2 ? pwbuf[tid + 2] : 0u;
+                ext[2 * r2] = pw1;
+                ext[2 * r2 + 1] = pw2;
+                atomicXor(&tile_chk[0], fin[0] ^ fin[4]); // word-wise XOR of its two granules
+                atomicXor(&tile_chk[1], fin[1] ^ fin[5]);
+                atomicXor(&tile_chk[2], fin[2] ^ pw1);
+                atomicXor(&tile_chk[3], fin[3] ^ pw2);
+                atomicAdd(tile_sum, record_term(r2, fin[0], fin[1]));
             }
         }
         if (to_stream) {
-            // One record per RUN OF COPIES.  A frame decodes at two or three neighbouring offsets (the half-sample shifts); an
-            // isolated frame's extra copies went with the filter above, but where frames stand back to back every copy is
-            // reachable -- which one the scan lands on is decided by where the previous frame ended (demod.c:125-141) -- and a
-            // full channel would cost three records per frame (310 k per 256 Mi samples at BASELINE configs[2]'s density, which
-            // the host then has to read, check and walk: 3 x the kernel's time).  Records r-1 and r are LINKED when r's offset is
-            // the next one and its four frame words (bytes, length, repair flag) are the same; a chain of links is cut into
-            // records of up to three offsets: the first one's {g_rel, pw}, the others' pw in the second granule's spare words,
-            // their number in flags bits 1..2 (scan_kernel_format.h).  The host expands them where the greedy rule needs them.
-            __syncthreads();
-            const uint32_t nk = *tile_n; // ranked records in cl_rec
-            uint32_t *ext = queue, *wl = queue + kQueueCap - 4; // the copies' pw (two per record); leaders per wave
-            bool lead = false;
-            uint32_t out[8];
-            if ((uint32_t)tid < nk) {
-                auto linked = [&](uint32_t a) { // is record a the previous record's frame, one offset on?
-                    if (a == 0 || a >= nk)
-                        return false;
-                    const uint32_t *p = cl_rec + (a - 1) * kCandWords, *q = p + kCandWords;
-                    return q[0] == p[0] + 1u && q[2] == p[2] && q[3] == p[3] && q[4] == p[4] && q[5] == p[5];
-                };
-                uint32_t back = 0; // links behind this record
-                while (linked((uint32_t)tid - back))
-                    back++;
-                lead = back % 3u == 0;
-                if (lead) {
-                    const uint32_t *r = cl_rec + tid * kCandWords;
-                    const bool c1 = linked((uint32_t)tid + 1), c2 = c1 && linked((uint32_t)tid + 2);
-#pragma unroll
-                    for (int k = 0; k < 6; k++)
-                        out[k] = r[k];
-                    out[5] |= ((c1 ? 1u : 0u) + (c2 ? 1u : 0u)) << kRecCopiesShift;
-                    out[6] = c1 ? r[kCandWords + 1] : 0u;
-                    out[7] = c2 ? r[2 * kCandWords + 1] : 0u;
-                }
-            }
-            const unsigned long long leaders = __ballot(lead);
-            if ((tid & 63) == 0)
-                wl[tid >> 6] = (uint32_t)__popcll(leaders);
-            __syncthreads(); // every record has been read: the leaders' records go back into the list, compacted
-            uint32_t nrec = 0, r2 = (uint32_t)__popcll(leaders & ((1ull << (tid & 63)) - 1ull));
-#pragma unroll
-            for (int w = 0; w < kWaves; w++) {
-                r2 += w < (tid >> 6) ? wl[w] : 0u;
-                nrec += wl[w];
-            }
+            __syncthreads(); // every pw has been read: the records go back into the list, compacted
             if (lead) {
                 uint32_t *o = cl_rec + r2 * kCandWords;
 #pragma unroll
                 for (int k = 0; k < 6; k++)
-                    o[k] = out[k];
-                ext[2 * r2] = out[6];
-                ext[2 * r2 + 1] = out[7];
-                atomicXor(&tile_chk[0], out[0] ^ out[4]); // word-wise XOR of its two granules
-                atomicXor(&tile_chk[1], out[1] ^ out[5]);
-                atomicXor(&tile_chk[2], out[2] ^ out[6]);
-                atomicXor(&tile_chk[3], out[3] ^ out[7]);
-                atomicAdd(tile_sum, record_term(r2, out[0], out[1]));
+                    o[k] = fin[k];
             }
             if (tid == 0)
-                *tile_n = nrec; // (the marker's count; the lines the tile reserved stay what they were)
+                *tile_n = nrec; // (the marker's count)
             // the tile's range {marker, records} leaves as one store of adjacent lanes
             __syncthreads();
             for (uint32_t L = tid; L < 1u + 2u * nrec; L += NT) {

@@ -119,6 +119,10 @@ typedef struct adsb_config {
     int32_t debug_shard_head;       /* resolved shards: offsets whose candidates are all kept for the stitcher (16384) */
     int32_t debug_passes;           /* passes per tile of every launch (2..32) instead of the cost model's choice      */
     int32_t debug_stagger;          /* leading tiles of staggered size (scan_kernel.h tile_passes)                      */
+    int32_t wait_timeout_s;    /* No wait for the device inside the library lasts longer than this many seconds (0 = default,
+                                  120): a launch or copy that never completes -- a wedged queue, a lost device -- ends the
+                                  call with -1 and adsb_last_error() names what was waited for; the multi-GPU driver gives
+                                  its workers the same limit (plus 30 s) and names the worker.  Nothing is retried. */
 } adsb_config;
 
 /* Counters accumulate over the life of the handle (adsb_reset keeps them: a caller that

@@ -65,6 +65,7 @@ inline bool try_at(const uint16_t *x, uint64_t first, uint64_t g, unsigned *code
 struct Fault { // test hooks: which device cannot be created, how many pushes a handle survives
     std::atomic<int> dead_device{-1};
     std::atomic<int> push_budget{-1};
+    std::atomic<int> hang_ms{0}; // a handle's SECOND push sleeps this long: a device that stops answering
 };
 Fault g_fault;
 thread_local std::string g_err;
@@ -92,6 +93,7 @@ struct adsb_decoder {
     std::vector<adsb_candidate> cands;
     std::vector<uint64_t> tries;
     int pushes_left = -1;
+    int pushes = 0;
 };
 
 static int dfail(adsb_decoder *d, const char *what)
@@ -171,6 +173,8 @@ int adsb_push_async(adsb_decoder *d, const uint16_t *samples, size_t n)
         return dfail(d, "hipMemcpyAsync failed (fake)");
     if (d->pushes_left > 0)
         d->pushes_left--;
+    if (++d->pushes == 2 && fake::g_fault.hang_ms.load() > 0)
+        std::this_thread::sleep_for(std::chrono::milliseconds(fake::g_fault.hang_ms.load()));
     d->x.insert(d->x.end(), samples, samples + n);
     return 0;
 }
@@ -517,6 +521,35 @@ int main(int argc, char **argv)
         if (adsb_multi_decode_file(m, "/nonexistent/capture.u16", &fp) >= 0)
             return 1;
         adsb_multi_destroy(m);
+        // ---- a device that stops answering in the middle of a shard: the driver gives up after cfg.wait_timeout_s + margin,
+        // names the worker, stays broken, and adsb_multi_destroy returns at once (the worker cleans up after itself later)
+        cfg.wait_timeout_s = 1; // + 5 s of margin
+        fake::g_fault.hang_ms.store(9000);
+        m = adsb_multi_create(&cfg, 2, devs);
+        if (!m)
+            return 1;
+        // (the capture of a decode that was given up stays borrowed by the workers that may still be inside it: it is the
+        // caller's to keep alive -- here for the rest of the process, reachable from a global so that no leak is reported)
+        static uint16_t *hang_x = nullptr;
+        hang_x = static_cast<uint16_t *>(malloc(x.size() * sizeof(uint16_t)));
+        std::memcpy(hang_x, x.data(), x.size() * sizeof(uint16_t));
+        const auto t_h = std::chrono::steady_clock::now();
+        const long rc_h = adsb_multi_decode_host(m, hang_x, x.size(), &fp);
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_h).count();
+        if (rc_h >= 0 || !strstr(adsb_multi_last_error(m), "no sign of life") || !strstr(adsb_multi_last_error(m), "worker") || waited < 5.5 || waited > 8.5) {
+            fprintf(stderr, "a worker that stops answering must end the decode after the limit and be named: rc %ld after %.1f s, '%s'\n", rc_h, waited, adsb_multi_last_error(m));
+            return 1;
+        }
+        if (adsb_multi_decode_host(m, hang_x, x.size(), &fp) >= 0 || !strstr(adsb_multi_last_error(m), "unusable"))
+            return 1;
+        const auto t_d = std::chrono::steady_clock::now();
+        adsb_multi_destroy(m);
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_d).count() > 1.0) {
+            fprintf(stderr, "destroying a broken driver must not wait for its workers\n");
+            return 1;
+        }
+        fake::g_fault.hang_ms.store(0);
+        std::this_thread::sleep_for(std::chrono::milliseconds(4500)); // the orphaned workers come back, free their handles and end
     }
     unlink(path);
     printf("ok: %d sharded decodes (%d shards, %d fell back to one stream), streams and error paths\n", decodes, shards, fallbacks);
