@@ -26,7 +26,7 @@ $(LIBDIR)/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(LIBDIR)
 	g++ -O2 -fPIC -std=c++17 -Wall -Wextra -pthread -c $< -o $@
 
-$(LIB): $(LIBDIR)/scan_kernel.hip.o $(LIBDIR)/decoder.hip.o $(LIBDIR)/format.c.o $(LIBDIR)/multi.cpp.o $(LIBDIR)/host_abi.cpp.o
+$(LIB): $(LIBDIR)/scan_kernel.hip.o $(LIBDIR)/decoder.hip.o $(LIBDIR)/format.c.o $(LIBDIR)/multi.cpp.o $(LIBDIR)/host_abi.cpp.o $(LIBDIR)/numa.cpp.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm -lpthread
 
 $(CLI): $(CSRC)/cli/adsbdec_amd_cli.c $(CSRC)/cli/sink.c $(CSRC)/cli/sink.h $(LIB) include/adsbdec_amd.h

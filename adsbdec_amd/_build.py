@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_SOURCES = ["scan_kernel.hip", "decoder.hip"]
 C_SOURCES = ["format.c"]
 # host-only C++ (no HIP): the multi-GPU driver over the C-ABI, and the part of the C-ABI that needs no device
-CXX_SOURCES = ["multi.cpp", "host_abi.cpp"]
+CXX_SOURCES = ["multi.cpp", "host_abi.cpp", "numa.cpp"]
 HEADERS = ["scan_kernel.h", "scan_kernel_format.h", "handoff.hpp", "resolver.hpp", "stitch.hpp",
            os.path.join(ROOT, "include", "adsbdec_amd.h")]
 # -ffp-contract=off: the reference arithmetic is binary32 multiply THEN add

@@ -71,6 +71,11 @@ class MultiInfo(C.Structure):
                 ("total_ms", C.c_double), ("workers_bound", C.c_int32), ("reserved", C.c_int32)]
 
 
+class WorkerPlacement(C.Structure):
+    _fields_ = [("device", C.c_int32), ("device_node", C.c_int32), ("thread_bound", C.c_int32), ("slice_node", C.c_int32),
+                ("local_fraction", C.c_double)]
+
+
 class Profile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("relaunches", C.c_uint64), ("offsets", C.c_uint64),
                 ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double), ("last_offsets", C.c_uint64),
@@ -114,6 +119,14 @@ SYMBOLS = {
     "adsb_resolver_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "adsb_handoff_walk": (C.c_long, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "adsb_shard_layout_check": (C.c_int, [C.c_size_t, C.c_size_t]),
+    "adsb_device_numa_node": (C.c_int, [C.c_int]),
+    "adsb_host_alloc_on": (C.c_void_p, [C.c_size_t, C.c_int]),
+    "adsb_host_alloc_sharded": (C.c_void_p, [C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "adsb_host_placement": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "adsb_host_release_mapped": (C.c_int, [C.c_void_p]),
+    "adsb_multi_host_alloc": (C.c_void_p, [C.c_void_p, C.c_uint64]),
+    "adsb_multi_worker_placement": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(WorkerPlacement)]),
     "adsb_resolver_advance_stream": (C.c_long, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64,
                                                 C.c_uint64, C.c_uint64, C.c_int]),
     "adsb_scan_shard_resolved": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64, C.c_uint64,

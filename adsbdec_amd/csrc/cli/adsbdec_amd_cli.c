@@ -29,9 +29,13 @@
  *   - Beast to stdout is written with its real length (the reference uses strlen()
  *     on a binary buffer).
  * The stderr statistics table has the reference's format (valid.c:84-100).
+ * Signals as in main.c:91-99: SIGPIPE ignored; SIGINT / SIGTERM / SIGQUIT stop the pushes, what has been decoded is
+ * finished and written, the table is printed, exit status 0.
  */
 #include <fcntl.h>
+#include <errno.h>
 #include <pthread.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -158,6 +162,42 @@ static void usage(void)
 
 static sink out_sink; /* stdout unless -s / -l */
 
+/* main.c:91-99: SIGINT / SIGTERM / SIGQUIT end the run in an orderly way -- the reference's handlerExit sets do_exit, the
+ * writer loop ends, main prints the Try/Ok table and returns runOutput()'s 0 -- and SIGPIPE is ignored, so that a closed
+ * stdout or peer shows up as a failed write, not as death by signal.  Here: the handler sets a flag (no SA_RESTART: a
+ * blocking accept / connect / read returns), the push loop stops at the next buffer, what has been decoded is finished,
+ * written and counted, the table is printed, exit status 0. */
+static volatile int stop_requested;
+static void on_stop_signal(int sig)
+{
+    (void)sig;
+    stop_requested = 1;
+}
+static void install_signals(void)
+{
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sigemptyset(&sa.sa_mask);
+    sa.sa_handler = on_stop_signal;
+    sigaction(SIGTERM, &sa, NULL);
+    sigaction(SIGQUIT, &sa, NULL);
+    sigaction(SIGINT, &sa, NULL);
+    sa.sa_handler = SIG_IGN;
+    sigaction(SIGPIPE, &sa, NULL);
+}
+/* pthread_cond_wait that wakes up ten times a second to look at stop_requested (a signal does not wake a condition wait) */
+static void cond_wait_tick(pthread_cond_t *cv, pthread_mutex_t *mu)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    ts.tv_nsec += 100 * 1000 * 1000;
+    if (ts.tv_nsec >= 1000000000L) {
+        ts.tv_sec++;
+        ts.tv_nsec -= 1000000000L;
+    }
+    pthread_cond_timedwait(cv, mu, &ts);
+}
+
 /* Packets leave in batches of up to 64 KiB: one fwrite / send per batch. */
 static int write_frames(sink *out, const adsb_frame *fr, long n, int outformat)
 {
@@ -282,7 +322,8 @@ static int run_multi(const adsb_config *cfg, int *devs, int ndev, char **files, 
         } else {
             if (write_frames(&out_sink, fr, n, outformat) != 0)
                 rc = 1;
-            sink_close(&out_sink);
+            if (sink_close(&out_sink) != 0)
+                rc = 1;
             if (timing) {
                 adsb_multi_info inf;
                 adsb_multi_get_info(m, &inf);
@@ -336,8 +377,11 @@ int main(int argc, char **argv)
         switch (c) {
         case 'f':
             filename = optarg;
-            if (nfiles < MAX_FILES)
-                files[nfiles++] = optarg;
+            if (nfiles == MAX_FILES) { /* (more captures than this program keeps track of: say so, do not drop them) */
+                usage();
+                return 1;
+            }
+            files[nfiles++] = optarg;
             break;
         case 'd': {
             char *end;
@@ -388,7 +432,9 @@ int main(int argc, char **argv)
         usage();
         return 1;
     }
+    install_signals();
     sink_init(&out_sink, outmode, rawaddr);
+    out_sink.stop = &stop_requested;
     if (getenv("ADSB_CLI_RETRY_S")) /* (a test's knob: the reference waits 3 s between attempts, output.c:282) */
         out_sink.retry_s = (unsigned)atoi(getenv("ADSB_CLI_RETRY_S"));
 
@@ -399,10 +445,27 @@ int main(int argc, char **argv)
         mcfg.df18 = df18;
         mcfg.fix_1bit = fix1;
         mcfg.collect_stats = 1; /* the reference always prints Try/Ok */
-        restrict_visible_devices(devs, ndev);
-        if (sink_wait_peer(&out_sink) != 0)
-            return 255; /* unusable address: runOutput() == -1 (output.c:278-279) */
-        return run_multi(&mcfg, devs, ndev, files, nfiles, outformat, timing);
+        /* The driver cuts FILES into slices (every device preads its own): what the reference accepts beyond that goes the
+         * way the one-device run goes it -- a single -f that is a pipe, a FIFO or a device node is streamed through one
+         * device (the first one listed), a single -f that cannot be opened ends the run silently with an empty table
+         * (air.c:225-228), same bytes on stdout and stderr either way. */
+        struct stat sb;
+        const int one_ok = nfiles > 1 || (stat(files[0], &sb) == 0 && S_ISREG(sb.st_mode) && access(files[0], R_OK) == 0);
+        if (one_ok) {
+            restrict_visible_devices(devs, ndev);
+            const int prc = sink_wait_peer(&out_sink);
+            if (prc == 2) { /* told to end before a peer came: nothing decoded, the table (all zero) and status 0 (main.c:101-105) */
+                adsb_stats z;
+                memset(&z, 0, sizeof z);
+                print_stats(&z);
+                return 0;
+            }
+            if (prc != 0)
+                return 255; /* unusable address: runOutput() == -1 (output.c:278-279) */
+            return run_multi(&mcfg, devs, ndev, files, nfiles, outformat, timing);
+        }
+        device = devs[0];
+        ndev = 0;
     }
     if (device >= 0) {
         restrict_visible_devices(&device, 1);
@@ -438,8 +501,18 @@ int main(int argc, char **argv)
 
     /* -s / -l: the peer first (output.c:277-285: no peer, no packets; an unusable address ends the run with
      * runOutput() == -1).  The file is being read meanwhile. */
-    if (sink_wait_peer(&out_sink) != 0)
-        return 255;
+    {
+        const int prc = sink_wait_peer(&out_sink);
+        if (prc == 2) { /* told to end before a peer came */
+            adsb_stats z;
+            memset(&z, 0, sizeof z);
+            print_stats(&z);
+            fflush(stderr);
+            _exit(0);
+        }
+        if (prc != 0)
+            return 255;
+    }
 
     adsb_config cfg;
     adsb_config_default(&cfg);
@@ -459,15 +532,21 @@ int main(int argc, char **argv)
     rg.use_register = use_register;
     if (have_reader && pthread_create(&locker, NULL, locker_main, &rg) != 0)
         have_reader = 0;
+    int stopped = 0;
     if (have_reader) {
         int prev = -1;
         for (int k = 0;; k++) {
             ring_slot *s = &rg.slot[k % rg.nbuf];
             pthread_mutex_lock(&rg.mu);
-            while (!s->ready)
-                pthread_cond_wait(&rg.cv, &rg.mu);
+            while (!s->ready && !stop_requested)
+                cond_wait_tick(&rg.cv, &rg.mu);
             const int reader_failed = rg.failed; /* (written under the mutex by the reader) */
+            const int is_ready = s->ready;
             pthread_mutex_unlock(&rg.mu);
+            if (stop_requested && !is_ready) {
+                stopped = 1; /* SIGINT / SIGTERM / SIGQUIT: no more pushes; what is in the decoder is finished below */
+                break;
+            }
             if (reader_failed) {
                 fprintf(stderr, "out of memory for the read buffers\n");
                 rc = 255;
@@ -497,6 +576,10 @@ int main(int argc, char **argv)
             prev = k % rg.nbuf;
             if (bytes < (size_t)BUF_SAMPLES * 2)
                 break; /* that was the last buffer */
+            if (stop_requested) {
+                stopped = 1;
+                break;
+            }
         }
         if (rc == 0 && adsb_finish(dec) != 0) {
             fprintf(stderr, "adsb_finish() failed: %s\n", adsb_last_error(dec));
@@ -504,8 +587,9 @@ int main(int argc, char **argv)
         }
         if (flush_frames(dec, outformat) != 0 && rc == 0)
             rc = 1;
-        sink_close(&out_sink);
-        if (rc != 0) { /* let the reader run out: hand every buffer back */
+        if (sink_close(&out_sink) != 0 && rc == 0)
+            rc = 1; /* the last block did not reach the file (ENOSPC, EIO, a closed pipe) */
+        if (rc != 0 || stopped) { /* let the reader run out: hand every buffer back */
             pthread_mutex_lock(&rg.mu);
             for (int i = 0; i < rg.nbuf; i++)
                 rg.slot[i].ready = rg.slot[i].filled = 0;
@@ -513,7 +597,7 @@ int main(int argc, char **argv)
             pthread_mutex_unlock(&rg.mu);
             close(rg.fd); /* read() fails from here on */
         }
-        if (rc == 0) { /* (after a failure the threads are left to the process exit) */
+        if (rc == 0 && !stopped) { /* (after a failure or a signal the threads are left to the process exit) */
             pthread_join(reader, NULL);
             pthread_join(locker, NULL);
             close(rg.fd);

@@ -112,10 +112,12 @@ int sink_establish(sink *s)
 int sink_wait_peer(sink *s)
 {
     while (s->mode != SINK_STDOUT && s->fd < 0) {
-        const int rc = sink_establish(s);
+        if (s->stop && *s->stop)
+            return 2;
+        const int rc = sink_establish(s); /* (a signal interrupts accept() / connect(): no SA_RESTART, like main.c:91-96) */
         if (rc < 0)
             return -1;
-        if (rc > 0)
+        if (rc > 0 && !(s->stop && *s->stop))
             sleep(s->retry_s);
     }
     return 0;
@@ -132,8 +134,11 @@ int sink_write(sink *s, const char *buf, size_t len, unsigned long packets)
          * connecting sink makes one attempt per batch and drops the batch without a peer, and a listening sink does
          * not listen again: the rest of the run's packets are dropped. */
         int rc;
-        if (!s->had_peer)
+        if (!s->had_peer) {
             rc = sink_wait_peer(s);
+            if (rc == 2)
+                rc = 1; /* told to end while waiting for the first peer: the batch goes nowhere */
+        }
         else if (s->mode == SINK_CONNECT)
             rc = sink_establish(s);
         else
@@ -161,12 +166,13 @@ int sink_write(sink *s, const char *buf, size_t len, unsigned long packets)
     return 0;
 }
 
-void sink_close(sink *s)
+int sink_close(sink *s)
 {
-    if (s->mode == SINK_STDOUT) {
-        fflush(stdout);
-    } else if (s->fd >= 0) {
+    if (s->mode == SINK_STDOUT) /* the last block only reaches the file now: ENOSPC / EIO / EPIPE show up here */
+        return (fflush(stdout) != 0 || ferror(stdout)) ? -1 : 0;
+    if (s->fd >= 0) {
         close(s->fd);
         s->fd = -1;
     }
+    return 0;
 }

@@ -1659,18 +1659,22 @@ int adsb_sync(adsb_decoder *d)
     return 0;
 }
 
-int adsb_device_cpulist(int device, char *out, size_t cap)
+// "0000:c1:00.0" of HIP device `device`, as sysfs spells it (lower case); false: the runtime does not say
+static bool device_bdf(int device, char (&bdf)[64])
 {
-    if (!out || cap < 2)
-        return -1;
-    out[0] = 0;
-    char bdf[64];
     if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess)
-        return -1;
-    for (char *c = bdf; *c; c++) // sysfs spells the address in lower case
+        return false;
+    for (char *c = bdf; *c; c++)
         if (*c >= 'A' && *c <= 'F')
             *c = (char)(*c - 'A' + 'a');
-    char path[160];
+    return true;
+}
+
+int adsb_device_numa_node(int device)
+{
+    char bdf[64], path[160];
+    if (!device_bdf(device, bdf))
+        return -1;
     snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
     FILE *f = fopen(path, "r");
     int node = -1;
@@ -1679,10 +1683,22 @@ int adsb_device_cpulist(int device, char *out, size_t cap)
             node = -1;
         fclose(f);
     }
-    if (node < 0)
+    return node;
+}
+
+int adsb_device_cpulist(int device, char *out, size_t cap)
+{
+    if (!out || cap < 2)
+        return -1;
+    out[0] = 0;
+    char bdf[64];
+    if (!device_bdf(device, bdf))
+        return -1;
+    char path[160];
+    if (adsb_device_numa_node(device) < 0)
         return 0;
     snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
-    f = fopen(path, "r");
+    FILE *f = fopen(path, "r");
     if (!f)
         return 0;
     const bool got = fgets(out, (int)cap, f) != nullptr;
@@ -1717,7 +1733,7 @@ void *adsb_host_alloc(size_t bytes)
 
 void adsb_host_free(void *p)
 {
-    if (p)
+    if (p && !adsb_host_release_mapped(p)) // (adsb_host_alloc_on / adsb_multi_host_alloc: a mapping of numa.cpp's)
         (void)hipHostFree(p);
 }
 

@@ -57,7 +57,10 @@ struct HandCursor {
     double wait_ms = 0;
     clk::time_point t_last_wait;
     uint32_t streak = 0; // tiles taken in a row without having to wait for the device
-    static constexpr uint32_t kPrefetchAfter = 8, kPrefetchGranules = 96; // (1.5 KB ahead: beyond what the stream prefetcher holds)
+#ifndef ADSB_PREFETCH_AFTER
+#define ADSB_PREFETCH_AFTER 8 // (A/B builds override it; a huge value turns the prefetch off)
+#endif
+    static constexpr uint32_t kPrefetchAfter = ADSB_PREFETCH_AFTER, kPrefetchGranules = 96; // (1.5 KB ahead: beyond what the stream prefetcher holds)
 
     HandCursor(const HandJob &job, uint32_t *ts, uint32_t *tc)
         : s(job), t_start(ts), t_count(tc), gen(job.gen), cap(job.cap), t_last_wait(clk::now())

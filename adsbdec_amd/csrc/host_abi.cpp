@@ -57,6 +57,11 @@ int adsb_stitch_shards_stats(const adsb_shard_part *parts, int n_parts, uint64_t
     return adsb::stitch_shards(parts, n_parts, total_samples, fix, new_frames, new_cap, n_new_total, walk_stats, stats);
 }
 
+int adsb_shard_layout_check(size_t sizeof_shard_head, size_t sizeof_shard_part)
+{
+    return sizeof_shard_head == sizeof(adsb_shard_head) && sizeof_shard_part == sizeof(adsb_shard_part) ? 0 : -1;
+}
+
 size_t adsb_shard_walk(adsb_shard_head *head, const adsb_frame *frames, uint64_t total_samples, uint64_t *bases, size_t cap)
 {
     if (!head || (head->n_frames && !frames) || (cap && !bases))

@@ -120,6 +120,12 @@ struct Worker {
     std::atomic<uint64_t> beat{0}; // signs of life inside a job (one per piece pushed, window scanned, stream ended): what the
                                    // caller's deadline watches (wait_done)
     bool orphaned = false;         // (under mu) the driver gave this worker up: it cleans up after itself and ends
+    // where the worker's slice of the last host-resident capture lives (adsb_multi_worker_placement); asked of the kernel
+    // once per slice, not per decode
+    int device_node = -1, slice_node = -1;
+    double local_fraction = 0;
+    const void *placed_ptr = nullptr;
+    uint64_t placed_bytes = 0;
     Job job;
     // result of the last job
     int rc = 0;
@@ -318,6 +324,20 @@ void run_shard(Worker &w, const Job &j, uint64_t piece)
             return;
         }
     } else {
+    if (j.src.mem) { // which socket does this link pull its slice from?  (a move_pages query of 256 pages, once per slice)
+        const void *sp = j.src.mem + j.first;
+        if (sp != w.placed_ptr || 2 * j.n != w.placed_bytes) {
+            w.placed_ptr = sp;
+            w.placed_bytes = 2 * j.n;
+            w.slice_node = -1;
+            w.local_fraction = 0;
+            (void)adsb_host_placement(sp, (size_t)(2 * j.n), w.device_node, &w.slice_node, &w.local_fraction);
+        }
+    } else {
+        w.placed_ptr = nullptr;
+        w.slice_node = -1;
+        w.local_fraction = 0;
+    }
     if (adsb_shard_begin(w.dec, j.first, j.g_begin, j.g_end, j.total, w.bases.data(), w.bases.size())) {
         w.fail_dec("adsb_shard_begin");
         return;
@@ -425,6 +445,7 @@ void worker_main(Worker *w, uint64_t piece)
         cfg.device = w->device;
         cfg.stream = nullptr;
         w->bound = bind_near_device(w->device); // first: the handle's page-locked buffers are then allocated from this thread's node
+        w->device_node = adsb_device_numa_node(w->device);
         w->dec = adsb_create(&cfg);
         if (!w->dec)
             w->fail_dec("adsb_create");
@@ -560,8 +581,8 @@ long whole_stream(adsb_multi *m, const Source &src, uint64_t total)
     return (long)m->out.size();
 }
 
-long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices, int n_slices, uint64_t total,
-                    const adsb_frame **frames)
+long decode_sharded_impl(adsb_multi *m, const Source &src, const void *const *slices, int n_slices, uint64_t total,
+                         const adsb_frame **frames)
 {
     if (m->broken)
         return m->fail("this adsb_multi handle is unusable: a worker stopped answering earlier (destroy it)");
@@ -636,9 +657,13 @@ long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices,
         rc = stats ? adsb_stitch_shards_stats(parts.data(), n, total, fix.data(), m->new_frames.data(), m->new_frames.size(), &n_new,
                                               ws, &m->stats)
                    : adsb_stitch_shards_ex(parts.data(), n, total, fix.data(), m->new_frames.data(), m->new_frames.size(), &n_new, ws);
-        if (rc != -1 || m->new_frames.size() >= (1u << 22))
+        if (rc != -2 || m->new_frames.size() >= (1u << 22))
             break;
-        m->new_frames.resize(m->new_frames.size() * 8); // (-1 is also "new_cap too small": seams that accept many frames)
+        m->new_frames.resize(std::max(m->new_frames.size() * 4, n_new + 4096)); // new_cap too small: seams that accept many frames
+    }
+    if (rc != 0 && m->new_frames.size() > (1u << 16)) { // (a failure does not leave a grown buffer behind in the handle)
+        m->new_frames.resize(4096);
+        m->new_frames.shrink_to_fit();
     }
     m->info.shards = n;
     for (int i = 0; i < n; i++)
@@ -699,7 +724,7 @@ long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices,
     return (long)count;
 }
 
-int decode_streams(adsb_multi *m, const std::vector<Source> &src, const std::vector<uint64_t> &n)
+int decode_streams_impl(adsb_multi *m, const std::vector<Source> &src, const std::vector<uint64_t> &n)
 {
     if (m->broken)
         return (int)m->fail("this adsb_multi handle is unusable: a worker stopped answering earlier (destroy it)");
@@ -733,6 +758,27 @@ int decode_streams(adsb_multi *m, const std::vector<Source> &src, const std::vec
     return 0;
 }
 
+// No exception crosses the C ABI: a bad_alloc of a plan, gather or result vector (a dense 2 Gi-sample capture gathers
+// millions of frames) ends the call with -1 and a message.  Every allocation of the two functions lies outside the
+// windows in which a worker runs a job that points into the caller's frame, so returning from the catch is safe.
+long decode_sharded(adsb_multi *m, const Source &src, const void *const *slices, int n_slices, uint64_t total,
+                    const adsb_frame **frames)
+{
+    try {
+        return decode_sharded_impl(m, src, slices, n_slices, total, frames);
+    } catch (const std::exception &e) {
+        return m->fail("adsb_multi decode: %s (out of memory?)", e.what());
+    }
+}
+int decode_streams(adsb_multi *m, const std::vector<Source> &src, const std::vector<uint64_t> &n)
+{
+    try {
+        return decode_streams_impl(m, src, n);
+    } catch (const std::exception &e) {
+        return (int)m->fail("adsb_multi decode of independent streams: %s (out of memory?)", e.what());
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -760,16 +806,29 @@ adsb_multi *adsb_multi_create(const adsb_config *cfg_in, int n_devices, const in
     }
     if (m->cfg.stage_samples) // a piece must fit the staging buffer beside the tail it keeps
         m->piece_samples = std::max<uint64_t>(1u << 15, std::min<uint64_t>(kPieceSamples, m->cfg.stage_samples / 2));
-    for (int i = 0; i < n_devices; i++) {
-        std::unique_ptr<Worker> w(new Worker());
-        w->index = i;
-        w->device = devices ? devices[i] : i;
-        w->cfg = m->cfg;
-        w->piece = m->piece_samples;
-        m->w.push_back(std::move(w));
+    try {
+        for (int i = 0; i < n_devices; i++) {
+            std::unique_ptr<Worker> w(new Worker());
+            w->index = i;
+            w->device = devices ? devices[i] : i;
+            w->cfg = m->cfg;
+            w->piece = m->piece_samples;
+            m->w.push_back(std::move(w));
+        }
+        for (auto &w : m->w)
+            w->th = std::thread(worker_main, w.get(), m->piece_samples);
+    } catch (const std::exception &e) { // no memory for a worker, no thread to be had: the ones that started wait for their first job
+        g_multi_create_error = std::string("adsb_multi_create: ") + e.what();
+        for (auto &w : m->w)
+            if (w->th.joinable()) {
+                std::unique_lock<std::mutex> lk(w->mu);
+                w->cv.wait(lk, [&] { return w->done >= 1; });
+                w->posted = 1;
+                w->posted_a.store(1, std::memory_order_release);
+            }
+        adsb_multi_destroy(m);
+        return nullptr;
     }
-    for (auto &w : m->w)
-        w->th = std::thread(worker_main, w.get(), m->piece_samples);
     bool ok = true;
     for (auto &w : m->w) {
         std::unique_lock<std::mutex> lk(w->mu);
@@ -842,12 +901,16 @@ int adsb_multi_plan(const adsb_multi *m, uint64_t total_samples, uint64_t *g_beg
 {
     if (!m || !g_begin || !g_end || !first_sample || !n_samples)
         return -1;
-    std::vector<uint64_t> p[4];
-    const int n = plan((int)m->w.size(), total_samples, p);
-    uint64_t *dst[4] = {g_begin, g_end, first_sample, n_samples};
-    for (int k = 0; k < 4; k++)
-        std::memcpy(dst[k], p[k].data(), (size_t)n * sizeof(uint64_t));
-    return n;
+    try {
+        std::vector<uint64_t> p[4];
+        const int n = plan((int)m->w.size(), total_samples, p);
+        uint64_t *dst[4] = {g_begin, g_end, first_sample, n_samples};
+        for (int k = 0; k < 4; k++)
+            std::memcpy(dst[k], p[k].data(), (size_t)n * sizeof(uint64_t));
+        return n;
+    } catch (const std::exception &) {
+        return -1;
+    }
 }
 
 long adsb_multi_decode_host(adsb_multi *m, const uint16_t *samples, size_t n, const adsb_frame **frames)
@@ -895,8 +958,14 @@ int adsb_multi_decode_streams_host(adsb_multi *m, int n_streams, const uint16_t 
 {
     if (!m || n_streams <= 0 || !samples || !n)
         return -1;
-    std::vector<Source> src((size_t)n_streams);
-    std::vector<uint64_t> len((size_t)n_streams);
+    std::vector<Source> src;
+    std::vector<uint64_t> len;
+    try {
+        src.resize((size_t)n_streams);
+        len.resize((size_t)n_streams);
+    } catch (const std::exception &e) {
+        return (int)m->fail("adsb_multi_decode_streams_host: %s", e.what());
+    }
     for (int s = 0; s < n_streams; s++) {
         if (n[s] && !samples[s])
             return (int)m->fail("adsb_multi_decode_streams_host: stream %d is NULL", s);
@@ -911,8 +980,14 @@ int adsb_multi_decode_streams_file(adsb_multi *m, int n_streams, const char *con
 {
     if (!m || n_streams <= 0 || !paths)
         return -1;
-    std::vector<Source> src((size_t)n_streams);
-    std::vector<uint64_t> len((size_t)n_streams);
+    std::vector<Source> src;
+    std::vector<uint64_t> len;
+    try {
+        src.resize((size_t)n_streams);
+        len.resize((size_t)n_streams);
+    } catch (const std::exception &e) {
+        return (int)m->fail("adsb_multi_decode_streams_file: %s", e.what());
+    }
     int rc = 0;
     for (int s = 0; s < n_streams && rc == 0; s++) {
         struct stat sb;
@@ -944,6 +1019,39 @@ int adsb_multi_stream_stats(const adsb_multi *m, int stream, adsb_stats *out)
     if (!m || !out || stream < 0 || (size_t)stream >= m->streams.size() || m->streams[stream].rc)
         return -1;
     *out = m->streams[stream].stats;
+    return 0;
+}
+
+uint16_t *adsb_multi_host_alloc(adsb_multi *m, uint64_t total_samples)
+{
+    if (!m)
+        return nullptr;
+    try {
+        std::vector<uint64_t> p[4];
+        const int n = plan((int)m->w.size(), total_samples, p);
+        std::vector<int> devs((size_t)n);
+        for (int i = 0; i < n; i++)
+            devs[(size_t)i] = m->w[(size_t)i]->device;
+        uint16_t *x = adsb_host_alloc_sharded(total_samples, n, p[2].data(), p[3].data(), devs.data());
+        if (!x)
+            m->fail("adsb_multi_host_alloc: cannot map and page-lock %llu bytes", (unsigned long long)(2 * total_samples));
+        return x;
+    } catch (const std::exception &e) {
+        m->fail("adsb_multi_host_alloc: %s", e.what());
+        return nullptr;
+    }
+}
+
+int adsb_multi_worker_placement(const adsb_multi *m, int worker, adsb_worker_placement *out)
+{
+    if (!m || !out || worker < 0 || (size_t)worker >= m->w.size())
+        return -1;
+    const Worker &w = *m->w[(size_t)worker];
+    out->device = w.device;
+    out->device_node = w.device_node;
+    out->thread_bound = w.bound ? 1 : 0;
+    out->slice_node = w.slice_node;
+    out->local_fraction = w.local_fraction;
     return 0;
 }
 

@@ -15,15 +15,63 @@
 // queues are flat vectors with a head index, and records are consumed in place.
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <utility>
 #include <vector>
 
 #include "../../include/adsbdec_amd.h"
 #include "scan_kernel_format.h"
 
+#ifndef ADSB_RESOLVE_PREFETCH
+#define ADSB_RESOLVE_PREFETCH 0 // records ahead that run_call_tiles asks for (tools/hostpath_bench.cpp measures it)
+#endif
+
 namespace adsb {
+
+// The accepted frames: a flat array of PODs whose slots are handed out uninitialised (a std::vector value-initialises 40
+// bytes per emplace_back and checks its capacity per frame: at the channel's capacity the resolver emits 100 k frames per
+// launch and every nanosecond per frame is a tenth of the kernel's time).
+class FrameVec {
+public:
+    FrameVec() = default;
+    FrameVec(const FrameVec &) = delete;
+    FrameVec &operator=(const FrameVec &) = delete;
+    ~FrameVec() { std::free(p_); }
+    size_t size() const { return n_; }
+    adsb_frame *data() { return p_; }
+    const adsb_frame *data() const { return p_; }
+    void clear() { n_ = 0; }
+    // room for `more` frames behind the ones that are there; the pointer to the first free slot
+    adsb_frame *room(size_t more)
+    {
+        if (n_ + more > cap_) {
+            size_t cap = cap_ ? cap_ : 1024;
+            while (cap < n_ + more)
+                cap *= 2;
+            void *q = std::realloc(p_, cap * sizeof(adsb_frame));
+            if (!q)
+                throw std::bad_alloc();
+            p_ = static_cast<adsb_frame *>(q);
+            cap_ = cap;
+        }
+        return p_ + n_;
+    }
+    void grew(size_t k) { n_ += k; } // k slots behind room()'s pointer have been filled
+    adsb_frame &push()
+    {
+        adsb_frame *f = room(1);
+        n_++;
+        return *f;
+    }
+
+private:
+    adsb_frame *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
 
 class Resolver {
 public:
@@ -440,9 +488,120 @@ private:
         batch_ = Batch{};
     }
 
+    // run_call for the usual case -- nothing waiting in the queue, the candidates come from the tile ranges of a hand-off
+    // stream where they lie -- as one tight loop: at the channel's capacity (BASELINE configs[2]: 106 k accepted frames per
+    // 256 Mi-sample launch) the general loop below cost 8 ns per accepted frame, four times the kernel's share.  Same rules,
+    // same order of side effects; the dependent chain per frame is idx -> which copy of the record -> idx + span.
+    void run_call_tiles(uint64_t limit)
+    {
+        // Everything the loop touches lives in locals (the stores of a frame are plain uint64_t stores: with the cursor, the
+        // output size and the counters in members the compiler has to reload and store them around every frame -- 90
+        // instructions per frame, 22 cycles; so: 40).
+        Batch &b = batch_;
+        const uint32_t *cur = b.cur;
+        uint32_t left = b.left, copies = b.copies, u = b.u;
+        const uint32_t *const recs = b.recs, *const starts = b.starts, *const counts = b.counts;
+        const uint32_t u_end = b.u_end;
+        const uint64_t g_base = b.g_base;
+        const bool tries = thead_ < tries_.size(), walk = w_on_ && !w_stop_, log = log_on_;
+        uint64_t idx = base_, skipped = skipped_;
+        uint64_t ok[3] = {0, 0, 0}, fixed_n = 0;
+        size_t room = 256, made = 0;
+        uint64_t *f = reinterpret_cast<uint64_t *>(out_.room(room));
+        auto next_record = [&]() {
+            if (--left) {
+                cur += 8; // two granules per record
+            } else {
+                cur = nullptr;
+                for (u++; u < u_end; u++)
+                    if (counts[u]) {
+                        left = counts[u];
+                        cur = recs + (size_t)starts[u] * 4;
+                        break;
+                    }
+                if (!cur)
+                    return;
+            }
+            copies = rec_copies(cur);
+        };
+        while (cur) {
+            const uint32_t *r = cur;
+            const uint64_t g0 = g_base + r[0];
+            if (g0 + copies <= idx) { // every offset of the record lies inside an accepted frame: never evaluated
+                next_record();
+                continue;
+            }
+            const uint32_t sub = idx > g0 ? (uint32_t)(idx - g0) : 0u; // the first of its offsets the scan can visit
+            const uint64_t g = g0 + sub;
+            if (g >= limit)
+                break;
+            if (tries)
+                count_tries(idx, g);
+            if (made == room) {
+                out_.grew(made);
+                made = 0;
+                f = reinterpret_cast<uint64_t *>(out_.room(room = 4096));
+            }
+            // the frame leaves as five aligned 8-byte stores: {g}{ts}{pw, len, bytes 0..2}{bytes 3..10}{bytes 11..13, reserved, 0}
+            // (the record holds the 14 bytes in w0..w3, the length and the flags behind them: scan_kernel_format.h)
+            static_assert(sizeof(adsb_frame) == 40 && offsetof(adsb_frame, pw) == 16 && offsetof(adsb_frame, len) == 20 &&
+                              offsetof(adsb_frame, frame) == 21 && offsetof(adsb_frame, reserved) == 35,
+                          "adsb_frame layout");
+            const uint32_t w0 = r[2], w1 = r[3], w2 = r[4], w3 = r[5];
+            const uint32_t len = (w3 >> 16) & 0xFFu, fixed = (w3 >> 24) & 1u;
+            const uint32_t pw = sub ? r[5 + sub] : r[1];
+            uint64_t *o = f + 5 * made++;
+            o[0] = g;
+            o[1] = g + 1 - skipped; // demod.c:99: one ts++ per visited offset
+            o[2] = (uint64_t)pw | (uint64_t)len << 32 | (uint64_t)(w0 & 0xFFFFFFu) << 40;
+            o[3] = (uint64_t)(w0 >> 24) | (uint64_t)w1 << 8 | (uint64_t)(w2 & 0xFFFFFFu) << 40;
+            o[4] = (uint64_t)(w2 >> 24) | (uint64_t)(w3 & 0xFFFFu) << 8 | (uint64_t)fixed << 24; // (tail padding zero: frames are compared and copied as bytes)
+            const uint64_t span = 80 + 80 * (uint64_t)len; // demod.c:109,120,123: lidx
+            const uint32_t df = (w0 & 0xFFu) >> 3;
+            ok[df == 11 ? 0 : df == 17 ? 1 : 2]++;
+            fixed_n += fixed;
+            skipped += span - 1;
+            if (walk)
+                w_acc_.emplace_back(g, g + span);
+            if (log) {
+                if (ext_n_ < ext_cap_ && log_.empty())
+                    ext_[ext_n_++] = LogEntry{g, (uint32_t)span, 0};
+                else
+                    log_.emplace_back(g, (uint32_t)span);
+            }
+            idx = g + span; // demod.c:128,134 -- the record's other offsets lie inside this frame
+            next_record();
+#if ADSB_RESOLVE_PREFETCH > 0
+            __builtin_prefetch(r + 8 * ADSB_RESOLVE_PREFETCH); // the records lie in another core's cache (the reader's) or in DRAM
+#endif
+            if (idx >= limit)
+                break;
+        }
+        out_.grew(made);
+        b.cur = cur;
+        b.left = left;
+        b.copies = copies;
+        b.u = u;
+        b.sub = 0;
+        skipped_ = skipped;
+        for (int k = 0; k < 3; k++)
+            stats_.ok[k] += ok[k];
+        stats_.fixed += fixed_n;
+        if (idx < limit) { // no candidate left below the limit: all remaining offsets advance by one (demod.c:141)
+            if (tries)
+                count_tries(idx, limit - 1);
+            idx = limit;
+        }
+        base_ = idx; // deqframe's return value; air.c:96-98 carries the rest
+    }
+
     // One deqframe(ampbuff, len) call: visits offsets from base_ while < limit.
     void run_call(uint64_t limit)
     {
+        if (chead_ == cands_.size() && !batch_.order && batch_.starts) {
+            run_call_tiles(limit);
+            return;
+        }
         uint64_t idx = base_;
         while (idx < limit) {
             // next candidate at or after idx: the queue first, then the in-place batch
@@ -463,8 +622,8 @@ private:
                 break;
             }
             count_tries(idx, g);
-            out_.emplace_back();
-            adsb_frame &f = out_.back();
+            adsb_frame &f = out_.push();
+            std::memset(reinterpret_cast<char *>(&f) + 32, 0, 8); // (the struct's tail padding: frames are compared and copied as bytes)
             f.g = g;
             f.ts = g + 1 - skipped_; // demod.c:99: one ts++ per visited offset
             if (from_queue) {
@@ -518,7 +677,7 @@ private:
     size_t ext_cap_ = 0, ext_n_ = 0;
     std::vector<uint64_t> tries_;
     size_t thead_ = 0;
-    std::vector<adsb_frame> out_;
+    FrameVec out_;
     size_t ohead_ = 0;
     adsb_stats stats_{};
 };

@@ -112,8 +112,10 @@ inline int stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t tot
                     // (speculative frames in [idx, c.g) cannot exist: they would be head candidates themselves)
                     if (fi < nF && F[fi].g == c.g)
                         break; // the speculative chain accepted it as well: same chain from here on
-                    if (n_new >= new_cap)
-                        return -1;
+                    if (n_new >= new_cap) {
+                        *n_new_total = n_new + 1; // (at least: the caller grows new_frames and calls again)
+                        return -2;
+                    }
                     adsb_frame &f = new_frames[n_new++];
                     std::memset(&f, 0, sizeof f);
                     f.g = c.g;

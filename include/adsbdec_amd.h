@@ -41,7 +41,12 @@ extern "C" {
  * built against a shorter adsb_config keeps working (the members it does not know default to 0).
  * 3: `push_overlap` took the place of ABI 2's `reserved0`; it is only honoured when struct_size covers `host_threads`
  *    (a caller built against ABI 2 that left garbage in reserved0 keeps ABI 2's behaviour).
- * 4: adsb_shard_head / adsb_shard_part carry the statistics of a resolved shard (round 4). */
+ * 4: adsb_shard_head / adsb_shard_part carry the statistics of a resolved shard (round 4): adsb_shard_head grew from 80 to
+ *    144 bytes and adsb_shard_part by four members, and the library fills / reads all of them -- a binary built against
+ *    ABI 3 that calls the shard API (adsb_scan_shard_resolved*, adsb_shard_end, adsb_stitch_shards*) MUST be rebuilt; it
+ *    can find out at run time: adsb_shard_layout_check(sizeof(adsb_shard_head), sizeof(adsb_shard_part)) != 0.  The
+ *    streaming API (adsb_create / adsb_push* / adsb_drain ...) and adsb_multi_* are unaffected.
+ *    adsb_stitch_shards* answer -2 (not -1) when new_cap is too small (round 5). */
 #define ADSB_ABI_VERSION 4
 
 /* Constants of the path (adsbdec.h:1-3, air.c:32,47). */
@@ -373,8 +378,12 @@ int adsb_scan_shard_resolved_take(adsb_decoder *d, const void *device_samples, u
                                   const adsb_frame **frames, const adsb_candidate **head_cands, uint64_t *bases, size_t bases_cap);
 /* A shard's own walk of the deqframe call chain over its speculative frames (each rank, in parallel, after its scan):
  * fills bases[0 .. min(cap, n)) and head->n_bases / walk_final; returns n (> cap: too small, n_bases is left 0). */
+/* 0 when the caller's adsb_shard_head / adsb_shard_part have the size this library writes and reads (see ADSB_ABI_VERSION 4);
+ * -1 otherwise: the caller was built against another layout and must not call the shard API. */
+int adsb_shard_layout_check(size_t sizeof_shard_head, size_t sizeof_shard_part);
 size_t adsb_shard_walk(adsb_shard_head *head, const adsb_frame *frames, uint64_t total_samples, uint64_t *bases, size_t cap);
-/* The serial part, on one rank: parts in shard order.  0; -1 on bad arguments or new_cap too small; -3 when a seam cannot
+/* The serial part, on one rank: parts in shard order.  0; -1 on bad arguments (or inconsistent statistics input); -2 when
+ * new_cap is too small (*n_new_total = a lower bound of what is needed: grow new_frames and call again); -3 when a seam cannot
  * be decided from the head candidates (dense overlapping frames through a whole head window): fall back to
  * adsb_scan_shard + adsb_resolver_*. */
 int adsb_stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
@@ -424,6 +433,27 @@ uint64_t adsb_resolver_skipped(const adsb_resolver *r);
  * own does the same for the thread that calls adsb_push*.  Returns the string's length, 0 when the platform does not say
  * (numa_node = -1), -1 on error. */
 int adsb_device_cpulist(int device, char *out, size_t cap);
+/* The NUMA node HIP device `device` hangs off (/sys/bus/pci/devices/<bdf>/numa_node); -1 when the platform does not say. */
+int adsb_device_numa_node(int device);
+
+/* ---- where a host-resident capture lives (csrc/numa.cpp) ---------------------------------------------------------------
+ * Stands where the reference has `iqbuff = malloc(...)` (air.c:230).  A capture in host memory that eight devices pull at
+ * once, each over its own link, should have every slice on the socket its device hangs off: a slice on the other socket
+ * crosses the socket fabric, which four of the eight links then share.
+ * adsb_host_alloc_on: page-locked memory (2 MiB-aligned, huge pages advised) bound to the node of `device` with mbind(),
+ *   first-touched there, then registered with the runtime.  Best effort: where there is one node, or the policy call is
+ *   refused, the memory is page-locked where the kernel put it.  NULL when it cannot be mapped or page-locked.
+ * adsb_host_alloc_sharded: ONE array of total_samples samples for a capture that will be decoded in shards (first_sample /
+ *   n_samples as adsb_plan_shards / adsb_multi_plan give them), shard i's part on the node of devices[i]; the boundary
+ *   between two nodes lies where the next shard starts, rounded to a huge page.
+ * Both are freed with adsb_host_free.
+ * adsb_host_placement: on which node do the pages of [p, p + bytes) live?  Samples up to 256 pages with move_pages():
+ *   *major_node = the node most of them are on, *fraction_on_want = the share on want_node.  -1 when the kernel does not say. */
+void *adsb_host_alloc_on(size_t bytes, int device);
+uint16_t *adsb_host_alloc_sharded(uint64_t total_samples, int n_shards, const uint64_t *first_sample, const uint64_t *n_samples,
+                                  const int *devices);
+int adsb_host_placement(const void *p, size_t bytes, int want_node, int *major_node, double *fraction_on_want);
+int adsb_host_release_mapped(void *p); /* adsb_host_free's first look (1: p was a mapping of the two calls above and is gone) */
 
 /* ---- ONE process, several GPUs (csrc/multi.cpp) ---------------------------------------------------------------
  * The host of BASELINE configs[3] / configs[4]: a worker thread and a decoder handle per device; no collective on the
@@ -483,6 +513,19 @@ long adsb_multi_stream_frames(const adsb_multi *m, int stream, const adsb_frame 
 int adsb_multi_stream_stats(const adsb_multi *m, int stream, adsb_stats *out);
 
 int adsb_multi_get_info(const adsb_multi *m, adsb_multi_info *out);
+/* A page-locked array for ONE capture of total_samples samples that adsb_multi_decode_host will decode: laid out with
+ * adsb_host_alloc_sharded over m's own plan and devices, so that every worker pulls its slice from its own socket.  Free
+ * with adsb_host_free.  adsb_multi_worker_placement says, per worker, whether that held for the last host-fed decode. */
+uint16_t *adsb_multi_host_alloc(adsb_multi *m, uint64_t total_samples);
+typedef struct adsb_worker_placement {
+    int32_t device, device_node; /* the worker's HIP device and its NUMA node (-1: the platform does not say)            */
+    int32_t thread_bound;        /* the worker's thread runs on the CPUs of that node                                    */
+    int32_t slice_node;          /* the node most pages of the worker's slice of the last adsb_multi_decode_host capture
+                                    live on; -1: not a host source, or the kernel does not say                           */
+    double local_fraction;       /* share of the sampled pages of that slice on device_node (1.0 = the link is fed from
+                                    its own socket)                                                                      */
+} adsb_worker_placement;
+int adsb_multi_worker_placement(const adsb_multi *m, int worker, adsb_worker_placement *out);
 /* adsb_get_profile of worker `worker`'s handle (launches, kernel time on the device clock with cfg.profile ...). */
 int adsb_multi_worker_profile(const adsb_multi *m, int worker, adsb_profile *out);
 /* Last error text of m, or of the last failed adsb_multi_create() when m == NULL; names the device and worker. */

@@ -26,6 +26,7 @@
 
 #include "../../adsbdec_amd/csrc/host_abi.cpp"
 #include "../../adsbdec_amd/csrc/multi.cpp"
+#include "../../adsbdec_amd/csrc/numa.cpp"
 
 // ---------------------------------------------------------------- the model: what a "scan" finds in a capture
 namespace fake {
@@ -141,7 +142,14 @@ adsb_decoder *adsb_create(const adsb_config *cfg)
 void adsb_destroy(adsb_decoder *d) { delete d; }
 const char *adsb_last_error(const adsb_decoder *d) { return d ? d->err.c_str() : fake::g_err.c_str(); }
 void *adsb_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
-void adsb_host_free(void *p) { free(p); }
+void adsb_host_free(void *p)
+{
+    if (!adsb_host_release_mapped(p)) // (numa.cpp's mappings, like the real adsb_host_free)
+        free(p);
+}
+int adsb_host_register(void *, size_t) { return 0; }
+int adsb_host_unregister(void *) { return 0; }
+int adsb_device_numa_node(int device) { return device % 2; } // a made-up two-socket machine: even devices on node 0, odd ones on node 1
 int adsb_device_cpulist(int, char *out, size_t cap)
 {
     if (cap)
@@ -412,7 +420,7 @@ int main(int argc, char **argv)
     if (tfd < 0)
         return 2;
     close(tfd);
-    int decodes = 0, shards = 0, fallbacks = 0;
+    int decodes = 0, shards = 0, fallbacks = 0, placements = 0;
     for (int round = 0; round < rounds; round++) {
         const bool stats = round % 2 == 0;
         const int workers = 1 + (int)(rng() % 7);
@@ -434,7 +442,34 @@ int main(int argc, char **argv)
             const adsb_frame *fp = nullptr;
             long n = -1;
             const int src = (round + rep) % 3;
-            if (src == 0) {
+            uint16_t *placed = nullptr;
+            if (src == 0 && rep == 0) {
+                // the capture in an array laid out shard by shard on the nodes of the devices that pull it (numa.cpp); this
+                // machine has one node, the made-up map two: mbind for node 1 is refused or not, the pages live on node 0
+                // either way, and the placement query must say so -- workers on even devices local, on odd devices remote
+                placed = adsb_multi_host_alloc(m, x.size());
+                if (!placed) {
+                    fprintf(stderr, "adsb_multi_host_alloc failed: %s\n", adsb_multi_last_error(m));
+                    return 1;
+                }
+                std::memcpy(placed, x.data(), x.size() * sizeof(uint16_t));
+                n = adsb_multi_decode_host(m, placed, x.size(), &fp);
+                adsb_multi_info inf;
+                adsb_multi_get_info(m, &inf);
+                for (int i = 0; n >= 0 && !inf.fallback && i < inf.shards; i++) {
+                    adsb_worker_placement pl;
+                    if (adsb_multi_worker_placement(m, i, &pl) != 0 || pl.device != devs[i] || pl.device_node != devs[i] % 2) {
+                        fprintf(stderr, "worker %d: placement of the wrong device\n", i);
+                        return 1;
+                    }
+                    if (pl.slice_node >= 0 && (pl.slice_node != 0 || pl.local_fraction != (pl.device_node == 0 ? 1.0 : 0.0))) {
+                        fprintf(stderr, "worker %d (device %d, node %d): slice on node %d, local fraction %.2f\n", i, pl.device, pl.device_node,
+                                pl.slice_node, pl.local_fraction);
+                        return 1;
+                    }
+                    placements += pl.slice_node >= 0;
+                }
+            } else if (src == 0) {
                 n = adsb_multi_decode_host(m, x.data(), x.size(), &fp);
             } else if (src == 1) {
                 FILE *f = fopen(path, "wb");
@@ -462,6 +497,8 @@ int main(int argc, char **argv)
             adsb_stats st;
             if (stats && (adsb_multi_get_stats(m, &st) != 0 || !same_stats(st, want.stats, what)))
                 return 1;
+            if (placed)
+                adsb_host_free(placed); // (the workers are done with it: the call has returned)
             adsb_multi_info inf;
             adsb_multi_get_info(m, &inf);
             decodes++;
@@ -552,6 +589,7 @@ int main(int argc, char **argv)
         std::this_thread::sleep_for(std::chrono::milliseconds(4500)); // the orphaned workers come back, free their handles and end
     }
     unlink(path);
-    printf("ok: %d sharded decodes (%d shards, %d fell back to one stream), streams and error paths\n", decodes, shards, fallbacks);
+    printf("ok: %d sharded decodes (%d shards, %d fell back to one stream), streams and error paths; %d slices asked where they live\n", decodes,
+           shards, fallbacks, placements);
     return 0;
 }

@@ -59,7 +59,11 @@ int main(int argc, char **argv)
         }
     }
     fclose(copy);
-    sink_close(&s);
+    const int close_rc = sink_close(&s);
+    if (close_rc != 0) {
+        fprintf(stderr, "the last block could not be written\n");
+        return 1; /* (the host program's status for a stdout that is gone) */
+    }
     fprintf(stderr, "batches sent %lu, lost %lu, packets dropped %llu\n", sent_batches, lost_batches, s.dropped);
     return 0;
 }

@@ -207,3 +207,52 @@ def test_the_host_program_refuses_unusable_addresses_before_it_touches_the_gpu(t
     assert p.returncode == 1 and b"usage" in p.stdout
     p = subprocess.run([capi.CLI_PATH, "-s"], capture_output=True, timeout=60)      # option without its argument
     assert p.returncode == 1
+
+
+# ---- the host program's signal behaviour (main.c:91-99), as far as it can be seen without a GPU ---------------------------
+CLI = os.path.join(ROOT, "adsbdec_amd", "lib", "adsbdec_amd_cli")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    from adsbdec_amd import _build
+    _build.build()
+    assert os.path.exists(CLI)
+    return CLI
+
+
+@pytest.mark.parametrize("extra", [[], ["-G", "1"]])
+@pytest.mark.parametrize("sig", ["SIGINT", "SIGTERM", "SIGQUIT"])
+def test_a_signal_while_waiting_for_a_peer_ends_the_run_with_the_table(cli, tmp_path, sig, extra):
+    """The reference sits in accept() (output.c:139) until a peer connects; SIGINT / SIGTERM / SIGQUIT (handlerExit,
+    main.c:91-96, no SA_RESTART) end runOutput() with 0 and main prints the Try/Ok table (main.c:103).  The peer is waited
+    for BEFORE the GPU runtime is started, so this much of the program runs anywhere."""
+    import signal
+    cap = tmp_path / "c.u16"
+    cap.write_bytes(bytes(4096))
+    port = _free_port()
+    p = subprocess.Popen([cli] + extra + ["-l", f"127.0.0.1:{port}", "-f", str(cap)], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    assert p.stderr.readline().strip() == "listening"
+    time.sleep(0.2)
+    p.send_signal(getattr(signal, sig))
+    out, err = p.communicate(timeout=20)
+    assert p.returncode == 0, (p.returncode, err)
+    lines = err.splitlines()
+    assert [ln.split(":")[0].strip() for ln in lines[-3:]] == ["Try", "Ok", "Total"], err
+    assert lines[-1].split()[-1] == "0" and out == ""
+
+
+def test_more_f_arguments_than_the_program_keeps_are_refused_not_dropped(cli, tmp_path):
+    args = []
+    for k in range(65):
+        args += ["-f", str(tmp_path / f"c{k}.u16")]
+    p = subprocess.run([cli, "-G", "2"] + args, capture_output=True, text=True, timeout=20)
+    assert p.returncode == 1 and "usage" in p.stdout
+
+
+def test_a_failed_last_flush_is_an_error_not_a_silent_truncation(harness):
+    """ENOSPC on the LAST buffered block only shows when stdout is flushed (sink_close): the status must say so."""
+    with open("/dev/full", "wb") as full:
+        few = subprocess.run([harness, "0", "x", "0", "10", "/dev/null"], stdout=full, stderr=subprocess.PIPE, timeout=60)
+        many = subprocess.run([harness, "0", "x", "0", "5000", "/dev/null"], stdout=full, stderr=subprocess.PIPE, timeout=60)
+    assert few.returncode != 0 and many.returncode != 0

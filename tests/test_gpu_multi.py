@@ -360,3 +360,78 @@ def test_bench_shard_mode_runs_the_c_driver(tmp_path):
         assert line["config"]["frames_decoded"] > 3000 and line["config"]["serial_us"] > 0
         if "--stats" in extra:
             assert sum(line["config"]["statistics"]["ok"].values()) == line["config"]["frames_decoded"]
+
+
+def test_cli_signals_and_a_closed_pipe(capi, oracle, tmp_path):
+    """main.c:91-99 on the -f path: SIGPIPE is ignored -- a reader of stdout that goes away makes the program end with status 1
+    and the Try/Ok table, not die by signal -- and SIGTERM in the middle of a capture (here: a FIFO that is being fed slowly)
+    ends the run in an orderly way: what was pushed is decoded and written (a prefix of the full output), the table is
+    printed, status 0."""
+    import signal
+    import threading
+    import time
+    from tools import gen_signal as G
+    x, _ = G.dense_capture((48 << 20) + 4, seed=611, sigma=25.0, n_frames=9000, amp=(150, 1800))
+    path = str(tmp_path / "cap.u16")
+    x.tofile(path)
+    full = subprocess.run([capi.CLI_PATH, "-a", "-f", path], capture_output=True, timeout=600)
+    assert full.returncode == 0 and full.stdout.count(b"\n") > 3000
+    # (1) the reader of stdout closes after the first bytes
+    p = subprocess.Popen([capi.CLI_PATH, "-a", "-f", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p.stdout.read(64)
+    p.stdout.close()
+    err = p.stderr.read().decode()
+    assert p.wait(120) == 1, (p.returncode, err)          # not -SIGPIPE
+    assert [ln.split(":")[0].strip() for ln in err.splitlines()[-3:]] == ["Try", "Ok", "Total"], err
+    # (2) SIGTERM while the capture is still arriving through a FIFO
+    fifo = str(tmp_path / "cap.fifo")
+    os.mkfifo(fifo)
+    raw = x.tobytes()
+    fed = {"n": 0}
+
+    def feed():
+        try:
+            with open(fifo, "wb", buffering=0) as w:
+                for at in range(0, len(raw), 4 << 20):
+                    w.write(raw[at:at + (4 << 20)])
+                    fed["n"] = at + (4 << 20)
+                    time.sleep(0.25)
+        except BrokenPipeError:
+            pass
+    p = subprocess.Popen([capi.CLI_PATH, "-a", "-f", fifo], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t = threading.Thread(target=feed, daemon=True)
+    t.start()
+    time.sleep(3.0)                                        # the runtime is up, some buffers have been read
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=120)
+    assert p.returncode == 0, (p.returncode, err)
+    err = err.decode()
+    assert [ln.split(":")[0].strip() for ln in err.splitlines()[-3:]] == ["Try", "Ok", "Total"], err
+    assert len(out) < len(full.stdout) and full.stdout.startswith(out[: out.rfind(b"\n", 0, max(0, len(out) - 4000)) + 1])
+    t.join(30)
+
+
+def test_cli_G_accepts_what_the_one_device_run_accepts(capi, oracle, tmp_path):
+    """-G with a single -f that is not a regular file (a FIFO: the reference reads pipes, air.c:224-239) streams it through one
+    device, same bytes as the plain run; a file that cannot be opened ends the run silently with an empty table and status
+    0 (air.c:225-228), with and without -G."""
+    import threading
+    from tools import gen_signal as G
+    x, _ = G.dense_capture((6 << 20) + 2, seed=612, sigma=25.0, n_frames=900, amp=(150, 1800))
+    path = str(tmp_path / "cap.u16")
+    x.tofile(path)
+    plain = subprocess.run([capi.CLI_PATH, "-a", "-f", path], capture_output=True, timeout=600)
+    assert plain.returncode == 0 and plain.stdout.count(b"\n") > 300
+    fifo = str(tmp_path / "cap.fifo")
+    os.mkfifo(fifo)
+    t = threading.Thread(target=lambda: open(fifo, "wb").write(x.tobytes()), daemon=True)
+    t.start()
+    p = subprocess.run([capi.CLI_PATH, "-a", "-G", "0,0", "-f", fifo], capture_output=True, timeout=600)
+    t.join(30)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == plain.stdout and p.stderr.splitlines()[-3:] == plain.stderr.splitlines()[-3:]
+    for opts in ([], ["-G", "0,0"]):
+        q = subprocess.run([capi.CLI_PATH, "-a"] + opts + ["-f", str(tmp_path / "nothing-here.u16")], capture_output=True, timeout=600)
+        assert q.returncode == 0 and q.stdout == b"", (opts, q.stderr)
+        tail = q.stderr.decode().splitlines()[-3:]
+        assert [ln.split(":")[0].strip() for ln in tail] == ["Try", "Ok", "Total"] and tail[-1].split()[-1] == "0"

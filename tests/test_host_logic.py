@@ -386,3 +386,24 @@ def test_incremental_call_walk_equals_the_walk_over_the_finished_shard(capi, see
         assert n_inc == n_ref > 100 and list(inc[:n_inc]) == list(ref[:n_ref])
         assert fin.value == int(hd.walk_final) and (fin.value == 1) == (g_end == n_off)
         r.close()
+
+
+def test_host_placement_query_and_mapped_block_registry(capi):
+    """numa.cpp without a device: adsb_host_placement says on which node the pages of a range live (one node here: all of
+    them on it, or "unknown" where move_pages is not allowed); adsb_host_release_mapped knows its own blocks only;
+    adsb_host_alloc_on needs the runtime to page-lock and fails cleanly without one."""
+    import ctypes as C
+    L = capi.load()
+    a = np.ones(1 << 21, np.uint16)
+    node, frac = C.c_int(-5), C.c_double(-1.0)
+    rc = L.adsb_host_placement(a.ctypes.data, a.nbytes, 0, C.byref(node), C.byref(frac))
+    assert rc in (0, -1)
+    if rc == 0:
+        assert node.value >= 0 and 0.0 <= frac.value <= 1.0
+        if not os.path.isdir("/sys/devices/system/node/node1"):
+            assert node.value == 0 and frac.value == 1.0
+    assert L.adsb_host_placement(None, 16, 0, C.byref(node), C.byref(frac)) == -1
+    assert L.adsb_host_release_mapped(a.ctypes.data) == 0      # not one of its mappings
+    import torch
+    if not torch.cuda.is_available():
+        assert not L.adsb_host_alloc_on(1 << 20, 0)            # no runtime, no page-locking: NULL, and nothing leaks

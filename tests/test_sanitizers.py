@@ -47,3 +47,6 @@ def test_handoff_reader_under_sanitizers(tmp_path, san):
 def test_multi_gpu_driver_under_sanitizers(tmp_path, san):
     out = _run(_build(tmp_path, "multi_tsan.cpp", san), 8)
     assert "24 sharded decodes" in out and "streams and error paths" in out, out
+    # adsb_multi_host_alloc + adsb_multi_worker_placement against a made-up two-node map (numa.cpp): where the kernel answers
+    # the placement query at all, every slice was asked about and the answers were what a one-node machine must give
+    assert "slices asked where they live" in out

@@ -10,8 +10,8 @@ for s in scan_kernel decoder; do
   /opt/rocm/bin/hipcc $FLAGS -c adsbdec_amd/csrc/$s.hip -o "$out/$s.o" || exit 1
 done
 gcc -O2 -fPIC -c adsbdec_amd/csrc/format.c -o "$out/format.o" || exit 1
-for s in multi host_abi; do
+for s in multi host_abi numa; do
   g++ -O2 -fPIC -std=c++17 -pthread -c adsbdec_amd/csrc/$s.cpp -o "$out/$s.o" || exit 1
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libadsbdec_amd.so" "$out"/scan_kernel.o "$out"/decoder.o "$out"/format.o "$out"/multi.o "$out"/host_abi.o -lm -lpthread || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libadsbdec_amd.so" "$out"/scan_kernel.o "$out"/decoder.o "$out"/format.o "$out"/multi.o "$out"/host_abi.o "$out"/numa.o -lm -lpthread || exit 1
 echo "$out/libadsbdec_amd.so"

@@ -15,7 +15,7 @@
 using namespace adsb;
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_gap, int copies)
+static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_gap, int copies, bool collapse, bool two_threads = false, bool flush_lines = false)
 {
     const uint32_t gen = 0x1234567u;
     std::mt19937 rng(1);
@@ -23,11 +23,21 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
     uint64_t nrec = 0;
     uint64_t next_frame = 500;
     for (uint32_t t = 0; t < ntiles; t++) {
-        std::vector<uint32_t> gs;
+        std::vector<uint32_t> gs, cp;
         while (next_frame < (uint64_t)(t + 1) * per) {
+            int nc = 0;
             for (int c = 0; c < copies; c++)
                 if (next_frame + c < (uint64_t)(t + 1) * per)
+                    nc++;
+            if (collapse) { // one record per run of copies (what the kernel writes since round 5)
+                gs.push_back((uint32_t)next_frame);
+                cp.push_back((uint32_t)nc);
+            } else {
+                for (int c = 0; c < nc; c++) {
                     gs.push_back((uint32_t)(next_frame + c));
+                    cp.push_back(1u);
+                }
+            }
             next_frame += frame_gap + (frame_gap > 2000 ? rng() % frame_gap : 0);
         }
         const uint32_t n = (uint32_t)gs.size(), reserve = stream_granules(n);
@@ -36,7 +46,8 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
         hv.insert(hv.end(), 4 * reserve, 0u);
         for (uint32_t i = 0; i < n; i++) {
             uint32_t r[8] = {gs[i], 1000 + gs[i] % 77, (17u << 3) | (uint32_t)(rng() << 8), (uint32_t)rng(), (uint32_t)rng(),
-                             ((uint32_t)rng() & 0xFFFFu) | (14u << 16), 0, 0};
+                             ((uint32_t)rng() & 0xFFFFu) | (14u << 16) | ((cp[i] - 1u) << kRecCopiesShift), cp[i] > 1 ? 1001 + gs[i] % 77 : 0,
+                             cp[i] > 2 ? 1002 + gs[i] % 77 : 0};
             for (int k = 0; k < 8; k++) a[k & 3] ^= r[k];
             sum += record_term(i, r[0], r[1]);
             std::memcpy(hv.data() + mpos + 4 + 8 * i, r, 32);
@@ -51,12 +62,21 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
     std::vector<__m128i> store(hv.size() / 4 + 1);
     uint32_t *hand = reinterpret_cast<uint32_t *>(store.data());
     std::memcpy(hand, hv.data(), hv.size() * 4);
-    printf("%s: %u tiles, %llu records, %zu KiB stream\n", name, ntiles, (unsigned long long)nrec, hv.size() * 4 / 1024);
+    printf("%s%s%s: %u tiles, %llu records, %zu KiB stream\n", name, two_threads ? " [reader thread + resolver]" : " [one thread]",
+           flush_lines ? " [stream flushed from the caches before every pass]" : "", ntiles, (unsigned long long)nrec, hv.size() * 4 / 1024);
     Resolver res;
     std::vector<uint32_t> t_start(ntiles), t_count(ntiles);
+    StreamReader rd;
+    if (two_threads)
+        rd.start();
     for (int rep = 0; rep < 6; rep++) {
         res.reset();
         std::fill(t_count.begin(), t_count.end(), ~0u);
+        if (flush_lines) { // what the device's writes leave behind: no line of the stream in any cache
+            for (size_t b = 0; b < hv.size() * 4; b += 64)
+                _mm_clflush(reinterpret_cast<const char *>(hand) + b);
+            _mm_mfence();
+        }
         HandJob job;
         job.hand = hand, job.ntiles = ntiles, job.gen = gen, job.cap = (uint32_t)(hv.size() / 4);
         double tr = 0, wait_ms = 0;
@@ -69,18 +89,25 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
             delivered = upto;
             tr += now() - ta;
         };
-        const CollectEnd end = collect_alone(job, t_start.data(), t_count.data(), delivered, flush, wait_ms, tl);
+        const CollectEnd end = two_threads ? collect_behind_reader(rd, job, t_start.data(), t_count.data(), delivered, flush, wait_ms, tl)
+                                           : collect_alone(job, t_start.data(), t_count.data(), delivered, flush, wait_ms, tl);
         const double t1 = now();
         const adsb_frame *fp;
         const size_t nf = res.take(&fp);
         printf("  rep %d: status %d, check + bookkeeping %.1f us, resolve %.1f us, total %.1f us = %.1f ns per record, %zu frames\n", rep, end.status,
                t1 - t0 - tr, tr, t1 - t0, (t1 - t0) * 1e3 / nrec, nf);
     }
+    rd.stop();
 }
 
 int main()
 {
-    run("sparse", 2786, 48188, 10000, 1);
-    run("dense10", 2786, 48188, 1200, 3);
+    run("sparse", 2786, 48188, 10000, 1, false);
+    run("dense10, one record per candidate (round 4)", 2786, 48188, 1200, 3, false);
+    run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true);
+    run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true, false, true);
+    run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true, true, false);
+    run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true, true, true);
+    run("sparse", 2786, 48188, 10000, 1, false, false, true);
     return 0;
 }
