@@ -438,7 +438,7 @@ int main(int argc, char **argv)
     if (getenv("ADSB_CLI_RETRY_S")) /* (a test's knob: the reference waits 3 s between attempts, output.c:282) */
         out_sink.retry_s = (unsigned)atoi(getenv("ADSB_CLI_RETRY_S"));
 
-    const int timing = getenv("ADSB_CLI_TIMING") != NULL;
+    const int timing = getenv("ADSB_CLI_TIMING") ? (atoi(getenv("ADSB_CLI_TIMING")) > 1 ? 2 : 1) : 0;
     if (ndev) {
         adsb_config mcfg;
         adsb_config_default(&mcfg);
@@ -532,17 +532,20 @@ int main(int argc, char **argv)
     rg.use_register = use_register;
     if (have_reader && pthread_create(&locker, NULL, locker_main, &rg) != 0)
         have_reader = 0;
-    int stopped = 0;
+    int stopped = 0, n_push = 0;
+    double t_wait_ring = 0, t_push = 0, t_flush = 0, t_finish = 0;
     if (have_reader) {
         int prev = -1;
         for (int k = 0;; k++) {
             ring_slot *s = &rg.slot[k % rg.nbuf];
+            const double t_w0 = now_ms();
             pthread_mutex_lock(&rg.mu);
             while (!s->ready && !stop_requested)
                 cond_wait_tick(&rg.cv, &rg.mu);
             const int reader_failed = rg.failed; /* (written under the mutex by the reader) */
             const int is_ready = s->ready;
             pthread_mutex_unlock(&rg.mu);
+            t_wait_ring += now_ms() - t_w0;
             if (stop_requested && !is_ready) {
                 stopped = 1; /* SIGINT / SIGTERM / SIGQUIT: no more pushes; what is in the decoder is finished below */
                 break;
@@ -555,13 +558,21 @@ int main(int argc, char **argv)
             const size_t bytes = s->bytes;
             if (bytes >= 2) {
                 /* a trailing odd byte is dropped, like decodeiq(iqbuff, n / 2) (air.c:239) */
+                const double t_p0 = now_ms();
                 const int prc = s->registered ? adsb_push_async(dec, s->buf, bytes / 2) : adsb_push(dec, s->buf, bytes / 2);
+                t_push += now_ms() - t_p0;
+                n_push++;
+                if (timing > 1)
+                    fprintf(stderr, "  push %d (%s): %.2f ms at +%.1f ms\n", n_push, s->registered ? "async" : "sync", now_ms() - t_p0, t_p0 - t_init);
                 if (prc != 0) {
                     fprintf(stderr, "adsb_push() failed: %s\n", adsb_last_error(dec));
                     rc = 255;
                     break;
                 }
-                if (flush_frames(dec, outformat) != 0) { /* stdout is gone (EPIPE, disk full): stop, and say so */
+                const double t_f0 = now_ms();
+                const int frc = flush_frames(dec, outformat);
+                t_flush += now_ms() - t_f0;
+                if (frc != 0) { /* stdout is gone (EPIPE, disk full): stop, and say so */
                     rc = 1;
                     break;
                 }
@@ -581,12 +592,14 @@ int main(int argc, char **argv)
                 break;
             }
         }
+        const double t_fin0 = now_ms();
         if (rc == 0 && adsb_finish(dec) != 0) {
             fprintf(stderr, "adsb_finish() failed: %s\n", adsb_last_error(dec));
             rc = 255;
         }
         if (flush_frames(dec, outformat) != 0 && rc == 0)
             rc = 1;
+        t_finish = now_ms() - t_fin0;
         if (sink_close(&out_sink) != 0 && rc == 0)
             rc = 1; /* the last block did not reach the file (ENOSPC, EIO, a closed pipe) */
         if (rc != 0 || stopped) { /* let the reader run out: hand every buffer back */
@@ -605,8 +618,9 @@ int main(int argc, char **argv)
     }
     const double t_done = now_ms();
     if (timing)
-        fprintf(stderr, "timing: runtime init %.1f ms, decode %.1f ms (page-locking, on its own thread: %.1f ms), total %.1f ms\n",
-                t_init - t_start, t_done - t_init, rg.t_reg, t_done - t_start);
+        fprintf(stderr, "timing: runtime init %.1f ms, decode %.1f ms (page-locking, on its own thread: %.1f ms; main thread: %d pushes %.1f ms, "
+                        "waiting for a read + locked buffer %.1f ms, formatting + writing %.1f ms, finish %.1f ms), total %.1f ms\n",
+                t_init - t_start, t_done - t_init, rg.t_reg, n_push, t_push, t_wait_ring, t_flush, t_finish, t_done - t_start);
 
     adsb_stats st;
     if (adsb_get_stats(dec, &st) == 0)

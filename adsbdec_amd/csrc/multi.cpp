@@ -138,7 +138,9 @@ struct Worker {
     std::vector<uint64_t> bases, head_tries, tail_tries;
     uint64_t head_tries_end = 0, tail_from = ~0ull;
     std::vector<adsb_candidate> scratch_cands;
-    uint16_t *ring[2] = {nullptr, nullptr}; // page-locked pieces of a file source
+    static constexpr int kRing = 10;         // page-locked pieces of a file source: kFileReaders being read + one being copied + one
+    uint16_t *ring[kRing] = {};
+    int ring_slots = 0;                      // of them allocated (a short slice needs fewer)
     uint64_t ring_samples = 0, piece = kPieceSamples;
 
     int fail(const char *fmt, ...)
@@ -203,35 +205,136 @@ namespace {
 
 // The next piece of a source: memory is pushed where it lies; a file is read into one of two page-locked buffers in turn
 // (adsb_push_async borrows a buffer until the NEXT push returns, so two suffice).
+// `slots` page-locked buffers of at least n samples each.  On the device's NUMA node and through adsb_host_alloc_on (huge
+// pages registered with the runtime: 0.01 ms per MiB) where that works, else adsb_host_alloc (0.17 ms per MiB: for a
+// one-shot host program the ring's allocation is part of the decode time).
+bool ring_ready(Worker &w, uint64_t n, int slots = 2)
+{
+    slots = std::min(std::max(slots, 2), (int)Worker::kRing);
+    if (w.ring_slots < slots || w.ring_samples < n) {
+        const uint64_t cap = std::max(n, w.ring_samples);
+        for (int i = 0; i < Worker::kRing; i++) {
+            uint16_t *&b = w.ring[i];
+            if (b && w.ring_samples >= cap)
+                continue; // big enough already
+            if (b)
+                adsb_host_free(b);
+            b = nullptr;
+            if (i >= std::max(slots, w.ring_slots))
+                continue;
+            b = static_cast<uint16_t *>(adsb_host_alloc_on(2 * cap, w.device));
+            if (!b)
+                b = static_cast<uint16_t *>(adsb_host_alloc(2 * cap));
+            if (!b) {
+                w.ring_samples = 0;
+                w.ring_slots = 0;
+                w.fail("device %d (worker %d): cannot page-lock a %llu-byte read buffer", w.device, w.index, (unsigned long long)(2 * cap));
+                return false;
+            }
+        }
+        w.ring_samples = cap;
+        w.ring_slots = std::max(slots, w.ring_slots);
+    }
+    return true;
+}
+bool read_samples(int fd, uint16_t *dst, uint64_t at, uint64_t n)
+{
+    uint64_t got = 0;
+    while (got < 2 * n) {
+        const ssize_t k = pread(fd, reinterpret_cast<char *>(dst) + got, 2 * n - got, (off_t)(2 * at + got));
+        if (k <= 0)
+            return false;
+        got += (uint64_t)k;
+    }
+    return true;
+}
 const uint16_t *fetch(Worker &w, const Source &src, uint64_t at, uint64_t n, int turn)
 {
     if (src.mem)
         return src.mem + at;
-    if (!w.ring[0] || w.ring_samples < n) {
-        const uint64_t cap = std::max(n, w.piece);
-        for (uint16_t *&b : w.ring) {
-            if (b)
-                adsb_host_free(b);
-            b = static_cast<uint16_t *>(adsb_host_alloc(2 * cap));
-            if (!b) {
-                w.ring_samples = 0;
-                w.fail("device %d (worker %d): cannot page-lock a %llu-byte read buffer", w.device, w.index, (unsigned long long)(2 * cap));
-                return nullptr;
-            }
-        }
-        w.ring_samples = cap;
-    }
+    if (!ring_ready(w, n))
+        return nullptr;
     uint16_t *dst = w.ring[turn & 1];
-    uint64_t got = 0;
-    while (got < 2 * n) {
-        const ssize_t k = pread(src.fd, reinterpret_cast<char *>(dst) + got, 2 * n - got, (off_t)(2 * at + got));
-        if (k <= 0) {
-            w.fail("device %d (worker %d): read of samples %llu.. failed or fell short", w.device, w.index, (unsigned long long)at);
-            return nullptr;
-        }
-        got += (uint64_t)k;
+    if (!read_samples(src.fd, dst, at, n)) {
+        w.fail("device %d (worker %d): read of samples %llu.. failed or fell short", w.device, w.index, (unsigned long long)at);
+        return nullptr;
     }
     return dst;
+}
+
+// A FILE source at the link's rate.  One thread's pread() from the page cache delivers 11.6 GB/s on the host measured
+// (profiles/r5_ingest_probe.txt), a device's link takes 56: kFileReaders helper threads, started for the feed and gone
+// with it, read pieces AHEAD into the worker's ring of page-locked buffers -- piece k by whichever thread claims it, into
+// slot k mod kRing once the push of piece k - kRing + 1 has returned -- and the worker pushes them in order.  (Zero copy
+// -- windows of an mmap of the file registered with the runtime -- was measured too: the copies then run at the link's rate,
+// but registering page-cache pages costs as much CPU per byte as copying them)
+constexpr int kFileReaders = 8;
+constexpr uint64_t kFilePieceSamples = 4ull << 20; // 8 MiB: ten of them page-locked per worker
+int feed_file(Worker &w, const Source &src, uint64_t first, uint64_t n, uint64_t piece)
+{
+    piece = std::min(piece, kFilePieceSamples);
+    const uint64_t npieces = (n + piece - 1) / piece;
+    if (!ring_ready(w, piece, (int)std::min<uint64_t>(Worker::kRing, npieces + 1)))
+        return -1;
+    const uint64_t nring = (uint64_t)w.ring_slots;
+    std::atomic<uint64_t> next{0}, freed{0}; // next piece to claim; pieces [0, freed) have left their buffers
+    std::atomic<bool> abort{false};
+    std::unique_ptr<std::atomic<int>[]> state(new std::atomic<int>[npieces]);
+    for (uint64_t k = 0; k < npieces; k++)
+        state[k].store(0, std::memory_order_relaxed);
+    auto reader = [&] {
+        for (;;) {
+            const uint64_t k = next.fetch_add(1, std::memory_order_relaxed);
+            if (k >= npieces)
+                return;
+            for (unsigned spins = 0; k >= freed.load(std::memory_order_acquire) + nring; spins++) { // its slot is still borrowed
+                if (abort.load(std::memory_order_relaxed))
+                    return;
+                if (spins < 64)
+                    relax_burst();
+                else
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+            if (abort.load(std::memory_order_relaxed))
+                return;
+            const uint64_t at = first + k * piece, len = std::min(piece, first + n - at);
+            const bool ok = read_samples(src.fd, w.ring[k % nring], at, len);
+            state[k].store(ok ? 1 : -1, std::memory_order_release);
+            if (!ok)
+                return;
+        }
+    };
+    std::vector<std::thread> readers;
+    const int nthreads = (int)std::min<uint64_t>({(uint64_t)kFileReaders, npieces, nring > 2 ? nring - 2 : 1});
+    int rc = 0;
+    try {
+        for (int t = 0; t < nthreads; t++)
+            readers.emplace_back(reader);
+    } catch (const std::exception &) { // no (more) threads to be had: with the ones that started; with none, the worker reads alone
+    }
+    if (readers.empty())
+        return 1;
+    for (uint64_t k = 0; k < npieces && rc == 0; k++) {
+        int st;
+        for (unsigned spins = 0; (st = state[k].load(std::memory_order_acquire)) == 0; spins++) {
+            if (spins < 256)
+                relax_burst();
+            else
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        const uint64_t at = first + k * piece, len = std::min(piece, first + n - at);
+        if (st < 0)
+            rc = w.fail("device %d (worker %d): read of samples %llu.. failed or fell short", w.device, w.index, (unsigned long long)at);
+        else if (adsb_push_async(w.dec, w.ring[k % nring], (size_t)len))
+            rc = w.fail_dec("adsb_push_async");
+        else
+            freed.store(k, std::memory_order_release); // piece k - 1's buffer is free (adsb_push_async's contract); piece k's stays borrowed
+        w.beat.fetch_add(1, std::memory_order_relaxed);
+    }
+    abort.store(true, std::memory_order_relaxed);
+    for (auto &t : readers)
+        t.join();
+    return rc;
 }
 
 // DF-gate passes of the offsets [g_lo, g_hi) of the job's stream, through a stateless scan of just that window.
@@ -273,6 +376,12 @@ int window_tries(Worker &w, const Job &j, uint64_t g_lo, uint64_t g_hi, std::vec
 
 int feed(Worker &w, const Source &src, uint64_t first, uint64_t n, uint64_t piece)
 {
+    if (!src.mem && src.fd >= 0) {
+        const int rc = feed_file(w, src, first, n, piece);
+        if (rc <= 0)
+            return rc;
+        // (1: no helper thread could be started: piece by piece on this thread, a read and a copy in turn)
+    }
     int turn = 0;
     for (uint64_t at = first; at < first + n; at += piece, turn++) {
         const uint64_t len = std::min(piece, first + n - at);

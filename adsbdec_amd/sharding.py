@@ -98,6 +98,25 @@ class MultiDecoder:
         self._L.adsb_multi_get_info(self._h, C.byref(i))
         return {k: getattr(i, k) for k, _ in capi.MultiInfo._fields_}
 
+    def host_alloc(self, total_samples: int):
+        """adsb_multi_host_alloc: a page-locked uint16 array for ONE capture, every shard's part on the NUMA node of the device
+        that will pull it.  Returns (ndarray view, address); release with host_free(address)."""
+        addr = self._L.adsb_multi_host_alloc(self._h, total_samples)
+        if not addr:
+            raise self._err("adsb_multi_host_alloc")
+        buf = (C.c_uint16 * total_samples).from_address(addr)
+        return np.frombuffer(buf, dtype=np.uint16), addr
+
+    def host_free(self, addr: int):
+        self._L.adsb_host_free(addr)
+
+    def placement(self, worker: int):
+        """adsb_multi_worker_placement: where worker's slice of the last host-fed capture lives, and where its device is."""
+        pl = capi.WorkerPlacement()
+        if self._L.adsb_multi_worker_placement(self._h, worker, C.byref(pl)) != 0:
+            raise self._err("adsb_multi_worker_placement")
+        return {k: getattr(pl, k) for k, _ in capi.WorkerPlacement._fields_}
+
     def worker_profile(self, worker: int):
         p = capi.Profile()
         if self._L.adsb_multi_worker_profile(self._h, worker, C.byref(p)) != 0:

@@ -971,7 +971,14 @@ def run_shard(args, torch, capi, rank, world, fence):
         def step(_i=0):
             return md.decode_device(total, ptrs)
     else:
-        host = pinned_capture(torch, total, 9)
+        # The capture in page-locked host memory laid out shard by shard on the NUMA node of the device that pulls it
+        # (adsb_multi_host_alloc, csrc/numa.cpp: where the reference has `iqbuff = malloc`, air.c:230).
+        host_np, host_addr = md.host_alloc(total)
+        host = torch.from_numpy(host_np.view(np.int16))
+        for lo in range(0, total, 64 << 20):
+            hi = min(total, lo + (64 << 20))
+            host[lo:hi].copy_(make_workload(torch, total, seed=9, lo=lo, hi=hi)[0])
+        torch.cuda.synchronize()
         keep.append(host)
         if source == "file":
             import tempfile
@@ -1056,7 +1063,11 @@ def run_shard(args, torch, capi, rank, world, fence):
                    "stitch_us": round(float(np.median(stitch)), 1),
                    "slowest_worker_ms": round(float(np.median(workers)), 4),
                    "deqframe_calls_walked": int(info["calls_walked"]), "deqframe_calls_jumped": int(info["calls_jumped"]),
-                   "create_ms": round(info["create_ms"], 1)},
+                   "create_ms": round(info["create_ms"], 1),
+                   "placement": ([md.placement(i) for i in range(len(plan))] if source == "host" else None),
+                   "placement_what": "per worker: the NUMA node of its device, whether its thread runs on that node's CPUs, the node "
+                                     "most pages of its slice of the capture live on and the share of them on the device's node "
+                                     "(adsb_multi_worker_placement; the capture came from adsb_multi_host_alloc)"},
         "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
     }
     emit_line(line)
