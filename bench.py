@@ -116,7 +116,7 @@ def gate(got, want, what):
         raise SystemExit(f"PARITY FAILURE ({what}): GPU path returned {len(a)} frames, expected {len(b)}; first difference at index {i}")
 
 
-def roofline_objects(p0, p1, steps, profiles_tag="r4", clock=None, step_ms=None):
+def roofline_objects(p0, p1, steps, profiles_tag="r5", clock=None, step_ms=None):
     """HBM roofline of the dominant launch + the VALU-issue roofline that actually binds it."""
     kernel_ms = p1["kernel_ms"] - p0["kernel_ms"]
     big_off = p1["big_offsets"]
@@ -127,7 +127,7 @@ def roofline_objects(p0, p1, steps, profiles_tag="r4", clock=None, step_ms=None)
     avg_ms = ms_big / n_big if n_big else 0.0
     achieved = 4.0 * big_off / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, traffic_source, valu = None, None, None
-    for name in (f"{profiles_tag}_pmc.json", f"{profiles_tag.replace('r4', 'r3')}_pmc.json", f"{profiles_tag.replace('r4', 'r2')}_pmc.json"):
+    for name in (f"{profiles_tag}_pmc.json", f"{profiles_tag.replace('r5', 'r4', 1)}_pmc.json", f"{profiles_tag.replace('r5', 'r3', 1)}_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -745,7 +745,7 @@ def main():
     value = world * n * args.steps / dt / 1e6  # Msamples/s, whole job
     frames = capi._frames_to_dicts(raw[0], raw[1])
     p1 = dec.profile()
-    roofline, roofline_valu = roofline_objects(p0, p1, args.steps, "r4_dense" if args.dense else "r4", clock, dt / args.steps * 1e3)
+    roofline, roofline_valu = roofline_objects(p0, p1, args.steps, "r5_dense" if args.dense else "r5", clock, dt / args.steps * 1e3)
 
     # ---- the same step 1000 more times (the driver's default is 20 steps = 3 ms of measurement; box-to-box the kernel
     # spreads by 7 %): a sturdier sample of the same quantity, every rank, same fences
@@ -756,7 +756,7 @@ def main():
             dt2, _ = timed_steps(step, 1000, fence, torch.cuda.synchronize)
         dt2 = max_over_ranks(dt2)
         q1 = dec.profile()
-        roof2, _ = roofline_objects(q0, q1, 1000, "r4_dense" if args.dense else "r4", sampler2.ghz(), dt2 / 1000 * 1e3)
+        roof2, _ = roofline_objects(q0, q1, 1000, "r5_dense" if args.dense else "r5", sampler2.ghz(), dt2 / 1000 * 1e3)
         steady = {"steps": 1000, "value": round(world * n * 1000 / dt2 / 1e6, 1), "unit": "Msamples/s",
                   "ms_per_step": round(dt2 / 1000 * 1e3, 4), "launch_ms": roof2["launch_ms"], "roofline_frac": roof2["frac"],
                   "what": "the timed region repeated with 1000 steps right behind the K steps of `value` (same captures in rotation, "
@@ -825,7 +825,7 @@ def main():
             s0 = ds.profile()
             sdt, _ = timed_steps(sstep, 50, torch.cuda.synchronize)
             s1 = ds.profile()
-            sroof, _ = roofline_objects(s0, s1, 50, "r4_dense" if args.dense else "r4")
+            sroof, _ = roofline_objects(s0, s1, 50, "r5_dense" if args.dense else "r5")
             with_stats = {"what": "collect_stats=1: the step above + the Try table of valid.c:84-100", "steps": 50, "preroll_ms": args.preroll_ms,
                           "value": round(n * 50 / sdt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(sdt / 50 * 1e3, 4),
                           "launch_ms": sroof["launch_ms"]}
@@ -879,7 +879,7 @@ def main():
                     q0 = dd.profile()
                     ddt, draw = timed_steps(dstep, 20, torch.cuda.synchronize)
                     q1 = dd.profile()
-                    droof, _ = roofline_objects(q0, q1, 20, profiles_tag="r4_dense")
+                    droof, _ = roofline_objects(q0, q1, 20, profiles_tag="r5_dense")
                     r = {"value": round(n * 20 / ddt / 1e6, 1), "ms_per_step": round(ddt / 20 * 1e3, 4), "launch_ms": droof["launch_ms"],
                          "roofline_frac": droof["frac"], "frames": int(draw[1]), "relaunches": int(q1["relaunches"] - q0["relaunches"])}
                     if not args.no_cpu_baseline and not stats:
