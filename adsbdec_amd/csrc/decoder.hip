@@ -228,6 +228,7 @@ struct adsb_decoder {
     hipStream_t copy_stream[kCopyStreams] = {nullptr, nullptr};
     hipEvent_t ev_copy[kCopyStreams] = {nullptr, nullptr};
     hipEvent_t ev_tail = nullptr; // behind a staging compaction's tail copy (process_stage): the copy streams wait for it
+    hipEvent_t ev_wait = nullptr; // wait_stream's marker (created at its first use)
     uint64_t piece = 0;        // pieces pushed asynchronously so far
 
     // Shard-stream mode (adsb_shard_begin .. adsb_shard_end): the stream starts at sample shard_first instead of 0, ends
@@ -301,11 +302,38 @@ out:
 }
 inline int wait_event(adsb_decoder *d, hipEvent_t ev, const char *what)
 {
+#ifdef ADSB_BLOCKING_WAITS // (A/B builds: the runtime's own blocking waits, as until round 4)
+    const hipError_t e = hipEventSynchronize(ev);
+    return e == hipSuccess ? 0 : d->fail("waiting for %s failed: %s", what, hipGetErrorString(e));
+#endif
     return wait_until_done(d, [ev] { return hipEventQuery(ev); }, what);
 }
+// "Everything enqueued on st so far": ONE marker (an event recorded behind it) and polls of that event.  Not polls of
+// hipStreamQuery: each of those has the runtime enqueue a marker of its own while the stream is busy, and a statistics step,
+// which waits for its count pass this way once per call, got 6 % slower for it (profiles/r5_ab_runs.txt section 5).
 inline int wait_stream(adsb_decoder *d, hipStream_t st, const char *what)
 {
-    return wait_until_done(d, [st] { return hipStreamQuery(st); }, what);
+#ifdef ADSB_BLOCKING_WAITS
+    const hipError_t es = hipStreamSynchronize(st);
+    return es == hipSuccess ? 0 : d->fail("waiting for %s failed: %s", what, hipGetErrorString(es));
+#endif
+    if (!d->ev_wait && hipEventCreateWithFlags(&d->ev_wait, hipEventDisableTiming) != hipSuccess) {
+        d->ev_wait = nullptr;
+        (void)hipGetLastError();
+        return wait_until_done(d, [st] { return hipStreamQuery(st); }, what);
+    }
+    // (an idle stream -- most of the streams adsb_reset and adsb_finish wait for -- answers the first question; a marker
+    // recorded on an idle stream would cost a round trip to the device, five of them per adsb_reset: measured, +9 % on the
+    // statistics step)
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess)
+        return 0;
+    if (q != hipErrorNotReady)
+        return d->fail("waiting for %s failed: %s", what, hipGetErrorString(q));
+    const hipError_t e = hipEventRecord(d->ev_wait, st);
+    if (e != hipSuccess)
+        return d->fail("hipEventRecord (waiting for %s) failed: %s", what, hipGetErrorString(e));
+    return wait_event(d, d->ev_wait, what);
 }
 #define WAIT_EVENT(d, ev, what)   do { if (wait_event((d), (ev), (what))) return -1; } while (0)
 #define WAIT_STREAM(d, st, what)  do { if (wait_stream((d), (st), (what))) return -1; } while (0)
@@ -1491,6 +1519,7 @@ void adsb_destroy(adsb_decoder *d)
         if (d->copy_stream[i]) (void)hipStreamDestroy(d->copy_stream[i]);
     }
     if (d->ev_tail) (void)hipEventDestroy(d->ev_tail);
+    if (d->ev_wait) (void)hipEventDestroy(d->ev_wait);
     for (int i = 0; i < 2; i++)
         if (d->stage[i])
             (void)hipFree(d->stage[i]);

@@ -23,6 +23,9 @@
 #include <mutex>
 #include <thread>
 
+#if !defined(__x86_64__)
+#error "handoff.hpp reads the device's stores with SSE2 loads and paces its polls with `pause`: x86-64 hosts only (the hosts MI355X ships in); see DESIGN.md section 4"
+#endif
 #include <emmintrin.h>
 #include <pthread.h>
 #include <sched.h>
@@ -56,11 +59,6 @@ struct HandCursor {
     uint32_t tile = 0, nf = 0; // the marker tile_in() accepted last
     double wait_ms = 0;
     clk::time_point t_last_wait;
-    uint32_t streak = 0; // tiles taken in a row without having to wait for the device
-#ifndef ADSB_PREFETCH_AFTER
-#define ADSB_PREFETCH_AFTER 8 // (A/B builds override it; a huge value turns the prefetch off)
-#endif
-    static constexpr uint32_t kPrefetchAfter = ADSB_PREFETCH_AFTER, kPrefetchGranules = 96; // (1.5 KB ahead: beyond what the stream prefetcher holds)
 
     HandCursor(const HandJob &job, uint32_t *ts, uint32_t *tc)
         : s(job), t_start(ts), t_count(tc), gen(job.gen), cap(job.cap), t_last_wait(clk::now())
@@ -88,15 +86,8 @@ struct HandCursor {
         // of every record (scan_kernel_format.h) -- from the first granule's low words while it is in a register
         __m128i acc = _mm_setzero_si128();
         uint32_t sum = 0;
-        // Running behind the device (a full channel: the kernel writes ~4 MB of records per launch, which land in DRAM, and
-        // one core's hardware prefetcher streams them at ~10 GB/s -- twice the kernel's time): ask for the lines a kilobyte
-        // ahead as well.  Not when the host is waiting at the device's heels (the sparse case): the lines ahead are not
-        // written yet, and a line this core holds has to be taken away from it by the very write that is awaited.
-        const bool ahead = streak >= kPrefetchAfter;
         if (fits)
             for (uint32_t r = 0; r < n; r++) {
-                if (ahead && !(r & 1u))
-                    _mm_prefetch(reinterpret_cast<const char *>(gp + 1 + 2 * r + kPrefetchGranules), _MM_HINT_T0);
                 const __m128i g0 = _mm_load_si128(gp + 1 + 2 * r), g1 = _mm_load_si128(gp + 2 + 2 * r);
                 acc = _mm_xor_si128(acc, _mm_xor_si128(g0, g1));
                 const uint64_t w01 = (uint64_t)_mm_cvtsi128_si64(g0);
@@ -118,7 +109,6 @@ struct HandCursor {
         const auto t_w = clk::now();
         bool ok = false;
         uint64_t after_done = 0;
-        streak = 0;
         for (uint64_t spins = 1;; spins++) {
             if (tile_in()) {
                 ok = true;
@@ -155,7 +145,6 @@ struct HandCursor {
             return 1;
         t_start[tile] = pos + 1;
         t_count[tile] = n;
-        streak++;
         pos += std::max(marker_granules(nf), stream_granules(n)); // what the tile reserved (it may have kept fewer records than it reserved for)
         while (frontier < s.ntiles && t_count[frontier] != ~0u)
             frontier++;

@@ -26,10 +26,6 @@
 #include "../../include/adsbdec_amd.h"
 #include "scan_kernel_format.h"
 
-#ifndef ADSB_RESOLVE_PREFETCH
-#define ADSB_RESOLVE_PREFETCH 0 // records ahead that run_call_tiles asks for (tools/hostpath_bench.cpp measures it)
-#endif
-
 namespace adsb {
 
 // The accepted frames: a flat array of PODs whose slots are handed out uninitialised (a std::vector value-initialises 40
@@ -251,6 +247,10 @@ public:
             return;
         }
         for (;;) {
+            if (tiles_fast_path()) { // every remaining call of this advance in one tight loop (run_calls_tiles)
+                run_calls_tiles(power_samples, g_complete, 0);
+                break;
+            }
             // air.c:94: the test `aidx >= APBUFFSZ` is made after every second
             // power sample, so the call fires at the first EVEN total T with
             // T - base >= 40980.
@@ -492,7 +492,12 @@ private:
     // stream where they lie -- as one tight loop: at the channel's capacity (BASELINE configs[2]: 106 k accepted frames per
     // 256 Mi-sample launch) the general loop below cost 8 ns per accepted frame, four times the kernel's share.  Same rules,
     // same order of side effects; the dependent chain per frame is idx -> which copy of the record -> idx + span.
-    void run_call_tiles(uint64_t limit)
+    bool tiles_fast_path() const { return chead_ == cands_.size() && !batch_.order && batch_.starts; }
+    // single_limit != 0: ONE call with that limit (chain mode: run_call(g_complete)).  Else: the stream's deqframe calls, one
+    // after the other while they have fired (air.c:94: at the first EVEN total T with T - base >= 40980) and the device has
+    // scanned up to their limit (demod.c:89: T - 1200) -- the loop of advance(), inside: on sparse input a call holds four
+    // frames, and entering and leaving this function once per call cost as much as the frames.
+    void run_calls_tiles(uint64_t power_samples, uint64_t g_complete, uint64_t single_limit)
     {
         // Everything the loop touches lives in locals (the stores of a frame are plain uint64_t stores: with the cursor, the
         // output size and the counters in members the compiler has to reload and store them around every frame -- 90
@@ -504,7 +509,7 @@ private:
         const uint32_t u_end = b.u_end;
         const uint64_t g_base = b.g_base;
         const bool tries = thead_ < tries_.size(), walk = w_on_ && !w_stop_, log = log_on_;
-        uint64_t idx = base_, skipped = skipped_;
+        uint64_t base = base_, skipped = skipped_;
         uint64_t ok[3] = {0, 0, 0}, fixed_n = 0;
         size_t room = 256, made = 0;
         uint64_t *f = reinterpret_cast<uint64_t *>(out_.room(room));
@@ -524,6 +529,17 @@ private:
             }
             copies = rec_copies(cur);
         };
+        for (;;) { // one deqframe call per round
+        uint64_t limit = single_limit;
+        if (!single_limit) {
+            const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1);
+            if (fire > power_samples)
+                break; // the reference has not called deqframe yet (never, at EOF)
+            limit = fire - ADSB_DECOFFSET;
+            if (limit > g_complete)
+                break; // the device has not scanned that far yet
+        }
+        uint64_t idx = base;
         while (cur) {
             const uint32_t *r = cur;
             const uint64_t g0 = g_base + r[0];
@@ -571,11 +587,17 @@ private:
             }
             idx = g + span; // demod.c:128,134 -- the record's other offsets lie inside this frame
             next_record();
-#if ADSB_RESOLVE_PREFETCH > 0
-            __builtin_prefetch(r + 8 * ADSB_RESOLVE_PREFETCH); // the records lie in another core's cache (the reader's) or in DRAM
-#endif
             if (idx >= limit)
                 break;
+        }
+        if (idx < limit) { // no candidate left below the limit: all remaining offsets advance by one (demod.c:141)
+            if (tries)
+                count_tries(idx, limit - 1);
+            idx = limit;
+        }
+        base = idx; // deqframe's return value; air.c:96-98 carries the rest
+        if (single_limit)
+            break;
         }
         out_.grew(made);
         b.cur = cur;
@@ -584,22 +606,17 @@ private:
         b.u = u;
         b.sub = 0;
         skipped_ = skipped;
+        base_ = base;
         for (int k = 0; k < 3; k++)
             stats_.ok[k] += ok[k];
         stats_.fixed += fixed_n;
-        if (idx < limit) { // no candidate left below the limit: all remaining offsets advance by one (demod.c:141)
-            if (tries)
-                count_tries(idx, limit - 1);
-            idx = limit;
-        }
-        base_ = idx; // deqframe's return value; air.c:96-98 carries the rest
     }
 
     // One deqframe(ampbuff, len) call: visits offsets from base_ while < limit.
     void run_call(uint64_t limit)
     {
-        if (chead_ == cands_.size() && !batch_.order && batch_.starts) {
-            run_call_tiles(limit);
+        if (tiles_fast_path()) {
+            run_calls_tiles(0, 0, limit);
             return;
         }
         uint64_t idx = base_;

@@ -10,9 +10,18 @@
 #include <random>
 #include <vector>
 
+#ifndef HP_HDR
+#define HP_HDR "../adsbdec_amd/csrc/"
+#endif
+#define HP_STR2(x) #x
 #include "../adsbdec_amd/csrc/handoff.hpp"
 #include "../adsbdec_amd/csrc/resolver.hpp"
 using namespace adsb;
+#ifdef HP_R4 // built against round 4's headers (-I a checkout of them): no records of copies there
+#define HP_COPIES_SHIFT 25
+#else
+#define HP_COPIES_SHIFT kRecCopiesShift
+#endif
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_gap, int copies, bool collapse, bool two_threads = false, bool flush_lines = false)
@@ -46,7 +55,7 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
         hv.insert(hv.end(), 4 * reserve, 0u);
         for (uint32_t i = 0; i < n; i++) {
             uint32_t r[8] = {gs[i], 1000 + gs[i] % 77, (17u << 3) | (uint32_t)(rng() << 8), (uint32_t)rng(), (uint32_t)rng(),
-                             ((uint32_t)rng() & 0xFFFFu) | (14u << 16) | ((cp[i] - 1u) << kRecCopiesShift), cp[i] > 1 ? 1001 + gs[i] % 77 : 0,
+                             ((uint32_t)rng() & 0xFFFFu) | (14u << 16) | ((cp[i] - 1u) << HP_COPIES_SHIFT), cp[i] > 1 ? 1001 + gs[i] % 77 : 0,
                              cp[i] > 2 ? 1002 + gs[i] % 77 : 0};
             for (int k = 0; k < 8; k++) a[k & 3] ^= r[k];
             sum += record_term(i, r[0], r[1]);
@@ -65,12 +74,19 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
     printf("%s%s%s: %u tiles, %llu records, %zu KiB stream\n", name, two_threads ? " [reader thread + resolver]" : " [one thread]",
            flush_lines ? " [stream flushed from the caches before every pass]" : "", ntiles, (unsigned long long)nrec, hv.size() * 4 / 1024);
     Resolver res;
+#ifdef HP_LOG // a statistics run: every accepted frame is also logged for the device's count pass (Resolver::log_into)
+    std::vector<Resolver::LogEntry> logbuf(400000);
+#endif
     std::vector<uint32_t> t_start(ntiles), t_count(ntiles);
     StreamReader rd;
     if (two_threads)
         rd.start();
     for (int rep = 0; rep < 6; rep++) {
         res.reset();
+#ifdef HP_LOG
+        res.log_accepted(true);
+        res.log_into(logbuf.data(), logbuf.size());
+#endif
         std::fill(t_count.begin(), t_count.end(), ~0u);
         if (flush_lines) { // what the device's writes leave behind: no line of the stream in any cache
             for (size_t b = 0; b < hv.size() * 4; b += 64)
@@ -104,10 +120,12 @@ int main()
 {
     run("sparse", 2786, 48188, 10000, 1, false);
     run("dense10, one record per candidate (round 4)", 2786, 48188, 1200, 3, false);
+#ifndef HP_R4
     run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true);
     run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true, false, true);
     run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true, true, false);
     run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true, true, true);
     run("sparse", 2786, 48188, 10000, 1, false, false, true);
+#endif
     return 0;
 }
