@@ -762,6 +762,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         uint32_t rank = 0; // kept entries with a smaller offset: the record's place behind the tile's marker
         const uint32_t *ri = cl_rec + tid * kCandWords;
         const bool one_wave = ncl <= 64; // workgroup-uniform; the usual case (a tile stages ~20 candidates)
+        uint32_t *any_nb = queue + kQueueCap - 8; // (a word of the survivor queue's LDS, free behind the rounds) do entries that stay sit next to each other?
         if (one_wave) {
             // Every entry sits in a lane of wave 0 and the all-pairs comparisons run on lane broadcasts
             // (v_readlane: the loop index is wave-uniform) instead of dependent LDS reads: measured with
@@ -798,13 +799,20 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                 keep = has && !drop;
                 const unsigned long long kept = __ballot(keep);
                 const int kk = keep ? key : 0x7fffffff; // the entries that stay, as keys; the others never count
+                bool nb = false; // an entry that stays sits one offset below this one (same length class): a possible copy
                 for (int j = 0; j < ncl; j += 4) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        rank += (uint32_t)(__builtin_amdgcn_readlane(kk, j + u) < g2);
+                    for (int u = 0; u < 4; u++) {
+                        const int kj = __builtin_amdgcn_readlane(kk, j + u);
+                        rank += (uint32_t)(kj < g2);
+                        nb |= kj == key - 2;
+                    }
                 }
-                if (tid == 0)
+                const unsigned long long nbs = __ballot(keep && nb);
+                if (tid == 0) {
                     *tile_n = (uint32_t)__popcll(kept);
+                    *any_nb = nbs != 0 ? 1u : 0u;
+                }
             }
         } else {
             // More than a wave of entries (a tile of 48 k offsets full of 112-bit frames back to back stages ~150: BASELINE
@@ -842,6 +850,8 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             const unsigned long long kept = __ballot(keep);
             if ((tid & 63) == 0 && kept)
                 atomicAdd(tile_n, (uint32_t)__popcll(kept));
+            if (tid == 0)
+                *any_nb = 1; // (more than a wave of entries: frames back to back, copies everywhere)
             __syncthreads();
             if (keep)
                 for (int j = 0; j < n4; j += 4) {
@@ -866,40 +876,59 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             st[1] &= 0xFFFFu; // (the multi-wave filter's "kept" bit never existed here, but a link compares the whole word)
         }
         __syncthreads(); // every thread has read what it needs of the staged list (the filter's loops included)
-        if (keep) {      // the entries that stay replace the list, in ascending offset
-            uint32_t *o = cl_rec + rank * kCandWords;
+        const uint32_t nk = *tile_n;       // entries that stay
+        const bool links = *any_nb != 0;   // workgroup-uniform: some of them are neighbours -- runs of copies are possible
+        uint32_t *pwbuf = queue, *ext = queue + kClistCap, *wl = queue + kQueueCap - 4; // every entry's pw; the copies' pw (two per record); leaders per wave
+        // e[]: the entry this thread finishes.  No neighbours (the usual tile: the filter has dropped an isolated frame's
+        // copies): every entry that stays is a record of its own, finished by the thread that holds it, two barriers and the
+        // re-ordering saved (the link logic cost the sparse launch 1.5 %).  Else: the entries replace the list in ascending
+        // offset, thread r takes entry r, links are found and counted.
+        uint32_t e[kCandWords] = {0, 0, 0, 0, 0, 0};
+        bool act = keep, lead = keep, c1 = false, c2 = false;
+        uint32_t nrec = nk, r2 = rank;
+        if (!links) {
 #pragma unroll
             for (int k = 0; k < kCandWords; k++)
-                o[k] = st[k];
-        }
-        __syncthreads();
-        const uint32_t nk = *tile_n; // entries in cl_rec now; thread r < nk takes entry r from here on
-        uint32_t *pwbuf = queue, *ext = queue + kClistCap, *wl = queue + kQueueCap - 4; // every entry's pw; the copies' pw (two per record); leaders per wave
-        const uint32_t *my = cl_rec + tid * kCandWords;
-        bool lead = false, c1 = false, c2 = false;
-        if ((uint32_t)tid < nk) {
-            auto linked = [&](uint32_t a) { // is entry a the previous entry's frame, one offset on?
-                if (a == 0 || a >= nk)
-                    return false;
-                const uint32_t *p = cl_rec + (a - 1) * kCandWords, *q = p + kCandWords;
-                return q[0] == p[0] + 1u && q[1] == p[1] && q[2] == p[2] && q[3] == p[3] && q[4] == p[4] && q[5] == p[5];
-            };
-            uint32_t back = 0; // links behind this entry
-            while (linked((uint32_t)tid - back))
-                back++;
-            lead = back % 3u == 0;
-            c1 = lead && linked((uint32_t)tid + 1);
-            c2 = c1 && linked((uint32_t)tid + 2);
-        }
-        const unsigned long long leaders = __ballot(lead);
-        if ((tid & 63) == 0)
-            wl[tid >> 6] = (uint32_t)__popcll(leaders);
-        __syncthreads();
-        uint32_t nrec = 0, r2 = (uint32_t)__popcll(leaders & ((1ull << (tid & 63)) - 1ull)); // records; this leader's place among them
+                e[k] = st[k];
+        } else {
+            if (keep) {
+                uint32_t *o = cl_rec + rank * kCandWords;
 #pragma unroll
-        for (int w = 0; w < kWaves; w++) {
-            r2 += w < (tid >> 6) ? wl[w] : 0u;
-            nrec += wl[w];
+                for (int k = 0; k < kCandWords; k++)
+                    o[k] = st[k];
+            }
+            __syncthreads();
+            act = (uint32_t)tid < nk;
+            lead = false;
+            if (act) {
+                auto linked = [&](uint32_t a) { // is entry a the previous entry's frame, one offset on?
+                    if (a == 0 || a >= nk)
+                        return false;
+                    const uint32_t *p = cl_rec + (a - 1) * kCandWords, *q = p + kCandWords;
+                    return q[0] == p[0] + 1u && q[1] == p[1] && q[2] == p[2] && q[3] == p[3] && q[4] == p[4] && q[5] == p[5];
+                };
+                uint32_t back = 0; // links behind this entry
+                while (linked((uint32_t)tid - back))
+                    back++;
+                lead = back % 3u == 0;
+                c1 = lead && linked((uint32_t)tid + 1);
+                c2 = c1 && linked((uint32_t)tid + 2);
+                const uint32_t *my = cl_rec + tid * kCandWords;
+#pragma unroll
+                for (int k = 0; k < kCandWords; k++)
+                    e[k] = my[k];
+            }
+            const unsigned long long leaders = __ballot(lead);
+            if ((tid & 63) == 0)
+                wl[tid >> 6] = (uint32_t)__popcll(leaders);
+            __syncthreads();
+            nrec = 0;
+            r2 = (uint32_t)__popcll(leaders & ((1ull << (tid & 63)) - 1ull)); // this leader's place among the records
+#pragma unroll
+            for (int w = 0; w < kWaves; w++) {
+                r2 += w < (tid >> 6) ? wl[w] : 0u;
+                nrec += wl[w];
+            }
         }
         // The tile reserves its range of the hand-off stream -- one marker granule plus two per record, in whole 64-byte
         // lines -- with one device-scope atomic whose answer takes ~2 us under the scan's traffic: the round trip runs beside
@@ -912,14 +941,15 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         }
         // finish the entry: bytes in order, pw (demod.c:127,133) -- every offset has a pw of its own
         uint32_t fin[6] = {0, 0, 0, 0, 0, 0};
-        if ((uint32_t)tid < nk) {
-            const uint32_t cw[4] = {my[2], my[3], my[4], my[5]};
+        if (act) {
+            const uint32_t cw[4] = {e[2], e[3], e[4], e[5]};
             uint32_t wds[4];
-            columns_to_bytes(cw, (my[1] & 0xFFu) == 0, wds);
-            wds[3] |= ((my[1] >> 8) & 1u) << 24; // repaired-by-extension flag
-            const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + my[0]);
-            fin[0] = my[0], fin[1] = pw, fin[2] = wds[0], fin[3] = wds[1], fin[4] = wds[2], fin[5] = wds[3];
-            pwbuf[tid] = pw;
+            columns_to_bytes(cw, (e[1] & 0xFFu) == 0, wds);
+            wds[3] |= ((e[1] >> 8) & 1u) << 24; // repaired-by-extension flag
+            const uint32_t pw = pw_at(xin, pbuf0, p_lo, p_hi, (int64_t)args.g_begin + e[0]);
+            fin[0] = e[0], fin[1] = pw, fin[2] = wds[0], fin[3] = wds[1], fin[4] = wds[2], fin[5] = wds[3];
+            if (links)
+                pwbuf[tid] = pw;
         }
         if (reserves) {
             *tile_base = res_base;
@@ -929,7 +959,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         }
         __syncthreads(); // tile_base / tile_fit are in, every entry has been read, every pw is known
         const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
-        if ((uint32_t)tid < nk) {
+        if (act) {
             if (!to_stream) {
                 const uint32_t wds[4] = {fin[2], fin[3], fin[4], fin[5]};
                 emit_loose(fin[0], fin[1], wds); // (one by one: records of the loose list never carry copies)
@@ -943,16 +973,15 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                 atomicXor(&tile_chk[2], fin[2] ^ pw1);
                 atomicXor(&tile_chk[3], fin[3] ^ pw2);
                 atomicAdd(tile_sum, record_term(r2, fin[0], fin[1]));
-            }
-        }
-        if (to_stream) {
-            __syncthreads(); // every pw has been read: the records go back into the list, compacted
-            if (lead) {
+                // the finished record goes back into the list, in its place among the records (the list was last READ in
+                // front of the barrier above: by its holders, or by the threads that took the entries in ascending offset)
                 uint32_t *o = cl_rec + r2 * kCandWords;
 #pragma unroll
                 for (int k = 0; k < 6; k++)
                     o[k] = fin[k];
             }
+        }
+        if (to_stream) {
             if (tid == 0)
                 *tile_n = nrec; // (the marker's count)
             // the tile's range {marker, records} leaves as one store of adjacent lanes
