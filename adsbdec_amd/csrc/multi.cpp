@@ -138,7 +138,7 @@ struct Worker {
     std::vector<uint64_t> bases, head_tries, tail_tries;
     uint64_t head_tries_end = 0, tail_from = ~0ull;
     std::vector<adsb_candidate> scratch_cands;
-    static constexpr int kRing = 10;         // page-locked pieces of a file source: kFileReaders being read + one being copied + one
+    static constexpr int kRing = 4;          // page-locked pieces of a file source: one borrowed by the copy in flight, one ready, two being read
     uint16_t *ring[kRing] = {};
     int ring_slots = 0;                      // of them allocated (a short slice needs fewer)
     uint64_t ring_samples = 0, piece = kPieceSamples;
@@ -264,29 +264,37 @@ const uint16_t *fetch(Worker &w, const Source &src, uint64_t at, uint64_t n, int
 
 // A FILE source at the link's rate.  One thread's pread() from the page cache delivers 11.6 GB/s on the host measured
 // (profiles/r5_ingest_probe.txt), a device's link takes 56: kFileReaders helper threads, started for the feed and gone
-// with it, read pieces AHEAD into the worker's ring of page-locked buffers -- piece k by whichever thread claims it, into
-// slot k mod kRing once the push of piece k - kRing + 1 has returned -- and the worker pushes them in order.  (Zero copy
-// -- windows of an mmap of the file registered with the runtime -- was measured too: the copies then run at the link's rate,
-// but registering page-cache pages costs as much CPU per byte as copying them)
+// with it, read AHEAD into the worker's ring of page-locked buffers.  The unit a thread claims is a 4 MiB block, not a
+// piece: all of them work on the piece the worker needs next (the first piece of a feed is there after one block's time,
+// not after one thread has read 32 MiB), a piece is pushed when its last block is in, and its buffer is free again once the
+// push of the NEXT piece has returned (adsb_push_async's contract).  Pieces are the host source's 32 MiB: with 8 MiB
+// pieces the same readers delivered 23.0 instead of 26.4 Gsamples/s, and twelve readers no more than eight -- the short
+// pushes, not the reading, were the limit (profiles/r5_file_readers.txt).  (Zero copy -- windows of an mmap of the file
+// registered with the runtime -- was measured too: the copies then run at the link's rate, but registering page-cache pages
+// costs as much CPU per byte as copying them and does not scale with threads)
 constexpr int kFileReaders = 8;
-constexpr uint64_t kFilePieceSamples = 4ull << 20; // 8 MiB: ten of them page-locked per worker
+constexpr uint64_t kFileBlockSamples = 2ull << 20; // 4 MiB
 int feed_file(Worker &w, const Source &src, uint64_t first, uint64_t n, uint64_t piece)
 {
-    piece = std::min(piece, kFilePieceSamples);
     const uint64_t npieces = (n + piece - 1) / piece;
     if (!ring_ready(w, piece, (int)std::min<uint64_t>(Worker::kRing, npieces + 1)))
         return -1;
     const uint64_t nring = (uint64_t)w.ring_slots;
-    std::atomic<uint64_t> next{0}, freed{0}; // next piece to claim; pieces [0, freed) have left their buffers
+    const uint64_t bpp = (piece + kFileBlockSamples - 1) / kFileBlockSamples; // blocks per piece
+    const uint64_t nblocks = (npieces - 1) * bpp + ((n - (npieces - 1) * piece) + kFileBlockSamples - 1) / kFileBlockSamples;
+    std::atomic<uint64_t> next{0}, freed{0}; // next block to claim; pieces [0, freed) have left their buffers
     std::atomic<bool> abort{false};
-    std::unique_ptr<std::atomic<int>[]> state(new std::atomic<int>[npieces]);
-    for (uint64_t k = 0; k < npieces; k++)
-        state[k].store(0, std::memory_order_relaxed);
+    std::unique_ptr<std::atomic<int>[]> left(new std::atomic<int>[npieces]); // blocks of the piece still to come; < 0: a read failed
+    for (uint64_t k = 0; k < npieces; k++) {
+        const uint64_t len = std::min(piece, n - k * piece);
+        left[k].store((int)((len + kFileBlockSamples - 1) / kFileBlockSamples), std::memory_order_relaxed);
+    }
     auto reader = [&] {
         for (;;) {
-            const uint64_t k = next.fetch_add(1, std::memory_order_relaxed);
-            if (k >= npieces)
+            const uint64_t b = next.fetch_add(1, std::memory_order_relaxed);
+            if (b >= nblocks)
                 return;
+            const uint64_t k = b / bpp, off = (b % bpp) * kFileBlockSamples; // piece, and where in it
             for (unsigned spins = 0; k >= freed.load(std::memory_order_acquire) + nring; spins++) { // its slot is still borrowed
                 if (abort.load(std::memory_order_relaxed))
                     return;
@@ -297,15 +305,17 @@ int feed_file(Worker &w, const Source &src, uint64_t first, uint64_t n, uint64_t
             }
             if (abort.load(std::memory_order_relaxed))
                 return;
-            const uint64_t at = first + k * piece, len = std::min(piece, first + n - at);
-            const bool ok = read_samples(src.fd, w.ring[k % nring], at, len);
-            state[k].store(ok ? 1 : -1, std::memory_order_release);
-            if (!ok)
+            const uint64_t plen = std::min(piece, n - k * piece), len = std::min(kFileBlockSamples, plen - off);
+            if (read_samples(src.fd, w.ring[k % nring] + off, first + k * piece + off, len)) {
+                left[k].fetch_sub(1, std::memory_order_acq_rel);
+            } else {
+                left[k].store(-1000000, std::memory_order_release);
                 return;
+            }
         }
     };
     std::vector<std::thread> readers;
-    const int nthreads = (int)std::min<uint64_t>({(uint64_t)kFileReaders, npieces, nring > 2 ? nring - 2 : 1});
+    const int nthreads = (int)std::min<uint64_t>((uint64_t)kFileReaders, nblocks);
     int rc = 0;
     try {
         for (int t = 0; t < nthreads; t++)
@@ -316,7 +326,7 @@ int feed_file(Worker &w, const Source &src, uint64_t first, uint64_t n, uint64_t
         return 1;
     for (uint64_t k = 0; k < npieces && rc == 0; k++) {
         int st;
-        for (unsigned spins = 0; (st = state[k].load(std::memory_order_acquire)) == 0; spins++) {
+        for (unsigned spins = 0; (st = left[k].load(std::memory_order_acquire)) > 0; spins++) {
             if (spins < 256)
                 relax_burst();
             else
