@@ -42,7 +42,7 @@ def results():
 | `bench.py`, default line (one box) | **{d['value'] / 1e6:.3f} Tsamples/s**, {d['ms_per_step']:.4f} ms per 256 Mi-sample step; scan kernel {d['roofline']['launch_ms'] * 1e3:.1f} µs on its own clock = {d['roofline']['achieved']:.0f} GB/s = **{d['roofline']['frac']:.3f} of 8 TB/s** | `r5_bench.json` |
 | ... the same region with 1000 steps instead of the driver's 20 (`value_1000_steps`) | {k['value'] / 1e6:.3f} Tsamples/s, {k['ms_per_step']:.4f} ms per step, kernel {k['launch_ms'] * 1e3:.1f} µs = {k['roofline_frac']:.3f} | `r5_bench.json` |
 | the same command under `rocprofv3 --kernel-trace --stats`, 1000 timed steps (the same box, the same gpurun call) | `scan_kernel<false>`: {len(dur)} dispatches, average **{statistics.mean(dur):.1f} µs** (pre-roll and warm-up included) = {frac(statistics.mean(dur)):.3f}; last 1000: {statistics.mean(dur[-1000:]):.1f} µs = **{frac(statistics.mean(dur[-1000:])):.3f}**; minimum {min(dur):.1f} µs; the bench line of that very run read {u['roofline']['launch_ms'] * 1e3:.1f} µs in-kernel (1 % below the trace, as in every round) | `r5_kernel_stats.csv`, `r5_dispatches.csv`, `r5_bench_under_rocprofv3.json` |
-| spread of the kernel | box to box 0.137–0.148 ms (0.453–0.490), same build, same command (rounds 3 to 5's boxes); on one box the 200 default steps read ≈ 3 % longer than 1000 steps right behind them (the clock governor is still ramping: rows 1 and 2) | `r3_ab_runs.txt`, `r4_ab_runs.txt`, `r5_ab_runs.txt` |
+| spread of the kernel | box to box 0.132–0.148 ms (0.453–0.508) for the same command (rounds 3 to 5's boxes; the round-5 kernel is 0.85 % slower than round 4's on one box: `r5_ab_runs.txt` §6); on one box the 200 default steps read ≈ 3 % longer than 1000 steps right behind them (the clock governor is still ramping: rows 1 and 2) | `r3_ab_runs.txt`, `r4_ab_runs.txt`, `r5_ab_runs.txt` |
 | HBM traffic per launch | {pmc['hbm_bytes_per_launch'] / 1e6:.1f} MB = {pmc['hbm_bytes_per_launch'] / B:.3f} × the 536.9 MB of algorithmic input (FETCH_SIZE × 2 + WRITE_SIZE, separate passes) | `r5_pmc.json` |
 | VALU wave-instructions per launch | {c['SQ_INSTS_VALU']['mean'] / 1e6:.2f} M; Stage A's pass 661 instructions = 2 558 issue cycles (3.87 per instruction) | `r5_pmc.json`, `r5_isa_mix.json` |
 | wave time | issuing {c['SQ_ACTIVE_INST_ANY']['mean'] / wc * 100:.0f} %, stalled wanting to issue {c['SQ_WAIT_INST_ANY']['mean'] / wc * 100:.0f} %, parked on `s_waitcnt` / `s_barrier` {c['SQ_WAIT_ANY']['mean'] / wc * 100:.0f} % | `r5_pmc.json` |
@@ -78,10 +78,18 @@ def shards():
             "|---|---|---|---|---|---|---|\n" + "\n".join(rows)).replace("\\n", "\n")
 
 
+def file_source():
+    h1, f1 = J("r5_bench_shard_host_fed_N1_512Mi.json"), J("r5_bench_shard_file_fed_N1_512Mi.json")
+    h4, f4 = J("r5_bench_shard_host_fed_4handles_512Mi.json"), J("r5_bench_shard_file_fed_4handles_512Mi.json")
+    return (f"**{f1['value'] / 1e3:.1f} of the host source's {h1['value'] / 1e3:.1f} Gsamples/s with one handle ({f1['value'] / h1['value']:.2f}), "
+            f"{f4['value'] / 1e3:.1f} of {h4['value'] / 1e3:.1f} with four on the one link ({f4['value'] / h4['value']:.2f})** "
+            "(`profiles/r5_bench_shard_file_fed_*`, `…host_fed_*`: one box, one call; run to run the file source spreads by 10 %, `r5_file_readers.txt`)")
+
+
 def main():
     path = os.path.join(ROOT, "DESIGN.md")
     t = open(path).read()
-    for tag, text in (("results", results()), ("shards", shards())):
+    for tag, text in (("results", results()), ("shards", shards()), ("file", file_source())):
         a, b = f"<!-- r5-{tag}:begin -->", f"<!-- r5-{tag}:end -->"
         assert a in t and b in t, tag
         t = t[: t.index(a) + len(a)] + "\n" + text + "\n" + t[t.index(b):]
