@@ -42,7 +42,7 @@ extern "C" {
  * 3: `push_overlap` took the place of ABI 2's `reserved0`; it is only honoured when struct_size covers `host_threads`
  *    (a caller built against ABI 2 that left garbage in reserved0 keeps ABI 2's behaviour).
  * 4: adsb_shard_head / adsb_shard_part carry the statistics of a resolved shard (round 4): adsb_shard_head grew from 80 to
- *    144 bytes and adsb_shard_part by four members, and the library fills / reads all of them -- a binary built against
+ *    136 bytes and adsb_shard_part by four members, and the library fills / reads all of them -- a binary built against
  *    ABI 3 that calls the shard API (adsb_scan_shard_resolved*, adsb_shard_end, adsb_stitch_shards*) MUST be rebuilt; it
  *    can find out at run time: adsb_shard_layout_check(sizeof(adsb_shard_head), sizeof(adsb_shard_part)) != 0.  The
  *    streaming API (adsb_create / adsb_push* / adsb_drain ...) and adsb_multi_* are unaffected.

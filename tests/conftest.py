@@ -80,7 +80,7 @@ def _per_test_time_limit(request):
     call that never returns (the signal handler only runs between bytecodes), a watchdog of faulthandler's own (a C thread:
     it needs no GIL) dumps the stacks 45 s later and ENDS the process -- a red run with a cause instead of a killed one."""
     m = request.node.get_closest_marker("limit")
-    limit = float(m.args[0]) if m else (150.0 if request.node.get_closest_marker("gpu") else 300.0)
+    limit = float(m.args[0]) if m else 300.0
     if threading.current_thread() is not threading.main_thread() or not hasattr(signal, "SIGALRM"):
         yield
         return

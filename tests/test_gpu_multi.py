@@ -435,3 +435,52 @@ def test_cli_G_accepts_what_the_one_device_run_accepts(capi, oracle, tmp_path):
         assert q.returncode == 0 and q.stdout == b"", (opts, q.stderr)
         tail = q.stderr.decode().splitlines()[-3:]
         assert [ln.split(":")[0].strip() for ln in tail] == ["Try", "Ok", "Total"] and tail[-1].split()[-1] == "0"
+
+
+def test_multi_host_alloc_places_the_capture_and_says_where(capi, captures, torch_cuda):
+    """adsb_multi_host_alloc (csrc/numa.cpp): one page-locked array laid out shard by shard on the NUMA node of the device
+    that pulls it; the decode from it equals the oracle's, adsb_multi_worker_placement reports for every worker the node of
+    its device, whether its thread is bound there and where its slice lives -- on this pool's boxes (one GPU: every handle
+    on device 0) every slice must be on the device's node -- and adsb_host_free takes the mapping back.  adsb_host_alloc_on
+    is the one-device form."""
+    import ctypes as C
+    from adsbdec_amd import sharding
+    L = capi.load()
+    node = L.adsb_device_numa_node(0)
+    md = sharding.MultiDecoder(3, [0, 0, 0], df18=True, collect_stats=True)
+    try:
+        for name, x, want, wstats in captures:
+            arr, addr = md.host_alloc(x.size)
+            try:
+                arr[:] = x
+                assert _recs(capi, md.decode_host(addr, x.size)) == want, name
+                assert md.stats() == wstats
+                inf = md.info()
+                for i in range(inf["shards"]):
+                    pl = md.placement(i)
+                    assert pl["device"] == 0 and pl["device_node"] == node
+                    if node >= 0 and pl["slice_node"] >= 0:       # (the platform names the device's node and answers move_pages)
+                        assert pl["slice_node"] == node and pl["local_fraction"] == 1.0, (name, i, pl)
+                        assert pl["thread_bound"] == 1
+            finally:
+                md.host_free(addr)
+            assert L.adsb_host_release_mapped(addr) == 0          # gone: a second release finds nothing
+    finally:
+        md.close()
+    p = L.adsb_host_alloc_on(3 << 20, 0)
+    assert p
+    n2, fr = C.c_int(-1), C.c_double(-1.0)
+    if L.adsb_host_placement(p, 3 << 20, node, C.byref(n2), C.byref(fr)) == 0 and node >= 0:
+        assert n2.value == node and fr.value == 1.0
+    d = capi.Decoder(df18=True)
+    try:
+        name, x, want, _ = captures[0]
+        buf = np.frombuffer((C.c_uint16 * (3 << 19)).from_address(p), dtype=np.uint16)
+        k = min(buf.size, x.size)
+        buf[:k] = x[:k]
+        d.push_async((p, k))
+        d.finish()
+        assert len(d.drain()) > 10
+    finally:
+        d.close()
+        L.adsb_host_free(p)

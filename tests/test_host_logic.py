@@ -407,3 +407,19 @@ def test_host_placement_query_and_mapped_block_registry(capi):
     import torch
     if not torch.cuda.is_available():
         assert not L.adsb_host_alloc_on(1 << 20, 0)            # no runtime, no page-locking: NULL, and nothing leaks
+
+
+def test_shard_layout_check_and_config_growth(capi):
+    """adsb_shard_layout_check: the run-time answer to "was this caller built against the layout the library writes?" (ABI 4
+    grew adsb_shard_head from 80 to 136 bytes); adsb_config_init fills what the caller's struct holds, wait_timeout_s included."""
+    import ctypes as C
+    L = capi.load()
+    assert L.adsb_shard_layout_check(C.sizeof(capi.ShardHead), C.sizeof(capi.ShardPart)) == 0
+    assert C.sizeof(capi.ShardHead) == 136
+    assert L.adsb_shard_layout_check(80, C.sizeof(capi.ShardPart)) == -1          # an ABI-3 caller's head
+    assert L.adsb_shard_layout_check(C.sizeof(capi.ShardHead), C.sizeof(capi.ShardPart) - 32) == -1
+    cfg = capi.make_config(wait_timeout_s=7)
+    assert cfg.struct_size == C.sizeof(capi.Config) and cfg.wait_timeout_s == 7
+    short = capi.Config()
+    L.adsb_config_init(C.byref(short), capi.Config.wait_timeout_s.offset)         # a caller built before the member existed
+    assert short.struct_size == capi.Config.wait_timeout_s.offset and short.wait_timeout_s == 0
