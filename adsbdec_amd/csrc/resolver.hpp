@@ -69,6 +69,25 @@ private:
     size_t n_ = 0, cap_ = 0;
 };
 
+// One accepted frame out of a hand-off record, as five aligned 8-byte stores: {g}{ts}{pw, len, bytes 0..2}{bytes 3..10}
+// {bytes 11..13, reserved, 0} (the record holds the 14 bytes in w0..w3, the length and the flags behind them, the copies' pw in
+// its last two words: scan_kernel_format.h).  Returns the frame's span (demod.c:109,120,123: lidx).
+static_assert(sizeof(adsb_frame) == 40 && offsetof(adsb_frame, pw) == 16 && offsetof(adsb_frame, len) == 20 &&
+                  offsetof(adsb_frame, frame) == 21 && offsetof(adsb_frame, reserved) == 35,
+              "adsb_frame layout");
+inline uint64_t write_frame(uint64_t *o, const uint32_t *r, uint32_t sub, uint64_t g, uint64_t ts)
+{
+    const uint32_t w0 = r[2], w1 = r[3], w2 = r[4], w3 = r[5];
+    const uint32_t len = (w3 >> 16) & 0xFFu, fixed = (w3 >> 24) & 1u;
+    const uint32_t pw = sub ? r[5 + sub] : r[1];
+    o[0] = g;
+    o[1] = ts;
+    o[2] = (uint64_t)pw | (uint64_t)len << 32 | (uint64_t)(w0 & 0xFFFFFFu) << 40;
+    o[3] = (uint64_t)(w0 >> 24) | (uint64_t)w1 << 8 | (uint64_t)(w2 & 0xFFFFFFu) << 40;
+    o[4] = (uint64_t)(w2 >> 24) | (uint64_t)(w3 & 0xFFFFu) << 8 | (uint64_t)fixed << 24; // (tail padding zero: frames are compared and copied as bytes)
+    return 80 + 80 * (uint64_t)len;
+}
+
 class Resolver {
 public:
     void reset()
@@ -164,6 +183,8 @@ public:
         batch_.u_end = t1;
         batch_.g_base = g_base;
         batch_.seek_tile(t0);
+        for (uint32_t u = t0; u < t1; u++)
+            batch_.records_left += counts[u];
         advance(power_samples, g_complete);
         keep_leftovers();
     }
@@ -425,6 +446,7 @@ private:
         // a stream record stands for `copies` candidates at consecutive offsets (scan_kernel_format.h); `sub` is the one `cur`
         // means at the moment.  Index-list records (6 words) are always single.
         uint32_t sub = 0, copies = 1;
+        size_t records_left = 0; // tile mode: records of the batch (an upper bound of the frames it can yield)
 
         uint64_t g() const { return g_base + cur[0] + sub; }
         uint32_t pw() const { return sub ? cur[5 + sub] : cur[1]; }
@@ -492,124 +514,120 @@ private:
     // stream where they lie -- as one tight loop: at the channel's capacity (BASELINE configs[2]: 106 k accepted frames per
     // 256 Mi-sample launch) the general loop below cost 8 ns per accepted frame, four times the kernel's share.  Same rules,
     // same order of side effects; the dependent chain per frame is idx -> which copy of the record -> idx + span.
-    bool tiles_fast_path() const { return chead_ == cands_.size() && !batch_.order && batch_.starts; }
+    // (host-side try words -- per-shard scans that hand the list back -- are counted between the frames: the general loop)
+    bool tiles_fast_path() const { return chead_ == cands_.size() && !batch_.order && batch_.starts && thead_ == tries_.size(); }
     // single_limit != 0: ONE call with that limit (chain mode: run_call(g_complete)).  Else: the stream's deqframe calls, one
     // after the other while they have fired (air.c:94: at the first EVEN total T with T - base >= 40980) and the device has
     // scanned up to their limit (demod.c:89: T - 1200) -- the loop of advance(), inside: on sparse input a call holds four
     // frames, and entering and leaving this function once per call cost as much as the frames.
+    //
+    // The loop is written for the register file.  Its first form kept some twenty values alive -- cursor, tile bookkeeping,
+    // four counters, flags for the log and the call walk -- and the compiler kept half of them on the stack: every one a
+    // load-add-store through memory per frame, five or six cycles of chain each, 16 cycles per frame in all (the frame's own
+    // dependent chain is max(idx, g0) + span: two).  Now: the cursor is two pointers, the output one, and everything else --
+    // the Ok row's counters, what a statistics run or a shard's call walk wants per frame (Resolver::log_into, start_walk) --
+    // is read back from the frames just written, behind the loop.
     void run_calls_tiles(uint64_t power_samples, uint64_t g_complete, uint64_t single_limit)
     {
-        // Everything the loop touches lives in locals (the stores of a frame are plain uint64_t stores: with the cursor, the
-        // output size and the counters in members the compiler has to reload and store them around every frame -- 90
-        // instructions per frame, 22 cycles; so: 40).
         Batch &b = batch_;
-        const uint32_t *cur = b.cur;
-        uint32_t left = b.left, copies = b.copies, u = b.u;
         const uint32_t *const recs = b.recs, *const starts = b.starts, *const counts = b.counts;
         const uint32_t u_end = b.u_end;
         const uint64_t g_base = b.g_base;
-        const bool tries = thead_ < tries_.size(), walk = w_on_ && !w_stop_, log = log_on_;
+        uint32_t u = b.u;
+        const uint32_t *cur = b.cur, *tile_end = b.cur ? b.cur + 8 * (size_t)b.left : nullptr; // records are two granules
         uint64_t base = base_, skipped = skipped_;
-        uint64_t ok[3] = {0, 0, 0}, fixed_n = 0;
-        size_t room = 256, made = 0;
-        uint64_t *f = reinterpret_cast<uint64_t *>(out_.room(room));
-        auto next_record = [&]() {
-            if (--left) {
-                cur += 8; // two granules per record
-            } else {
-                cur = nullptr;
-                for (u++; u < u_end; u++)
-                    if (counts[u]) {
-                        left = counts[u];
-                        cur = recs + (size_t)starts[u] * 4;
-                        break;
-                    }
-                if (!cur)
-                    return;
-            }
-            copies = rec_copies(cur);
-        };
+        const size_t n_before = out_.size();
+        uint64_t *o = reinterpret_cast<uint64_t *>(out_.room(b.records_left + 1)); // an accepted frame per record at most
+        uint64_t *const o_first = o;
         for (;;) { // one deqframe call per round
-        uint64_t limit = single_limit;
-        if (!single_limit) {
-            const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1);
-            if (fire > power_samples)
-                break; // the reference has not called deqframe yet (never, at EOF)
-            limit = fire - ADSB_DECOFFSET;
-            if (limit > g_complete)
-                break; // the device has not scanned that far yet
-        }
-        uint64_t idx = base;
-        while (cur) {
-            const uint32_t *r = cur;
-            const uint64_t g0 = g_base + r[0];
-            if (g0 + copies <= idx) { // every offset of the record lies inside an accepted frame: never evaluated
-                next_record();
-                continue;
+            uint64_t limit = single_limit;
+            if (!single_limit) {
+                const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1);
+                if (fire > power_samples)
+                    break; // the reference has not called deqframe yet (never, at EOF)
+                limit = fire - ADSB_DECOFFSET;
+                if (limit > g_complete)
+                    break; // the device has not scanned that far yet
             }
-            const uint32_t sub = idx > g0 ? (uint32_t)(idx - g0) : 0u; // the first of its offsets the scan can visit
-            const uint64_t g = g0 + sub;
-            if (g >= limit)
-                break;
-            if (tries)
-                count_tries(idx, g);
-            if (made == room) {
-                out_.grew(made);
-                made = 0;
-                f = reinterpret_cast<uint64_t *>(out_.room(room = 4096));
+            uint64_t idx = base;
+            while (cur) {
+                if (cur == tile_end) { // on to the next tile that has records
+                    cur = nullptr;
+                    for (u++; u < u_end; u++)
+                        if (counts[u]) {
+                            cur = recs + (size_t)starts[u] * 4;
+                            tile_end = cur + 8 * (size_t)counts[u];
+                            break;
+                        }
+                    continue;
+                }
+                const uint64_t g0 = g_base + cur[0];
+                if (g0 + rec_copies(cur) <= idx) { // every offset of the record lies inside an accepted frame: never evaluated
+                    cur += 8;
+                    continue;
+                }
+                const uint64_t g = idx > g0 ? idx : g0; // the first of its offsets the scan can visit
+                if (g >= limit)
+                    break;
+                const uint64_t span = write_frame(o, cur, (uint32_t)(g - g0), g, g + 1 - skipped); // demod.c:99: one ts++ per visited offset
+                o += 5;
+                skipped += span - 1;
+                idx = g + span; // demod.c:128,134 -- the record's other offsets lie inside this frame
+                cur += 8;
+                if (idx >= limit)
+                    break;
             }
-            // the frame leaves as five aligned 8-byte stores: {g}{ts}{pw, len, bytes 0..2}{bytes 3..10}{bytes 11..13, reserved, 0}
-            // (the record holds the 14 bytes in w0..w3, the length and the flags behind them: scan_kernel_format.h)
-            static_assert(sizeof(adsb_frame) == 40 && offsetof(adsb_frame, pw) == 16 && offsetof(adsb_frame, len) == 20 &&
-                              offsetof(adsb_frame, frame) == 21 && offsetof(adsb_frame, reserved) == 35,
-                          "adsb_frame layout");
-            const uint32_t w0 = r[2], w1 = r[3], w2 = r[4], w3 = r[5];
-            const uint32_t len = (w3 >> 16) & 0xFFu, fixed = (w3 >> 24) & 1u;
-            const uint32_t pw = sub ? r[5 + sub] : r[1];
-            uint64_t *o = f + 5 * made++;
-            o[0] = g;
-            o[1] = g + 1 - skipped; // demod.c:99: one ts++ per visited offset
-            o[2] = (uint64_t)pw | (uint64_t)len << 32 | (uint64_t)(w0 & 0xFFFFFFu) << 40;
-            o[3] = (uint64_t)(w0 >> 24) | (uint64_t)w1 << 8 | (uint64_t)(w2 & 0xFFFFFFu) << 40;
-            o[4] = (uint64_t)(w2 >> 24) | (uint64_t)(w3 & 0xFFFFu) << 8 | (uint64_t)fixed << 24; // (tail padding zero: frames are compared and copied as bytes)
-            const uint64_t span = 80 + 80 * (uint64_t)len; // demod.c:109,120,123: lidx
-            const uint32_t df = (w0 & 0xFFu) >> 3;
-            ok[df == 11 ? 0 : df == 17 ? 1 : 2]++;
-            fixed_n += fixed;
-            skipped += span - 1;
-            if (walk)
-                w_acc_.emplace_back(g, g + span);
-            if (log) {
-                if (ext_n_ < ext_cap_ && log_.empty())
-                    ext_[ext_n_++] = LogEntry{g, (uint32_t)span, 0};
-                else
-                    log_.emplace_back(g, (uint32_t)span);
-            }
-            idx = g + span; // demod.c:128,134 -- the record's other offsets lie inside this frame
-            next_record();
-            if (idx >= limit)
+            if (idx < limit)
+                idx = limit; // no candidate left below the limit: all remaining offsets advance by one (demod.c:141)
+            base = idx; // deqframe's return value; air.c:96-98 carries the rest
+            if (single_limit)
                 break;
         }
-        if (idx < limit) { // no candidate left below the limit: all remaining offsets advance by one (demod.c:141)
-            if (tries)
-                count_tries(idx, limit - 1);
-            idx = limit;
-        }
-        base = idx; // deqframe's return value; air.c:96-98 carries the rest
-        if (single_limit)
-            break;
-        }
+        const size_t made = (size_t)(o - o_first) / 5;
         out_.grew(made);
+        if (cur && cur == tile_end) { // (the cursor never rests behind a tile's last record)
+            cur = nullptr;
+            for (u++; u < u_end; u++)
+                if (counts[u]) {
+                    cur = recs + (size_t)starts[u] * 4;
+                    tile_end = cur + 8 * (size_t)counts[u];
+                    break;
+                }
+        }
         b.cur = cur;
-        b.left = left;
-        b.copies = copies;
+        b.left = cur ? (uint32_t)((tile_end - cur) / 8) : 0;
+        b.copies = cur ? rec_copies(cur) : 1;
         b.u = u;
         b.sub = 0;
         skipped_ = skipped;
         base_ = base;
-        for (int k = 0; k < 3; k++)
-            stats_.ok[k] += ok[k];
-        stats_.fixed += fixed_n;
+        // The Ok row (valid.c:53,75) and the repair count, read back from the frames just written (they are in the cache): a
+        // counter in the loop above is one more value than the register file holds, i.e. a load-add-store per frame.
+        const adsb_frame *const f = out_.data() + n_before;
+        uint64_t n11 = 0, n17 = 0, nfix = 0;
+        for (size_t i = 0; i < made; i++) {
+            const uint32_t df = f[i].frame[0] >> 3;
+            n11 += df == 11;
+            n17 += df == 17;
+            nfix += f[i].reserved & 1u;
+        }
+        stats_.ok[0] += n11;
+        stats_.ok[1] += n17;
+        stats_.ok[2] += made - n11 - n17;
+        stats_.fixed += nfix;
+        if ((w_on_ && !w_stop_) || log_on_) { // ... and what a shard's call walk or a statistics run wants per frame
+            for (size_t i = 0; i < made; i++) {
+                const uint64_t g = f[i].g, span = 80 + 80 * (uint64_t)f[i].len;
+                if (w_on_ && !w_stop_)
+                    w_acc_.emplace_back(g, g + span);
+                if (log_on_) {
+                    if (ext_n_ < ext_cap_ && log_.empty())
+                        ext_[ext_n_++] = LogEntry{g, (uint32_t)span, 0};
+                    else
+                        log_.emplace_back(g, (uint32_t)span);
+                }
+            }
+        }
     }
 
     // One deqframe(ampbuff, len) call: visits offsets from base_ while < limit.
