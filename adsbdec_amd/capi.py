@@ -112,6 +112,7 @@ SYMBOLS = {
     "adsb_format_frame": (C.c_int, [C.POINTER(Frame), C.c_int, C.c_char_p]),
     "adsb_resolver_create": (C.c_void_p, []),
     "adsb_resolver_destroy": (None, [C.c_void_p]),
+    "adsb_resolver_set_threads": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "adsb_resolver_feed": (C.c_int, [C.c_void_p, C.POINTER(Candidate), C.c_size_t,
                                      C.POINTER(C.c_uint64), C.c_size_t]),
     "adsb_resolver_advance": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),

@@ -173,6 +173,9 @@ struct adsb_decoder {
     adsb::StreamReader *reader = nullptr;    // the thread that reads the hand-off stream (slot_collect_streaming): cfg.host_threads = 2
                                              // from the start, 0 (auto) from the first launch that follows a dense one
     bool reader_failed = false;              // no thread could be had: do not try again
+    adsb::FormatGang *gang = nullptr;        // the threads that write the frames of dense launches (gang.hpp): cfg.host_threads >= 3, or auto
+    bool gang_failed = false;
+    int gang_l3 = -1;
     uint32_t reader_min_tiles = 1024; // launches below this many tiles are collected by the calling thread alone
     uint64_t last_launch_records = 0; // records the previous launch handed over (auto: the thread pays from kAutoReaderRecords on)
     bool no_streaming = false; // cfg.debug_no_streaming: always collect after completion
@@ -714,6 +717,27 @@ void start_reader(adsb_decoder *d)
     }
 }
 
+// More hands for a channel at its capacity (gang.hpp): the calling thread decides, `helpers` threads on its L3 write the frames.
+void start_gang(adsb_decoder *d, int helpers)
+{
+    if (d->gang || d->gang_failed)
+        return;
+    d->gang = new (std::nothrow) adsb::FormatGang;
+    if (d->gang && !d->gang->start(helpers)) { // no thread to be had: the calling thread writes its frames itself, as without
+        delete d->gang;
+        d->gang = nullptr;
+    }
+    if (!d->gang) {
+        d->gang_failed = true;
+        return;
+    }
+    const int cpu = sched_getcpu();
+    for (std::thread &t : d->gang->threads())
+        d->gang_l3 = adsb::place_reader_thread(t, cpu);
+}
+
+constexpr int kAutoGangHelpers = 4; // (measured on the dense capture: profiles/r5_gang_runs.txt)
+
 int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, uint32_t *tiles_in, bool *tries_listed)
 {
     using clk = std::chrono::steady_clock;
@@ -748,9 +772,21 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     const adsb::HandJob job = hand_job(s);
     adsb::CollectEnd end;
     const bool after_dense = d->cfg.host_threads == 0 && d->last_launch_records >= kAutoReaderRecords;
-    if (after_dense)
+    if (after_dense) {
         start_reader(d);
-    if (d->reader && s.ntiles >= d->reader_min_tiles && (d->cfg.host_threads == 2 || after_dense)) {
+        start_gang(d, kAutoGangHelpers);
+    }
+    const bool with_gang = d->gang && !d->sink.cands && (uint64_t)s.args.hand_cap * adsb::kGranuleWords * 4 <= adsb::kDecMaxStreamBytes && (d->cfg.host_threads >= 3 || after_dense);
+    d->res.set_gang(with_gang ? d->gang : nullptr);
+    if (with_gang) {
+        const int cpu = sched_getcpu(); // the caller may have moved since the threads were placed
+        const int l3 = adsb::l3_of_cpu(cpu);
+        if (l3 >= 0 && l3 != d->gang_l3)
+            for (std::thread &t : d->gang->threads())
+                d->gang_l3 = adsb::place_reader_thread(t, cpu);
+        d->gang->begin();
+    }
+    if (d->reader && s.ntiles >= d->reader_min_tiles && (d->cfg.host_threads >= 2 || after_dense)) {
         adsb::StreamReader &rd = *d->reader;
         if (rd.place) { // the caller may have moved since the thread was placed
             const int cpu = sched_getcpu();
@@ -764,11 +800,19 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     } else {
         end = adsb::collect_alone(job, t_start.data(), t_count.data(), delivered, flush, wait_ms, t_last_wait);
     }
+    if (end.status < 0 && with_gang) {
+        d->res.sync();
+        d->gang->end();
+    }
     if (end.status == -1)
         return d->fail("hand-off stream corrupt at granule %u (tile %u twice)", end.pos, end.tile);
     if (end.status == -2)
         return d->fail("scan kernel finished without publishing granule %u (tile %u of %u pending)", end.pos, end.tile, s.ntiles);
     overflowed = end.status == 1;
+    if (with_gang) { // the frames of this launch are whole before its stream is touched again (and before anyone counts the time)
+        d->res.sync();
+        d->gang->end();
+    }
     if (dbg_on)
         fprintf(stderr,
                 "stream collect: %.1f us in all, resolve %.1f us in %d batches, waits %.1f us; %.1f us after the last wait\n",
@@ -1131,6 +1175,7 @@ int slot_collect(adsb_decoder *d)
             return -1;
         }
     }
+    d->res.sync(); // (tiles handed on after completion may have gone to the gang as well)
     d->prof.host_ms += std::chrono::duration<double, std::milli>(clk::now() - t_host).count();
     s.busy = false;
     d->slot_head = (d->slot_head + 1) % kSlots;
@@ -1481,8 +1526,10 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
     {
         if (cfg.debug_reader_min_tiles > 0)
             d->reader_min_tiles = (uint32_t)cfg.debug_reader_min_tiles;
-        if (d->cfg.host_threads == 2)
+        if (d->cfg.host_threads >= 2)
             start_reader(d);
+        if (d->cfg.host_threads >= 3)
+            start_gang(d, std::min(d->cfg.host_threads - 2, 15));
     }
     d->no_streaming = cfg.debug_no_streaming != 0;
     if (cfg.debug_shard_head > 0)
@@ -1500,6 +1547,11 @@ void adsb_destroy(adsb_decoder *d)
     if (d->reader) {
         d->reader->stop();
         delete d->reader;
+    }
+    if (d->gang) {
+        d->res.set_gang(nullptr);
+        d->gang->stop();
+        delete d->gang;
     }
     for (hipStream_t cs : d->copy_stream)
         if (cs)
@@ -1946,7 +1998,7 @@ int adsb_get_stats(const adsb_decoder *d, adsb_stats *out)
     adsb_decoder *m = const_cast<adsb_decoder *>(d); // the try counters live on the device until asked for
     if (m->cfg.collect_stats && (hipSetDevice(m->device) != hipSuccess || read_tries(m)))
         return -1;
-    *out = d->res.stats();
+    *out = m->res.stats();
     return 0;
 }
 

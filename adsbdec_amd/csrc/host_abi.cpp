@@ -108,6 +108,8 @@ int adsb_plan_shards(uint64_t total_samples, int n_shards, uint64_t *g_begin, ui
 struct adsb_resolver {
     adsb::Resolver r;
     std::vector<adsb_candidate> head;
+    adsb::FormatGang gang; // adsb_resolver_set_threads
+    ~adsb_resolver() { r.set_gang(nullptr); }
 };
 
 adsb_resolver *adsb_resolver_create(void)
@@ -119,6 +121,20 @@ adsb_resolver *adsb_resolver_create(void)
 }
 
 void adsb_resolver_destroy(adsb_resolver *r) { delete r; }
+
+int adsb_resolver_set_threads(adsb_resolver *r, int helpers, size_t min_frames)
+{
+    if (!r || helpers < 0 || helpers > 15)
+        return -1;
+    if (helpers == 0) {
+        r->r.set_gang(nullptr);
+        return 0;
+    }
+    if (!r->gang.start(helpers))
+        return -1;
+    r->r.set_gang(&r->gang, min_frames);
+    return (int)r->gang.helpers();
+}
 
 int adsb_resolver_feed(adsb_resolver *r, const adsb_candidate *cands, size_t n_cands,
                        const uint64_t *tries, size_t n_tries)
@@ -186,7 +202,7 @@ int adsb_resolver_stats(const adsb_resolver *r, adsb_stats *out)
 {
     if (!r || !out)
         return -1;
-    *out = r->r.stats();
+    *out = const_cast<adsb_resolver *>(r)->r.stats(); // (waits for the frames that are still being written)
     return 0;
 }
 
@@ -268,6 +284,7 @@ long adsb_resolver_advance_stream(adsb_resolver *r, const void *stream, size_t g
         } catch (const std::exception &) {
             rc = -1;
         }
+        r->r.sync(); // (the gang's threads read the records where they lie: in the copy)
     }
     free(copy);
     return rc;

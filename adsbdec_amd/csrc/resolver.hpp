@@ -15,6 +15,7 @@
 // queues are flat vectors with a head index, and records are consumed in place.
 #pragma once
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
@@ -25,6 +26,7 @@
 
 #include "../../include/adsbdec_amd.h"
 #include "scan_kernel_format.h"
+#include "gang.hpp"
 
 namespace adsb {
 
@@ -57,6 +59,7 @@ public:
         return p_ + n_;
     }
     void grew(size_t k) { n_ += k; } // k slots behind room()'s pointer have been filled
+    bool fits(size_t more) const { return n_ + more <= cap_; } // room(more) would not move the array
     adsb_frame &push()
     {
         adsb_frame *f = room(1);
@@ -69,29 +72,36 @@ private:
     size_t n_ = 0, cap_ = 0;
 };
 
-// One accepted frame out of a hand-off record, as five aligned 8-byte stores: {g}{ts}{pw, len, bytes 0..2}{bytes 3..10}
-// {bytes 11..13, reserved, 0} (the record holds the 14 bytes in w0..w3, the length and the flags behind them, the copies' pw in
-// its last two words: scan_kernel_format.h).  Returns the frame's span (demod.c:109,120,123: lidx).
-static_assert(sizeof(adsb_frame) == 40 && offsetof(adsb_frame, pw) == 16 && offsetof(adsb_frame, len) == 20 &&
-                  offsetof(adsb_frame, frame) == 21 && offsetof(adsb_frame, reserved) == 35,
-              "adsb_frame layout");
-inline uint64_t write_frame(uint64_t *o, const uint32_t *r, uint32_t sub, uint64_t g, uint64_t ts)
-{
-    const uint32_t w0 = r[2], w1 = r[3], w2 = r[4], w3 = r[5];
-    const uint32_t len = (w3 >> 16) & 0xFFu, fixed = (w3 >> 24) & 1u;
-    const uint32_t pw = sub ? r[5 + sub] : r[1];
-    o[0] = g;
-    o[1] = ts;
-    o[2] = (uint64_t)pw | (uint64_t)len << 32 | (uint64_t)(w0 & 0xFFFFFFu) << 40;
-    o[3] = (uint64_t)(w0 >> 24) | (uint64_t)w1 << 8 | (uint64_t)(w2 & 0xFFFFFFu) << 40;
-    o[4] = (uint64_t)(w2 >> 24) | (uint64_t)(w3 & 0xFFFFu) << 8 | (uint64_t)fixed << 24; // (tail padding zero: frames are compared and copied as bytes)
-    return 80 + 80 * (uint64_t)len;
-}
-
 class Resolver {
 public:
+    // More hands (gang.hpp): from now on a batch of tiles that yields kGangMinFrames frames or more is only DECIDED here; the
+    // frames are written by the gang's threads.  Every way to the frames or the counters -- drain, take, stats, reset, an
+    // output array that has to move -- waits for them (sync); whoever recycles the hand-off stream calls sync() first.
+    static constexpr size_t kGangMinFrames = 1024; // (a hand-over has a latency: a small batch is written faster than handed on)
+    void set_gang(FormatGang *g, size_t min_frames = kGangMinFrames)
+    {
+        sync();
+        gang_ = g;
+        gang_min_frames_ = min_frames;
+    }
+    void sync()
+    {
+        if (!gang_busy_)
+            return;
+        gang_->wait_all();
+        const FormatGang::Counts c = gang_->take_counts();
+        stats_.ok[0] += c.n11;
+        stats_.ok[1] += c.n17;
+        stats_.ok[2] += gang_frames_ - c.n11 - c.n17;
+        stats_.fixed += c.nfix;
+        gang_frames_ = 0;
+        gang_busy_ = false;
+        dec_n_ = 0;
+    }
+
     void reset()
     {
+        sync();
         base_ = 0;
         chain_ = false;
         w_on_ = false;
@@ -320,6 +330,7 @@ public:
     size_t pending() const { return out_.size() - ohead_; }
     size_t drain(adsb_frame *dst, size_t cap)
     {
+        sync();
         size_t n = out_.size() - ohead_;
         if (n > cap)
             n = cap;
@@ -336,12 +347,17 @@ public:
     // advance / reset, which recycles the storage); they count as drained
     size_t take(const adsb_frame **p)
     {
+        sync();
         const size_t n = out_.size() - ohead_;
         *p = n ? out_.data() + ohead_ : nullptr;
         ohead_ = out_.size();
         return n;
     }
-    const adsb_stats &stats() const { return stats_; }
+    const adsb_stats &stats()
+    {
+        sync();
+        return stats_;
+    }
     uint64_t base() const { return base_; }
 
 private:
@@ -511,122 +527,179 @@ private:
     }
 
     // run_call for the usual case -- nothing waiting in the queue, the candidates come from the tile ranges of a hand-off
-    // stream where they lie -- as one tight loop: at the channel's capacity (BASELINE configs[2]: 106 k accepted frames per
-    // 256 Mi-sample launch) the general loop below cost 8 ns per accepted frame, four times the kernel's share.  Same rules,
-    // same order of side effects; the dependent chain per frame is idx -> which copy of the record -> idx + span.
+    // stream where they lie -- in two tight loops: DECIDE (which record is accepted, at which of its offsets, with which ts:
+    // 16 bytes per accepted frame, gang.hpp Decision), then FORMAT (the 40-byte frames, from the decisions and the records).
+    // At the channel's capacity (BASELINE configs[2]: 106 k accepted frames out of 123 k records per 256 Mi-sample launch)
+    // the general loop below cost 8 ns per accepted frame, four times the kernel's share; and the second loop is work that
+    // other threads can do (set_gang).
     // (host-side try words -- per-shard scans that hand the list back -- are counted between the frames: the general loop)
     bool tiles_fast_path() const { return chead_ == cands_.size() && !batch_.order && batch_.starts && thead_ == tries_.size(); }
+
+    // The deciding loop, written for the register file -- twice.  Round 5's first form was one loop that decided and wrote
+    // the frame, inside the function that also walks the tiles and the deqframe calls: some twenty values alive, and both
+    // compilers (g++ for the tests, clang for the library) kept the ones that CHANGE per record -- the position idx, the ts
+    // count, the output pointer -- on the stack: load-modify-store chains of six cycles each beside a dependent chain of
+    // three (idx -> max(idx, g0) -> idx + span).  So: a function of its own (noinline), in which everything that is touched
+    // once per tile or once per call stays in memory (this struct, read through the reference) and the seven values of the
+    // inner loop are all there is to allocate: cursor, tile end, idx, ts count, output, limit, the stream's base.
+    // And no branch on a record's fate: on a full channel one record in seven lies inside the frame before it, at random --
+    // as a branch that is a misprediction every few records, 5 ns each, more than the loop's own work.  The slot at `o` is
+    // written either way and kept by advancing `o`; the array has a slot to spare.
+    struct Walk {
+        const uint32_t *cur, *tile_end; // the next record, and the end of its tile's records (records are two granules)
+        uint64_t base, tsb;             // where the next call starts; g_base + 1 - (offsets jumped so far): ts = g_rel + tsb
+        uint64_t *o;                    // the next decision
+        const uint32_t *recs, *starts, *counts;
+        uint32_t u, u_end;
+        uint64_t g_base, power_samples, g_complete, single_limit;
+    };
     // single_limit != 0: ONE call with that limit (chain mode: run_call(g_complete)).  Else: the stream's deqframe calls, one
     // after the other while they have fired (air.c:94: at the first EVEN total T with T - base >= 40980) and the device has
     // scanned up to their limit (demod.c:89: T - 1200) -- the loop of advance(), inside: on sparse input a call holds four
     // frames, and entering and leaving this function once per call cost as much as the frames.
-    //
-    // The loop is written for the register file.  Its first form kept some twenty values alive -- cursor, tile bookkeeping,
-    // four counters, flags for the log and the call walk -- and the compiler kept half of them on the stack: every one a
-    // load-add-store through memory per frame, five or six cycles of chain each, 16 cycles per frame in all (the frame's own
-    // dependent chain is max(idx, g0) + span: two).  Now: the cursor is two pointers, the output one, and everything else --
-    // the Ok row's counters, what a statistics run or a shard's call walk wants per frame (Resolver::log_into, start_walk) --
-    // is read back from the frames just written, behind the loop.
+    __attribute__((noinline)) static void decide_calls(Walk &w)
+    {
+        const uint32_t *cur = w.cur, *end = w.tile_end;
+        const uint32_t *const recs = w.recs;
+        uint64_t base = w.base, tsb = w.tsb;
+        uint64_t *o = w.o;
+        for (;;) { // one deqframe call per round
+            uint64_t limit = w.single_limit;
+            if (!limit) {
+                const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1);
+                if (fire > w.power_samples)
+                    break; // the reference has not called deqframe yet (never, at EOF)
+                limit = fire - ADSB_DECOFFSET;
+                if (limit > w.g_complete)
+                    break; // the device has not scanned that far yet
+            }
+            // offsets relative to the launch's first from here on (signed: the call may start before the launch)
+            int64_t idx = (int64_t)(base - w.g_base);
+            const int64_t lim = (int64_t)(limit - w.g_base);
+            while (cur) {
+                if (cur == end) { // on to the next tile that has records
+                    cur = nullptr;
+                    for (uint32_t u = w.u + 1; u < w.u_end; u++)
+                        if (w.counts[u]) {
+                            cur = recs + (size_t)w.starts[u] * 4;
+                            end = cur + 8 * (size_t)w.counts[u];
+                            w.u = u;
+                            break;
+                        }
+                    if (!cur)
+                        w.u = w.u_end;
+                    continue;
+                }
+                for (;;) {
+                    const uint32_t w3 = cur[5];
+                    const int64_t g0 = (int64_t)cur[0];
+                    const int64_t g = idx > g0 ? idx : g0; // the first of the record's offsets the scan can visit, if any ...
+                    if (g >= lim)
+                        goto call_over; // (... which lies ahead: an offset inside an accepted frame is below idx, and idx < lim here)
+                    const uint64_t take = 0 - (uint64_t)((uint64_t)(g - g0) < 1u + ((w3 >> kRecCopiesShift) & 3u)); // all ones: g is one of its offsets
+                    const uint64_t span = 80 + 80 * (uint64_t)((w3 >> 16) & 0xFFu); // demod.c:109,120,123: lidx
+                    o[0] = (uint64_t)g + tsb; // demod.c:99: one ts++ per visited offset
+                    reinterpret_cast<uint32_t *>(o)[2] = (uint32_t)g;
+                    reinterpret_cast<uint32_t *>(o)[3] = (uint32_t)(reinterpret_cast<const char *>(cur) - reinterpret_cast<const char *>(recs));
+                    o += 2 & take;
+                    tsb -= (span - 1) & take;
+                    idx ^= (idx ^ (g + (int64_t)span)) & (int64_t)take; // demod.c:128,134 -- the record's other offsets lie inside this frame
+                    cur += 8;
+                    if (idx >= lim)
+                        goto call_over;
+                    if (cur == end)
+                        break;
+                }
+            }
+        call_over:
+            if (idx < lim)
+                idx = lim; // no candidate left below the limit: all remaining offsets advance by one (demod.c:141)
+            base = w.g_base + (uint64_t)idx; // deqframe's return value; air.c:96-98 carries the rest
+            if (w.single_limit)
+                break;
+        }
+        w.cur = cur, w.tile_end = end, w.base = base, w.tsb = tsb, w.o = o;
+    }
+
     void run_calls_tiles(uint64_t power_samples, uint64_t g_complete, uint64_t single_limit)
     {
         Batch &b = batch_;
-        const uint32_t *const recs = b.recs, *const starts = b.starts, *const counts = b.counts;
-        const uint32_t u_end = b.u_end;
-        const uint64_t g_base = b.g_base;
-        uint32_t u = b.u;
-        const uint32_t *cur = b.cur, *tile_end = b.cur ? b.cur + 8 * (size_t)b.left : nullptr; // records are two granules
-        uint64_t base = base_, skipped = skipped_;
-        const size_t n_before = out_.size();
-        uint64_t *o = reinterpret_cast<uint64_t *>(out_.room(b.records_left + 1)); // an accepted frame per record at most
-        uint64_t *const o_first = o;
-        for (;;) { // one deqframe call per round
-            uint64_t limit = single_limit;
-            if (!single_limit) {
-                const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1);
-                if (fire > power_samples)
-                    break; // the reference has not called deqframe yet (never, at EOF)
-                limit = fire - ADSB_DECOFFSET;
-                if (limit > g_complete)
-                    break; // the device has not scanned that far yet
-            }
-            uint64_t idx = base;
-            while (cur) {
-                if (cur == tile_end) { // on to the next tile that has records
-                    cur = nullptr;
-                    for (u++; u < u_end; u++)
-                        if (counts[u]) {
-                            cur = recs + (size_t)starts[u] * 4;
-                            tile_end = cur + 8 * (size_t)counts[u];
-                            break;
-                        }
-                    continue;
-                }
-                const uint64_t g0 = g_base + cur[0];
-                if (g0 + rec_copies(cur) <= idx) { // every offset of the record lies inside an accepted frame: never evaluated
-                    cur += 8;
-                    continue;
-                }
-                const uint64_t g = idx > g0 ? idx : g0; // the first of its offsets the scan can visit
-                if (g >= limit)
-                    break;
-                const uint64_t span = write_frame(o, cur, (uint32_t)(g - g0), g, g + 1 - skipped); // demod.c:99: one ts++ per visited offset
-                o += 5;
-                skipped += span - 1;
-                idx = g + span; // demod.c:128,134 -- the record's other offsets lie inside this frame
-                cur += 8;
-                if (idx >= limit)
-                    break;
-            }
-            if (idx < limit)
-                idx = limit; // no candidate left below the limit: all remaining offsets advance by one (demod.c:141)
-            base = idx; // deqframe's return value; air.c:96-98 carries the rest
-            if (single_limit)
-                break;
+        const size_t need = b.records_left + 1; // an accepted frame per record at most, and the slot to spare
+        if (dec_n_ + need > dec_.size()) {
+            sync(); // (nobody reads the decisions any more: the array starts over, or moves)
+            if (need > dec_.size())
+                dec_.resize(std::max(need, 2 * dec_.size()));
         }
-        const size_t made = (size_t)(o - o_first) / 5;
-        out_.grew(made);
-        if (cur && cur == tile_end) { // (the cursor never rests behind a tile's last record)
-            cur = nullptr;
-            for (u++; u < u_end; u++)
-                if (counts[u]) {
-                    cur = recs + (size_t)starts[u] * 4;
-                    tile_end = cur + 8 * (size_t)counts[u];
+        Decision *const dc = dec_.data() + dec_n_;
+        Walk w;
+        w.cur = b.cur, w.tile_end = b.cur ? b.cur + 8 * (size_t)b.left : nullptr;
+        w.base = base_, w.tsb = b.g_base + 1 - skipped_;
+        w.o = reinterpret_cast<uint64_t *>(dc);
+        w.recs = b.recs, w.starts = b.starts, w.counts = b.counts;
+        w.u = b.u, w.u_end = b.u_end;
+        w.g_base = b.g_base, w.power_samples = power_samples, w.g_complete = g_complete, w.single_limit = single_limit;
+        decide_calls(w);
+        const size_t made = (size_t)(reinterpret_cast<Decision *>(w.o) - dc);
+        if (w.cur && w.cur == w.tile_end) { // (the cursor never rests behind a tile's last record)
+            w.cur = nullptr;
+            for (w.u++; w.u < w.u_end; w.u++)
+                if (w.counts[w.u]) {
+                    w.cur = w.recs + (size_t)w.starts[w.u] * 4;
+                    w.tile_end = w.cur + 8 * (size_t)w.counts[w.u];
                     break;
                 }
         }
-        b.cur = cur;
-        b.left = cur ? (uint32_t)((tile_end - cur) / 8) : 0;
-        b.copies = cur ? rec_copies(cur) : 1;
-        b.u = u;
+        b.cur = w.cur;
+        b.left = w.cur ? (uint32_t)((w.tile_end - w.cur) / 8) : 0;
+        b.copies = w.cur ? rec_copies(w.cur) : 1;
+        b.u = w.u;
         b.sub = 0;
-        skipped_ = skipped;
-        base_ = base;
-        // The Ok row (valid.c:53,75) and the repair count, read back from the frames just written (they are in the cache): a
-        // counter in the loop above is one more value than the register file holds, i.e. a load-add-store per frame.
-        const adsb_frame *const f = out_.data() + n_before;
-        uint64_t n11 = 0, n17 = 0, nfix = 0;
-        for (size_t i = 0; i < made; i++) {
-            const uint32_t df = f[i].frame[0] >> 3;
-            n11 += df == 11;
-            n17 += df == 17;
-            nfix += f[i].reserved & 1u;
-        }
-        stats_.ok[0] += n11;
-        stats_.ok[1] += n17;
-        stats_.ok[2] += made - n11 - n17;
-        stats_.fixed += nfix;
-        if ((w_on_ && !w_stop_) || log_on_) { // ... and what a shard's call walk or a statistics run wants per frame
-            for (size_t i = 0; i < made; i++) {
-                const uint64_t g = f[i].g, span = 80 + 80 * (uint64_t)f[i].len;
-                if (w_on_ && !w_stop_)
-                    w_acc_.emplace_back(g, g + span);
-                if (log_on_) {
-                    if (ext_n_ < ext_cap_ && log_.empty())
-                        ext_[ext_n_++] = LogEntry{g, (uint32_t)span, 0};
-                    else
-                        log_.emplace_back(g, (uint32_t)span);
-                }
+        skipped_ = b.g_base + 1 - w.tsb;
+        base_ = w.base;
+        if (!made)
+            return;
+        if (gang_busy_ && !out_.fits(made))
+            sync(); // (the array is about to move under the gang's hands; dc stays where it is: dec_n_ = 0 only frees what lies below it)
+        adsb_frame *const dst = out_.room(made);
+        out_.grew(made);
+        FormatGang::Task t;
+        t.stream = b.recs;
+        t.g_base = b.g_base;
+        if (gang_ && made >= gang_min_frames_) { // the frames, the Ok row and the repair count are the gang's work
+            for (size_t i = 0; i < made; i += FormatGang::kBlock) {
+                t.dec = dc + i;
+                t.n = (uint32_t)std::min<size_t>(FormatGang::kBlock, made - i);
+                t.dst = dst + i;
+                gang_->post(t);
             }
+            gang_busy_ = true;
+            gang_frames_ += made;
+            dec_n_ = (size_t)(dc - dec_.data()) + made;
+        } else { // ... or this thread's, right away (the decisions are not kept)
+            t.dec = dc;
+            t.n = (uint32_t)made;
+            t.dst = dst;
+            FormatGang::Counts c;
+            FormatGang::format(t, c);
+            stats_.ok[0] += c.n11;
+            stats_.ok[1] += c.n17;
+            stats_.ok[2] += made - c.n11 - c.n17;
+            stats_.fixed += c.nfix;
+        }
+        if ((w_on_ && !w_stop_) || log_on_) // what a shard's call walk or a statistics run wants per frame
+            for (size_t i = 0; i < made; i++)
+                note_accepted(b.g_base + dc[i].g_rel, 80 + 80 * ((b.recs[(dc[i].where >> 2) + 5] >> 16) & 0xFFu));
+    }
+
+    void note_accepted(uint64_t g, uint32_t span)
+    {
+        if (w_on_ && !w_stop_)
+            w_acc_.emplace_back(g, g + span);
+        if (log_on_) {
+            if (ext_n_ < ext_cap_ && log_.empty())
+                ext_[ext_n_++] = LogEntry{g, span, 0};
+            else
+                log_.emplace_back(g, span);
         }
     }
 
@@ -657,6 +730,8 @@ private:
                 break;
             }
             count_tries(idx, g);
+            if (gang_busy_ && !out_.fits(1))
+                sync(); // (the array is about to move under the gang's hands)
             adsb_frame &f = out_.push();
             std::memset(reinterpret_cast<char *>(&f) + 32, 0, 8); // (the struct's tail padding: frames are compared and copied as bytes)
             f.g = g;
@@ -715,6 +790,12 @@ private:
     FrameVec out_;
     size_t ohead_ = 0;
     adsb_stats stats_{};
+    FormatGang *gang_ = nullptr;
+    size_t gang_min_frames_ = kGangMinFrames;
+    bool gang_busy_ = false;     // tasks posted since the last sync()
+    uint64_t gang_frames_ = 0;   // ... and the frames they stand for
+    std::vector<Decision> dec_;  // the decisions of the tasks in flight
+    size_t dec_n_ = 0;
 };
 
 } // namespace adsb

@@ -248,6 +248,10 @@ int adsb_format_frame(const adsb_frame *f, int outformat, char *pkt);
 typedef struct adsb_resolver adsb_resolver;
 adsb_resolver *adsb_resolver_create(void);
 void adsb_resolver_destroy(adsb_resolver *r);
+/* More hands (cfg.host_threads >= 3 in a decoder handle): `helpers` threads (0..15; 0 = none again) write the frames of every
+ * adsb_resolver_advance_stream batch that yields at least min_frames frames, the caller only decides them.  Same frames, same
+ * order, same counters.  Returns the threads that run, or -1. */
+int adsb_resolver_set_threads(adsb_resolver *r, int helpers, size_t min_frames);
 /* Candidates (ascending g) and tries (ascending; (g<<2)|code, code 0/1/2 = DF11/17/18),
  * all with g >= the previous g_complete. */
 int adsb_resolver_feed(adsb_resolver *r, const adsb_candidate *cands, size_t n_cands,

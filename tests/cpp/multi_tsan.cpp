@@ -207,7 +207,7 @@ int adsb_finish(adsb_decoder *d)
 long adsb_take(adsb_decoder *d, const adsb_frame **frames) { return (long)d->res.take(frames); }
 int adsb_get_stats(const adsb_decoder *d, adsb_stats *out)
 {
-    *out = d->res.stats();
+    *out = const_cast<adsb_decoder *>(d)->res.stats();
     return 0;
 }
 

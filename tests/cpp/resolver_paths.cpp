@@ -3,6 +3,8 @@
 //                                                           real deqframe by tests/test_host_logic.py)
 //   (b) device records through an index list, in place      advance_device()
 //   (c) tile ranges of a hand-off stream, in place          advance_tiles()
+//   (d) the same, decided here and written by a gang of     set_gang() + advance_tiles()
+//       three threads (gang.hpp), drained every few batches  [also under ThreadSanitizer: tests/test_sanitizers.py]
 // Random candidate sets with the shifted copies, overlaps and chains the device really
 // emits, fed in random batch sizes; frames (g, ts, pw, len, bytes, flag) and Ok counters
 // must be identical.  Built and run by tests/test_host_logic.py (g++, no GPU).
@@ -32,6 +34,11 @@ int main(int argc, char **argv)
 {
     const int rounds = argc > 1 ? atoi(argv[1]) : 200;
     std::mt19937_64 rng(12345);
+    adsb::FormatGang gang;
+    if (!gang.start(3)) {
+        printf("no threads\n");
+        return 2;
+    }
     for (int round = 0; round < rounds; round++) {
         // a stream of `total` offsets; candidates in clusters (a frame + shifted copies + overlapping others)
         const uint64_t total = 200000 + rng() % 2000000;
@@ -56,9 +63,10 @@ int main(int argc, char **argv)
         }
         const uint64_t power_samples = total + 1195 + (rng() % 2) * 2; // even
         // (a) queue path
-        adsb::Resolver ra, rb, rc;
-        ra.reset(), rb.reset(), rc.reset();
-        std::vector<adsb_frame> fa, fb, fc;
+        adsb::Resolver ra, rb, rc, rd;
+        ra.reset(), rb.reset(), rc.reset(), rd.reset();
+        rd.set_gang(&gang, round % 3 == 0 ? 64 : 1); // (with a threshold, small batches are written by the caller in between)
+        std::vector<adsb_frame> fa, fb, fc, fd;
         {
             size_t i = 0;
             uint64_t gc = 0;
@@ -136,8 +144,15 @@ int main(int argc, char **argv)
                                  std::min<uint64_t>(total, (uint64_t)t1 * per));
                 auto f = drain_all(rc);
                 fc.insert(fc.end(), f.begin(), f.end());
+                rd.advance_tiles(stream.data(), starts.data(), counts.data(), t, t1, 0, 0, power_samples,
+                                 std::min<uint64_t>(total, (uint64_t)t1 * per));
+                if (rng() % 4 == 0 || t1 == ntiles) {
+                    f = drain_all(rd);
+                    fd.insert(fd.end(), f.begin(), f.end());
+                }
                 t = t1;
             }
+            rd.sync(); // (the stream goes away with this block)
         }
         auto same = [](const std::vector<adsb_frame> &x, const std::vector<adsb_frame> &y) {
             if (x.size() != y.size())
@@ -148,10 +163,10 @@ int main(int argc, char **argv)
                     return false;
             return true;
         };
-        const bool ok = same(fa, fb) && same(fa, fc) && !std::memcmp(&ra.stats(), &rb.stats(), sizeof(adsb_stats)) &&
-                        !std::memcmp(&ra.stats(), &rc.stats(), sizeof(adsb_stats));
+        const bool ok = same(fa, fb) && same(fa, fc) && same(fa, fd) && !std::memcmp(&ra.stats(), &rb.stats(), sizeof(adsb_stats)) &&
+                        !std::memcmp(&ra.stats(), &rc.stats(), sizeof(adsb_stats)) && !std::memcmp(&ra.stats(), &rd.stats(), sizeof(adsb_stats));
         if (!ok || fa.empty()) {
-            printf("round %d: MISMATCH (%zu / %zu / %zu frames of %zu candidates)\n", round, fa.size(), fb.size(), fc.size(),
+            printf("round %d: MISMATCH (%zu / %zu / %zu / %zu frames of %zu candidates)\n", round, fa.size(), fb.size(), fc.size(), fd.size(),
                    recs.size());
             return 1;
         }

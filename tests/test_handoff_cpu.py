@@ -317,3 +317,26 @@ def test_records_that_stand_for_copies_resolve_like_their_expansion(capi, seed):
     # the greedy rule really does land on later copies here: not every accepted frame is a run's first offset
     firsts = {c[0] for i, c in enumerate(cands) if i == 0 or not (cands[i - 1][0] == c[0] - 1 and cands[i - 1][2] == c[2])}
     assert any(g - g_base not in firsts for g, *_ in ref[False])
+    # more hands (cfg.host_threads >= 3: gang.hpp): the caller decides, three threads write the frames -- the same frames, in the
+    # same order, with the same Ok row, in stream and in chain mode; twice through one handle (the decision array starts over)
+    img = _stream_of(tiles, 0xABCD + seed, True)
+    buf = np.ascontiguousarray(img.w)
+    for chain in (False, True):
+        alone, gang = capi.Resolver(), capi.Resolver()
+        assert L.adsb_resolver_set_threads(gang._h, 3, 1) == 3
+        for r in (alone, gang):
+            for rep in range(2):
+                if chain:
+                    assert L.adsb_resolver_start_chain(r._h, g_base, g_base + 16_384) == 0
+                elif rep:
+                    break
+                assert L.adsb_resolver_advance_stream(r._h, buf.ctypes.data, buf.size // 4, n_tiles, img.gen, g_base, m,
+                                                      g_base + n_tiles * tile_offsets, 0) == n_tiles
+                if rep == 0 and chain:
+                    assert r.stats()["ok"] == alone.stats()["ok"]
+                    r.drain()
+        assert gang.stats() == alone.stats() and sum(alone.stats()["ok"].values()) > 100
+        got = [(f["g"], f["ts"], f["pw"], bytes(f["frame"])) for f in gang.drain()]
+        assert got == [(f["g"], f["ts"], f["pw"], bytes(f["frame"])) for f in alone.drain()] == ref[chain]
+        assert L.adsb_resolver_set_threads(gang._h, 0, 0) == 0
+        alone.close(), gang.close()

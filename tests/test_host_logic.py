@@ -185,20 +185,27 @@ def test_resolver_input_paths_agree(tmp_path):
     oracle above), device records through an index list, and tile ranges of the hand-off
     stream consumed in place -- and the last two only run on a GPU box otherwise.  A C++
     harness (tests/cpp/resolver_paths.cpp, g++) feeds random clustered candidate sets
-    through all three in random batch sizes and compares frames, ts and Ok counters."""
+    through all three (and through the third with a gang of frame-writing threads) in random batch sizes and compares frames, ts and Ok counters."""
     import subprocess
     exe = tmp_path / "resolver_paths"
     src = os.path.join(ROOT, "tests", "cpp", "resolver_paths.cpp")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", src, "-o", str(exe)], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-pthread", src, "-o", str(exe)], check=True)
     out = subprocess.run([str(exe), "150"], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
     # and once more under AddressSanitizer + UBSan (the in-place batch paths juggle raw pointers)
     san = tmp_path / "resolver_paths_san"
     built = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                            src, "-o", str(san)], capture_output=True, text=True)
+                            "-pthread", src, "-o", str(san)], capture_output=True, text=True)
     if built.returncode == 0:  # sanitizer runtimes present in this image
         out = subprocess.run([str(san), "40"], capture_output=True, text=True)
         assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+    # ... and under ThreadSanitizer: path (d) hands the frames to a gang of three threads (csrc/gang.hpp)
+    tsan = tmp_path / "resolver_paths_tsan"
+    built = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", src, "-o", str(tsan)],
+                           capture_output=True, text=True)
+    if built.returncode == 0:
+        out = subprocess.run([str(tsan), "40"], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.startswith("ok") and "ThreadSanitizer" not in out.stderr, out.stdout + out.stderr
 
 
 def test_formatter_under_sanitizers(tmp_path):
