@@ -62,7 +62,7 @@ class Config(C.Structure):
                 ("debug_clist_cap", C.c_int32), ("push_overlap", C.c_int32),
                 ("host_threads", C.c_int32), ("debug_no_streaming", C.c_int32), ("debug_frames_cap", C.c_int32),
                 ("debug_reader_min_tiles", C.c_int32), ("debug_shard_head", C.c_int32), ("debug_passes", C.c_int32),
-                ("debug_stagger", C.c_int32), ("wait_timeout_s", C.c_int32)]
+                ("debug_stagger", C.c_int32), ("wait_timeout_s", C.c_int32), ("debug_gang_min", C.c_int32)]
 
 
 class MultiInfo(C.Structure):
@@ -237,7 +237,7 @@ def make_config(df18: bool = False, device: int = -1, collect_stats: bool = Fals
                 debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0, push_overlap: bool = False,
                 host_threads: int = 0, debug_no_streaming: bool = False, debug_frames_cap: int = 0,
                 debug_reader_min_tiles: int = 0, debug_shard_head: int = 0, debug_passes: int = 0, debug_stagger: int = 0,
-                wait_timeout_s: int = 0):
+                wait_timeout_s: int = 0, debug_gang_min: int = 0):
     """adsb_config from keywords (adsb_config_default + the members named)."""
     cfg = Config()
     load().adsb_config_init(C.byref(cfg), C.sizeof(cfg))
@@ -263,6 +263,8 @@ def make_config(df18: bool = False, device: int = -1, collect_stats: bool = Fals
     cfg.debug_stagger = debug_stagger
     if cfg.struct_size >= Config.wait_timeout_s.offset + 4:   # (an older library in an A/B run fills, and accepts, a shorter struct)
         cfg.wait_timeout_s = wait_timeout_s
+    if cfg.struct_size >= Config.debug_gang_min.offset + 4:
+        cfg.debug_gang_min = debug_gang_min
     return cfg
 
 

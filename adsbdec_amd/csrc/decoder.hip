@@ -754,11 +754,36 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     const bool dbg_on = tuning_env("ADSB_DEBUG_HOST") != nullptr;
     double wait_ms = 0;
     auto t_last_wait = t_begin;
+    // With more hands (gang.hpp) a batch is handed to the resolver one flush LATE: meanwhile one of the gang's threads decides
+    // it ahead (Resolver::speculate_tiles), and the resolver only takes the decisions over.
+    constexpr int kHold = 2;               // batches that wait for their turn while the gang decides them
+    uint32_t held[kHold + 1][2];
+    int n_held = 0;
+    bool ahead = false;                    // (set below, once it is known whether this launch goes through the gang)
+    auto deliver_held = [&](int keep) {    // the oldest first, until `keep` are left
+        size_t nc = 0;
+        int k = 0;
+        for (; n_held - k > keep; k++)
+            nc += deliver_tiles(d, s, held[k][0], held[k][1]);
+        for (int i = k; i < n_held; i++)
+            held[i - k][0] = held[i][0], held[i - k][1] = held[i][1];
+        n_held -= k;
+        return nc;
+    };
     auto flush = [&](uint32_t upto) { // tiles [delivered, upto): their ranges, one after the other, are sorted
         clk::time_point tp;
         if (dbg_on)
             tp = clk::now();
-        const size_t nc = deliver_tiles(d, s, delivered, upto);
+        size_t nc = 0;
+        const bool hold = ahead && d->res.speculate_tiles(s.hand, d->tile_start.data(), d->tile_count.data(), delivered, upto, s.args.g_begin);
+        if (hold) {
+            held[n_held][0] = delivered, held[n_held][1] = upto;
+            n_held++;
+            nc += deliver_held(kHold);
+        } else {
+            nc += deliver_held(0);
+            nc += deliver_tiles(d, s, delivered, upto);
+        }
         delivered = upto;
         recs_handed += nc;
         if (dbg_on) {
@@ -777,7 +802,12 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
         start_gang(d, kAutoGangHelpers);
     }
     const bool with_gang = d->gang && !d->sink.cands && (uint64_t)s.args.hand_cap * adsb::kGranuleWords * 4 <= adsb::kDecMaxStreamBytes && (d->cfg.host_threads >= 3 || after_dense);
-    d->res.set_gang(with_gang ? d->gang : nullptr);
+    if (d->cfg.debug_gang_min > 0) {
+        d->res.set_gang(with_gang ? d->gang : nullptr, (size_t)d->cfg.debug_gang_min);
+        d->res.set_ahead_min_records((size_t)d->cfg.debug_gang_min);
+    } else {
+        d->res.set_gang(with_gang ? d->gang : nullptr);
+    }
     if (with_gang) {
         const int cpu = sched_getcpu(); // the caller may have moved since the threads were placed
         const int l3 = adsb::l3_of_cpu(cpu);
@@ -785,6 +815,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
             for (std::thread &t : d->gang->threads())
                 d->gang_l3 = adsb::place_reader_thread(t, cpu);
         d->gang->begin();
+        ahead = true;
     }
     if (d->reader && s.ntiles >= d->reader_min_tiles && (d->cfg.host_threads >= 2 || after_dense)) {
         adsb::StreamReader &rd = *d->reader;
@@ -799,6 +830,12 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
             fprintf(stderr, "stream reader thread: busy %.1f us, waits %.1f us\n", rd.busy_ms * 1e3, rd.wait_ms * 1e3);
     } else {
         end = adsb::collect_alone(job, t_start.data(), t_count.data(), delivered, flush, wait_ms, t_last_wait);
+    }
+    if (n_held) { // the batches that were still waiting for their turn
+        const auto tp = clk::now();
+        recs_handed += deliver_held(0);
+        if (dbg_on)
+            dbg[1] += std::chrono::duration<double, std::micro>(clk::now() - tp).count();
     }
     if (end.status < 0 && with_gang) {
         d->res.sync();

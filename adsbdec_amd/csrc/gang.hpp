@@ -30,13 +30,15 @@
 namespace adsb {
 
 // One accepted frame, decided: ts (demod.c:99), the offset relative to the launch's first, and where the record lies (bytes
-// from the stream's first granule).  Which of the record's offsets it is follows: g_rel - the record's own.
+// from the stream's first granule, a multiple of 16) | 1 for a 112-bit frame.  Which of the record's offsets it is follows:
+// g_rel - the record's own.
 struct Decision {
     uint64_t ts;
     uint32_t g_rel, where;
 };
 static_assert(sizeof(Decision) == 16, "Decision is two 8-byte stores");
 constexpr uint64_t kDecMaxStreamBytes = 1ull << 32;
+constexpr uint32_t kDecLong = 1u;
 
 // One accepted frame out of a hand-off record, as five aligned 8-byte stores: {g}{ts}{pw, len, bytes 0..2}{bytes 3..10}
 // {bytes 11..13, reserved, 0} (the record holds the 14 bytes in w0..w3, the length and the flags behind them, the copies' pw in
@@ -59,15 +61,18 @@ inline uint64_t write_frame(uint64_t *o, const uint32_t *r, uint32_t sub, uint64
 
 class FormatGang {
 public:
+    struct Counts { // of the frames written since the last take_counts(): the Ok row (valid.c:53,75), repaired frames
+        uint64_t n11 = 0, n17 = 0, nfix = 0;
+    };
     struct Task {
+        void (*fn)(const Task &, Counts &) = nullptr; // null: format() -- write the frames of n decisions; else the resolver's own (a batch decided ahead: ctx)
         const uint32_t *stream = nullptr; // the launch's granules
         const Decision *dec = nullptr;
         uint32_t n = 0;
         adsb_frame *dst = nullptr; // n slots
         uint64_t g_base = 0;
-    };
-    struct Counts { // of the frames written since the last take_counts(): the Ok row (valid.c:53,75), repaired frames
-        uint64_t n11 = 0, n17 = 0, nfix = 0;
+        uint64_t ts_add = 0; // added to every decision's ts (a batch decided ahead counts its ts from zero: resolver.hpp)
+        void *ctx = nullptr;
     };
     static constexpr uint32_t kBlock = 512; // decisions per task
 
@@ -167,8 +172,8 @@ public:
         uint64_t n11 = 0, n17 = 0, nfix = 0;
         for (uint32_t i = 0; i < t.n; i++, o += 5) {
             const Decision d = t.dec[i];
-            const uint32_t *r = t.stream + (d.where >> 2);
-            write_frame(o, r, d.g_rel - r[0], t.g_base + d.g_rel, d.ts);
+            const uint32_t *r = t.stream + ((d.where & ~15u) >> 2);
+            write_frame(o, r, d.g_rel - r[0], t.g_base + d.g_rel, d.ts + t.ts_add);
             const uint32_t df = (r[2] & 0xFFu) >> 3;
             n11 += df == 11;
             n17 += df == 17;
@@ -200,7 +205,10 @@ private:
                     continue;
                 const Task t = s.task;
                 s.seq.store(c + kRing, std::memory_order_release);
-                format(t, acc_[me].c);
+                if (t.fn)
+                    t.fn(t, acc_[me].c);
+                else
+                    format(t, acc_[me].c);
                 completed_.fetch_add(1, std::memory_order_release);
                 t_idle = clk::now();
                 continue;

@@ -16,7 +16,9 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
+#include <memory>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -96,7 +98,8 @@ public:
         stats_.fixed += c.nfix;
         gang_frames_ = 0;
         gang_busy_ = false;
-        dec_n_ = 0;
+        if (!arena_pins_)
+            arena_.reset();
     }
 
     void reset()
@@ -195,7 +198,21 @@ public:
         batch_.seek_tile(t0);
         for (uint32_t u = t0; u < t1; u++)
             batch_.records_left += counts[u];
+        Ahead &a = ahead_[ahead_head_ % kAheadSlots]; // the oldest batch that was posted, if any
+        if (a.posted) { // (decided ahead: speculate_tiles)
+            if (a.stream == stream && a.t0 == t0 && a.t1 == t1 && a.g_base == g_base)
+                ahead_now_ = &a;
+            else
+                for (uint32_t spins = 1; a.n.load(std::memory_order_acquire) < 0; spins++) // not this batch: let it end, and forget it
+                    FormatGang::relax(spins);
+        }
         advance(power_samples, g_complete);
+        if (a.posted) {
+            ahead_now_ = nullptr;
+            a.posted = false;
+            arena_pins_--;
+            ahead_head_++;
+        }
         keep_leftovers();
     }
 
@@ -552,6 +569,11 @@ private:
         const uint32_t *recs, *starts, *counts;
         uint32_t u, u_end;
         uint64_t g_base, power_samples, g_complete, single_limit;
+        // a call can be left and re-entered in its middle (a batch decided ahead is taken over tile by tile, then decision by
+        // decision: run_calls_tiles_ahead): the position and the limit, relative to g_base
+        int64_t idx = 0, lim = 0;
+        bool in_call = false;         // in: resume the call at (idx, lim); out: left inside a call
+        bool stop_when_empty = false; // leave when the records are used up, inside the call, instead of finishing the calls
     };
     // single_limit != 0: ONE call with that limit (chain mode: run_call(g_complete)).  Else: the stream's deqframe calls, one
     // after the other while they have fired (air.c:94: at the first EVEN total T with T - base >= 40980) and the device has
@@ -563,19 +585,27 @@ private:
         const uint32_t *const recs = w.recs;
         uint64_t base = w.base, tsb = w.tsb;
         uint64_t *o = w.o;
+        bool resume = w.in_call;
+        w.in_call = false;
         for (;;) { // one deqframe call per round
-            uint64_t limit = w.single_limit;
-            if (!limit) {
-                const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1);
-                if (fire > w.power_samples)
-                    break; // the reference has not called deqframe yet (never, at EOF)
-                limit = fire - ADSB_DECOFFSET;
-                if (limit > w.g_complete)
-                    break; // the device has not scanned that far yet
-            }
             // offsets relative to the launch's first from here on (signed: the call may start before the launch)
-            int64_t idx = (int64_t)(base - w.g_base);
-            const int64_t lim = (int64_t)(limit - w.g_base);
+            int64_t idx, lim;
+            if (resume) {
+                idx = w.idx, lim = w.lim;
+                resume = false;
+            } else {
+                uint64_t limit = w.single_limit;
+                if (!limit) {
+                    const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1);
+                    if (fire > w.power_samples)
+                        break; // the reference has not called deqframe yet (never, at EOF)
+                    limit = fire - ADSB_DECOFFSET;
+                    if (limit > w.g_complete)
+                        break; // the device has not scanned that far yet
+                }
+                idx = (int64_t)(base - w.g_base);
+                lim = (int64_t)(limit - w.g_base);
+            }
             while (cur) {
                 if (cur == end) { // on to the next tile that has records
                     cur = nullptr;
@@ -600,7 +630,8 @@ private:
                     const uint64_t span = 80 + 80 * (uint64_t)((w3 >> 16) & 0xFFu); // demod.c:109,120,123: lidx
                     o[0] = (uint64_t)g + tsb; // demod.c:99: one ts++ per visited offset
                     reinterpret_cast<uint32_t *>(o)[2] = (uint32_t)g;
-                    reinterpret_cast<uint32_t *>(o)[3] = (uint32_t)(reinterpret_cast<const char *>(cur) - reinterpret_cast<const char *>(recs));
+                    reinterpret_cast<uint32_t *>(o)[3] =
+                        (uint32_t)(reinterpret_cast<const char *>(cur) - reinterpret_cast<const char *>(recs)) | ((w3 >> 19) & 1u); // (len 14 = 0b1110, 7 = 0b0111)
                     o += 2 & take;
                     tsb -= (span - 1) & take;
                     idx ^= (idx ^ (g + (int64_t)span)) & (int64_t)take; // demod.c:128,134 -- the record's other offsets lie inside this frame
@@ -610,6 +641,10 @@ private:
                     if (cur == end)
                         break;
                 }
+            }
+            if (w.stop_when_empty) { // (no record left, the call not over)
+                w.idx = idx, w.lim = lim, w.in_call = true;
+                break;
             }
         call_over:
             if (idx < lim)
@@ -623,14 +658,12 @@ private:
 
     void run_calls_tiles(uint64_t power_samples, uint64_t g_complete, uint64_t single_limit)
     {
-        Batch &b = batch_;
-        const size_t need = b.records_left + 1; // an accepted frame per record at most, and the slot to spare
-        if (dec_n_ + need > dec_.size()) {
-            sync(); // (nobody reads the decisions any more: the array starts over, or moves)
-            if (need > dec_.size())
-                dec_.resize(std::max(need, 2 * dec_.size()));
+        if (ahead_now_) {
+            run_calls_tiles_ahead(power_samples, g_complete);
+            return;
         }
-        Decision *const dc = dec_.data() + dec_n_;
+        Batch &b = batch_;
+        Decision *const dc = arena_.alloc(b.records_left + 1); // an accepted frame per record at most, and the slot to spare
         Walk w;
         w.cur = b.cur, w.tile_end = b.cur ? b.cur + 8 * (size_t)b.left : nullptr;
         w.base = base_, w.tsb = b.g_base + 1 - skipped_;
@@ -656,16 +689,28 @@ private:
         b.sub = 0;
         skipped_ = b.g_base + 1 - w.tsb;
         base_ = w.base;
+        arena_pins_++; // (emit may have to wait for the gang: the arena must not start over under dc)
+        const bool handed = emit(dc, made);
+        arena_pins_--;
+        arena_.shrink_to(dc + (handed ? made : 0));
+    }
+    // `made` decisions become frames: written by the gang's threads (true: the decisions must stay where they are until
+    // sync()) or by this thread, right away (false).
+    bool emit(const Decision *dc, size_t made, uint64_t ts_add = 0)
+    {
         if (!made)
-            return;
+            return false;
+        const Batch &b = batch_;
         if (gang_busy_ && !out_.fits(made))
-            sync(); // (the array is about to move under the gang's hands; dc stays where it is: dec_n_ = 0 only frees what lies below it)
+            sync(); // (the array is about to move under the gang's hands)
         adsb_frame *const dst = out_.room(made);
         out_.grew(made);
         FormatGang::Task t;
         t.stream = b.recs;
         t.g_base = b.g_base;
-        if (gang_ && made >= gang_min_frames_) { // the frames, the Ok row and the repair count are the gang's work
+        t.ts_add = ts_add;
+        const bool handed = gang_ && made >= gang_min_frames_;
+        if (handed) { // the frames, the Ok row and the repair count are the gang's work
             for (size_t i = 0; i < made; i += FormatGang::kBlock) {
                 t.dec = dc + i;
                 t.n = (uint32_t)std::min<size_t>(FormatGang::kBlock, made - i);
@@ -674,8 +719,7 @@ private:
             }
             gang_busy_ = true;
             gang_frames_ += made;
-            dec_n_ = (size_t)(dc - dec_.data()) + made;
-        } else { // ... or this thread's, right away (the decisions are not kept)
+        } else { // ... or this thread's
             t.dec = dc;
             t.n = (uint32_t)made;
             t.dst = dst;
@@ -688,7 +732,223 @@ private:
         }
         if ((w_on_ && !w_stop_) || log_on_) // what a shard's call walk or a statistics run wants per frame
             for (size_t i = 0; i < made; i++)
-                note_accepted(b.g_base + dc[i].g_rel, 80 + 80 * ((b.recs[(dc[i].where >> 2) + 5] >> 16) & 0xFFu));
+                note_accepted(b.g_base + dc[i].g_rel, dc[i].where & kDecLong ? 1200u : 640u);
+        return handed;
+    }
+
+    // ---- a batch decided AHEAD (speculate_tiles) -----------------------------------------------------------------------------
+    // The greedy rule forgets: whatever the position was before, once the scan accepts a frame at offset g the rest follows
+    // from g alone.  So a batch of tiles can be decided before the position at its entry is known -- as if no earlier frame
+    // reached into it, in ONE call without a limit, ts counted from zero -- by another thread, while this one is busy with the
+    // batch before.  Taking such a batch over: decide its first tile for real (from the true position, under the true calls);
+    // if the last decision of that tile is one the other thread made too, everything behind it is the same chain -- only the
+    // ts count (a constant to add) and the call pattern (air.c:94-99: which decision is the first of a new call, and where
+    // the stream's last executed call ends) are missing, and adopt_calls() puts them in at ten instructions per decision
+    // instead of forty per record.  No match (a frame of the tile before reaches far in): the next tile for real, and so on.
+    struct Ahead {
+        const uint32_t *stream = nullptr, *starts = nullptr, *counts = nullptr;
+        uint32_t t0 = 0, t1 = 0;
+        uint64_t g_base = 0;
+        Decision *d = nullptr;
+        uint32_t *g = nullptr;      // g_rel | (a 112-bit frame) << 31 of every decision, packed: what adopt_calls reads (a launch has < 2^31 offsets)
+        std::atomic<int64_t> n{-1}; // decisions made; -1: not decided yet
+        bool posted = false;
+    };
+    static void decide_ahead(const FormatGang::Task &t, FormatGang::Counts &)
+    {
+        Ahead &a = *static_cast<Ahead *>(t.ctx);
+        Walk w;
+        w.cur = w.tile_end = nullptr;
+        w.recs = a.stream, w.starts = a.starts, w.counts = a.counts;
+        w.u = a.t1, w.u_end = a.t1;
+        for (uint32_t u = a.t0; u < a.t1; u++)
+            if (a.counts[u]) {
+                w.cur = a.stream + (size_t)a.starts[u] * 4;
+                w.tile_end = w.cur + 8 * (size_t)a.counts[u];
+                w.u = u;
+                break;
+            }
+        w.base = a.g_base, w.tsb = 0; // position 0 of the launch, no offset jumped yet
+        w.o = reinterpret_cast<uint64_t *>(a.d);
+        w.g_base = a.g_base, w.power_samples = w.g_complete = 0;
+        w.single_limit = a.g_base + (1ull << 62);
+        decide_calls(w);
+        const int64_t n = reinterpret_cast<Decision *>(w.o) - a.d;
+        for (int64_t i = 0; i < n; i++)
+            a.g[i] = a.d[i].g_rel | (a.d[i].where & kDecLong) << 31;
+        a.n.store(n, std::memory_order_release);
+    }
+
+public:
+    static constexpr size_t kAheadMinRecords = 2048;
+    // Tiles [t0, t1) will be handed to advance_tiles() later, behind the batches posted before (at most kAheadSlots wait): have
+    // them decided ahead.  Returns false if that is not to be had (no gang, a chain, a small batch): advance_tiles() then decides itself.
+    bool speculate_tiles(const uint32_t *stream, const uint32_t *starts, const uint32_t *counts, uint32_t t0, uint32_t t1, uint64_t g_base)
+    {
+        Ahead &a = ahead_[ahead_tail_ % kAheadSlots];
+        if (!gang_ || chain_ || w_on_ || head_ || ahead_tail_ - ahead_head_ == kAheadSlots)
+            return false;
+        size_t records = 0;
+        for (uint32_t u = t0; u < t1; u++)
+            records += counts[u];
+        if (records < ahead_min_records_)
+            return false;
+        a.stream = stream, a.starts = starts, a.counts = counts, a.t0 = t0, a.t1 = t1, a.g_base = g_base;
+        a.d = arena_.alloc(records + 1 + (records + 4) / 4); // (the packed offsets behind the decisions: 4 bytes each)
+        a.g = reinterpret_cast<uint32_t *>(a.d + records + 1);
+        a.n.store(-1, std::memory_order_relaxed);
+        a.posted = true;
+        arena_pins_++;
+        ahead_tail_++;
+        FormatGang::Task t;
+        t.fn = decide_ahead;
+        t.ctx = &a;
+        gang_->post(t);
+        gang_busy_ = true;
+        return true;
+    }
+    void set_ahead_min_records(size_t n) { ahead_min_records_ = n; }
+    void set_arena_chunk(size_t n) { arena_.chunk = n; } // (before the first batch)
+    uint64_t ahead_taken() const { return ahead_taken_; } // frames whose decision was made ahead and taken over as it was
+
+private:
+    // The decisions [j, n) of a batch decided ahead, under the true calls (air.c:94-99: which decision is the first of a new
+    // call, where the last executed call ends).  Reads only the packed offsets G -- the decisions themselves stay in the cache
+    // of the thread that made them and will write the frames; their ts is off by a constant, which the caller works out.
+    // Enters and leaves like decide_calls (Walk::in_call; tsb is not kept here); `j` ends at the first decision that is not
+    // taken over (a call that has not fired yet, or will not: the stream's last executed call ends before it).
+    static void adopt_calls(Walk &w, const uint32_t *G, size_t &j, size_t n)
+    {
+        uint64_t base = w.base;
+        int64_t idx = w.idx, lim = w.lim;
+        size_t i = j;
+        bool in_call = w.in_call;
+        for (;;) {
+            if (!in_call) {
+                const uint64_t fire = base + ADSB_APBUFFSZ + (base & 1);
+                if (fire > w.power_samples)
+                    break;
+                const uint64_t limit = fire - ADSB_DECOFFSET;
+                if (limit > w.g_complete)
+                    break;
+                idx = (int64_t)(base - w.g_base);
+                lim = (int64_t)(limit - w.g_base);
+                in_call = true;
+            }
+            // the decisions of this call: all those below the limit -- the chain is theirs already; only the last one's end matters
+            const size_t i0 = i;
+            while (i < n && (int64_t)(G[i] & 0x7FFFFFFFu) < lim)
+                i++;
+            if (i > i0)
+                idx = (int64_t)(G[i - 1] & 0x7FFFFFFFu) + (G[i - 1] >> 31 ? 1200 : 640);
+            if (i == n && idx < lim)
+                break; // (no decision left, the call not over)
+            if (idx < lim)
+                idx = lim;
+            base = w.g_base + (uint64_t)idx;
+            in_call = false;
+        }
+        w.base = base, w.idx = idx, w.lim = lim, w.in_call = in_call;
+        j = i;
+    }
+
+    void run_calls_tiles_ahead(uint64_t power_samples, uint64_t g_complete)
+    {
+        Batch &b = batch_;
+        Ahead &a = *ahead_now_;
+        for (uint32_t spins = 1; a.n.load(std::memory_order_acquire) < 0; spins++)
+            FormatGang::relax(spins);
+        const size_t n = (size_t)a.n.load(std::memory_order_relaxed);
+        Walk w;
+        w.recs = b.recs, w.starts = b.starts, w.counts = b.counts;
+        w.g_base = b.g_base, w.power_samples = power_samples, w.g_complete = g_complete, w.single_limit = 0;
+        w.base = base_, w.tsb = b.g_base + 1 - skipped_;
+        w.in_call = false;
+        uint32_t u = b.u;
+        const uint32_t *cur = b.cur, *tile_end = b.cur ? b.cur + 8 * (size_t)b.left : nullptr;
+        auto next_tile = [&] {
+            cur = nullptr;
+            for (u++; u < b.u_end; u++)
+                if (b.counts[u]) {
+                    cur = b.recs + (size_t)b.starts[u] * 4;
+                    tile_end = cur + 8 * (size_t)b.counts[u];
+                    break;
+                }
+        };
+        auto park = [&] { // the cursor and the resolver's own state, as run_calls_tiles leaves them
+            b.cur = cur;
+            b.left = cur ? (uint32_t)((tile_end - cur) / 8) : 0;
+            b.copies = cur ? rec_copies(cur) : 1;
+            b.u = u;
+            b.sub = 0;
+            skipped_ = b.g_base + 1 - w.tsb;
+            base_ = w.base;
+        };
+        while (cur) { // a tile for real ...
+            Decision *const dc = arena_.alloc((size_t)(tile_end - cur) / 8 + 1);
+            w.cur = cur, w.tile_end = tile_end, w.u = u, w.u_end = u + 1;
+            w.o = reinterpret_cast<uint64_t *>(dc);
+            w.stop_when_empty = true;
+            decide_calls(w);
+            const size_t made = (size_t)(reinterpret_cast<Decision *>(w.o) - dc);
+            arena_.shrink_to(dc + (emit(dc, made) ? made : 0));
+            if (w.cur && w.cur != w.tile_end) { // a call that has not fired: the rest waits (keep_leftovers)
+                cur = w.cur;
+                park();
+                return;
+            }
+            next_tile();
+            if (!w.in_call) { // the tile's last record ended a call, and the next one has not fired
+                park();
+                return;
+            }
+            if (!made)
+                continue;
+            // ... and is its last decision one of the batch's?
+            const Decision last = dc[made - 1];
+            size_t lo = 0, hi = n;
+            while (lo < hi) {
+                const size_t mid = (lo + hi) / 2;
+                if (a.d[mid].g_rel < last.g_rel)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            if (lo == n || a.d[lo].g_rel != last.g_rel || a.d[lo].where != last.where)
+                continue;
+            size_t j = lo + 1;
+            adopt_calls(w, a.g, j, n);
+            if (j > lo + 1) {
+                // ts = g_rel + tsb on both sides, and tsb moves by the same spans from here on: the difference is a constant
+                const uint64_t ts_add = last.ts - a.d[lo].ts; // (the same decision on both sides: the true ts count minus the batch's own)
+                emit(a.d + lo + 1, j - (lo + 1), ts_add); // (the batch's decisions stay where they are: the arena is pinned)
+                ahead_taken_ += j - (lo + 1);
+                // the ts count behind the last decision taken over: its own ts, its offset, its span
+                const Decision &e = a.d[j - 1];
+                w.tsb = e.ts + ts_add - e.g_rel - ((e.where & kDecLong ? 1200u : 640u) - 1);
+            }
+            if (j == n) { // every record of the batch is behind the position
+                cur = nullptr;
+                u = b.u_end;
+                break;
+            }
+            // the first decision that was not taken over: the cursor goes back to its record (the calls end before it)
+            const uint32_t at = (a.d[j].where & ~15u) >> 4; // granule
+            for (u = b.u_end; u-- > a.t0;)
+                if (b.counts[u] && at >= b.starts[u] && at < b.starts[u] + 2 * b.counts[u])
+                    break;
+            cur = b.recs + (size_t)at * 4;
+            tile_end = b.recs + ((size_t)b.starts[u] + 2 * (size_t)b.counts[u]) * 4;
+            park();
+            return;
+        }
+        // no record left: the calls that have fired run out over the rest of the batch's offsets
+        w.cur = w.tile_end = nullptr, w.u = w.u_end = b.u_end;
+        Decision spare[2];
+        w.o = reinterpret_cast<uint64_t *>(spare);
+        w.stop_when_empty = false;
+        decide_calls(w);
+        park();
     }
 
     void note_accepted(uint64_t g, uint32_t span)
@@ -794,8 +1054,37 @@ private:
     size_t gang_min_frames_ = kGangMinFrames;
     bool gang_busy_ = false;     // tasks posted since the last sync()
     uint64_t gang_frames_ = 0;   // ... and the frames they stand for
-    std::vector<Decision> dec_;  // the decisions of the tasks in flight
-    size_t dec_n_ = 0;
+    // The decisions of the tasks in flight: chunks that never move (a task holds a pointer into them).
+    class DecArena {
+    public:
+        Decision *alloc(size_t n)
+        {
+            while (cur_ < chunks_.size() && chunks_[cur_].second - pos_ < n)
+                cur_++, pos_ = 0;
+            if (cur_ == chunks_.size()) {
+                const size_t sz = std::max(n, chunk);
+                chunks_.emplace_back(std::unique_ptr<Decision[]>(new Decision[sz]), sz);
+            }
+            Decision *p = chunks_[cur_].first.get() + pos_;
+            pos_ += n;
+            return p;
+        }
+        void shrink_to(Decision *end) { pos_ = (size_t)(end - chunks_[cur_].first.get()); } // (of the latest alloc)
+        void reset() { cur_ = 0, pos_ = 0; }
+        size_t chunk = 1u << 16; // decisions per chunk (tests make it small: every path across a chunk's end)
+
+    private:
+        std::vector<std::pair<std::unique_ptr<Decision[]>, size_t>> chunks_;
+        size_t cur_ = 0, pos_ = 0;
+    };
+    DecArena arena_;
+    int arena_pins_ = 0;          // batches decided ahead whose decisions are still needed: no reset
+    static constexpr unsigned kAheadSlots = 4;
+    Ahead ahead_[kAheadSlots];    // the batch being taken over, and the ones being decided behind it (posted in order: a ring)
+    unsigned ahead_head_ = 0, ahead_tail_ = 0;
+    Ahead *ahead_now_ = nullptr;  // advance_tiles: this batch was decided ahead
+    size_t ahead_min_records_ = kAheadMinRecords;
+    uint64_t ahead_taken_ = 0;
 };
 
 } // namespace adsb

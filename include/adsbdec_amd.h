@@ -114,9 +114,13 @@ typedef struct adsb_config {
                                   2: the handle owns a second thread that reads and checks the stream of large launches
                                   while the caller resolves behind it; same frames, same order.  The thread spins for
                                   ~0.4 ms after a launch, then sleeps until the next one.
+                                  N >= 3 (at most 17): that thread, and N - 2 more that decide batches of tiles ahead of
+                                  the caller (which only takes their decisions over) and write the frames; same frames,
+                                  same order, same counters.  They poll during a launch and for ~0.4 ms after it.
                                   0 (default): 1, until a launch hands over 65 536 records or more (a channel near its
-                                  capacity: ~20 k frames per second of signal); from the next launch on, 2 for every
-                                  launch that follows such a one. */
+                                  capacity: ~20 k frames per second of signal); from the next launch on, 6 for every
+                                  launch that follows such a one (BASELINE configs[2]: a 256 Mi-sample step takes
+                                  1.2 x its kernel instead of 3.3 x). */
     /* more test knobs (0 = default).  The library reads no environment variable: whatever a test has to force is here. */
     int32_t debug_no_streaming;     /* 1: every launch is collected after completion (no hand-off stream)              */
     int32_t debug_frames_cap;       /* collect_stats: accepted frames the upload buffers start with (regrow path)      */
@@ -128,6 +132,8 @@ typedef struct adsb_config {
                                   120): a launch or copy that never completes -- a wedged queue, a lost device -- ends the
                                   call with -1 and adsb_last_error() names what was waited for; the multi-GPU driver gives
                                   its workers the same limit (plus 30 s) and names the worker.  Nothing is retried. */
+    int32_t debug_gang_min;    /* test knob: host_threads >= 3 -- batches of at least this many records go through the
+                                  threads (0 = default: 2048 records decided ahead, 1024 frames written) */
 } adsb_config;
 
 /* Counters accumulate over the life of the handle (adsb_reset keeps them: a caller that

@@ -5,6 +5,8 @@
 //   (c) tile ranges of a hand-off stream, in place          advance_tiles()
 //   (d) the same, decided here and written by a gang of     set_gang() + advance_tiles()
 //       three threads (gang.hpp), drained every few batches  [also under ThreadSanitizer: tests/test_sanitizers.py]
+//   (e) the same, every batch decided AHEAD by the gang     speculate_tiles() + advance_tiles()
+//       while the batch before it is taken over
 // Random candidate sets with the shifted copies, overlaps and chains the device really
 // emits, fed in random batch sizes; frames (g, ts, pw, len, bytes, flag) and Ok counters
 // must be identical.  Built and run by tests/test_host_logic.py (g++, no GPU).
@@ -17,9 +19,10 @@
 
 #include "../../adsbdec_amd/csrc/resolver.hpp"
 
-struct Rec {
+struct Rec { // a candidate -- or, with copies > 1, the same frame at that many consecutive offsets (one stream record)
     uint64_t g;
     uint32_t pw, w[4];
+    uint32_t copies = 1, pw2 = 0, pw3 = 0;
 };
 
 static std::vector<adsb_frame> drain_all(adsb::Resolver &r)
@@ -39,6 +42,7 @@ int main(int argc, char **argv)
         printf("no threads\n");
         return 2;
     }
+    uint64_t taken = 0, frames_e = 0;
     for (int round = 0; round < rounds; round++) {
         // a stream of `total` offsets; candidates in clusters (a frame + shifted copies + overlapping others)
         const uint64_t total = 200000 + rng() % 2000000;
@@ -56,17 +60,36 @@ int main(int argc, char **argv)
                 r.w[3] = (r.w[3] & 0xFFFFu) | ((is_short ? 7u : 14u) << 16) | ((uint32_t)(rng() & 1) << 24);
                 if (is_short)
                     r.w[1] &= 0x00FFFFFFu, r.w[2] = 0, r.w[3] &= 0xFFFF0000u;
-                if (recs.empty() || r.g > recs.back().g)
+                if (rng() % 3 == 0) { // the half-sample shifted copies of one frame, as one record (scan_kernel_format.h)
+                    r.copies = 2 + (uint32_t)(rng() % 2);
+                    r.pw2 = (uint32_t)(rng() % 100000), r.pw3 = (uint32_t)(rng() % 100000);
+                }
+                if (recs.empty() || r.g > recs.back().g + recs.back().copies - 1)
                     recs.push_back(r);
             }
             g += (rng() % 3 == 0) ? 200 + rng() % 1200 : 1500 + rng() % 60000; // some overlap chains
         }
+        const std::vector<Rec> collapsed = recs; // (c), (d), (e) see these; (a), (b) one candidate per offset
+        {
+            std::vector<Rec> expanded;
+            for (const Rec &r : collapsed)
+                for (uint32_t k = 0; k < r.copies; k++) {
+                    Rec e = r;
+                    e.g = r.g + k, e.pw = k == 0 ? r.pw : k == 1 ? r.pw2 : r.pw3, e.copies = 1;
+                    expanded.push_back(e);
+                }
+            recs = expanded;
+        }
         const uint64_t power_samples = total + 1195 + (rng() % 2) * 2; // even
         // (a) queue path
-        adsb::Resolver ra, rb, rc, rd;
-        ra.reset(), rb.reset(), rc.reset(), rd.reset();
+        adsb::Resolver ra, rb, rc, rd, re;
+        ra.reset(), rb.reset(), rc.reset(), rd.reset(), re.reset();
+        re.set_gang(&gang, round % 2 ? 16 : 1);
+        re.set_ahead_min_records(round % 5 == 0 ? 40 : 1);
+        if (round % 2) // decisions in chunks of 48: allocations cross chunk ends, and the arena starts over while tasks are in flight
+            rd.set_arena_chunk(48), re.set_arena_chunk(48);
         rd.set_gang(&gang, round % 3 == 0 ? 64 : 1); // (with a threshold, small batches are written by the caller in between)
-        std::vector<adsb_frame> fa, fb, fc, fd;
+        std::vector<adsb_frame> fa, fb, fc, fd, fe;
         {
             size_t i = 0;
             uint64_t gc = 0;
@@ -121,8 +144,8 @@ int main(int argc, char **argv)
             const uint32_t per = 12880 + 7056 * (uint32_t)(rng() % 4);
             const uint32_t ntiles = (uint32_t)((total + per - 1) / per);
             std::vector<std::vector<size_t>> by_tile(ntiles);
-            for (size_t i = 0; i < recs.size(); i++)
-                by_tile[recs[i].g / per].push_back(i);
+            for (size_t i = 0; i < collapsed.size(); i++)
+                by_tile[collapsed[i].g / per].push_back(i);
             std::vector<uint32_t> tile_order(ntiles), starts(ntiles), counts(ntiles), stream;
             for (uint32_t t = 0; t < ntiles; t++)
                 tile_order[t] = t;
@@ -134,7 +157,8 @@ int main(int argc, char **argv)
                 starts[t] = (uint32_t)(stream.size() / 4);
                 counts[t] = (uint32_t)by_tile[t].size();
                 for (size_t i : by_tile[t]) {
-                    const uint32_t w[8] = {(uint32_t)recs[i].g, recs[i].pw, recs[i].w[0], recs[i].w[1], recs[i].w[2], recs[i].w[3], 0, 0};
+                    const Rec &r = collapsed[i];
+                    const uint32_t w[8] = {(uint32_t)r.g, r.pw, r.w[0], r.w[1], r.w[2], r.w[3] | (r.copies - 1) << adsb::kRecCopiesShift, r.pw2, r.pw3};
                     stream.insert(stream.end(), w, w + 8);
                 }
             }
@@ -153,6 +177,28 @@ int main(int argc, char **argv)
                 t = t1;
             }
             rd.sync(); // (the stream goes away with this block)
+            // (e): the batches first, so that each can be posted one ahead
+            std::vector<std::pair<uint32_t, uint32_t>> bt;
+            for (uint32_t t = 0; t < ntiles;) {
+                const uint32_t t1 = std::min<uint32_t>(ntiles, t + 1 + (uint32_t)(rng() % 40));
+                bt.emplace_back(t, t1);
+                t = t1;
+            }
+            const size_t depth = 1 + round % 3; // batches posted ahead of the one that is handed over
+            for (size_t k = 0; k < depth && k < bt.size(); k++)
+                re.speculate_tiles(stream.data(), starts.data(), counts.data(), bt[k].first, bt[k].second, 0);
+            for (size_t k = 0; k < bt.size(); k++) {
+                if (k + depth < bt.size())
+                    re.speculate_tiles(stream.data(), starts.data(), counts.data(), bt[k + depth].first, bt[k + depth].second, 0);
+                re.advance_tiles(stream.data(), starts.data(), counts.data(), bt[k].first, bt[k].second, 0, 0, power_samples,
+                                 std::min<uint64_t>(total, (uint64_t)bt[k].second * per));
+                if (rng() % 4 == 0 || k + 1 == bt.size()) {
+                    auto f = drain_all(re);
+                    fe.insert(fe.end(), f.begin(), f.end());
+                }
+            }
+            re.sync();
+            taken += re.ahead_taken(), frames_e += fe.size();
         }
         auto same = [](const std::vector<adsb_frame> &x, const std::vector<adsb_frame> &y) {
             if (x.size() != y.size())
@@ -163,14 +209,19 @@ int main(int argc, char **argv)
                     return false;
             return true;
         };
-        const bool ok = same(fa, fb) && same(fa, fc) && same(fa, fd) && !std::memcmp(&ra.stats(), &rb.stats(), sizeof(adsb_stats)) &&
+        const bool ok = same(fa, fb) && same(fa, fc) && same(fa, fd) && same(fa, fe) && !std::memcmp(&ra.stats(), &re.stats(), sizeof(adsb_stats)) && !std::memcmp(&ra.stats(), &rb.stats(), sizeof(adsb_stats)) &&
                         !std::memcmp(&ra.stats(), &rc.stats(), sizeof(adsb_stats)) && !std::memcmp(&ra.stats(), &rd.stats(), sizeof(adsb_stats));
         if (!ok || fa.empty()) {
-            printf("round %d: MISMATCH (%zu / %zu / %zu / %zu frames of %zu candidates)\n", round, fa.size(), fb.size(), fc.size(), fd.size(),
+            printf("round %d: MISMATCH (%zu / %zu / %zu / %zu / %zu frames of %zu candidates)\n", round, fa.size(), fb.size(), fc.size(), fd.size(), fe.size(),
                    recs.size());
             return 1;
         }
     }
-    printf("ok: %d rounds\n", rounds);
+    if (taken * 2 < frames_e) { // (e) must really take batches over, not decide them all again
+        printf("only %llu of %llu frames were taken over from batches decided ahead\n", (unsigned long long)taken, (unsigned long long)frames_e);
+        return 1;
+    }
+    printf("ok: %d rounds (%llu of %llu frames of path (e) taken over from batches decided ahead)\n", rounds, (unsigned long long)taken,
+           (unsigned long long)frames_e);
     return 0;
 }

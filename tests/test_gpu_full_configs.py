@@ -38,16 +38,25 @@ def _host(t):
     return t.cpu().numpy().view(np.uint16)
 
 
-def _reader_threads():
-    """Threads of this process named "adsb-reader" (handoff.hpp StreamReader: a handle's second host thread)."""
+def _threads_named(name):
     n = 0
     for tid in os.listdir("/proc/self/task"):
         try:
             with open(f"/proc/self/task/{tid}/comm") as f:
-                n += f.read().strip() == "adsb-reader"
+                n += f.read().strip() == name
         except OSError:
             pass
     return n
+
+
+def _reader_threads():
+    """Threads of this process named "adsb-reader" (handoff.hpp StreamReader: a handle's second host thread)."""
+    return _threads_named("adsb-reader")
+
+
+def _format_threads():
+    """... and "adsb-format" (gang.hpp FormatGang: the threads that decide batches ahead and write the frames)."""
+    return _threads_named("adsb-format")
 
 
 def _ts_checksum(frames):
@@ -127,11 +136,12 @@ def test_config2_256Mi_at_ten_percent_density_and_the_gate_storm(capi, oracle, t
         want, wstats = oracle.decode(x, df18=True)
         assert len(want) >= min_frames
         for stats in (False, True):
-            assert _reader_threads() == 0
+            assert _reader_threads() == 0 and _format_threads() == 0
             d = capi.Decoder(df18=True, collect_stats=stats, profile=True)
             try:
                 # three times on one handle: cfg.host_threads = 0 (auto) hands the stream of a launch that FOLLOWS a dense one
-                # (65 536 records or more) to the handle's second host thread, which is started then; same records either way
+                # (65 536 records or more) to the handle's reader thread and its gang of four (batches decided ahead, frames
+                # written by the gang), which are started then; same records either way
                 for rep in range(3):
                     d.reset()
                     d.push_device_final(t.data_ptr(), t.numel())
@@ -139,16 +149,16 @@ def test_config2_256Mi_at_ten_percent_density_and_the_gate_storm(capi, oracle, t
                     assert records(got) == records(want), rep
                     if stats:
                         assert d.stats() == wstats, rep
-                    extra = _reader_threads()
-                    if make is make_dense10:        # 310 k records per launch
-                        assert extra == (0 if rep == 0 else 1), (rep, extra)
-                    else:                            # one record: the thread never exists
-                        assert extra == 0
+                    extra = (_reader_threads(), _format_threads())
+                    if make is make_dense10:        # 123 k records per launch
+                        assert extra == ((0, 0) if rep == 0 else (1, 4)), (rep, extra)
+                    else:                            # one record: the threads never exist
+                        assert extra == (0, 0)
                 if make is make_gate_storm:
                     assert sum(wstats["try"].values()) > 0.05 * (n // 2)
             finally:
                 d.close()
-            assert _reader_threads() == 0
+            assert _reader_threads() == 0 and _format_threads() == 0
         del t
         torch_cuda.cuda.empty_cache()
 

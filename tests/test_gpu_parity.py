@@ -681,13 +681,16 @@ def test_streaming_handoff_is_stable_over_many_launches(oracle, dec_factory, tor
         assert records(d.drain()) == exp, it
 
 
-def test_reader_thread_consumes_the_handoff_stream(capi, oracle, dec_factory, torch_cuda):
+@pytest.mark.parametrize("threads", [2, 5])
+def test_reader_thread_consumes_the_handoff_stream(capi, oracle, dec_factory, torch_cuda, threads):
     """cfg.host_threads = 2: a second host thread reads and checks the hand-off stream while the caller resolves behind
-    it (decoder.hip StreamReader).  Same frames, same statistics, on every path a launch's collect can take: rotating
-    captures on one handle (stale bytes of the previous launch must not be taken), chunked pushes, a statistics run,
-    tiles that flag "finish after completion" (staged-list overflow, loose list, relaunch)."""
+    it (decoder.hip StreamReader); cfg.host_threads = 5: that thread, and three more that decide every batch of tiles ahead
+    of the caller and write the frames (gang.hpp, Resolver::speculate_tiles).  Same frames, same statistics, on every path a
+    launch's collect can take: rotating captures on one handle (stale bytes of the previous launch must not be taken),
+    chunked pushes, a statistics run, tiles that flag "finish after completion" (staged-list overflow, loose list, relaunch)."""
     from tools import gen_signal as G
-    rd = dict(host_threads=2, debug_reader_min_tiles=1)   # also the small launches of this test go through the thread
+    # also the small launches of this test go through the threads
+    rd = dict(host_threads=threads, debug_reader_min_tiles=1, **(dict(debug_gang_min=1) if threads > 2 else {}))
     caps = []
     for seed, n, nfr in ((61, 1 << 22, 1500), (62, (1 << 22) - 300_000, 900), (63, (1 << 21) + 4096, 1100)):
         x, _ = G.dense_capture(n, seed=seed, sigma=30.0, n_frames=nfr, amp=(150, 1800))

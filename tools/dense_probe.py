@@ -10,7 +10,7 @@ n = (256 << 20); n -= n % 28
 for name, make in (("noise", lambda: make_dense(torch, n, 100)), ("dense10", lambda: make_dense10(torch, n, 101)), ("gate_storm", lambda: make_gate_storm(torch, n, 102))):
     x = make()
     torch.cuda.synchronize()
-    for kw in (dict(), dict(host_threads=1), dict(host_threads=2), dict(host_threads=4), dict(host_threads=5), dict(host_threads=12), dict(host_threads=13), dict(host_threads=14)):
+    for kw in (dict(), dict(host_threads=1), dict(host_threads=2), dict(host_threads=3), dict(host_threads=4), dict(host_threads=5), dict(host_threads=6), dict(host_threads=8)):
         d = capi.Decoder(df18=True, profile=True, **kw)
         for _ in range(3): d.decode_device_raw(x.data_ptr(), x.numel())
         a = d.profile(); t0 = time.perf_counter()

@@ -90,11 +90,14 @@ def run(seconds: float, seed: int = 1, log=print):
     def dec(df18, stats, fix, caps=0, overlap=False):
         k = (df18, stats, fix, caps, overlap)
         if k not in decs:
-            # every other handle consumes its hand-off streams with the second host thread (cfg.host_threads = 2)
+            # every other handle consumes its hand-off streams with the second host thread (cfg.host_threads = 2), every
+            # fourth with three more that decide the batches ahead and write the frames (cfg.host_threads = 5)
             reader = len(decs) % 2 == 1
+            gang = len(decs) % 4 == 3
             decs[k] = capi.Decoder(df18=df18, collect_stats=stats, fix_1bit=fix, push_overlap=overlap,
                                    stage_samples=[0, 1 << 17, 1 << 16][len(decs) % 3],
-                                   host_threads=2 if reader else 0, debug_reader_min_tiles=1 if reader else 0, **tight[caps])
+                                   host_threads=5 if gang else 2 if reader else 0, debug_reader_min_tiles=1 if reader else 0,
+                                   debug_gang_min=1 if gang else 0, **tight[caps])
             decs[k].fuzz_reader = reader
         return decs[k]
 

@@ -24,7 +24,7 @@ using namespace adsb;
 #endif
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_gap, int copies, bool collapse, bool two_threads = false, bool flush_lines = false, int gang_helpers = 0)
+static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_gap, int copies, bool collapse, bool two_threads = false, bool flush_lines = false, int gang_helpers = 0, bool ahead = false)
 {
     const uint32_t gen = 0x1234567u;
     std::mt19937 rng(1);
@@ -75,7 +75,7 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
     uint32_t *hand = reinterpret_cast<uint32_t *>(store.data());
     std::memcpy(hand, hv.data(), hv.size() * 4);
     if (gang_helpers)
-        printf("[the caller decides, %d threads write the frames] ", gang_helpers);
+        printf(ahead ? "[%d threads decide each batch ahead and write the frames, the caller takes the decisions over] " : "[the caller decides, %d threads write the frames] ", gang_helpers);
     printf("%s%s%s: %u tiles, %llu records, %zu KiB stream\n", name, two_threads ? " [reader thread + resolver]" : " [one thread]",
            flush_lines ? " [stream flushed from the caches before every pass]" : "", ntiles, (unsigned long long)nrec, hv.size() * 4 / 1024);
     Resolver res;
@@ -107,20 +107,47 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
         auto tl = HandCursor::clk::now();
         uint32_t delivered = 0;
         const double t0 = now();
+        uint32_t held[3][2];
+        int n_held = 0;
+        auto adv = [&](uint32_t from, uint32_t upto) {
+            res.advance_tiles(hand, t_start.data(), t_count.data(), from, upto, 0, 0, (uint64_t)ntiles * per + 100000, (uint64_t)upto * per);
+        };
+        auto deliver_held = [&](int keep) {
+            int k = 0;
+            for (; n_held - k > keep; k++)
+                adv(held[k][0], held[k][1]);
+            for (int i = k; i < n_held; i++)
+                held[i - k][0] = held[i][0], held[i - k][1] = held[i][1];
+            n_held -= k;
+        };
         auto flush = [&](uint32_t upto) {
             const double ta = now();
-            res.advance_tiles(hand, t_start.data(), t_count.data(), delivered, upto, 0, 0, (uint64_t)ntiles * per + 100000, (uint64_t)upto * per);
+            if (ahead && res.speculate_tiles(hand, t_start.data(), t_count.data(), delivered, upto, 0)) {
+                held[n_held][0] = delivered, held[n_held][1] = upto;
+                n_held++;
+                deliver_held(2);
+            } else {
+                deliver_held(0);
+                adv(delivered, upto);
+            }
             delivered = upto;
             tr += now() - ta;
         };
         const CollectEnd end = two_threads ? collect_behind_reader(rd, job, t_start.data(), t_count.data(), delivered, flush, wait_ms, tl)
                                            : collect_alone(job, t_start.data(), t_count.data(), delivered, flush, wait_ms, tl);
+        if (n_held) {
+            const double ta = now();
+            deliver_held(0);
+            tr += now() - ta;
+        }
         res.sync(); // (the frames are whole)
         const double t1 = now();
         const adsb_frame *fp;
         const size_t nf = res.take(&fp);
         printf("  rep %d: status %d, check + bookkeeping %.1f us, resolve %.1f us, total %.1f us = %.1f ns per record, %zu frames\n", rep, end.status,
                t1 - t0 - tr, tr, t1 - t0, (t1 - t0) * 1e3 / nrec, nf);
+        if (ahead && rep == 5)
+            printf("  (%llu frames taken over from batches decided ahead, all passes)\n", (unsigned long long)res.ahead_taken());
     }
     rd.stop();
     res.set_gang(nullptr);
@@ -141,6 +168,11 @@ int main()
         run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true, false, true, h);
     }
     run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true, true, true, 3);
+    for (int h = 2; h <= 5; h++) {
+        run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true, false, true, h, true);
+        run("dense10, one record per run of copies", 2786, 48188, 1200, 3, true, true, true, h, true);
+    }
+    run("sparse", 2786, 48188, 10000, 1, false, false, true, 4, true);
 #endif
     return 0;
 }
