@@ -862,8 +862,9 @@ def main():
                      "alone makes 7 % of the offsets pass the preamble test)"),
                     ("target_10_percent", lambda: make_dense10(torch, n, 101),
                      "BASELINE configs[2] at its stated density: 112-bit frames packed back to back in sigma=300 noise, 3 % of the "
-                     "1 ms slots filled with frame starts: ~10 % of the offsets pass the preamble test, ~100 k frames decode (310 k records per "
-                     "launch: the handle's second host thread starts by itself behind the first launch, cfg.host_threads = 0)"),
+                     "1 ms slots filled with frame starts: ~10 % of the offsets pass the preamble test, ~100 k frames decode (123 k records per "
+                     "launch: the handle's reader thread and its gang of four -- batches decided ahead, frames written by the gang -- "
+                     "start by themselves behind the first launch, cfg.host_threads = 0)"),
                     ("gate_storm", lambda: make_gate_storm(torch, n, 102),
                      "adversarial: frame starts (preamble + DF17's five bits) packed back to back: ~30 % of the offsets pass the "
                      "preamble test, ~7 % the DF gate -- every tile's survivor queue overflows and the tile is redone in ranges of chunks -- no CRC matches")):
