@@ -799,7 +799,9 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     const bool after_dense = d->cfg.host_threads == 0 && d->last_launch_records >= kAutoReaderRecords;
     if (after_dense) {
         start_reader(d);
-        start_gang(d, kAutoGangHelpers);
+        cpu_set_t allowed; // (six threads that poll need cores of their own: on a small or confined host, round 4's pair)
+        if (sched_getaffinity(0, sizeof allowed, &allowed) != 0 || CPU_COUNT(&allowed) >= 2 * (kAutoGangHelpers + 2))
+            start_gang(d, kAutoGangHelpers);
     }
     const bool with_gang = d->gang && !d->sink.cands && (uint64_t)s.args.hand_cap * adsb::kGranuleWords * 4 <= adsb::kDecMaxStreamBytes && (d->cfg.host_threads >= 3 || after_dense);
     if (d->cfg.debug_gang_min > 0) {
