@@ -754,16 +754,19 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     const bool dbg_on = tuning_env("ADSB_DEBUG_HOST") != nullptr;
     double wait_ms = 0;
     auto t_last_wait = t_begin;
-    // With more hands (gang.hpp) a batch is handed to the resolver one flush LATE: meanwhile one of the gang's threads decides
-    // it ahead (Resolver::speculate_tiles), and the resolver only takes the decisions over.
-    constexpr int kHold = 2;               // batches that wait for their turn while the gang decides them
-    uint32_t held[kHold + 1][2];
+    // With more hands (gang.hpp) a batch is handed to the resolver LATE: meanwhile one of the gang's threads decides it ahead
+    // (Resolver::speculate_tiles), and the resolver only takes the decisions over.  A flush is cut into batches of kAheadTiles
+    // tiles, so that several threads decide side by side and the last batch of a launch is a short one; a batch goes on
+    // as soon as it has been decided (looked at with every flush), at the latest when kMaxHeld are waiting.
+    constexpr int kMaxHeld = 12;
+    constexpr uint32_t kAheadTiles = 64;
+    uint32_t held[kMaxHeld][2];
     int n_held = 0;
     bool ahead = false;                    // (set below, once it is known whether this launch goes through the gang)
-    auto deliver_held = [&](int keep) {    // the oldest first, until `keep` are left
+    auto deliver_held = [&](int keep, bool only_ready) { // the oldest first, until `keep` are left
         size_t nc = 0;
         int k = 0;
-        for (; n_held - k > keep; k++)
+        for (; n_held - k > keep && (!only_ready || d->res.ahead_ready()); k++)
             nc += deliver_tiles(d, s, held[k][0], held[k][1]);
         for (int i = k; i < n_held; i++)
             held[i - k][0] = held[i][0], held[i - k][1] = held[i][1];
@@ -775,13 +778,22 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
         if (dbg_on)
             tp = clk::now();
         size_t nc = 0;
-        const bool hold = ahead && d->res.speculate_tiles(s.hand, d->tile_start.data(), d->tile_count.data(), delivered, upto, s.args.g_begin);
-        if (hold) {
-            held[n_held][0] = delivered, held[n_held][1] = upto;
-            n_held++;
-            nc += deliver_held(kHold);
+        if (ahead) {
+            for (uint32_t from = delivered; from < upto;) {
+                const uint32_t to = std::min(upto, from + kAheadTiles);
+                if (n_held == kMaxHeld)
+                    nc += deliver_held(kMaxHeld - 1, false);
+                if (d->res.speculate_tiles(s.hand, d->tile_start.data(), d->tile_count.data(), from, to, s.args.g_begin)) {
+                    held[n_held][0] = from, held[n_held][1] = to;
+                    n_held++;
+                } else { // (a batch too small to be worth it: in its turn, by this thread)
+                    nc += deliver_held(0, false);
+                    nc += deliver_tiles(d, s, from, to);
+                }
+                from = to;
+            }
+            nc += deliver_held(0, true);
         } else {
-            nc += deliver_held(0);
             nc += deliver_tiles(d, s, delivered, upto);
         }
         delivered = upto;
@@ -835,7 +847,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     }
     if (n_held) { // the batches that were still waiting for their turn
         const auto tp = clk::now();
-        recs_handed += deliver_held(0);
+        recs_handed += deliver_held(0, false);
         if (dbg_on)
             dbg[1] += std::chrono::duration<double, std::micro>(clk::now() - tp).count();
     }

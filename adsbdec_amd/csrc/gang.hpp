@@ -87,7 +87,7 @@ public:
             return true;
         for (uint32_t i = 0; i < kRing; i++)
             ring_[i].seq.store(i, std::memory_order_relaxed);
-        acc_.reset(new (std::nothrow) Acc[(size_t)helpers]);
+        acc_.reset(new (std::nothrow) Acc[(size_t)helpers + 1]); // (the last one: the posting thread's own, when it lends a hand)
         if (!acc_)
             return false;
         try {
@@ -144,7 +144,25 @@ public:
     void wait_all()
     {
         for (uint32_t spins = 1; completed_.load(std::memory_order_acquire) != posted_; spins++)
-            relax(spins);
+            if (!help())
+                relax(spins);
+    }
+    // The posting thread lends a hand while it has to wait anyway: one task, if one is waiting.  (Its counts go to a slot of
+    // its own; only this thread ever calls it.)
+    bool help()
+    {
+        uint64_t c = claimed_.load(std::memory_order_relaxed);
+        Slot &s = ring_[c % kRing];
+        if (s.seq.load(std::memory_order_acquire) != c + 1 || !claimed_.compare_exchange_strong(c, c + 1, std::memory_order_acq_rel))
+            return false;
+        const Task t = s.task;
+        s.seq.store(c + kRing, std::memory_order_release);
+        if (t.fn)
+            t.fn(t, acc_[th_.size()].c);
+        else
+            format(t, acc_[th_.size()].c);
+        completed_.fetch_add(1, std::memory_order_release);
+        return true;
     }
     // One poll's pause.  Every 256th gives the processor away: should the scheduler ever put two of these threads on one CPU
     // (seen in an 8-CPU VM: 24 ms per launch, the two alternating at the 4 ms tick), they alternate at the speed of a
@@ -159,7 +177,7 @@ public:
     Counts take_counts()
     {
         Counts c;
-        for (size_t i = 0; i < th_.size(); i++) {
+        for (size_t i = 0; i <= th_.size(); i++) {
             c.n11 += acc_[i].c.n11, c.n17 += acc_[i].c.n17, c.nfix += acc_[i].c.nfix;
             acc_[i].c = Counts{};
         }

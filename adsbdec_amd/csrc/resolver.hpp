@@ -807,6 +807,12 @@ public:
         gang_busy_ = true;
         return true;
     }
+    // has the oldest batch that was posted been decided?  (advance_tiles() for it will not have to wait)
+    bool ahead_ready() const
+    {
+        const Ahead &a = ahead_[ahead_head_ % kAheadSlots];
+        return a.posted && a.n.load(std::memory_order_acquire) >= 0;
+    }
     void set_ahead_min_records(size_t n) { ahead_min_records_ = n; }
     void set_arena_chunk(size_t n) { arena_.chunk = n; } // (before the first batch)
     uint64_t ahead_taken() const { return ahead_taken_; } // frames whose decision was made ahead and taken over as it was
@@ -857,7 +863,8 @@ private:
         Batch &b = batch_;
         Ahead &a = *ahead_now_;
         for (uint32_t spins = 1; a.n.load(std::memory_order_acquire) < 0; spins++)
-            FormatGang::relax(spins);
+            if (!gang_->help()) // (the batch may still be waiting for a thread: then this one decides it, or writes frames meanwhile)
+                FormatGang::relax(spins);
         const size_t n = (size_t)a.n.load(std::memory_order_relaxed);
         Walk w;
         w.recs = b.recs, w.starts = b.starts, w.counts = b.counts;
@@ -1079,7 +1086,7 @@ private:
     };
     DecArena arena_;
     int arena_pins_ = 0;          // batches decided ahead whose decisions are still needed: no reset
-    static constexpr unsigned kAheadSlots = 4;
+    static constexpr unsigned kAheadSlots = 16;
     Ahead ahead_[kAheadSlots];    // the batch being taken over, and the ones being decided behind it (posted in order: a ring)
     unsigned ahead_head_ = 0, ahead_tail_ = 0;
     Ahead *ahead_now_ = nullptr;  // advance_tiles: this batch was decided ahead

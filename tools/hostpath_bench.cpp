@@ -107,14 +107,14 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
         auto tl = HandCursor::clk::now();
         uint32_t delivered = 0;
         const double t0 = now();
-        uint32_t held[3][2];
+        uint32_t held[12][2]; // (the streaming collect's own policy: decoder.hip slot_collect_streaming)
         int n_held = 0;
         auto adv = [&](uint32_t from, uint32_t upto) {
             res.advance_tiles(hand, t_start.data(), t_count.data(), from, upto, 0, 0, (uint64_t)ntiles * per + 100000, (uint64_t)upto * per);
         };
-        auto deliver_held = [&](int keep) {
+        auto deliver_held = [&](int keep, bool only_ready) {
             int k = 0;
-            for (; n_held - k > keep; k++)
+            for (; n_held - k > keep && (!only_ready || res.ahead_ready()); k++)
                 adv(held[k][0], held[k][1]);
             for (int i = k; i < n_held; i++)
                 held[i - k][0] = held[i][0], held[i - k][1] = held[i][1];
@@ -122,12 +122,22 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
         };
         auto flush = [&](uint32_t upto) {
             const double ta = now();
-            if (ahead && res.speculate_tiles(hand, t_start.data(), t_count.data(), delivered, upto, 0)) {
-                held[n_held][0] = delivered, held[n_held][1] = upto;
-                n_held++;
-                deliver_held(2);
+            if (ahead) {
+                for (uint32_t from = delivered; from < upto;) {
+                    const uint32_t to = std::min(upto, from + 64);
+                    if (n_held == 12)
+                        deliver_held(11, false);
+                    if (res.speculate_tiles(hand, t_start.data(), t_count.data(), from, to, 0)) {
+                        held[n_held][0] = from, held[n_held][1] = to;
+                        n_held++;
+                    } else {
+                        deliver_held(0, false);
+                        adv(from, to);
+                    }
+                    from = to;
+                }
+                deliver_held(0, true);
             } else {
-                deliver_held(0);
                 adv(delivered, upto);
             }
             delivered = upto;
@@ -137,7 +147,7 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
                                            : collect_alone(job, t_start.data(), t_count.data(), delivered, flush, wait_ms, tl);
         if (n_held) {
             const double ta = now();
-            deliver_held(0);
+            deliver_held(0, false);
             tr += now() - ta;
         }
         res.sync(); // (the frames are whole)
