@@ -120,7 +120,7 @@ typedef struct adsb_config {
                                   0 (default): 1, until a launch hands over 65 536 records or more (a channel near its
                                   capacity: ~20 k frames per second of signal); from the next launch on, 6 for every
                                   launch that follows such a one (BASELINE configs[2]: a 256 Mi-sample step takes
-                                  1.2 x its kernel instead of 3.3 x) -- 2 where the process may use fewer than 12 CPUs. */
+                                  1.3 x its kernel instead of 3.3 x) -- 2 where the process may use fewer than 12 CPUs. */
     /* more test knobs (0 = default).  The library reads no environment variable: whatever a test has to force is here. */
     int32_t debug_no_streaming;     /* 1: every launch is collected after completion (no hand-off stream)              */
     int32_t debug_frames_cap;       /* collect_stats: accepted frames the upload buffers start with (regrow path)      */
