@@ -48,7 +48,7 @@ def results():
 | wave time | issuing {c['SQ_ACTIVE_INST_ANY']['mean'] / wc * 100:.0f} %, stalled wanting to issue {c['SQ_WAIT_INST_ANY']['mean'] / wc * 100:.0f} %, parked on `s_waitcnt` / `s_barrier` {c['SQ_WAIT_ANY']['mean'] / wc * 100:.0f} % | `r5_pmc.json` |
 | with the Try/Ok table (`collect_stats=1`: what the drop-in runs) | {d['with_stats']['ms_per_step']:.4f} ms per step = **{d['with_stats']['value'] / 1e6:.3f} Tsamples/s** (`value_dropin`); under rocprofv3 `scan_kernel<true>` {statistics.mean(sdur[-1000:]):.1f} µs (last 1000 of {len(sdur)}), `count_tries_kernel` {float(cnt[3]) / 1e3:.1f} µs on its own stream | `r5_bench.json`, `r5_stats_kernel_stats.csv`, `r5_stats_dispatches.csv` |
 | dense, σ = 300 noise + one 112-bit frame per ms, `-a` (rounds 1–3's `configs[2]`) | {dn['noise']['plain']['ms_per_step']:.4f} ms per step, kernel {dn['noise']['plain']['launch_ms'] * 1e3:.1f} µs = {dn['noise']['plain']['roofline_frac']:.3f}; {dn['noise']['preamble_pass_fraction'] * 100:.2f} % of the offsets pass the preamble test, {dn['noise']['df_gate_pass_fraction_of_visited'] * 100:.3f} % the DF gate; with the table {dn['noise']['with_stats']['ms_per_step']:.4f} ms | `r5_bench.json` `dense.noise` |
-| dense, **`configs[2]` at its stated density** (112-bit frames packed back to back in σ = 300 noise, 3 % of the ms slots full of frame starts) | **{dn['target_10_percent']['preamble_pass_fraction'] * 100:.2f} %** of the offsets pass the preamble test; {dn['target_10_percent']['plain']['frames']} frames per step; {dn['target_10_percent']['plain']['ms_per_step']:.3f} ms per step = {dn['target_10_percent']['plain']['value'] / 1e3:.1f} Gsamples/s (kernel {dn['target_10_percent']['plain']['launch_ms']:.3f} ms, the rest is resolving behind it: see below); with the table {dn['target_10_percent']['with_stats']['ms_per_step']:.3f} ms; frames and table equal to the oracle's | `r5_bench.json` `dense.target_10_percent` |
+| dense, **`configs[2]` at its stated density** (112-bit frames packed back to back in σ = 300 noise, 3 % of the ms slots full of frame starts) | **{dn['target_10_percent']['preamble_pass_fraction'] * 100:.2f} %** of the offsets pass the preamble test; {dn['target_10_percent']['plain']['frames']} frames per step; {dn['target_10_percent']['plain']['ms_per_step']:.3f} ms per step = {dn['target_10_percent']['plain']['value'] / 1e3:.1f} Gsamples/s (kernel {dn['target_10_percent']['plain']['launch_ms']:.3f} ms: {dn['target_10_percent']['plain']['ms_per_step'] / dn['target_10_percent']['plain']['launch_ms']:.2f} × — the handle's reader thread and gang of four at work, see below); with the table {dn['target_10_percent']['with_stats']['ms_per_step']:.3f} ms; frames and table equal to the oracle's | `r5_bench.json` `dense.target_10_percent` |
 | adversarial: nothing but frame starts (`gate_storm`) | {dn['gate_storm']['preamble_pass_fraction'] * 100:.1f} % pass the preamble test, {dn['gate_storm']['df_gate_pass_fraction_of_visited'] * 100:.2f} % of ALL offsets the DF gate: every tile overflows its survivor queue; kernel {dn['gate_storm']['plain']['launch_ms']:.3f} ms = **{dn['gate_storm']['plain']['launch_ms'] / d['roofline']['launch_ms']:.1f} × the sparse launch**, step {dn['gate_storm']['plain']['ms_per_step']:.3f} ms; with the table step {dn['gate_storm']['with_stats']['ms_per_step']:.3f} ms (kernel {dn['gate_storm']['with_stats']['launch_ms']:.2f} ms, {dn['gate_storm']['with_stats']['relaunches']} relaunches); table equal to the oracle's | `r5_bench.json` `dense.gate_storm` |
 | cold (first steps after 0.5 s of idle) | {d['value_cold']['ms_each_step']} ms: only the FIRST step is slow; `value_cold` = {d['value_cold']['value'] / 1e6:.2f} Tsamples/s | `r5_bench.json` `value_cold` |
 | host-fed, PCIe-inclusive (never `value`) | 1 Mi-sample calls: `adsb_push` {e['push_1Mi_sync'] / 1e3:.1f}, with `push_overlap` {e['push_1Mi_overlap'] / 1e3:.1f}, `adsb_push_async` {e['push_1Mi_async'] / 1e3:.1f} GS/s; 16 Mi: {e['push_16Mi_sync'] / 1e3:.1f} / {e['push_16Mi_overlap'] / 1e3:.1f} / {e['push_16Mi_async'] / 1e3:.1f}; 1 / 2 / 4 streams on one GPU: {d['multi_stream_host_fed']['streams_1']['aggregate'] / 1e3:.1f} / {d['multi_stream_host_fed']['streams_2']['aggregate'] / 1e3:.1f} / {d['multi_stream_host_fed']['streams_4']['aggregate'] / 1e3:.1f} GS/s | `r5_bench.json` `e2e_host_fed`, `multi_stream_host_fed` |
