@@ -839,7 +839,18 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
             if (l3 >= 0 && l3 != rd.placed_l3)
                 rd.placed_l3 = adsb::place_reader_thread(rd.th, cpu);
         }
-        end = adsb::collect_behind_reader(rd, job, t_start.data(), t_count.data(), delivered, flush, wait_ms, t_last_wait);
+        auto idle = [&]() -> bool { // batches that have been decided meanwhile go on while the device is behind
+            if (!n_held || !d->res.ahead_ready())
+                return false;
+            clk::time_point tp;
+            if (dbg_on)
+                tp = clk::now();
+            recs_handed += deliver_held(0, true);
+            if (dbg_on)
+                dbg[1] += std::chrono::duration<double, std::micro>(clk::now() - tp).count();
+            return true;
+        };
+        end = adsb::collect_behind_reader(rd, job, t_start.data(), t_count.data(), delivered, flush, wait_ms, t_last_wait, idle);
         if (dbg_on)
             fprintf(stderr, "stream reader thread: busy %.1f us, waits %.1f us\n", rd.busy_ms * 1e3, rd.wait_ms * 1e3);
     } else {

@@ -409,9 +409,14 @@ CollectEnd collect_alone(const HandJob &job, uint32_t *t_start, uint32_t *t_coun
 }
 
 // Two threads: the reader publishes its frontier, the calling thread resolves behind it.
-template <class Flush>
+// (idle(): called while there is nothing to hand on -- the caller may have work of its own waiting, e.g. batches that other
+// threads have decided meanwhile; returns true if it did something)
+struct NoIdle {
+    bool operator()() const { return false; }
+};
+template <class Flush, class Idle = NoIdle>
 CollectEnd collect_behind_reader(StreamReader &rd, const HandJob &job, uint32_t *t_start, uint32_t *t_count, uint32_t &delivered,
-                                 Flush &&flush, double &wait_ms, HandCursor::clk::time_point &t_last_wait)
+                                 Flush &&flush, double &wait_ms, HandCursor::clk::time_point &t_last_wait, Idle &&idle = Idle())
 {
     using clk = HandCursor::clk;
     rd.post(job, t_start, t_count);
@@ -425,10 +430,15 @@ CollectEnd collect_behind_reader(StreamReader &rd, const HandJob &job, uint32_t 
         }
         if (fin)
             break;
+        if (idle())
+            continue;
         const auto t_w = clk::now();
-        while (rd.frontier.load(std::memory_order_relaxed) == f && rd.done_seq.load(std::memory_order_relaxed) != seq)
+        while (rd.frontier.load(std::memory_order_relaxed) == f && rd.done_seq.load(std::memory_order_relaxed) != seq) {
             for (int k = 0; k < 32; k++) // poll gently: every look takes the line away from the thread that writes it
                 __builtin_ia32_pause();
+            if (idle())
+                break;
+        }
         t_last_wait = clk::now();
         wait_ms += std::chrono::duration<double, std::milli>(t_last_wait - t_w).count();
     }
