@@ -113,6 +113,7 @@ public:
         for (std::thread &t : th_)
             t.join();
         th_.clear();
+        quit_.store(false); // (start() may follow)
     }
     size_t helpers() const { return th_.size(); }
     std::vector<std::thread> &threads() { return th_; }

@@ -104,7 +104,13 @@ public:
 
     void reset()
     {
-        sync();
+        sync(); // (also lets every batch that is being decided ahead end)
+        for (Ahead &a : ahead_)
+            a.posted = false;
+        ahead_head_ = ahead_tail_ = 0;
+        ahead_now_ = nullptr;
+        arena_pins_ = 0;
+        arena_.reset();
         base_ = 0;
         chain_ = false;
         w_on_ = false;
