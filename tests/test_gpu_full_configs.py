@@ -151,7 +151,8 @@ def test_config2_256Mi_at_ten_percent_density_and_the_gate_storm(capi, oracle, t
                         assert d.stats() == wstats, rep
                     extra = (_reader_threads(), _format_threads())
                     if make is make_dense10:        # 123 k records per launch
-                        assert extra == ((0, 0) if rep == 0 else (1, 4)), (rep, extra)
+                        gang = 4 if len(os.sched_getaffinity(0)) >= 12 else 0   # (a confined process keeps to the reader: decoder.hip)
+                        assert extra == ((0, 0) if rep == 0 else (1, gang)), (rep, extra)
                     else:                            # one record: the threads never exist
                         assert extra == (0, 0)
                 if make is make_gate_storm:
