@@ -876,6 +876,9 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
         d->gang->end();
     }
     if (dbg_on)
+        fprintf(stderr, "gang: %s, ahead %d, frames taken over so far %llu\n", with_gang ? "on" : "off", (int)ahead,
+                (unsigned long long)d->res.ahead_taken());
+    if (dbg_on)
         fprintf(stderr,
                 "stream collect: %.1f us in all, resolve %.1f us in %d batches, waits %.1f us; %.1f us after the last wait\n",
                 std::chrono::duration<double, std::micro>(clk::now() - t_begin).count(), dbg[1], (int)dbg[2], wait_ms * 1e3,

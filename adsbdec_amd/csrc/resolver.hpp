@@ -702,7 +702,9 @@ private:
     }
     // `made` decisions become frames: written by the gang's threads (true: the decisions must stay where they are until
     // sync()) or by this thread, right away (false).
-    bool emit(const Decision *dc, size_t made, uint64_t ts_add = 0)
+    // (packed: the decisions' offsets as adopt_calls read them -- a batch decided ahead: the decisions themselves lie in another
+    // core's cache, and a statistics run's log must not fetch them line by line)
+    bool emit(const Decision *dc, size_t made, uint64_t ts_add = 0, const uint32_t *packed = nullptr)
     {
         if (!made)
             return false;
@@ -736,9 +738,28 @@ private:
             stats_.ok[2] += made - c.n11 - c.n17;
             stats_.fixed += c.nfix;
         }
-        if ((w_on_ && !w_stop_) || log_on_) // what a shard's call walk or a statistics run wants per frame
-            for (size_t i = 0; i < made; i++)
-                note_accepted(b.g_base + dc[i].g_rel, dc[i].where & kDecLong ? 1200u : 640u);
+        if ((w_on_ && !w_stop_) || log_on_) { // what a shard's call walk or a statistics run wants per frame
+            size_t i = 0;
+            if (log_on_ && !(w_on_ && !w_stop_) && log_.empty()) {
+                // the usual case, with the log's end in locals (through the members every entry is a load-add-store of
+                // ext_n_ that the next one waits for -- the entries could alias it: 2.7 ns per frame on a full channel)
+                const size_t n = std::min(made, ext_cap_ - std::min(ext_cap_, ext_n_));
+                LogEntry *const e = ext_ + ext_n_;
+                const uint64_t g_base = b.g_base;
+                if (packed)
+                    for (; i < n; i++)
+                        e[i] = LogEntry{g_base + (packed[i] & 0x7FFFFFFFu), packed[i] >> 31 ? 1200u : 640u, 0};
+                else
+                    for (; i < n; i++)
+                        e[i] = LogEntry{g_base + dc[i].g_rel, dc[i].where & kDecLong ? 1200u : 640u, 0};
+                ext_n_ += n;
+            }
+            for (; i < made; i++)
+                if (packed)
+                    note_accepted(b.g_base + (packed[i] & 0x7FFFFFFFu), packed[i] >> 31 ? 1200u : 640u);
+                else
+                    note_accepted(b.g_base + dc[i].g_rel, dc[i].where & kDecLong ? 1200u : 640u);
+        }
         return handed;
     }
 
@@ -922,19 +943,19 @@ private:
             size_t lo = 0, hi = n;
             while (lo < hi) {
                 const size_t mid = (lo + hi) / 2;
-                if (a.d[mid].g_rel < last.g_rel)
+                if ((a.g[mid] & 0x7FFFFFFFu) < last.g_rel) // (the packed offsets: adopt_calls reads those lines anyway)
                     lo = mid + 1;
                 else
                     hi = mid;
             }
-            if (lo == n || a.d[lo].g_rel != last.g_rel || a.d[lo].where != last.where)
+            if (lo == n || (a.g[lo] & 0x7FFFFFFFu) != last.g_rel || a.d[lo].where != last.where)
                 continue;
             size_t j = lo + 1;
             adopt_calls(w, a.g, j, n);
             if (j > lo + 1) {
                 // ts = g_rel + tsb on both sides, and tsb moves by the same spans from here on: the difference is a constant
                 const uint64_t ts_add = last.ts - a.d[lo].ts; // (the same decision on both sides: the true ts count minus the batch's own)
-                emit(a.d + lo + 1, j - (lo + 1), ts_add); // (the batch's decisions stay where they are: the arena is pinned)
+                emit(a.d + lo + 1, j - (lo + 1), ts_add, a.g + lo + 1); // (the batch's decisions stay where they are: the arena is pinned)
                 ahead_taken_ += j - (lo + 1);
                 // the ts count behind the last decision taken over: its own ts, its offset, its span
                 const Decision &e = a.d[j - 1];

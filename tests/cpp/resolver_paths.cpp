@@ -86,6 +86,9 @@ int main(int argc, char **argv)
         ra.reset(), rb.reset(), rc.reset(), rd.reset(), re.reset();
         re.set_gang(&gang, round % 2 ? 16 : 1);
         re.set_ahead_min_records(round % 5 == 0 ? 40 : 1);
+        rc.log_accepted(true), re.log_accepted(true); // a statistics run's log of accepted frames: the same entries either way
+        std::vector<adsb::Resolver::LogEntry> lc(round % 4 == 0 ? 50 : 1 << 16), le(lc.size()); // (the caller's buffer; what does not fit: accepted_log())
+        rc.log_into(lc.data(), lc.size()), re.log_into(le.data(), le.size());
         if (round % 2) // decisions in chunks of 48: allocations cross chunk ends, and the arena starts over while tasks are in flight
             rd.set_arena_chunk(48), re.set_arena_chunk(48);
         rd.set_gang(&gang, round % 3 == 0 ? 64 : 1); // (with a threshold, small batches are written by the caller in between)
@@ -211,7 +214,10 @@ int main(int argc, char **argv)
         };
         const bool ok = same(fa, fb) && same(fa, fc) && same(fa, fd) && same(fa, fe) && !std::memcmp(&ra.stats(), &re.stats(), sizeof(adsb_stats)) && !std::memcmp(&ra.stats(), &rb.stats(), sizeof(adsb_stats)) &&
                         !std::memcmp(&ra.stats(), &rc.stats(), sizeof(adsb_stats)) && !std::memcmp(&ra.stats(), &rd.stats(), sizeof(adsb_stats));
-        if (!ok || fa.empty()) {
+        const bool same_log = rc.accepted_log() == re.accepted_log() && rc.logged_ext() == re.logged_ext() &&
+                              rc.logged_ext() + rc.accepted_log().size() == fc.size() &&
+                              !std::memcmp(lc.data(), le.data(), rc.logged_ext() * sizeof(adsb::Resolver::LogEntry));
+        if (!ok || !same_log || fa.empty()) {
             printf("round %d: MISMATCH (%zu / %zu / %zu / %zu / %zu frames of %zu candidates)\n", round, fa.size(), fb.size(), fc.size(), fd.size(), fe.size(),
                    recs.size());
             return 1;
