@@ -5,9 +5,10 @@
 // of an accepted record is not: it depends on the record and on the decision, on nothing before it.  So the resolver's
 // thread decides -- 16 bytes per accepted frame: {ts, offset, where the record lies} -- and hands blocks of decisions to the
 // threads of a FormatGang, which write the frames into the slots the resolver reserved for them in its output array
-// (resolver.hpp: Resolver::run_calls_tiles<true>).  A first attempt sent a word per frame through a ring to ONE writer
-// thread and lost (every line of a ring changes hands twice: 4-5 ns per frame on the deciding side); blocks of 512
-// decisions cost the deciding side one 40-byte task per block.
+// (resolver.hpp: Resolver::emit).  A first attempt sent a word per frame through a ring to ONE writer thread and lost
+// (every line of a ring changes hands twice: 4-5 ns per frame on the deciding side); blocks of 512 decisions cost the
+// deciding side one task per block.  The same threads decide whole batches of tiles AHEAD of the resolver's thread, which
+// then only takes the decisions over (Resolver::speculate_tiles, run_calls_tiles_ahead): a task is a function pointer.
 //
 // Host-only code, no HIP: built and run without a GPU (tests/cpp/resolver_paths.cpp under ThreadSanitizer).
 #pragma once

@@ -12,7 +12,10 @@
 // Also valid.c:30-31's Try/Ok counters, which only count VISITED offsets.
 //
 // Cost matters: at device speed the host sees ~2e8 candidates per second, so the
-// queues are flat vectors with a head index, and records are consumed in place.
+// queues are flat vectors with a head index, and records are consumed in place -- in two
+// tight loops (decide_calls: 16 bytes per accepted frame; FormatGang::format: the frames),
+// the second of which, and on a full channel the first as well, other threads can run
+// (gang.hpp; speculate_tiles / run_calls_tiles_ahead below).
 #pragma once
 
 #include <algorithm>
