@@ -10,21 +10,21 @@ CSRC     := adsbdec_amd/csrc
 LIBDIR   := adsbdec_amd/lib
 LIB      := $(LIBDIR)/libadsbdec_amd.so
 CLI      := $(LIBDIR)/adsbdec_amd_cli
-HDRS     := $(CSRC)/scan_kernel.h $(CSRC)/scan_kernel_format.h $(CSRC)/handoff.hpp $(CSRC)/resolver.hpp $(CSRC)/stitch.hpp include/adsbdec_amd.h
+# dependencies: every compile writes <object>.d (-MMD), included at the bottom -- no hand-kept header list to forget a file in
 
 all: $(LIB) $(CLI)
 
-$(LIBDIR)/%.hip.o: $(CSRC)/%.hip $(HDRS)
+$(LIBDIR)/%.hip.o: $(CSRC)/%.hip
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -MMD -MF $@.d -c $< -o $@
 
-$(LIBDIR)/format.c.o: $(CSRC)/format.c $(HDRS)
+$(LIBDIR)/format.c.o: $(CSRC)/format.c
 	@mkdir -p $(LIBDIR)
-	$(CC) -O2 -fPIC -Wall -c $< -o $@
+	$(CC) -O2 -fPIC -Wall -MMD -MF $@.d -c $< -o $@
 
-$(LIBDIR)/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
+$(LIBDIR)/%.cpp.o: $(CSRC)/%.cpp
 	@mkdir -p $(LIBDIR)
-	g++ -O2 -fPIC -std=c++17 -Wall -Wextra -pthread -c $< -o $@
+	g++ -O2 -fPIC -std=c++17 -Wall -Wextra -pthread -MMD -MF $@.d -c $< -o $@
 
 $(LIB): $(LIBDIR)/scan_kernel.hip.o $(LIBDIR)/decoder.hip.o $(LIBDIR)/format.c.o $(LIBDIR)/multi.cpp.o $(LIBDIR)/host_abi.cpp.o $(LIBDIR)/numa.cpp.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm -lpthread
@@ -41,6 +41,8 @@ check: all
 	python -m pytest tests -q -m "not gpu"
 
 clean:
-	rm -f $(LIBDIR)/*.o $(LIB) $(CLI)
+	rm -f $(LIBDIR)/*.o $(LIBDIR)/*.o.d $(LIB) $(CLI)
+
+-include $(wildcard $(LIBDIR)/*.o.d)
 
 .PHONY: all oracle check clean

@@ -24,8 +24,9 @@ HIP_SOURCES = ["scan_kernel.hip", "decoder.hip"]
 C_SOURCES = ["format.c"]
 # host-only C++ (no HIP): the multi-GPU driver over the C-ABI, and the part of the C-ABI that needs no device
 CXX_SOURCES = ["multi.cpp", "host_abi.cpp", "numa.cpp"]
-HEADERS = ["scan_kernel.h", "scan_kernel_format.h", "handoff.hpp", "resolver.hpp", "stitch.hpp",
-           os.path.join(ROOT, "include", "adsbdec_amd.h")]
+# What an object depends on is what the compiler says it read: every compile writes <object>.d (-MMD) and the next build
+# reads it.  (Until round 6 this was a hand-kept list of headers, and gang.hpp -- included by resolver.hpp -- was not on
+# it: editing it alone left stale objects.  tests/test_host_logic.py touches a header and watches the rebuild.)
 # -ffp-contract=off: the reference arithmetic is binary32 multiply THEN add
 # (SURVEY Q3); a fused multiply-add would change rounding.
 # -amdgpu-atomic-optimizer-strategy=None: the compiler otherwise turns the survivor queue's per-lane LDS
@@ -39,7 +40,23 @@ def _newer(target: str, deps: list[str]) -> bool:
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
+
+
+def _recorded_deps(obj: str) -> list[str] | None:
+    """The files the compiler read for `obj` last time (its -MMD depfile), or None when there is no record."""
+    path = obj + ".d"
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        text = f.read().replace("\\\n", " ")
+    _, _, rest = text.partition(":")
+    return [os.path.normpath(w) for w in rest.split()]
+
+
+def _stale(obj: str, src: str) -> bool:
+    deps = _recorded_deps(obj)
+    return deps is None or _newer(obj, [src] + deps)
 
 
 def _run(cmd: list[str]) -> None:
@@ -51,33 +68,35 @@ def _run(cmd: list[str]) -> None:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     for s in HIP_SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s + ".o")
-        if force or _newer(obj, [src] + hdrs):
+        if force or _stale(obj, src):
             if verbose:
                 print("hipcc", s)
-            _run([HIPCC] + HIP_FLAGS + os.environ.get("ADSB_EXTRA_HIPFLAGS", "").split() + ["-c", src, "-o", obj])
+            _run([HIPCC] + HIP_FLAGS + os.environ.get("ADSB_EXTRA_HIPFLAGS", "").split() + ["-MMD", "-MF", obj + ".d", "-c", src, "-o", obj])
         objs.append(obj)
     for s in C_SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s + ".o")
-        if force or _newer(obj, [src] + hdrs):
-            _run(["gcc", "-O2", "-fPIC", "-Wall", "-c", src, "-o", obj])
+        if force or _stale(obj, src):
+            _run(["gcc", "-O2", "-fPIC", "-Wall", "-MMD", "-MF", obj + ".d", "-c", src, "-o", obj])
         objs.append(obj)
     for s in CXX_SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s + ".o")
-        if force or _newer(obj, [src] + hdrs):
-            _run(["g++", "-O2", "-fPIC", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-c", src, "-o", obj])
+        if force or _stale(obj, src):
+            if verbose:
+                print("g++", s)
+            _run(["g++", "-O2", "-fPIC", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-MMD", "-MF", obj + ".d", "-c", src, "-o", obj])
         objs.append(obj)
     if force or _newer(LIB, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lm", "-lpthread"])
     cli_src = os.path.join(CSRC, "cli", "adsbdec_amd_cli.c")
     sink_src = os.path.join(CSRC, "cli", "sink.c")
-    if os.path.exists(cli_src) and (force or _newer(CLI, [cli_src, sink_src, os.path.join(CSRC, "cli", "sink.h"), LIB] + hdrs)):
+    if os.path.exists(cli_src) and (force or _newer(CLI, [cli_src, sink_src, os.path.join(CSRC, "cli", "sink.h"), LIB,
+                                                           os.path.join(ROOT, "include", "adsbdec_amd.h")])):
         _run(["gcc", "-O2", "-Wall", "-o", CLI, cli_src, sink_src, "-I", os.path.join(ROOT, "include"),
               "-L", LIBDIR, "-ladsbdec_amd", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
     return LIB

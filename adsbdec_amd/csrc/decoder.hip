@@ -277,7 +277,7 @@ int wait_until_done(adsb_decoder *d, Query &&query, const char *what)
     for (int spin = 0; spin < 4096; spin++) {
         if ((q = query()) != hipErrorNotReady)
             goto out;
-        __builtin_ia32_pause();
+        _mm_pause(); // (x86-64 only by handoff.hpp's #error: this file includes it)
     }
     {
         const auto t0 = clk::now();
@@ -287,7 +287,7 @@ int wait_until_done(adsb_decoder *d, Query &&query, const char *what)
             for (int spin = 0; spin < 256; spin++) {
                 if ((q = query()) != hipErrorNotReady)
                     goto out;
-                __builtin_ia32_pause();
+                _mm_pause(); // (x86-64 only by handoff.hpp's #error: this file includes it)
             }
             if (clk::now() - t0 > limit)
                 return d->fail("the device did not finish %s within %lld s (wedged queue or lost device?): giving up", what,
@@ -1241,6 +1241,9 @@ int slot_collect(adsb_decoder *d)
         }
     }
     d->res.sync(); // (tiles handed on after completion may have gone to the gang as well)
+    if (d->gang)
+        d->gang->end(); // ... and FormatGang::post() begins the gang again by itself: without this the helpers would poll on until
+                        // the next launch that goes through the gang -- under traffic that has turned sparse, until adsb_destroy
     d->prof.host_ms += std::chrono::duration<double, std::milli>(clk::now() - t_host).count();
     s.busy = false;
     d->slot_head = (d->slot_head + 1) % kSlots;

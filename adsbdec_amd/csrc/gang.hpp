@@ -77,7 +77,15 @@ public:
     };
     static constexpr uint32_t kBlock = 512; // decisions per task
 
-    FormatGang() = default;
+    FormatGang()
+    {
+        // The ring is initialised HERE and nowhere else: a quiescent ring (everything posted has completed) is consistent
+        // with posted_ / claimed_ / completed_ whatever their values, so stop() + start() need not touch it.  (Round 5's
+        // start() reset the slots' seq to their indices and left the three counters alone: after 256 tasks the first
+        // post() behind a restart waited for ever -- the advisor's finding; tests/cpp/resolver_paths.cpp restarts a gang now.)
+        for (uint32_t i = 0; i < kRing; i++)
+            ring_[i].seq.store(i, std::memory_order_relaxed);
+    }
     FormatGang(const FormatGang &) = delete;
     FormatGang &operator=(const FormatGang &) = delete;
     ~FormatGang() { stop(); }
@@ -86,8 +94,6 @@ public:
     {
         if (!th_.empty())
             return true;
-        for (uint32_t i = 0; i < kRing; i++)
-            ring_[i].seq.store(i, std::memory_order_relaxed);
         acc_.reset(new (std::nothrow) Acc[(size_t)helpers + 1]); // (the last one: the posting thread's own, when it lends a hand)
         if (!acc_)
             return false;
@@ -171,7 +177,11 @@ public:
     // system call instead.
     static void relax(uint32_t spins)
     {
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
         if ((spins & 0xFF) == 0)
             sched_yield();
     }

@@ -186,7 +186,7 @@ struct adsb_multi {
     {
         broken = true;
         return fail("device %d (worker %d) has shown no sign of life for %.0f s (adsb_config.wait_timeout_s + margin): giving up; "
-                    "this adsb_multi handle is unusable now -- destroy it",
+                    "this adsb_multi handle is unusable now -- destroy it, and keep the sample buffers / files of this call alive: the worker may still read them if it comes back",
                     w.device, w.index, worker_limit_s(cfg));
     }
     long fail(const char *fmt, ...)
@@ -985,20 +985,37 @@ void adsb_multi_destroy(adsb_multi *m)
         return;
     if (m->broken) {
         // some worker never answered: nobody can join it.  Every worker is cut loose instead -- it frees its handle and itself
-        // when (if) it comes back -- and the driver's own memory goes now; the workers hold no pointer into it ... except
-        // the source and result arrays of the job they may still be running, which stay the CALLER's to keep alive.
+        // when (if) it comes back -- and the driver's own memory goes now, except what a job in flight may still write
+        // (below).  The SOURCE buffers of that job stay the caller's to keep alive (adsb_multi_last_error says so).
+        // Order matters: a worker that sees `orphaned` deletes itself, thread object and condition variable included, so the
+        // thread is detached FIRST and the notification is sent while the lock is still held -- the last touch of *p here is
+        // the unlock (round 6: TSan caught ~Worker racing with the notify_all / detach that used to follow the unlock).
         for (auto &w : m->w) {
             Worker *p = w.release();
             if (!p->th.joinable()) {
                 delete p;
                 continue;
             }
-            {
-                std::lock_guard<std::mutex> lk(p->mu);
-                p->orphaned = true;
-            }
-            p->cv.notify_all();
             p->th.detach();
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->orphaned = true;
+            p->cv.notify_all();
+        }
+        // A worker that is still inside a job writes its results where the job told it to: the per-stream results
+        // (Job::results) and the gather's destination (Job::dst) are this handle's vectors.  They are given up with the
+        // workers -- moved to the heap and never freed -- instead of being freed under a thread that may come back
+        // (round 5's advisor finding).  A broken handle is a lost device: a few vectors are the smaller loss.  They stay
+        // reachable from a list that is itself never destroyed (no static destructor runs under a detached thread).
+        {
+            struct GivenUp {
+                std::vector<StreamResult> streams;
+                std::vector<adsb_frame> out, new_frames;
+            };
+            static std::mutex mu;
+            static auto *given_up = new std::vector<std::unique_ptr<GivenUp>>();
+            std::unique_ptr<GivenUp> g(new GivenUp{std::move(m->streams), std::move(m->out), std::move(m->new_frames)});
+            std::lock_guard<std::mutex> lk(mu);
+            given_up->push_back(std::move(g));
         }
         delete m;
         return;

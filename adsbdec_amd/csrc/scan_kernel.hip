@@ -66,6 +66,7 @@
 #include <type_traits>
 
 #include "scan_kernel.h"
+#include "scan_stamps.h" // ADSB_STAMP / ADSB_COUNT: nothing in the shipped build (a measurement build's per-phase tile clocks)
 
 namespace adsb {
 
@@ -474,7 +475,7 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
 template <bool kStats>
 __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t tile, const int K, const int64_t t0, const int tid,
                                         const uint32_t *pl_d, const uint32_t *pl_e1, const uint32_t *pl_e2, uint32_t *queue,
-                                        uint32_t *qcount, uint32_t *cl_rec, const int clist_cap)
+                                        uint32_t *qcount, uint32_t *cl_rec, const int clist_cap, uint64_t &stamp_last)
 {
     constexpr int NT = kThreads;
     constexpr int kFallbackChunks = 256 / NT; // a fallback round takes one bit position of 256 runs: <= 256 entries
@@ -613,8 +614,11 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             }
         }
         __syncthreads();
+        ADSB_STAMP(2); // gate words + queue
         const bool over = *qover != 0;
         const int qtotal = (int)*qcount; // every survivor of the range, queued or not
+        ADSB_COUNT(8, 1);
+        ADSB_COUNT(9, over ? 0 : qtotal);
         const int qn = over ? 0 : qtotal;
         // valid.c:46,68: every DF-gate pass that is visited is a Try -- the queue entries ARE the tries.  A
         // whole-tile round puts them into the tile's own region of args.tries (kTryRegion words; the count goes
@@ -717,6 +721,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                     dst[q] = ((tile_rel + (uint32_t)kRun * (ent >> 7) + ((ent >> 2) & 31u)) << 2) | (ent & 3u);
             }
         }
+        ADSB_STAMP(3); // slicer + CRC (+ try words)
         // next round (all of this is workgroup-uniform)
         first = false;
         if (grp >= 0) {
@@ -754,7 +759,9 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         // list is complete), and none does, c is unreachable.  These are the +-1/2
         // sample shifted copies of every real frame: 3 of 4 records.
         __syncthreads();
+        ADSB_STAMP(3);
         const int ncl = min((int)*cl_n, clist_cap); // <= kClistCap <= NT: one entry per thread
+        ADSB_COUNT(10, ncl);
         const bool complete = *cl_over == 0;
         uint32_t res_need = 0, res_base = 0; // (the tile's reservation in the hand-off stream: below, once its records are counted)
         const bool reserves = tid == 0 && args.hand;
@@ -876,6 +883,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             st[1] &= 0xFFFFu; // (the multi-wave filter's "kept" bit never existed here, but a link compares the whole word)
         }
         __syncthreads(); // every thread has read what it needs of the staged list (the filter's loops included)
+        ADSB_STAMP(4); // never-visited filter + ranking
         const uint32_t nk = *tile_n;       // entries that stay
         const bool links = *any_nb != 0;   // workgroup-uniform: some of them are neighbours -- runs of copies are possible
         uint32_t *pwbuf = queue, *ext = queue + kClistCap, *wl = queue + kQueueCap - 4; // every entry's pw; the copies' pw (two per record); leaders per wave
@@ -935,6 +943,9 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         // the finishing below.  (Until round 5 the tile reserved for every entry that stayed, BEFORE it knew its records:
         // with runs of copies that left two thirds of every range unwritten, and the host, which reads the stream
         // sequentially, lost its prefetcher at every tile: 1.0 ms per 2 800 tiles.)
+        ADSB_STAMP(5); // ascending order, links, leaders
+        ADSB_COUNT(11, nrec);
+        ADSB_COUNT(12, nk);
         if (reserves) { // the result is not looked at before this thread's own record is finished
             res_need = stream_granules(nrec);
             res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
@@ -958,6 +969,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             *tile_res = 1;
         }
         __syncthreads(); // tile_base / tile_fit are in, every entry has been read, every pw is known
+        ADSB_STAMP(6); // bytes in order, pw, the reservation's round trip
         const bool to_stream = args.hand && *tile_fit; // workgroup-uniform
         if (act) {
             if (!to_stream) {
@@ -1005,6 +1017,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     }
 
 
+    ADSB_STAMP(7); // records back into the list, check words, the store
     if (args.hand) {
         // Publish the tile: its marker granule {tile, count | flags, checksum} in front of
         // its records.  No fence: a system-scope release in every thread writes back the
@@ -1074,9 +1087,13 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArg
 
     // kernel arguments are only ever used by value (taking their address would
     // demote the sample pointer to a flat/scratch access)
+    ADSB_STAMP_BEGIN();
     stage_a(args.x, args.pbuf0, args.p_lo, args.p_hi, t0, K, wave, lane, pl_d, pl_e1, pl_e2);
     __syncthreads();
-    stage_b<kStats>(args, blockIdx.x, K, t0, tid, pl_d, pl_e1, pl_e2, queue, qcount, cl_rec, args.clist_cap);
+    ADSB_STAMP(1); // Stage A
+    ADSB_COUNT(0, 1);
+    stage_b<kStats>(args, blockIdx.x, K, t0, tid, pl_d, pl_e1, pl_e2, queue, qcount, cl_rec, args.clist_cap, stamp_last);
+    ADSB_STAMP_END(13); // the marker
 
     if (args.profile) { // the launch's duration is (latest tile end) - (earliest tile start)
         __syncthreads();

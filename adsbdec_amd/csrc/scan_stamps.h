@@ -1,0 +1,59 @@
+// scan_stamps.h -- per-phase clocks of a tile, for a MEASUREMENT build of scan_kernel.hip only:
+//     tools/build_variant.sh stamps -DADSB_PHASE_STAMPS   ->   tools/phase_probe.py   ->   profiles/r6_phase_stamps.txt
+// Thread 0 of every tile adds the ticks of the device's 100 MHz clock between phase boundaries to one accumulator per
+// phase (where does a tile's life go on the dense captures?).  In the shipped build every macro below is empty and the
+// library exports no adsb_debug_phase_read (tests/test_build_flags.py checks both): this header is the one build knob the
+// kernel source has.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifdef ADSB_PHASE_STAMPS
+namespace adsb {
+__device__ unsigned long long g_phase[24];
+}
+#define ADSB_STAMP_BEGIN()                                       \
+    uint64_t stamp_last = __builtin_amdgcn_s_memrealtime();      \
+    const uint64_t stamp_first = stamp_last
+#define ADSB_STAMP(i)                                                              \
+    do {                                                                           \
+        if (tid == 0) {                                                            \
+            const uint64_t now_ = __builtin_amdgcn_s_memrealtime();                \
+            atomicAdd(&adsb::g_phase[i], (unsigned long long)(now_ - stamp_last)); \
+            stamp_last = now_;                                                     \
+        }                                                                          \
+    } while (0)
+#define ADSB_COUNT(i, v)                                               \
+    do {                                                               \
+        if (tid == 0)                                                  \
+            atomicAdd(&adsb::g_phase[i], (unsigned long long)(v));     \
+    } while (0)
+#define ADSB_STAMP_END(i)                                                                          \
+    do {                                                                                           \
+        __syncthreads();                                                                           \
+        ADSB_STAMP(i);                                                                             \
+        if (tid == 0)                                                                              \
+            atomicMax(&adsb::g_phase[14], (unsigned long long)(stamp_last - stamp_first)); /* the longest tile */ \
+    } while (0)
+// the accumulators, and (reset != 0) back to zero
+extern "C" int adsb_debug_phase_read(unsigned long long *out, int n, int reset)
+{
+    unsigned long long v[24] = {};
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(adsb::g_phase), sizeof v) != hipSuccess)
+        return -1;
+    for (int i = 0; i < n && i < 24; i++)
+        out[i] = v[i];
+    if (reset) {
+        const unsigned long long z[24] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(adsb::g_phase), z, sizeof z) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+#else
+#define ADSB_STAMP_BEGIN() uint64_t stamp_last = 0
+#define ADSB_STAMP(i) do { (void)stamp_last; } while (0)
+#define ADSB_COUNT(i, v) do { } while (0)
+#define ADSB_STAMP_END(i) do { } while (0)
+#endif

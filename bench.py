@@ -116,7 +116,15 @@ def gate(got, want, what):
         raise SystemExit(f"PARITY FAILURE ({what}): GPU path returned {len(a)} frames, expected {len(b)}; first difference at index {i}")
 
 
-def roofline_objects(p0, p1, steps, profiles_tag="r5", clock=None, step_ms=None):
+PROFILE_ROUNDS = ("r6", "r5", "r4", "r3")   # committed rocprofv3 evidence sets, newest first (profiles/<round>[_<workload>]_pmc.json)
+
+
+def profile_tag(args) -> str:
+    """Suffix of the evidence set under profiles/ that belongs to the main workload of this run."""
+    return "_dense" if args.dense else "_dense10" if args.dense10 else "_storm" if args.gate_storm else ""
+
+
+def roofline_objects(p0, p1, steps, profiles_tag="", clock=None, step_ms=None):
     """HBM roofline of the dominant launch + the VALU-issue roofline that actually binds it."""
     kernel_ms = p1["kernel_ms"] - p0["kernel_ms"]
     big_off = p1["big_offsets"]
@@ -127,7 +135,7 @@ def roofline_objects(p0, p1, steps, profiles_tag="r5", clock=None, step_ms=None)
     avg_ms = ms_big / n_big if n_big else 0.0
     achieved = 4.0 * big_off / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, traffic_source, valu = None, None, None
-    for name in (f"{profiles_tag}_pmc.json", f"{profiles_tag.replace('r5', 'r4', 1)}_pmc.json", f"{profiles_tag.replace('r5', 'r3', 1)}_pmc.json"):
+    for name in tuple(f"{r}{profiles_tag}_pmc.json" for r in PROFILE_ROUNDS):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -612,6 +620,11 @@ def main():
     ap.add_argument("--samples", type=int, default=0,
                     help="input samples per GPU per step (stream mode, default 256 Mi) / in the whole stream (shard mode, default 2 Gi)")
     ap.add_argument("--dense", action="store_true", help="configs[2] as the main workload: wide-band noise, ~7%% preamble hits, -a")
+    ap.add_argument("--dense10", action="store_true",
+                    help="BASELINE configs[2] at its stated density as the main workload: 112-bit frames packed back to back in "
+                         "sigma=300 noise, ~10%% of the offsets pass the preamble test, ~106 k frames per 256 Mi samples, -a")
+    ap.add_argument("--gate-storm", action="store_true",
+                    help="the adversarial capture as the main workload: nothing but frame starts, every tile overflows its survivor queue, -a")
     ap.add_argument("--stats", action="store_true", help="also reproduce valid.c's Try counters (collect_stats=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold / dense / host-fed legs (profiling runs)")
@@ -673,10 +686,21 @@ def main():
 
     n = (args.samples or (256 << 20))
     n -= n % 28
+    if args.dense + args.dense10 + args.gate_storm > 1:
+        raise SystemExit("--dense, --dense10 and --gate-storm are three different main workloads: choose one")
+    df18 = bool(args.dense or args.dense10 or args.gate_storm)
     if args.dense:
         xs = [make_dense(torch, n, 100 + 10 * rank + j) for j in range(2)]
-        workload = (f"dense noise sigma=300 + one 112-bit frame per ms, {n} uint16 samples/GPU, -a (BASELINE configs[2]); "
-                    "the steps rotate over 2 captures")
+        workload = (f"dense noise sigma=300 + one 112-bit frame per ms, {n} uint16 samples/GPU, -a (what rounds 1-3 called BASELINE configs[2]: "
+                    "7 % of the offsets pass the preamble test); the steps rotate over 2 captures")
+    elif args.dense10:
+        xs = [make_dense10(torch, n, 101 + 10 * rank + j) for j in range(2)]
+        workload = (f"BASELINE configs[2] at its stated density: 112-bit frames packed back to back in sigma=300 noise, 3 % of the 1 ms slots "
+                    f"full of frame starts (~10 % of the offsets pass the preamble test), {n} uint16 samples/GPU, -a; the steps rotate over 2 captures")
+    elif args.gate_storm:
+        xs = [make_gate_storm(torch, n, 102 + 10 * rank + j) for j in range(2)]
+        workload = (f"adversarial: frame starts (preamble + DF17's five bits) packed back to back, {n} uint16 samples/GPU, -a: ~30 % of the offsets "
+                    "pass the preamble test, ~7.6 % of ALL offsets the DF gate (every tile's survivor queue overflows); the steps rotate over 2 captures")
     else:
         caps = [make_workload(torch, n, seed=1 + rank + 1000 * j) for j in range(3)]
         xs = [c[0] for c in caps]
@@ -686,7 +710,7 @@ def main():
         del caps
     torch.cuda.synchronize()
 
-    dec = capi.Decoder(df18=args.dense, device=local_rank, profile=True, collect_stats=args.stats)
+    dec = capi.Decoder(df18=df18, device=local_rank, profile=True, collect_stats=args.stats)
     ptrs = [(x.data_ptr(), x.numel()) for x in xs]
 
     def step(i=0):
@@ -745,7 +769,7 @@ def main():
     value = world * n * args.steps / dt / 1e6  # Msamples/s, whole job
     frames = capi._frames_to_dicts(raw[0], raw[1])
     p1 = dec.profile()
-    roofline, roofline_valu = roofline_objects(p0, p1, args.steps, "r5_dense" if args.dense else "r5", clock, dt / args.steps * 1e3)
+    roofline, roofline_valu = roofline_objects(p0, p1, args.steps, profile_tag(args), clock, dt / args.steps * 1e3)
 
     # ---- the same step 1000 more times (the driver's default is 20 steps = 3 ms of measurement; box-to-box the kernel
     # spreads by 7 %): a sturdier sample of the same quantity, every rank, same fences
@@ -756,7 +780,7 @@ def main():
             dt2, _ = timed_steps(step, 1000, fence, torch.cuda.synchronize)
         dt2 = max_over_ranks(dt2)
         q1 = dec.profile()
-        roof2, _ = roofline_objects(q0, q1, 1000, "r5_dense" if args.dense else "r5", sampler2.ghz(), dt2 / 1000 * 1e3)
+        roof2, _ = roofline_objects(q0, q1, 1000, profile_tag(args), sampler2.ghz(), dt2 / 1000 * 1e3)
         steady = {"steps": 1000, "value": round(world * n * 1000 / dt2 / 1e6, 1), "unit": "Msamples/s",
                   "ms_per_step": round(dt2 / 1000 * 1e3, 4), "launch_ms": roof2["launch_ms"], "roofline_frac": roof2["frac"],
                   "what": "the timed region repeated with 1000 steps right behind the K steps of `value` (same captures in rotation, "
@@ -784,11 +808,11 @@ def main():
         try:
             first = 0
             if rank == 0:
-                cpu, want = cpu_reference(xs[0].cpu().numpy().view(np.uint16), args.dense)
+                cpu, want = cpu_reference(xs[0].cpu().numpy().view(np.uint16), df18)
                 gate(per_capture[0], want, "capture 0 vs the CPU path")
                 first = 1
             for j in range(first, len(xs)):  # the other captures of the rotation: against the oracle
-                wj, _ = O.decode(xs[j].cpu().numpy().view(np.uint16), df18=args.dense)
+                wj, _ = O.decode(xs[j].cpu().numpy().view(np.uint16), df18=df18)
                 gate(per_capture[j], wj, f"rank {rank}, capture {j} vs the oracle")
         except SystemExit as e:  # a mismatch on one rank must fail the job, not hang the others in the all-reduce
             ok, why = False, str(e)
@@ -804,18 +828,18 @@ def main():
     sharded = None
     cli = None
     if rank == 0 and world == 1 and not args.no_extras:
-        e2e = host_fed_rates(torch, capi, xs[0], args.dense)
-        multi = multi_stream_host_fed(torch, capi, xs[0], args.dense)
-        dsx = capi.Decoder(df18=args.dense, device=local_rank, collect_stats=True)
+        e2e = host_fed_rates(torch, capi, xs[0], df18)
+        multi = multi_stream_host_fed(torch, capi, xs[0], df18)
+        dsx = capi.Decoder(df18=df18, device=local_rank, collect_stats=True)
         px, mx = ptrs[0]
         want_x = frames_key(capi._frames_to_dicts(*dsx.decode_device_raw(px, mx)))
-        sharded = host_fed_sharded(torch, capi, xs[0], args.dense, want_x, dsx.stats())
+        sharded = host_fed_sharded(torch, capi, xs[0], df18, want_x, dsx.stats())
         dsx.close()
-        cli = cli_whole_process(xs[0].cpu().numpy().view(np.uint16), capi, args.dense)
+        cli = cli_whole_process(xs[0].cpu().numpy().view(np.uint16), capi, df18)
         if not args.stats:
             # the same step with valid.c's Try/Ok table reproduced too (the reference always keeps it and prints
             # it at exit): tries counted on the device beside the next scan; the table is read once, after the loop
-            ds = capi.Decoder(df18=args.dense, device=local_rank, profile=True, collect_stats=True)
+            ds = capi.Decoder(df18=df18, device=local_rank, profile=True, collect_stats=True)
 
             def sstep(i=0):
                 p, m = ptrs[i % len(ptrs)]
@@ -825,14 +849,14 @@ def main():
             s0 = ds.profile()
             sdt, _ = timed_steps(sstep, 50, torch.cuda.synchronize)
             s1 = ds.profile()
-            sroof, _ = roofline_objects(s0, s1, 50, "r5_dense" if args.dense else "r5")
+            sroof, _ = roofline_objects(s0, s1, 50, profile_tag(args))
             with_stats = {"what": "collect_stats=1: the step above + the Try table of valid.c:84-100", "steps": 50, "preroll_ms": args.preroll_ms,
                           "value": round(n * 50 / sdt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(sdt / 50 * 1e3, 4),
                           "launch_ms": sroof["launch_ms"]}
             if not args.no_cpu_baseline:
                 from oracle import oracle as O
                 sstep(0)
-                _, wst = O.decode(xs[0].cpu().numpy().view(np.uint16), df18=args.dense)
+                _, wst = O.decode(xs[0].cpu().numpy().view(np.uint16), df18=df18)
                 got = ds.stats()
                 if got["try"] != wst["try"] or got["ok"] != wst["ok"]:
                     raise SystemExit(f"PARITY FAILURE: Try/Ok table {got} != oracle {wst}")
@@ -840,7 +864,7 @@ def main():
                 with_stats["parity_vs_oracle"] = True
             ds.close()
             # the same statistics step with cfg.host_threads = 2 (a second host thread reads the hand-off stream)
-            d2 = capi.Decoder(df18=args.dense, device=local_rank, profile=True, collect_stats=True, host_threads=2)
+            d2 = capi.Decoder(df18=df18, device=local_rank, profile=True, collect_stats=True, host_threads=2)
 
             def s2step(i=0):
                 p, m = ptrs[i % len(ptrs)]
@@ -852,20 +876,20 @@ def main():
                                             "frames": int(s2raw[1]),
                                             "what": "opt-in: the reader thread shares the caller's L3 (placed by the library)"}
             d2.close()
-        if not args.dense:
+        if not df18:
             del xs[1:], ptrs[1:]
             torch.cuda.empty_cache()
             dense = {}
-            for key, make, what in (
-                    ("noise", lambda: make_dense(torch, n, 100),
+            for key, ptag, make, what in (
+                    ("noise", "_dense", lambda: make_dense(torch, n, 100),
                      "sigma=300 noise + one 112-bit frame per ms at amplitude 1200-2000 (what rounds 1-3 called configs[2]: the noise "
                      "alone makes 7 % of the offsets pass the preamble test)"),
-                    ("target_10_percent", lambda: make_dense10(torch, n, 101),
+                    ("target_10_percent", "_dense10", lambda: make_dense10(torch, n, 101),
                      "BASELINE configs[2] at its stated density: 112-bit frames packed back to back in sigma=300 noise, 3 % of the "
                      "1 ms slots filled with frame starts: ~10 % of the offsets pass the preamble test, ~100 k frames decode (123 k records per "
                      "launch: the handle's reader thread and its gang of four -- batches decided ahead, frames written by the gang -- "
                      "start by themselves behind the first launch, cfg.host_threads = 0)"),
-                    ("gate_storm", lambda: make_gate_storm(torch, n, 102),
+                    ("gate_storm", "_storm", lambda: make_gate_storm(torch, n, 102),
                      "adversarial: frame starts (preamble + DF17's five bits) packed back to back: ~30 % of the offsets pass the "
                      "preamble test, ~7 % the DF gate -- every tile's survivor queue overflows and the tile is redone in ranges of chunks -- no CRC matches")):
                 xd = make()
@@ -880,7 +904,7 @@ def main():
                     q0 = dd.profile()
                     ddt, draw = timed_steps(dstep, 20, torch.cuda.synchronize)
                     q1 = dd.profile()
-                    droof, _ = roofline_objects(q0, q1, 20, profiles_tag="r5_dense")
+                    droof, _ = roofline_objects(q0, q1, 20, profiles_tag=ptag)
                     r = {"value": round(n * 20 / ddt / 1e6, 1), "ms_per_step": round(ddt / 20 * 1e3, 4), "launch_ms": droof["launch_ms"],
                          "roofline_frac": droof["frac"], "frames": int(draw[1]), "relaunches": int(q1["relaunches"] - q0["relaunches"])}
                     if not args.no_cpu_baseline and not stats:

@@ -60,6 +60,12 @@ def test_shipped_library_reads_no_environment():
     for f in ("scan_kernel.hip", "scan_kernel.h"):
         src = open(os.path.join(ROOT, "adsbdec_amd", "csrc", f)).read()
         assert "#if" not in src.replace("#ifndef ADSBDEC", ""), f
+    # The ONE knob the kernel source has lives in a header of its own: the per-phase tile clocks of a measurement build
+    # (scan_stamps.h, -DADSB_PHASE_STAMPS, round 6).  The shipped build defines every macro of it empty and exports no reader.
+    stamps = open(os.path.join(ROOT, "adsbdec_amd", "csrc", "scan_stamps.h")).read()
+    assert set(re.findall(r"#\s*if\w*\s+(\w+)", stamps)) == {"ADSB_PHASE_STAMPS"}
+    exported = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert "adsb_debug_phase_read" not in exported and "g_phase" not in exported
 
 
 def test_atomic_optimizer_off_and_bitop3_gate(isa):
