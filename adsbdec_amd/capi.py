@@ -55,6 +55,23 @@ class ShardFix(C.Structure):
 
 
 class Config(C.Structure):
+    """adsb_config, ABI 5 (include/adsbdec_amd.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("abi", C.c_uint32), ("df18", C.c_int32), ("device", C.c_int32),
+                ("collect_stats", C.c_int32), ("profile", C.c_int32), ("stage_samples", C.c_uint64), ("stream", C.c_void_p),
+                ("all_candidates", C.c_int32), ("fix_1bit", C.c_int32), ("push_overlap", C.c_int32), ("host_threads", C.c_int32),
+                ("wait_timeout_s", C.c_int32), ("reserved", C.c_int32), ("debug", C.c_void_p)]
+
+
+class DebugConfig(C.Structure):
+    """adsb_debug_config (include/adsbdec_amd_diag.h): the test knobs behind adsb_config.debug."""
+    _fields_ = [("struct_size", C.c_uint32), ("queue_cap", C.c_int32), ("cand_cap", C.c_int32), ("try_cap", C.c_int32),
+                ("clist_cap", C.c_int32), ("no_streaming", C.c_int32), ("frames_cap", C.c_int32), ("reader_min_tiles", C.c_int32),
+                ("shard_head", C.c_int32), ("passes", C.c_int32), ("stagger", C.c_int32), ("gang_min", C.c_int32)]
+
+
+class ConfigV4(C.Structure):
+    """adsb_config as ABI 4 had it (rounds 4-5): only for same-box A/B runs against an older build of the library
+    (ADSB_LIB_PATH); the tree's own library refuses it."""
     _fields_ = [("struct_size", C.c_uint32), ("df18", C.c_int32), ("device", C.c_int32),
                 ("collect_stats", C.c_int32), ("profile", C.c_int32), ("debug_queue_cap", C.c_int32),
                 ("stage_samples", C.c_uint64), ("stream", C.c_void_p), ("all_candidates", C.c_int32),
@@ -68,7 +85,7 @@ class Config(C.Structure):
 class MultiInfo(C.Structure):
     _fields_ = [("shards", C.c_int32), ("fallback", C.c_int32), ("calls_walked", C.c_uint64), ("calls_jumped", C.c_uint64),
                 ("create_ms", C.c_double), ("workers_ms", C.c_double), ("stitch_us", C.c_double), ("serial_us", C.c_double),
-                ("total_ms", C.c_double), ("workers_bound", C.c_int32), ("reserved", C.c_int32)]
+                ("total_ms", C.c_double), ("workers_bound", C.c_int32), ("helper_threads", C.c_int32)]
 
 
 class WorkerPlacement(C.Structure):
@@ -80,15 +97,16 @@ class Profile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("relaunches", C.c_uint64), ("offsets", C.c_uint64),
                 ("kernel_ms", C.c_double), ("last_kernel_ms", C.c_double), ("last_offsets", C.c_uint64),
                 ("candidates", C.c_uint64), ("tries", C.c_uint64), ("host_ms", C.c_double), ("wait_ms", C.c_double), ("big_offsets", C.c_uint64),
-                ("big_launches", C.c_uint64), ("big_ms", C.c_double)]
+                ("big_launches", C.c_uint64), ("big_ms", C.c_double),
+                ("host_threads_running", C.c_uint32), ("gang_launches", C.c_uint32), ("gang_batches", C.c_uint64)]
 
 
-# every symbol include/adsbdec_amd.h declares: (restype, argtypes)
+# every symbol include/adsbdec_amd.h and include/adsbdec_amd_diag.h declare: (restype, argtypes)
 SYMBOLS = {
     "adsb_abi_version": (C.c_int, []),
-    "adsb_config_default": (None, [C.POINTER(Config)]),
-    "adsb_config_init": (None, [C.POINTER(Config), C.c_size_t]),
-    "adsb_create": (C.c_void_p, [C.POINTER(Config)]),
+    "adsb_config_default": (None, [C.c_void_p]),          # (the symbol binaries of ABI <= 4 call: leaves a struct adsb_create refuses)
+    "adsb_config_init": (None, [C.c_void_p, C.c_size_t]),
+    "adsb_create": (C.c_void_p, [C.c_void_p]),
     "adsb_destroy": (None, [C.c_void_p]),
     "adsb_reset": (C.c_int, [C.c_void_p]),
     "adsb_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -107,7 +125,7 @@ SYMBOLS = {
     "adsb_take": (C.c_long, [C.c_void_p, C.POINTER(C.POINTER(Frame))]),
     "adsb_pending": (C.c_size_t, [C.c_void_p]),
     "adsb_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
-    "adsb_get_profile": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
+    "adsb_get_profile_sized": (C.c_int, [C.c_void_p, C.POINTER(Profile), C.c_size_t]),
     "adsb_last_error": (C.c_char_p, [C.c_void_p]),
     "adsb_format_frame": (C.c_int, [C.POINTER(Frame), C.c_int, C.c_char_p]),
     "adsb_resolver_create": (C.c_void_p, []),
@@ -160,7 +178,7 @@ SYMBOLS = {
                                        C.c_uint64, C.POINTER(Candidate), C.c_size_t,
                                        C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_size_t,
                                        C.POINTER(C.c_size_t)]),
-    "adsb_multi_create": (C.c_void_p, [C.POINTER(Config), C.c_int, C.POINTER(C.c_int)]),
+    "adsb_multi_create": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "adsb_multi_destroy": (None, [C.c_void_p]),
     "adsb_multi_devices": (C.c_int, [C.c_void_p]),
     "adsb_multi_decode_host": (C.c_long, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(Frame))]),
@@ -174,7 +192,7 @@ SYMBOLS = {
     "adsb_multi_stream_frames": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.POINTER(Frame))]),
     "adsb_multi_stream_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Stats)]),
     "adsb_multi_get_info": (C.c_int, [C.c_void_p, C.POINTER(MultiInfo)]),
-    "adsb_multi_worker_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Profile)]),
+    "adsb_multi_worker_profile_sized": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Profile), C.c_size_t]),
     "adsb_multi_last_error": (C.c_char_p, [C.c_void_p]),
     "adsb_scan_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t, C.c_uint64,
                                   C.c_uint64, C.POINTER(Candidate), C.c_size_t,
@@ -231,40 +249,49 @@ def format_frame(fr: dict, outformat: int) -> bytes:
     return buf.raw[:n]
 
 
+DEBUG_KNOBS = ("queue_cap", "cand_cap", "try_cap", "clist_cap", "no_streaming", "frames_cap", "reader_min_tiles", "shard_head",
+               "passes", "stagger", "gang_min")
+
+
 def make_config(df18: bool = False, device: int = -1, collect_stats: bool = False,
                 profile: bool = False, stage_samples: int = 0, stream: int | None = None,
-                debug_queue_cap: int = 0, all_candidates: bool = False, fix_1bit: bool = False,
-                debug_cand_cap: int = 0, debug_try_cap: int = 0, debug_clist_cap: int = 0, push_overlap: bool = False,
-                host_threads: int = 0, debug_no_streaming: bool = False, debug_frames_cap: int = 0,
-                debug_reader_min_tiles: int = 0, debug_shard_head: int = 0, debug_passes: int = 0, debug_stagger: int = 0,
-                wait_timeout_s: int = 0, debug_gang_min: int = 0):
-    """adsb_config from keywords (adsb_config_default + the members named)."""
-    cfg = Config()
-    load().adsb_config_init(C.byref(cfg), C.sizeof(cfg))
+                all_candidates: bool = False, fix_1bit: bool = False, push_overlap: bool = False,
+                host_threads: int = 0, wait_timeout_s: int = 0, **debug):
+    """adsb_config from keywords (adsb_config_default + the members named).  Keywords debug_<knob> (DEBUG_KNOBS) fill an
+    adsb_debug_config that the returned struct points at (and keeps alive: cfg._debug)."""
+    L = load()
+    unknown = [k for k in debug if not k.startswith("debug_") or k[6:] not in DEBUG_KNOBS]
+    if unknown:
+        raise TypeError(f"make_config: unknown keyword(s) {unknown}")
+    if L.adsb_abi_version() < 5:   # an A/B run against a build of rounds 4-5 (ADSB_LIB_PATH): its struct, its member names
+        cfg = ConfigV4()
+        L.adsb_config_init(C.byref(cfg), C.sizeof(cfg))
+        for k, v in debug.items():
+            if cfg.struct_size >= getattr(ConfigV4, k).offset + 4:
+                setattr(cfg, k, int(v))
+        if cfg.struct_size >= ConfigV4.wait_timeout_s.offset + 4:
+            cfg.wait_timeout_s = wait_timeout_s
+    else:
+        cfg = Config()
+        L.adsb_config_init(C.byref(cfg), C.sizeof(cfg))
+        cfg.wait_timeout_s = wait_timeout_s
+        if any(debug.values()):
+            dbg = DebugConfig()
+            dbg.struct_size = C.sizeof(dbg)
+            for k, v in debug.items():
+                setattr(dbg, k[6:], int(v))
+            cfg._debug = dbg                      # (the library copies it in adsb_create; until then it must live)
+            cfg.debug = C.addressof(dbg)
     cfg.df18 = int(df18)
     cfg.device = device
     cfg.collect_stats = int(collect_stats)
     cfg.profile = int(profile)
     cfg.stage_samples = stage_samples
     cfg.stream = stream
-    cfg.debug_queue_cap = debug_queue_cap
     cfg.all_candidates = int(all_candidates)
     cfg.fix_1bit = int(fix_1bit)
-    cfg.debug_cand_cap = debug_cand_cap
-    cfg.debug_try_cap = debug_try_cap
-    cfg.debug_clist_cap = debug_clist_cap
     cfg.push_overlap = int(push_overlap)
     cfg.host_threads = int(host_threads)
-    cfg.debug_no_streaming = int(debug_no_streaming)
-    cfg.debug_frames_cap = debug_frames_cap
-    cfg.debug_reader_min_tiles = debug_reader_min_tiles
-    cfg.debug_shard_head = debug_shard_head
-    cfg.debug_passes = debug_passes
-    cfg.debug_stagger = debug_stagger
-    if cfg.struct_size >= Config.wait_timeout_s.offset + 4:   # (an older library in an A/B run fills, and accepts, a shorter struct)
-        cfg.wait_timeout_s = wait_timeout_s
-    if cfg.struct_size >= Config.debug_gang_min.offset + 4:
-        cfg.debug_gang_min = debug_gang_min
     return cfg
 
 
@@ -372,7 +399,11 @@ class Decoder:
 
     def profile(self):
         p = Profile()
-        self._check(self._L.adsb_get_profile(self._h, C.byref(p)), "adsb_get_profile")
+        if hasattr(self._L, "adsb_get_profile_sized"):
+            self._check(self._L.adsb_get_profile_sized(self._h, C.byref(p), C.sizeof(p)), "adsb_get_profile")
+        else:   # (an A/B run against a build of rounds 4-5: its struct is a prefix of this one)
+            self._L.adsb_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
+            self._check(self._L.adsb_get_profile(self._h, C.byref(p)), "adsb_get_profile")
         return {k: getattr(p, k) for k, _ in Profile._fields_}
 
     def scan_shard(self, ptr: int, first_sample: int, n: int, g_begin: int, g_end: int,

@@ -45,7 +45,8 @@
 #include <pthread.h>
 #include <sched.h>
 
-#include "../../include/adsbdec_amd.h"
+#include "../../include/adsbdec_amd_diag.h"
+#include "config_abi.hpp"
 #include "handoff.hpp"
 #include "resolver.hpp"
 #include "scan_kernel.h"
@@ -133,6 +134,7 @@ struct ScanSink { // where collected records go: a caller's vectors, or (null) t
 
 struct adsb_decoder {
     adsb_config cfg{};
+    adsb_debug_config dbg{}; // the test knobs, copied at adsb_create (adsb_config.debug)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -178,8 +180,8 @@ struct adsb_decoder {
     int gang_l3 = -1;
     uint32_t reader_min_tiles = 1024; // launches below this many tiles are collected by the calling thread alone
     uint64_t last_launch_records = 0; // records the previous launch handed over (auto: the thread pays from kAutoReaderRecords on)
-    bool no_streaming = false; // cfg.debug_no_streaming: always collect after completion
-    uint64_t shard_head = 16384; // offsets of a resolved shard whose candidates are ALL kept for the stitcher (cfg.debug_shard_head)
+    bool no_streaming = false; // dbg.no_streaming: always collect after completion
+    uint64_t shard_head = 16384; // offsets of a resolved shard whose candidates are ALL kept for the stitcher (dbg.shard_head)
     int dbg_async = 0;         // tuning builds only (ADSB_DEBUG_ASYNC, tools/async_race.py): 1 = wait for every async copy,
                                // 2 = copies on the scan stream, 4 = tail copies not ordered before the next copy (the old race)
     // device-side visited-try count (scan_kernel.h TryCountArgs)
@@ -518,7 +520,7 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
         s.count_pending = false;
     }
     // debug_try_cap (tests of the relaunch path) wants every try on the launch-wide list
-    s.try_regions = s.tries_on_device && d->cfg.debug_try_cap <= 0;
+    s.try_regions = s.tries_on_device && d->dbg.try_cap <= 0;
     if (s.try_regions && slot_reserve_device_tries(d, s, s.d_try_cap, s.ntiles))
         return -1;
     s.args.tries = s.tries_on_device ? s.d_tries : s.tries;
@@ -673,7 +675,7 @@ size_t deliver_tiles(adsb_decoder *d, ScanSlot &s, uint32_t from, uint32_t upto)
         d->prof.candidates += nc;
         if (d->res.head_wanted(s.args.g_begin + adsb::kRun * adsb::tile_first_run(from, s.args.stagger, s.args.passes)))
             d->res.capture_head_tiles(s.hand, t_start, t_count, from, upto, s.args.g_begin);
-        d->res.advance_tiles(s.hand, t_start, t_count, from, upto, 0, s.args.g_begin, power_samples_produced(d->n_samples), g_complete);
+        d->res.advance_tiles(s.hand, t_start, t_count, from, upto, s.args.g_begin, power_samples_produced(d->n_samples), g_complete);
     }
     return nc;
 }
@@ -786,6 +788,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
                 if (d->res.speculate_tiles(s.hand, d->tile_start.data(), d->tile_count.data(), from, to, s.args.g_begin)) {
                     held[n_held][0] = from, held[n_held][1] = to;
                     n_held++;
+                    d->prof.gang_batches++;
                 } else { // (a batch too small to be worth it: in its turn, by this thread)
                     nc += deliver_held(0, false);
                     nc += deliver_tiles(d, s, from, to);
@@ -815,10 +818,13 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
         if (sched_getaffinity(0, sizeof allowed, &allowed) != 0 || CPU_COUNT(&allowed) >= 2 * (kAutoGangHelpers + 2))
             start_gang(d, kAutoGangHelpers);
     }
-    const bool with_gang = d->gang && !d->sink.cands && (uint64_t)s.args.hand_cap * adsb::kGranuleWords * 4 <= adsb::kDecMaxStreamBytes && (d->cfg.host_threads >= 3 || after_dense);
-    if (d->cfg.debug_gang_min > 0) {
-        d->res.set_gang(with_gang ? d->gang : nullptr, (size_t)d->cfg.debug_gang_min);
-        d->res.set_ahead_min_records((size_t)d->cfg.debug_gang_min);
+    // (a batch decided ahead packs an offset relative to the launch's first into 31 bits: chunk_offsets() keeps a launch below
+    // 2^30 offsets -- kMaxLaunchOffsets -- and this says so where it matters)
+    const bool with_gang = d->gang && !d->sink.cands && (uint64_t)s.args.hand_cap * adsb::kGranuleWords * 4 <= adsb::kDecMaxStreamBytes &&
+                           s.args.g_end - s.args.g_begin < (1ull << 31) && (d->cfg.host_threads >= 3 || after_dense);
+    if (d->dbg.gang_min > 0) {
+        d->res.set_gang(with_gang ? d->gang : nullptr, (size_t)d->dbg.gang_min);
+        d->res.set_ahead_min_records((size_t)d->dbg.gang_min);
     } else {
         d->res.set_gang(with_gang ? d->gang : nullptr);
     }
@@ -830,6 +836,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
                 d->gang_l3 = adsb::place_reader_thread(t, cpu);
         d->gang->begin();
         ahead = true;
+        d->prof.gang_launches++;
     }
     if (d->reader && s.ntiles >= d->reader_min_tiles && (d->cfg.host_threads >= 2 || after_dense)) {
         adsb::StreamReader &rd = *d->reader;
@@ -1276,8 +1283,8 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
         ScanSlot &s = d->slots[(d->slot_head + d->slot_count) % kSlots];
         const bool host_tries = stats && d->sink.cands; // per-shard scans return the try list
         // test knobs: start from buffers that are too small, so that the relaunch path runs
-        const size_t cand_want = d->cfg.debug_cand_cap > 0 ? (size_t)d->cfg.debug_cand_cap : (size_t)(n_off / 128 + 32768);
-        const size_t try_want = d->cfg.debug_try_cap > 0 ? (size_t)d->cfg.debug_try_cap : (size_t)(n_off / 32 + 65536);
+        const size_t cand_want = d->dbg.cand_cap > 0 ? (size_t)d->dbg.cand_cap : (size_t)(n_off / 128 + 32768);
+        const size_t try_want = d->dbg.try_cap > 0 ? (size_t)d->dbg.try_cap : (size_t)(n_off / 32 + 65536);
         if (slot_reserve(d, s, std::max<size_t>(s.cand_cap, cand_want),
                          host_tries ? std::max<size_t>(s.try_cap, try_want) : s.try_cap))
             return -1;
@@ -1292,15 +1299,15 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
         a.g_begin = g_begin;
         a.g_end = g_stop;
         a.df18 = d->cfg.df18 ? 1 : 0;
-        a.passes = (d->cfg.debug_passes >= 2 && d->cfg.debug_passes <= adsb::kMaxPasses) ? d->cfg.debug_passes
+        a.passes = (d->dbg.passes >= 2 && d->dbg.passes <= adsb::kMaxPasses) ? d->dbg.passes
                                                                                          : adsb::choose_passes(n_off, d->n_cus);
-        a.stagger = adsb::checked_stagger(n_off, a.passes, d->cfg.debug_stagger);
+        a.stagger = adsb::checked_stagger(n_off, a.passes, d->dbg.stagger);
         a.synd = d->d_synd;
-        a.queue_cap = (d->cfg.debug_queue_cap >= 256 && d->cfg.debug_queue_cap <= adsb::kQueueCap)
-                          ? d->cfg.debug_queue_cap
+        a.queue_cap = (d->dbg.queue_cap >= 256 && d->dbg.queue_cap <= adsb::kQueueCap)
+                          ? d->dbg.queue_cap
                           : adsb::kQueueCap;
         a.all_candidates = d->cfg.all_candidates ? 1 : 0;
-        a.clist_cap = (d->cfg.debug_clist_cap >= 1 && d->cfg.debug_clist_cap <= adsb::kClistCap) ? d->cfg.debug_clist_cap
+        a.clist_cap = (d->dbg.clist_cap >= 1 && d->dbg.clist_cap <= adsb::kClistCap) ? d->dbg.clist_cap
                                                                                                   : adsb::kClistCap;
         a.fix_tab = d->cfg.fix_1bit ? d->d_fix : nullptr;
         a.fix_mul = d->fix_mul;
@@ -1462,17 +1469,10 @@ extern "C" {
 adsb_decoder *adsb_create(const adsb_config *cfg_in)
 {
     adsb_config cfg;
-    adsb_config_default(&cfg);
-    if (cfg_in) {
-        if (cfg_in->struct_size == 0 || cfg_in->struct_size > sizeof cfg) {
-            g_create_error = "adsb_config.struct_size is not one this library knows";
-            return nullptr;
-        }
-        std::memcpy(&cfg, cfg_in, cfg_in->struct_size);
-        // ABI 2 called this member `reserved0` and did not ask for it to be zero: it only means push_overlap for
-        // callers whose struct already has the member behind it
-        if (cfg_in->struct_size < offsetof(adsb_config, host_threads) + sizeof(int32_t))
-            cfg.push_overlap = 0;
+    adsb_debug_config dbg;
+    if (const char *why = adsb::accept_config(cfg_in, cfg, dbg)) {
+        g_create_error = why;
+        return nullptr;
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1505,6 +1505,7 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         return nullptr;
     }
     d->cfg = cfg;
+    d->dbg = dbg;
     d->device = dev;
     d->stage_cap = cfg.stage_samples ? round_down(cfg.stage_samples + 7, 8) : kDefaultStageSamples;
     if (d->stage_cap < (1u << 16))
@@ -1572,8 +1573,8 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipMalloc(try counters)", e);
         d->d_carry_n = reinterpret_cast<uint32_t *>(d->d_try_acc + 4);
         d->frames_cap = 1u << 16; // accepted frames between two count passes (a 128 Mi-offset launch at 1 k frames/s: 13 k)
-        if (cfg.debug_frames_cap > 0) // tests: start small, so that the regrow path runs
-            d->frames_cap = std::max<size_t>(8, (size_t)cfg.debug_frames_cap);
+        if (dbg.frames_cap > 0) // tests: start small, so that the regrow path runs
+            d->frames_cap = std::max<size_t>(8, (size_t)dbg.frames_cap);
         for (int i = 0; i < adsb_decoder::kFrameBufs; i++)
             if ((e = hipHostMalloc(&d->h_frames[i], d->frames_cap * sizeof(adsb::TryFrame), hipHostMallocDefault)) != hipSuccess ||
                 (e = hipEventCreate(&d->ev_frames[i])) != hipSuccess)
@@ -1592,16 +1593,16 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
     }
     d->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     {
-        if (cfg.debug_reader_min_tiles > 0)
-            d->reader_min_tiles = (uint32_t)cfg.debug_reader_min_tiles;
+        if (dbg.reader_min_tiles > 0)
+            d->reader_min_tiles = (uint32_t)dbg.reader_min_tiles;
         if (d->cfg.host_threads >= 2)
             start_reader(d);
         if (d->cfg.host_threads >= 3)
             start_gang(d, std::min(d->cfg.host_threads - 2, 15));
     }
-    d->no_streaming = cfg.debug_no_streaming != 0;
-    if (cfg.debug_shard_head > 0)
-        d->shard_head = (uint64_t)cfg.debug_shard_head;
+    d->no_streaming = dbg.no_streaming != 0;
+    if (dbg.shard_head > 0)
+        d->shard_head = (uint64_t)dbg.shard_head;
     d->dbg_async = tuning_env("ADSB_DEBUG_ASYNC") ? atoi(tuning_env("ADSB_DEBUG_ASYNC")) : 0;
     d->res.reset();
     return d;
@@ -2070,16 +2071,20 @@ int adsb_get_stats(const adsb_decoder *d, adsb_stats *out)
     return 0;
 }
 
-int adsb_get_profile(const adsb_decoder *d, adsb_profile *out)
+int adsb_get_profile_sized(const adsb_decoder *d, adsb_profile *out, size_t size)
 {
-    if (!d || !out)
+    if (!d || !out || size < offsetof(adsb_profile, offsets))
         return -1;
     adsb_decoder *m = const_cast<adsb_decoder *>(d); // kernel times are read from their events on demand
     for (auto &sl : m->slots)
         for (int pair = 0; pair < 2; pair++)
             if (slot_settle_profile(m, sl, pair))
                 return -1;
-    *out = d->prof;
+    adsb_profile p = d->prof;
+    // the threads of the handle's own that exist at this moment (they are started by the first launch behind a dense one,
+    // or by adsb_create when cfg.host_threads asks for them, and live until adsb_destroy): none under ordinary traffic
+    p.host_threads_running = (d->reader ? 1u : 0u) + (d->gang ? (uint32_t)d->gang->helpers() : 0u);
+    std::memcpy(out, &p, std::min(size, sizeof p));
     return 0;
 }
 

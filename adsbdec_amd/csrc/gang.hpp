@@ -26,7 +26,7 @@
 #include <pthread.h>
 #include <sched.h>
 
-#include "../../include/adsbdec_amd.h"
+#include "../../include/adsbdec_amd_diag.h"
 
 namespace adsb {
 

@@ -8,7 +8,7 @@
 #include <new>
 #include <vector>
 
-#include "../../include/adsbdec_amd.h"
+#include "../../include/adsbdec_amd_diag.h"
 #include "handoff.hpp"
 #include "resolver.hpp"
 #include "stitch.hpp"
@@ -30,12 +30,20 @@ void adsb_config_init(adsb_config *cfg, size_t struct_size)
         struct_size = sizeof *cfg;
     std::memset(cfg, 0, struct_size);
     cfg->struct_size = (uint32_t)struct_size;
+    cfg->abi = ADSB_ABI_VERSION;
     cfg->device = -1;
 }
 
-// The symbol binaries built against ABI <= 3 call: their adsb_config ended behind host_threads (72 bytes); writing this
-// library's longer struct into it would run over the caller's stack (found in round 4 by a stale test binary).
-void (adsb_config_default)(adsb_config *cfg) { adsb_config_init(cfg, offsetof(adsb_config, host_threads) + 2 * sizeof(int32_t)); }
+// The symbol binaries built against ABI <= 4 call (their header had no macro of this name, or one that passed another size).
+// Their adsb_config has another layout: what this leaves behind -- 72 zero bytes, the smallest struct there ever was -- carries
+// no `abi`, so adsb_create / adsb_multi_create refuse it by name instead of misreading it.
+void (adsb_config_default)(adsb_config *cfg) // (the parentheses keep the header's macro of the same name out of the way)
+{
+    if (cfg) {
+        std::memset(cfg, 0, 72);
+        cfg->struct_size = 72;
+    }
+}
 
 int adsb_stitch_shards(const adsb_shard_part *parts, int n_parts, uint64_t total_samples, adsb_shard_fix *fix,
                        adsb_frame *new_frames, size_t new_cap, size_t *n_new_total)
@@ -280,7 +288,7 @@ long adsb_resolver_advance_stream(adsb_resolver *r, const void *stream, size_t g
         try {
             if (with_head)
                 r->r.capture_head_tiles(job.hand, ts.data(), tc.data(), 0, n_tiles, g_base);
-            r->r.advance_tiles(job.hand, ts.data(), tc.data(), 0, n_tiles, 0, g_base, power_samples, g_complete);
+            r->r.advance_tiles(job.hand, ts.data(), tc.data(), 0, n_tiles, g_base, power_samples, g_complete);
         } catch (const std::exception &) {
             rc = -1;
         }

@@ -39,7 +39,8 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/adsbdec_amd.h"
+#include "../../include/adsbdec_amd_diag.h"
+#include "config_abi.hpp"
 
 namespace {
 
@@ -111,6 +112,7 @@ struct Job {
 struct Worker {
     int index = 0, device = 0;
     adsb_config cfg{};
+    adsb_debug_config dbg{}; // (the driver's copy of the caller's test knobs: cfg.debug points here while the handle is created)
     std::thread th;
     adsb_decoder *dec = nullptr;
     std::mutex mu;
@@ -171,6 +173,7 @@ inline double worker_limit_s(const adsb_config &cfg)
 
 struct adsb_multi {
     adsb_config cfg{};
+    adsb_debug_config dbg{};
     std::vector<std::unique_ptr<Worker>> w;
     std::string err;
     std::vector<adsb_frame> out, new_frames;
@@ -425,7 +428,7 @@ void run_shard(Worker &w, const Job &j, uint64_t piece)
     // (the two windows are scanned outside the shard's stream: before it starts, and after it has ended -- a stateless
     // scan does not touch the resolver, so the frames adsb_shard_end handed out stay where they are)
     if (j.stats) {
-        const uint64_t head_span = w.cfg.debug_shard_head > 0 ? (uint64_t)w.cfg.debug_shard_head : 16384;
+        const uint64_t head_span = w.dbg.shard_head > 0 ? (uint64_t)w.dbg.shard_head : 16384;
         w.head_tries_end = std::min(j.g_end, j.g_begin + head_span + kHeadTryReach);
         if (window_tries(w, j, j.g_begin, w.head_tries_end, w.head_tries))
             return;
@@ -563,6 +566,7 @@ void worker_main(Worker *w, uint64_t piece)
         adsb_config cfg = w->cfg;
         cfg.device = w->device;
         cfg.stream = nullptr;
+        cfg.debug = &w->dbg;
         w->bound = bind_near_device(w->device); // first: the handle's page-locked buffers are then allocated from this thread's node
         w->device_node = adsb_device_numa_node(w->device);
         w->dec = adsb_create(&cfg);
@@ -913,15 +917,10 @@ adsb_multi *adsb_multi_create(const adsb_config *cfg_in, int n_devices, const in
         g_multi_create_error = "out of memory";
         return nullptr;
     }
-    adsb_config_default(&m->cfg);
-    if (cfg_in) {
-        if (cfg_in->struct_size == 0 || cfg_in->struct_size > sizeof m->cfg) {
-            g_multi_create_error = "adsb_config.struct_size is not one this library knows";
-            delete m;
-            return nullptr;
-        }
-        std::memcpy(&m->cfg, cfg_in, cfg_in->struct_size);
-        m->cfg.struct_size = sizeof m->cfg;
+    if (const char *why = adsb::accept_config(cfg_in, m->cfg, m->dbg)) {
+        g_multi_create_error = why;
+        delete m;
+        return nullptr;
     }
     if (m->cfg.stage_samples) // a piece must fit the staging buffer beside the tail it keeps
         m->piece_samples = std::max<uint64_t>(1u << 15, std::min<uint64_t>(kPieceSamples, m->cfg.stage_samples / 2));
@@ -931,6 +930,7 @@ adsb_multi *adsb_multi_create(const adsb_config *cfg_in, int n_devices, const in
             w->index = i;
             w->device = devices ? devices[i] : i;
             w->cfg = m->cfg;
+            w->dbg = m->dbg;
             w->piece = m->piece_samples;
             m->w.push_back(std::move(w));
         }
@@ -1199,11 +1199,11 @@ int adsb_multi_get_stats(const adsb_multi *m, adsb_stats *out)
     return 0;
 }
 
-int adsb_multi_worker_profile(const adsb_multi *m, int worker, adsb_profile *out)
+int adsb_multi_worker_profile_sized(const adsb_multi *m, int worker, adsb_profile *out, size_t size)
 {
     if (!m || !out || worker < 0 || (size_t)worker >= m->w.size() || !m->w[worker]->dec)
         return -1;
-    return adsb_get_profile(m->w[worker]->dec, out); // (no job is running: the decode calls return behind their workers)
+    return adsb_get_profile_sized(m->w[worker]->dec, out, size); // (no job is running: the decode calls return behind their workers)
 }
 
 int adsb_multi_get_info(const adsb_multi *m, adsb_multi_info *out)
@@ -1212,6 +1212,15 @@ int adsb_multi_get_info(const adsb_multi *m, adsb_multi_info *out)
         return -1;
     *out = m->info;
     out->create_ms = m->create_ms;
+    // the reader / gang threads the workers' handles own at this moment (a handle starts them behind its first dense launch and
+    // keeps them until adsb_multi_destroy; they sleep while nothing is in flight)
+    out->helper_threads = 0;
+    if (!m->broken)
+        for (const auto &w : m->w) {
+            adsb_profile p;
+            if (w->dec && adsb_get_profile_sized(w->dec, &p, sizeof p) == 0)
+                out->helper_threads += (int32_t)p.host_threads_running;
+        }
     return 0;
 }
 

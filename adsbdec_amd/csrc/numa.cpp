@@ -25,7 +25,7 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 
-#include "../../include/adsbdec_amd.h"
+#include "../../include/adsbdec_amd_diag.h"
 
 namespace {
 

@@ -29,7 +29,7 @@
 #include <utility>
 #include <vector>
 
-#include "../../include/adsbdec_amd.h"
+#include "../../include/adsbdec_amd_diag.h"
 #include "scan_kernel_format.h"
 #include "gang.hpp"
 
@@ -192,14 +192,15 @@ public:
 
     // The same for tiles [t0, t1) of a hand-off stream (scan_kernel.h): tile u's records
     // are the counts[u] consecutive 8-dword records from granule starts[u] on, each
-    // {g_rel, pw, frame | len << 16 | flags << 24} from dword `off`, ascending inside a
+    // {g_rel, pw, frame | len << 16 | flags << 24}, ascending inside a
     // tile and from tile to tile.
     void advance_tiles(const uint32_t *stream, const uint32_t *starts, const uint32_t *counts, uint32_t t0, uint32_t t1,
-                       int off, uint64_t g_base, uint64_t power_samples, uint64_t g_complete)
+                       uint64_t g_base, uint64_t power_samples, uint64_t g_complete)
     {
         compact();
         batch_ = Batch{};
-        batch_.recs = stream + off;
+        batch_.recs = stream; // (until round 6 a dword offset `off` could be added here; every caller passed 0, and a batch
+                              // decided ahead -- speculate_tiles -- never knew about it: the parameter is gone)
         batch_.starts = starts;
         batch_.counts = counts;
         batch_.u_end = t1;

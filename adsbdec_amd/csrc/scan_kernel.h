@@ -26,7 +26,7 @@ constexpr int kClistCap = 256;  // CRC-valid candidates staged per tile for the 
                                 // offsets full of 112-bit frames packed back to back decodes at ~130-190 offsets: BASELINE configs[2])
 constexpr int ADSB_DECOFFSET_K = 1200; // longest span an accepted frame jumps (adsbdec.h:3)
 constexpr int kCandWords = 6;   // {g_rel, pw, frame[0..13] | len<<16 in the last word}
-constexpr int kSyndWords = 14 * 256;
+constexpr int kSyndWords = 14 * 256 + 28 * 8; // the CRC-24 syndrome table, and behind it the slicer's column masks (slicer_bits.h: kColMaskWords)
 constexpr int kFixSlots = 512;
 constexpr int kCounterWords = 8; // the launch counters as the host sees them (ScanArgs::report)
 // On the device every counter has a 128-byte line of its own (ScanArgs::counters[i * kCounterPad]; the two
@@ -101,7 +101,7 @@ struct ScanArgs {
     uint32_t gen;
     const uint32_t *fix_tab; // EXTENSION (not in the reference): 512-entry perfect hash syndrome -> bit, or null
     uint32_t fix_mul;
-    const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
+    const uint32_t *synd; // [14][256] CRC-24 syndrome table + [28][8] column masks behind it (make_syndrome_table: kSyndWords)
     // Device counters, zero at launch: [0] loose candidates, [1] tries (may exceed the
     // capacities), [2] hand-off granules, [3] unused; with `profile` [4..5] max over tiles of
     // ~(start) and [6..7] max of end on the device's 100 MHz clock (64-bit).  launch_scan
@@ -113,15 +113,15 @@ struct ScanArgs {
     uint32_t *cands;     // kCandWords dwords per record
     uint32_t cand_cap;
     // Tries (statistics runs): words (g_rel << 2) | code.  With try_counts (device-resident counting of a
-    // stream): tile t's whole-tile round writes try_counts[t] words into tries[t * kTryRegion ..], and only
-    // queue-overflow rounds append to the launch-wide list tries[try_list_first ..] (try_cap words, counted in
+    // stream): tile t's rounds write try_counts[t] words into tries[t * kTryRegion ..], and only what does not fit
+    // the region is appended to the launch-wide list tries[try_list_first ..] (try_cap words, counted in
     // counters[1]).  Without (try_counts == null, try_list_first == 0): everything goes to the list.
     uint32_t *tries;
     uint32_t try_cap;
     uint32_t *try_counts;
     uint32_t try_list_first;
 };
-constexpr int kTryRegion = kQueueCap; // a whole-tile round queues at most queue_cap <= kQueueCap survivors
+constexpr int kTryRegion = 4 * kQueueCap; // try words per tile region: 8.5 % of a K = 7 tile's offsets (the adversarial capture has 7.6 %)
 
 // Second, tiny kernel of statistics runs (valid.c:46,68 count a Try only for VISITED
 // offsets): the try words of a launch stay on the device; once the host has
@@ -158,7 +158,7 @@ struct TryCountArgs {
 };
 hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream);
 
-// Host: fill the 14 x 256 syndrome table (crc.h generator 0xFFF409).
+// Host: fill the 14 x 256 syndrome table (crc.h generator 0xFFF409) and the slicer's 28 x 8 column masks behind it.
 void make_syndrome_table(uint32_t *out /* kSyndWords */);
 // Host: perfect hash of the single-bit syndromes of bits 5..111 of a long frame:
 // tab[(syn * mul) >> 23] = (syn << 8) | bit. Returns the multiplier.

@@ -66,6 +66,7 @@
 #include <type_traits>
 
 #include "scan_kernel.h"
+#include "slicer_bits.h"
 #include "scan_stamps.h" // ADSB_STAMP / ADSB_COUNT: nothing in the shipped build (a measurement build's per-phase tile clocks)
 
 namespace adsb {
@@ -480,6 +481,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     constexpr int NT = kThreads;
     constexpr int kFallbackChunks = 256 / NT; // a fallback round takes one bit position of 256 runs: <= 256 entries
     const uint32_t *__restrict__ xin = args.x;
+    const uint32_t *__restrict__ colmask = args.synd + 14 * 256; // (the slicer's column masks lie behind the syndrome table: kSyndWords)
     const int64_t pbuf0 = args.pbuf0, p_lo = args.p_lo, p_hi = args.p_hi;
     const int own = kPassRuns * K - kReachRuns;
     uint32_t *tile_n = qcount + 4;    // records this tile keeps (ranked into its hand-off range)
@@ -538,7 +540,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     // staged in the same list, which the filter behind the loop sees whole.
     constexpr int kGateBatch = 4; // chunks whose gate words are computed together
     int ch_lo = 0, ch_hi = nchunks, grp = -1, width = nchunks;
-    bool first = true;
+    uint32_t try_fill = 0; // (kStats) try words in the tile's region so far: workgroup-uniform
     const bool stage_cands = !args.all_candidates;
     for (;;) {
         if (tid == 0) {
@@ -620,21 +622,21 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
         ADSB_COUNT(8, 1);
         ADSB_COUNT(9, over ? 0 : qtotal);
         const int qn = over ? 0 : qtotal;
-        // valid.c:46,68: every DF-gate pass that is visited is a Try -- the queue entries ARE the tries.  A
-        // whole-tile round puts them into the tile's own region of args.tries (kTryRegion words; the count goes
-        // to args.try_counts[tile]): no launch-wide reservation -- one more device-scope atomic per tile, awaited
-        // by the wave that issued it at its next load, cost 22 % of the kernel (0.174 against 0.142 ms).  The rounds
-        // behind a queue overflow, and launches without regions (per-shard scans hand a dense list to the host),
-        // reserve a range of the launch-wide list behind the regions; that round trip runs under the slicer.
-        const bool try_region = kStats && args.try_counts && first; // workgroup-uniform
+        // valid.c:46,68: every DF-gate pass that is visited is a Try -- the queue entries ARE the tries.  The tile puts them
+        // into its OWN region of args.tries (kTryRegion words, filled round by round; the count goes to args.try_counts[tile]
+        // behind the rounds): no launch-wide reservation -- one more device-scope atomic per tile, awaited by the wave that
+        // issued it at its next load, cost 22 % of the kernel (0.174 against 0.142 ms).  Only what does not fit the region
+        // (a tile with more than 4 096 DF-gate passes: beyond 8 % of its offsets) and launches without regions (per-shard scans
+        // hand a dense list to the host) reserve a range of the launch-wide list behind the regions; that round trip runs
+        // under the slicer.  (Until round 6 a region held the whole-tile round only and every round behind a queue overflow
+        // went through the list: on the adversarial capture 10 M words per launch, which the count pass then looked up one
+        // binary search at a time -- 0.48 ms beside a 0.31 ms scan.)
+        const bool try_region = kStats && args.try_counts && try_fill + (uint32_t)qn <= (uint32_t)kTryRegion; // workgroup-uniform
         uint32_t try_res = 0;
-        if (kStats && tid == 0) {
-            if (over && args.hand)
+        if (kStats && tid == 0 && qn && !try_region) {
+            if (args.hand)
                 atomicOr(tile_over, 2u); // the launch-wide try list is in use: the count pass needs the launch's counters (kMarkTries)
-            if (try_region)
-                args.try_counts[tile] = (uint32_t)qn; // 0 when the queue overflowed: the rounds that follow list them
-            else if (qn)
-                try_res = atomicAdd(&args.counters[1 * kCounterPad], (uint32_t)qn);
+            try_res = atomicAdd(&args.counters[1 * kCounterPad], (uint32_t)qn);
         }
 #pragma unroll 1
         for (int q = tid; q < qn; q += NT) {
@@ -642,28 +644,21 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             const int sv = (int)(ent >> 7), sj = (int)((ent >> 2) & 31u);
             const uint32_t code = ent & 3u;
             const uint32_t g_rel = (uint32_t)(t0 - (int64_t)args.g_begin) + (uint32_t)(kRun * sv + sj);
-            // Frame bit k = 14 b + c lies 80 + 10 k samples after g: column c is
-            // at stream position sj + 80 + 10 c (+ 140 b = 5 words per b).
-            const uint32_t *dcol = pl_d + sv;
+            // Frame bit k = 14 b + c lies 80 + 10 k samples after g: the 14 column bytes come out of the D plane as word-wide
+            // logic (slicer_bits.h: masks, nibble merges, one funnel shift -- ~150 instructions and 41 LDS reads per entry
+            // where picking the 112 bits one by one took ~310 and 112; the same function runs on the CPU in
+            // tests/cpp/slicer_bits.cpp against the definition).
+            uint32_t cw[4];
+            gather_columns(pl_d + sv, sj, colmask, cw);
+            // short frames are bits 0..55 = rows b < 4; their syndromes are the long frame's 56 bits (4 rows) further
+            // on: the low nibble of every column byte, in the high nibble's place
             uint32_t syn = 0;
-            uint32_t cw[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int cc = 0; cc < 14; cc++) {
-                const int pos = sj + 80 + 10 * cc;
-                const int wi = (pos * 2341) >> 16; // pos / 28 for pos < 5000
-                const int bp = pos - 28 * wi;
-                // bit b of the column = bit bp of word wi + 5b: move it to the sign
-                // position and shift it in (2 operations per bit), highest row first
-                uint32_t col = 0;
-                const int up = 31 - bp;
+            for (int j = 0; j < 4; j++) {
+                const uint32_t iw = (code == 0) ? ((cw[j] & 0x0F0F0F0Fu) << 4) : cw[j];
 #pragma unroll
-                for (int b = 7; b >= 0; b--)
-                    col = push_sign(col, dcol[wi + 5 * b] << up);
-                // short frames are bits 0..55 = rows b < 4; their syndromes are the
-                // long frame's 56 bits (4 rows) further on
-                const uint32_t idx = (code == 0) ? ((col & 15u) << 4) : col;
-                syn ^= args.synd[cc * 256 + idx];
-                cw[cc >> 2] |= col << (8 * (cc & 3));
+                for (int k = 0; k < 4 && 4 * j + k < 14; k++)
+                    syn ^= args.synd[(4 * j + k) * 256 + ((iw >> (8 * k)) & 0xFFu)];
             }
             uint32_t fixed = 0;
             if (syn != 0) {
@@ -713,17 +708,18 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                 __syncthreads(); // (the slicer only reads the queue)
                 tb = *try_base;
             }
-            uint32_t *dst = args.tries + (try_region ? (size_t)tile * kTryRegion : (size_t)args.try_list_first + tb);
-            const uint32_t room = try_region ? (uint32_t)kTryRegion : (tb < args.try_cap ? args.try_cap - tb : 0u);
+            uint32_t *dst = args.tries + (try_region ? (size_t)tile * kTryRegion + try_fill : (size_t)args.try_list_first + tb);
+            const uint32_t room = try_region ? (uint32_t)qn : (tb < args.try_cap ? args.try_cap - tb : 0u);
             for (int q = tid; q < qn; q += NT) { // adjacent lanes, adjacent words
                 const uint32_t ent = queue[q];
                 if ((uint32_t)q < room)
                     dst[q] = ((tile_rel + (uint32_t)kRun * (ent >> 7) + ((ent >> 2) & 31u)) << 2) | (ent & 3u);
             }
+            if (try_region)
+                try_fill += (uint32_t)qn;
         }
         ADSB_STAMP(3); // slicer + CRC (+ try words)
         // next round (all of this is workgroup-uniform)
-        first = false;
         if (grp >= 0) {
             if (++grp == kRun) { // chunk ch_lo is done bit by bit: on with the rest
                 grp = -1;
@@ -748,6 +744,8 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             break;
         __syncthreads(); // queue is rewritten
     }
+    if (kStats && args.try_counts && tid == 0)
+        args.try_counts[tile] = try_fill;
 
     if (stage_cands) {
         // Drop candidates the greedy scan (demod.c:89,128,134,141) can never visit.
@@ -1196,26 +1194,48 @@ __global__ __launch_bounds__(kCountThreads) void count_tries_kernel(const TryCou
             const uint32_t w = (uint32_t)__popcll(__ballot(have));
             const bool fits = w < 64u || lo + 64u >= a.n_frames || a.frames[lo + 64u].g >= t1; // wave-uniform
             const uint32_t *reg = a.regions + (size_t)tile * kTryRegion;
-            for (uint32_t i = lane; i < n; i += 64u) {
-                const uint32_t word = reg[i], code = word & 3u;
-                const uint64_t g = a.g_base + (word >> 2);
-                if (g >= a.hi) {
-                    carry(g, code);
-                    continue;
+            // Four tries per lane and round: the four loads are in flight together (a region of the adversarial capture holds
+            // 3 600 words: one load per round and lane was 57 dependent round trips per tile), and a broadcast of the window
+            // serves four comparisons.
+            for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
+                uint32_t word[4];
+                bool live[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + 64u * (uint32_t)u + lane;
+                    live[u] = i < n;
+                    word[u] = live[u] ? reg[i] : 0u;
                 }
-                bool shadowed;
+                uint64_t g[4];
+                uint32_t rt[4];
+                bool shadowed[4] = {false, false, false, false};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    g[u] = a.g_base + (word[u] >> 2);
+                    rt[u] = (uint32_t)(g[u] - key); // (only looked at for tries below a.hi: those lie inside the tile)
+                    if (live[u] && g[u] >= a.hi) {
+                        carry(g[u], word[u] & 3u);
+                        live[u] = false;
+                    }
+                }
                 if (fits) {
-                    const uint32_t rt = (uint32_t)(g - key);
-                    shadowed = false;
-                    for (uint32_t j = 0; j < w; j++) { // (w is wave-uniform; lanes that left the loop above just idle)
+                    for (uint32_t j = 0; j < w; j++) { // (w is wave-uniform)
                         const uint32_t fj = __builtin_amdgcn_readlane(fr, j), ej = __builtin_amdgcn_readlane(fe, j);
-                        shadowed |= fj < rt && rt < ej;
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            shadowed[u] |= fj < rt[u] && rt[u] < ej;
                     }
                 } else {
-                    shadowed = try_shadowed(a, g);
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        shadowed[u] = live[u] && try_shadowed(a, g[u]);
                 }
-                if (!shadowed)
-                    cnt[code < 3 ? code : 2]++;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (live[u] && !shadowed[u]) {
+                        const uint32_t code = word[u] & 3u;
+                        cnt[code < 3 ? code : 2]++;
+                    }
             }
         }
       }
@@ -1268,7 +1288,11 @@ hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream)
     // the carry count lives on the device: a fixed number of blocks, grid-stride over whatever there is
     const uint32_t region_blocks = args.regions ? (args.n_tiles + 3u) / 4u : 0u;
     const uint32_t guess = args.n_tries + 65536u;
-    const unsigned list_blocks = (unsigned)std::min<uint32_t>((guess + kCountThreads - 1u) / kCountThreads, args.regions ? 64u : 2048u);
+    // (beside the tile regions the list is what did not fit them -- rare, short -- and the carry: 64 blocks, so that the pass stays
+    // small beside the next scan; a LONG list -- a launch forced onto it, tiles beyond 4 096 passes -- is a latency-bound chain
+    // of look-ups per thread and needs the threads: one block per 2 048 words, up to 1 024)
+    const uint32_t cap = args.regions ? std::min<uint32_t>(1024u, std::max<uint32_t>(64u, args.n_tries / 2048u)) : 2048u;
+    const unsigned list_blocks = (unsigned)std::min<uint32_t>((guess + kCountThreads - 1u) / kCountThreads, cap);
     const uint32_t region_grid = std::min<uint32_t>(region_blocks, (uint32_t)kCountRegionGrid);
     hipLaunchKernelGGL(count_tries_kernel, dim3(region_grid + list_blocks), dim3(kCountThreads), 0, stream, args);
     return hipGetLastError();
@@ -1276,6 +1300,7 @@ hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream)
 
 void make_syndrome_table(uint32_t *out)
 {
+    make_colmask_table(out + 14 * 256); // (the slicer's second table rides behind the first: one buffer, one kernel argument)
     // S[k] = x^(111-k) mod G, G = x^24 + 0xFFF409 (crc.h): the residual of
     // valid.c:49-51,71-73 is the XOR of S[k] over the set frame bits k.
     uint32_t s[112];

@@ -29,7 +29,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../include/adsbdec_amd.h"
+#include "../../include/adsbdec_amd_diag.h"
 
 namespace adsb {
 

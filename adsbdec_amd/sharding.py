@@ -119,7 +119,7 @@ class MultiDecoder:
 
     def worker_profile(self, worker: int):
         p = capi.Profile()
-        if self._L.adsb_multi_worker_profile(self._h, worker, C.byref(p)) != 0:
+        if self._L.adsb_multi_worker_profile_sized(self._h, worker, C.byref(p), C.sizeof(p)) != 0:
             raise self._err("adsb_multi_worker_profile")
         return {k: getattr(p, k) for k, _ in capi.Profile._fields_}
 

@@ -124,7 +124,7 @@ def profile_tag(args) -> str:
     return "_dense" if args.dense else "_dense10" if args.dense10 else "_storm" if args.gate_storm else ""
 
 
-def roofline_objects(p0, p1, steps, profiles_tag="", clock=None, step_ms=None):
+def roofline_objects(p0, p1, steps, profiles_tag="", clock=None, step_ms=None, rounds=PROFILE_ROUNDS):
     """HBM roofline of the dominant launch + the VALU-issue roofline that actually binds it."""
     kernel_ms = p1["kernel_ms"] - p0["kernel_ms"]
     big_off = p1["big_offsets"]
@@ -135,7 +135,7 @@ def roofline_objects(p0, p1, steps, profiles_tag="", clock=None, step_ms=None):
     avg_ms = ms_big / n_big if n_big else 0.0
     achieved = 4.0 * big_off / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, traffic_source, valu = None, None, None
-    for name in tuple(f"{r}{profiles_tag}_pmc.json" for r in PROFILE_ROUNDS):
+    for name in tuple(f"{r}{profiles_tag}_pmc.json" for r in rounds):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue

@@ -237,7 +237,7 @@ static int run(int rounds, StreamReader &reader)
                 tiles_checked++;
             }
             // ... and through the resolver, in place, as the decoder does
-            res.advance_tiles(hand, t_start.data(), t_count.data(), delivered, upto, 0, 0, (uint64_t)L.ntiles * kTileOffsets + 100000,
+            res.advance_tiles(hand, t_start.data(), t_count.data(), delivered, upto, 0, (uint64_t)L.ntiles * kTileOffsets + 100000,
                               (uint64_t)upto * kTileOffsets);
             delivered = upto;
         };

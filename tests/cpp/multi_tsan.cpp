@@ -156,9 +156,9 @@ int adsb_device_cpulist(int, char *out, size_t cap)
         out[0] = 0;
     return 0;
 }
-int adsb_get_profile(const adsb_decoder *, adsb_profile *out)
+int adsb_get_profile_sized(const adsb_decoder *, adsb_profile *out, size_t size)
 {
-    std::memset(out, 0, sizeof *out);
+    std::memset(out, 0, std::min(size, sizeof *out));
     return 0;
 }
 

@@ -42,8 +42,38 @@ int main(int argc, char **argv)
         printf("no threads\n");
         return 2;
     }
+    // stop() + start() with more tasks than the ring has slots on either side (round 5's advisor finding: start() used to
+    // reset the slots and not the counters, and the first post() behind a restart past 256 tasks never returned)
+    {
+        std::atomic<uint64_t> ran{0};
+        adsb::FormatGang::Task t;
+        t.fn = [](const adsb::FormatGang::Task &tk, adsb::FormatGang::Counts &) { static_cast<std::atomic<uint64_t> *>(tk.ctx)->fetch_add(1); };
+        t.ctx = &ran;
+        for (int leg = 0; leg < 3; leg++) {
+            for (int i = 0; i < 300 + 17 * leg; i++)
+                gang.post(t);
+            gang.wait_all();
+            gang.end();
+            gang.stop();
+            if (!gang.start(leg == 1 ? 2 : 3)) {
+                printf("no threads after a restart\n");
+                return 2;
+            }
+        }
+        if (ran.load() != 300 + 317 + 334) {
+            printf("gang restart: %llu tasks ran, %d were posted\n", (unsigned long long)ran.load(), 300 + 317 + 334);
+            return 1;
+        }
+    }
     uint64_t taken = 0, frames_e = 0;
     for (int round = 0; round < rounds; round++) {
+        if (round && round % 37 == 0) { // ... and between rounds of real work (nothing is in flight here)
+            gang.stop();
+            if (!gang.start(3)) {
+                printf("no threads after a restart\n");
+                return 2;
+            }
+        }
         // a stream of `total` offsets; candidates in clusters (a frame + shifted copies + overlapping others)
         const uint64_t total = 200000 + rng() % 2000000;
         std::vector<Rec> recs;
@@ -167,11 +197,11 @@ int main(int argc, char **argv)
             }
             for (uint32_t t = 0; t < ntiles;) {
                 const uint32_t t1 = std::min<uint32_t>(ntiles, t + 1 + (uint32_t)(rng() % 40));
-                rc.advance_tiles(stream.data(), starts.data(), counts.data(), t, t1, 0, 0, power_samples,
+                rc.advance_tiles(stream.data(), starts.data(), counts.data(), t, t1, 0, power_samples,
                                  std::min<uint64_t>(total, (uint64_t)t1 * per));
                 auto f = drain_all(rc);
                 fc.insert(fc.end(), f.begin(), f.end());
-                rd.advance_tiles(stream.data(), starts.data(), counts.data(), t, t1, 0, 0, power_samples,
+                rd.advance_tiles(stream.data(), starts.data(), counts.data(), t, t1, 0, power_samples,
                                  std::min<uint64_t>(total, (uint64_t)t1 * per));
                 if (rng() % 4 == 0 || t1 == ntiles) {
                     f = drain_all(rd);
@@ -193,7 +223,7 @@ int main(int argc, char **argv)
             for (size_t k = 0; k < bt.size(); k++) {
                 if (k + depth < bt.size())
                     re.speculate_tiles(stream.data(), starts.data(), counts.data(), bt[k + depth].first, bt[k + depth].second, 0);
-                re.advance_tiles(stream.data(), starts.data(), counts.data(), bt[k].first, bt[k].second, 0, 0, power_samples,
+                re.advance_tiles(stream.data(), starts.data(), counts.data(), bt[k].first, bt[k].second, 0, power_samples,
                                  std::min<uint64_t>(total, (uint64_t)bt[k].second * per));
                 if (rng() % 4 == 0 || k + 1 == bt.size()) {
                     auto f = drain_all(re);

@@ -66,7 +66,7 @@ def test_clock_sampler_rejects_readings_that_cannot_be_the_clock_under_load():
 def test_roofline_sources_are_named():
     p0 = dict(kernel_ms=0.0, big_offsets=134216525, big_launches=0, big_ms=0.0, offsets=0)
     p1 = dict(kernel_ms=28.0, big_offsets=134216525, big_launches=200, big_ms=28.0, offsets=200 * 134216525)
-    roof, valu = bench.roofline_objects(p0, p1, 200, "r3", clock=(2.39, 15), step_ms=0.155)
+    roof, valu = bench.roofline_objects(p0, p1, 200, "", clock=(2.39, 15), step_ms=0.155, rounds=("r3",))
     assert roof["launch_ms"] == 0.14 and abs(roof["frac"] - 4 * 134216525 / 0.14e-3 / 1e9 / 8000) < 1e-4
     assert roof["traffic"] and "profiles/r3_pmc.json" in roof["traffic_source"] and "NOT collected in this run" in roof["traffic_source"]
     assert "live" in roof["launch_ms_source"] and "launches_overlap" not in roof
@@ -74,7 +74,7 @@ def test_roofline_sources_are_named():
     assert 0.5 < valu["frac_at_peak_clock"] < 1.0 and "profiles/r3_pmc.json" in valu["pmc_source"]
     # a multi-launch step on two alternating streams: the rate is priced on the whole step
     p1b = dict(p1, big_launches=1600, big_ms=1600 * 0.26, kernel_ms=1600 * 0.26, offsets=1600 * 134216525)
-    roof2, _ = bench.roofline_objects(p0, p1b, 200, "r3", clock=None, step_ms=1.2)
+    roof2, _ = bench.roofline_objects(p0, p1b, 200, "", clock=None, step_ms=1.2, rounds=("r3",))
     assert roof2["launches_overlap"] is True and abs(roof2["achieved"] - 8 * 4 * 134216525 / 1.2e-3 / 1e9) < 1
 
 

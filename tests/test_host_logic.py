@@ -12,14 +12,17 @@ from conftest import ROOT, golden_cases, golden_records, load_golden, records, s
 
 
 def test_library_exports_every_declared_symbol(capi):
-    header = open(os.path.join(ROOT, "include", "adsbdec_amd.h")).read()
-    declared = set(re.findall(r"\b(adsb_[a-z0-9_]+)\s*\(", header))
+    declared = set()
+    for h in ("adsbdec_amd.h", "adsbdec_amd_diag.h"):   # comments stripped: they name macros and calls of other rounds
+        header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", h)).read(), flags=re.S)
+        declared |= set(re.findall(r"\b(adsb_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
+    declared -= {"adsb_get_profile", "adsb_multi_worker_profile"}   # macros that pass the caller's sizeof to the _sized calls
     L = capi.load()
     for name in sorted(declared):
-        assert hasattr(L, name), f"{name} declared in include/adsbdec_amd.h but not exported"
+        assert hasattr(L, name), f"{name} declared in include/ but not exported"
     assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
-    assert L.adsb_abi_version() == 4
+    assert L.adsb_abi_version() == 5
 
 
 def test_struct_layouts_match_header(capi):
@@ -27,7 +30,7 @@ def test_struct_layouts_match_header(capi):
     assert C.sizeof(capi.Frame) == 40 and C.sizeof(capi.Candidate) == 32
     assert C.sizeof(capi.Stats) == 56
     assert C.sizeof(capi.ShardHead) == 17 * 8 and C.sizeof(capi.ShardPart) == 10 * 8 and C.sizeof(capi.ShardFix) == 40
-    assert C.sizeof(capi.MultiInfo) == 72
+    assert C.sizeof(capi.MultiInfo) == 72 and C.sizeof(capi.Profile) == 104 + 16 and capi.Profile.host_threads_running.offset == 104
     assert capi.Frame.frame.offset == 21 and capi.Candidate.frame.offset == 13
 
 
@@ -67,29 +70,84 @@ def test_multi_create_without_gpu_fails_loudly(capi):
     assert threading.active_count() == before
 
 
-def test_config_grows_at_its_end_only(capi):
-    """adsb_create reads no further than cfg.struct_size: callers built against the round-2 adsb_config (64 bytes, no
-    host_threads) and the round-3 one (72 bytes, no debug_no_streaming ...) get past the size check (and, here, fail for
-    the lack of a GPU); a size from the future is refused."""
+def test_config_abi_guard_and_growth_rule(capi):
+    """ABI 5 (round 6): adsb_config carries `abi` in second place and the debug_* knobs left it for adsb_debug_config behind
+    `debug`.  adsb_create reads no further than cfg.struct_size (a struct that ends early gets past the check and, here,
+    fails for the lack of a GPU); a size from the future, a struct of ABI <= 4 (its df18 lies where `abi` is; the legacy
+    symbol adsb_config_default leaves one behind) and a debug struct of an unknown size are refused BY NAME."""
     import ctypes as C
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
     L = capi.load()
+    assert L.adsb_abi_version() == 5
+    assert capi.Config.abi.offset == 4 and capi.Config.host_threads.offset == 52 and capi.Config.debug.offset == 64
+    assert C.sizeof(capi.Config) == 72 and C.sizeof(capi.DebugConfig) == 48
     cfg = capi.Config()
     C.memset(C.byref(cfg), 0xEE, C.sizeof(cfg))
-    L.adsb_config_default(C.byref(cfg))      # the legacy symbol: exactly ABI 3's 72 bytes, nothing behind them
-    assert cfg.struct_size == 72 and cfg.device == -1 and cfg.host_threads == 0 and cfg.debug_frames_cap == -286331154
     L.adsb_config_init(C.byref(cfg), C.sizeof(cfg))
-    assert cfg.struct_size == C.sizeof(capi.Config) >= 96 and cfg.debug_stagger == 0
-    assert capi.Config.host_threads.offset == 64 and capi.Config.debug_no_streaming.offset == 68
-    for old_size in (64, 72):
-        cfg.struct_size = old_size
-        assert not L.adsb_create(C.byref(cfg))
-        assert b"no HIP device" in L.adsb_last_error(None)
+    assert cfg.struct_size == 72 and cfg.abi == 5 and cfg.device == -1 and cfg.host_threads == 0 and not cfg.debug
+    assert not L.adsb_create(C.byref(cfg)) and b"no HIP device" in L.adsb_last_error(None)
+    # a caller whose struct ends in front of wait_timeout_s / debug (a future ABI-5 header may be LONGER, never shorter -- but the
+    # rule is what is tested: nothing behind struct_size is read)
+    for end in (capi.Config.wait_timeout_s.offset, capi.Config.debug.offset):
+        short = capi.Config()
+        C.memset(C.byref(short), 0xEE, C.sizeof(short))
+        L.adsb_config_init(C.byref(short), end)
+        assert short.struct_size == end and short.abi == 5 and short.debug == 0xEEEEEEEEEEEEEEEE   # (untouched behind `end`)
+        assert not L.adsb_create(C.byref(short)) and b"no HIP device" in L.adsb_last_error(None)
     cfg.struct_size = 4096
-    assert not L.adsb_create(C.byref(cfg))
-    assert b"struct_size" in L.adsb_last_error(None)
+    assert not L.adsb_create(C.byref(cfg)) and b"struct_size" in L.adsb_last_error(None)
+    cfg.struct_size = 72
+    for wrong in (0, 1, 4, 6):     # ABI <= 4 binaries have df18 (0 / 1) there
+        cfg.abi = wrong
+        assert not L.adsb_create(C.byref(cfg))
+        assert b"adsb_config.abi" in L.adsb_last_error(None) and b"rebuilt" in L.adsb_last_error(None)
+        assert not L.adsb_multi_create(C.byref(cfg), 1, None) and b"adsb_config.abi" in L.adsb_multi_last_error(None)
+    legacy = (C.c_uint8 * 128)(*([0xEE] * 128))
+    L.adsb_config_default(legacy)                      # what a binary of ABI <= 4 calls: 72 zero bytes, struct_size 72, no abi
+    assert bytes(legacy[:4]) == (72).to_bytes(4, "little") and not any(legacy[4:72]) and all(v == 0xEE for v in legacy[72:])
+    assert not L.adsb_create(legacy) and b"adsb_config.abi" in L.adsb_last_error(None)
+    # the test knobs: copied at adsb_create, their struct has a size of its own
+    cfg = capi.make_config(debug_queue_cap=256, debug_gang_min=1)
+    assert cfg.debug and cfg._debug.queue_cap == 256 and cfg._debug.gang_min == 1 and cfg._debug.struct_size == 48
+    assert not L.adsb_create(C.byref(cfg)) and b"no HIP device" in L.adsb_last_error(None)
+    cfg._debug.struct_size = 4000
+    assert not L.adsb_create(C.byref(cfg)) and b"adsb_debug_config.struct_size" in L.adsb_last_error(None)
+    with pytest.raises(TypeError):
+        capi.make_config(debug_no_such_knob=1)
+    assert not capi.make_config(host_threads=1).debug
+
+
+def test_drop_in_header_is_short_and_self_contained(tmp_path):
+    """include/adsbdec_amd.h is what a drop-in and a multi-GPU host call (the reference's whole interface is one prototype,
+    adsbdec.h:5): it stays short, names no test knob, and the C host program, the patch of INTEGRATION.md and format.c build
+    against it ALONE; everything else is in adsbdec_amd_diag.h."""
+    import re
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    main = open(os.path.join(inc, "adsbdec_amd.h")).read()
+    assert len(main.splitlines()) <= 270
+    code = re.sub(r"/\*.*?\*/", "", main, flags=re.S)   # (comments may say where the knobs went)
+    assert "debug_" not in code and "adsb_resolver" not in code and "adsb_stitch" not in code and "adsb_candidate" not in code
+    src = tmp_path / "only_main.c"
+    src.write_text('#include "adsbdec_amd.h"\nint main(void) { adsb_config c; adsb_config_default(&c); adsb_profile p; (void)p; '
+                   'return c.abi == ADSB_ABI_VERSION ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(src), "-o", str(tmp_path / "o.o")], check=True)
+    for f in (os.path.join(ROOT, "adsbdec_amd", "csrc", "cli", "adsbdec_amd_cli.c"), os.path.join(ROOT, "adsbdec_amd", "csrc", "format.c"),
+              os.path.join(ROOT, "oracle", "dropin_decodeiq.c")):
+        text = open(f).read()
+        assert "adsbdec_amd_diag.h" not in text and re.search(r'#include\s+"[./]*(include/)?adsbdec_amd\.h"', text), f
+    # every entry point the two headers declare is exported, and nothing else with the library's prefix is
+    declared = set()
+    for h in ("adsbdec_amd.h", "adsbdec_amd_diag.h"):
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, h)).read(), flags=re.S)
+        declared |= set(re.findall(r"\b(adsb_[a-z0-9_]+)\s*\(", text))
+    declared -= {"adsb_get_profile", "adsb_multi_worker_profile"}          # macros over the _sized calls
+    from adsbdec_amd import _build
+    out = subprocess.run(["nm", "-D", "--defined-only", _build.LIB], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (adsb_[a-z0-9_]+)", out))
+    assert declared == exported, (sorted(declared - exported), sorted(exported - declared))
 
 
 @pytest.mark.parametrize("name", golden_cases())
@@ -426,7 +484,40 @@ def test_shard_layout_check_and_config_growth(capi):
     assert L.adsb_shard_layout_check(80, C.sizeof(capi.ShardPart)) == -1          # an ABI-3 caller's head
     assert L.adsb_shard_layout_check(C.sizeof(capi.ShardHead), C.sizeof(capi.ShardPart) - 32) == -1
     cfg = capi.make_config(wait_timeout_s=7)
-    assert cfg.struct_size == C.sizeof(capi.Config) and cfg.wait_timeout_s == 7
-    short = capi.Config()
-    L.adsb_config_init(C.byref(short), capi.Config.wait_timeout_s.offset)         # a caller built before the member existed
-    assert short.struct_size == capi.Config.wait_timeout_s.offset and short.wait_timeout_s == 0
+    assert cfg.struct_size == C.sizeof(capi.Config) and cfg.wait_timeout_s == 7 and cfg.abi == 5
+
+
+def test_slicer_column_gather_equals_the_definition(tmp_path):
+    """csrc/slicer_bits.h -- the word-wide form of the PPM slicer's bit gather the kernel runs since round 6 -- compiled
+    for the host and compared, column byte by column byte, with the definition (demod.c:31-44,109: frame bit k of the
+    candidate at g is a[g+80+10k] > a[g+85+10k]) for every offset-in-run, on random, sparse, dense and periodic planes."""
+    import subprocess
+    exe = tmp_path / "slicer_bits"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-Wno-unknown-pragmas", os.path.join(ROOT, "tests", "cpp", "slicer_bits.cpp"),
+                    "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok: 23520000 column bytes"), out.stdout + out.stderr
+
+
+def test_build_follows_the_headers_the_compiler_read(tmp_path):
+    """adsbdec_amd/_build.py rebuilds an object when ANY file its last compile read is newer (-MMD depfiles).  Round 5 kept
+    a list of headers by hand and gang.hpp (included by resolver.hpp) was not on it: editing it alone left stale objects."""
+    from adsbdec_amd import _build
+    _build.build()
+    obj = os.path.join(_build.LIBDIR, "host_abi.cpp.o")
+    deps = _build._recorded_deps(obj)
+    gang = os.path.normpath(os.path.join(_build.CSRC, "gang.hpp"))
+    assert deps and gang in deps and os.path.normpath(os.path.join(ROOT, "include", "adsbdec_amd_diag.h")) in deps
+    for o in ("scan_kernel.hip.o", "decoder.hip.o", "multi.cpp.o"):
+        assert _build._recorded_deps(os.path.join(_build.LIBDIR, o)), o
+    assert os.path.normpath(os.path.join(_build.CSRC, "slicer_bits.h")) in _build._recorded_deps(os.path.join(_build.LIBDIR, "scan_kernel.hip.o"))
+    assert not _build._stale(obj, os.path.join(_build.CSRC, "host_abi.cpp"))
+    st = os.stat(gang)
+    try:
+        newest = max(os.path.getmtime(os.path.join(_build.LIBDIR, f)) for f in os.listdir(_build.LIBDIR) if f.endswith(".o"))
+        os.utime(gang, (st.st_atime, newest + 5))                       # "edited" after the objects were built
+        assert _build._stale(obj, os.path.join(_build.CSRC, "host_abi.cpp"))
+        assert _build._stale(os.path.join(_build.LIBDIR, "decoder.hip.o"), os.path.join(_build.CSRC, "decoder.hip"))
+        assert not _build._stale(os.path.join(_build.LIBDIR, "numa.cpp.o"), os.path.join(_build.CSRC, "numa.cpp"))   # (does not include it)
+    finally:
+        os.utime(gang, (st.st_atime, st.st_mtime))

@@ -110,7 +110,7 @@ static void run(const char *name, uint32_t ntiles, uint32_t per, uint32_t frame_
         uint32_t held[12][2]; // (the streaming collect's own policy: decoder.hip slot_collect_streaming)
         int n_held = 0;
         auto adv = [&](uint32_t from, uint32_t upto) {
-            res.advance_tiles(hand, t_start.data(), t_count.data(), from, upto, 0, 0, (uint64_t)ntiles * per + 100000, (uint64_t)upto * per);
+            res.advance_tiles(hand, t_start.data(), t_count.data(), from, upto, 0, (uint64_t)ntiles * per + 100000, (uint64_t)upto * per);
         };
         auto deliver_held = [&](int keep, bool only_ready) {
             int k = 0;

@@ -45,8 +45,8 @@ def main():
             for _ in range(5):
                 d.decode_device_raw(x.data_ptr(), x.numel())
             torch.cuda.synchronize()
-            buf = (C.c_ulonglong * 24)()
-            rd(buf, 24, 1)
+            buf = (C.c_ulonglong * 16)()
+            rd(buf, 16, 1)
             p0 = d.profile()
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -54,8 +54,8 @@ def main():
             dt = (time.perf_counter() - t0) / steps * 1e3
             torch.cuda.synchronize()
             p1 = d.profile()
-            rd(buf, 24, 1)
-            v = [int(buf[i]) for i in range(24)]
+            rd(buf, 16, 1)
+            v = [int(buf[i]) for i in range(16)]
             tiles = max(1, v[0])
             print(f"== {name}, collect_stats={int(stats)}: step {dt:.4f} ms, kernel {(p1['kernel_ms'] - p0['kernel_ms']) / steps:.4f} ms, "
                   f"frames {r[1]}, tiles/launch {tiles // steps}")
