@@ -984,11 +984,24 @@ def run_shard(args, torch, capi, rank, world, fence):
     md = sharding.MultiDecoder(n_dev, devices, df18=True, profile=True, collect_stats=args.stats)
     plan = md.plan(total)
     keep = []
+    dense10 = bool(args.dense10)   # BASELINE configs[2]'s traffic through the multi-GPU driver (configs[4] x configs[2])
+    if args.dense or args.gate_storm:
+        raise SystemExit("--mode shard takes the sparse capture (default) or --dense10")
+
+    def capture(lo, hi):
+        """Samples [lo, hi) of THE capture of this run, on the current device."""
+        if not dense10:
+            return make_workload(torch, total, seed=9, lo=lo, hi=hi)[0]
+        if "whole" not in capture.__dict__:    # (the tiled generator makes a capture whole: once, on device 0)
+            with torch.cuda.device(devices[0]):
+                capture.whole = make_dense10(torch, total, 101)
+        return capture.whole[lo:hi].to(torch.cuda.current_device(), copy=True)
+
     if source == "device":
         ptrs = []
         for i, p in enumerate(plan):
             with torch.cuda.device(devices[i]):
-                t, _ = make_workload(torch, total, seed=9, lo=p["first_sample"], hi=p["first_sample"] + p["n_samples"])
+                t = capture(p["first_sample"], p["first_sample"] + p["n_samples"])
                 torch.cuda.synchronize()
             keep.append(t)
             ptrs.append(t.data_ptr())
@@ -1002,7 +1015,7 @@ def run_shard(args, torch, capi, rank, world, fence):
         host = torch.from_numpy(host_np.view(np.int16))
         for lo in range(0, total, 64 << 20):
             hi = min(total, lo + (64 << 20))
-            host[lo:hi].copy_(make_workload(torch, total, seed=9, lo=lo, hi=hi)[0])
+            host[lo:hi].copy_(capture(lo, hi))
         torch.cuda.synchronize()
         keep.append(host)
         if source == "file":
@@ -1043,7 +1056,7 @@ def run_shard(args, torch, capi, rank, world, fence):
     cpu, parity = None, None
     if not args.no_cpu_baseline:
         if source == "device":
-            whole, _ = make_workload(torch, total, seed=9)
+            whole = capture(0, total)
             x_host = None
         else:
             whole = keep[0].cuda()
@@ -1068,7 +1081,9 @@ def run_shard(args, torch, capi, rank, world, fence):
         "value": round(value, 1), "unit": "Msamples/s", "n_gpus": n_dev, "steps": args.steps,
         "warmup": args.warmup, "preroll_ms": args.preroll_ms, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[4]: ONE stream of {total} uint16 samples time-sharded over {len(plan)} "
+        "config": {"workload": ("BASELINE configs[4] x configs[2] (112-bit frames packed back to back, ~10 % of the offsets pass the preamble "
+                                "test: every worker's handle runs its reader thread and gang of four): " if dense10 else "BASELINE configs[4]: ")
+                               + f"ONE stream of {total} uint16 samples time-sharded over {len(plan)} "
                                f"device handle(s) by adsb_multi_decode_{source} (one process, one worker thread per handle), halo 8 "
                                "pairs + one 1196-sample window, -a, 1-bit repair off; "
                                + {"device": "every slice resident in its device's HBM",
@@ -1089,6 +1104,11 @@ def run_shard(args, torch, capi, rank, world, fence):
                    "slowest_worker_ms": round(float(np.median(workers)), 4),
                    "deqframe_calls_walked": int(info["calls_walked"]), "deqframe_calls_jumped": int(info["calls_jumped"]),
                    "create_ms": round(info["create_ms"], 1),
+                   "helper_threads": int(info.get("helper_threads", 0)),
+                   "helper_threads_per_worker": [int(p.get("host_threads_running", 0)) for p in prof1],
+                   "gang_launches_per_worker": [int(p1.get("gang_launches", 0) - p0.get("gang_launches", 0)) for p0, p1 in zip(prof0, prof1)],
+                   "helper_threads_what": "reader / gang threads the workers' handles own after the timed steps (adsb_multi_info.helper_threads, "
+                                          "adsb_profile.host_threads_running per worker): 0 under sparse traffic, 5 per worker on a full channel",
                    "placement": ([md.placement(i) for i in range(len(plan))] if source == "host" else None),
                    "placement_what": "per worker: the NUMA node of its device, whether its thread runs on that node's CPUs, the node "
                                      "most pages of its slice of the capture live on and the share of them on the device's node "

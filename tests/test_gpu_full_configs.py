@@ -217,6 +217,71 @@ def test_config4_2Gi_one_stream_in_8_shards(capi, oracle, torch_cuda):
     torch_cuda.cuda.empty_cache()
 
 
+def test_config2_dense_traffic_through_the_multi_gpu_driver(capi, oracle, torch_cuda):
+    """BASELINE configs[2]'s traffic (a channel at its capacity: 112-bit frames packed back to back, ~10 % of the offsets pass
+    the preamble test) through the multi-GPU driver: configs[4] x configs[2] -- ONE 512 Mi-sample capture resident in HBM cut
+    into 1 / 4 / 8 shards, the Try/Ok table included -- and configs[3] x configs[2] -- four independent dense captures on two
+    workers.  Frames, ts, pw and the table equal to the oracle's; and the helper threads are VISIBLE: every worker's handle
+    reports its reader thread and gang (adsb_profile.host_threads_running through adsb_multi_worker_profile, the sum in
+    adsb_multi_info.helper_threads), none exists with cfg.host_threads = 1.  (demod.c:125-141 is what makes a shard's host
+    side sequential; main.c:60-89 is N x -f.)"""
+    from adsbdec_amd import sharding
+    from tools.gen_signal import make_dense10
+    n = (512 << 20) - (512 << 20) % 28
+    t = make_dense10(torch_cuda, n, 131)
+    x = _host(t)
+    want, wstats = oracle.decode(x, df18=True)
+    want_r = records(want)
+    assert len(want) > 180_000
+    roomy = len(os.sched_getaffinity(0)) >= 12
+    assert _reader_threads() == 0 and _format_threads() == 0
+    # handles, cfg.host_threads, helper threads per worker once the traffic has been seen: auto (0) starts reader + 4 behind a
+    # launch of >= 65 536 records -- a 512 Mi-sample shard has two such launches, a 128 Mi-sample one stays below -- explicit 6
+    # starts them at adsb_create, 1 never starts any
+    for handles, host_threads, per_worker in ((1, 0, 5 if roomy else 1), (4, 6, 5), (8, 6, 5), (4, 1, 0)):
+        md = sharding.MultiDecoder(handles, [0] * handles, df18=True, collect_stats=True, host_threads=host_threads, profile=True)
+        try:
+            plan = md.plan(n)
+            assert len(plan) == handles
+            for rep in range(2):
+                raw = md.decode_device(n, [t.data_ptr() + 2 * p["first_sample"] for p in plan])
+                assert records(capi._frames_to_dicts(*raw)) == want_r, (handles, host_threads, rep)
+                assert md.stats() == wstats, (handles, host_threads, rep)
+            inf = md.info()
+            assert inf["fallback"] == 0
+            profs = [md.worker_profile(i) for i in range(handles)]
+            assert [p["host_threads_running"] for p in profs] == [per_worker] * handles, (handles, host_threads, profs)
+            assert inf["helper_threads"] == per_worker * handles
+            assert (_reader_threads(), _format_threads()) == ((handles, 4 * handles) if per_worker == 5 else (handles if per_worker else 0, 0))
+            if per_worker == 5:
+                assert all(p["gang_launches"] > 0 for p in profs), profs
+            else:
+                assert all(p["gang_launches"] == 0 and p["gang_batches"] == 0 for p in profs)
+        finally:
+            md.close()
+        assert _reader_threads() == 0 and _format_threads() == 0
+    del t
+    torch_cuda.cuda.empty_cache()
+    # configs[3] x configs[2]: four dense captures, stream s on worker s mod 2, each with its own ts and table
+    m = (64 << 20) - (64 << 20) % 28
+    xs = [_host(make_dense10(torch_cuda, m, 140 + s)) for s in range(4)]
+    wants = [oracle.decode(v, df18=True) for v in xs]
+    md = sharding.MultiDecoder(2, [0, 0], df18=True, collect_stats=True, host_threads=6)
+    try:
+        with capi.PinnedBuffers(4, m) as bufs:
+            for s in range(4):
+                bufs[s][:] = xs[s]
+            md.decode_streams_host([bufs[s] for s in range(4)])
+            for s in range(4):
+                assert records(capi._frames_to_dicts(*md.stream_frames(s))) == records(wants[s][0]), s
+                assert md.stream_stats(s) == wants[s][1], s
+        assert md.info()["helper_threads"] == 10
+        profs = [md.worker_profile(i) for i in range(2)]
+        assert all(p["gang_launches"] > 0 and p["gang_batches"] > 0 for p in profs), profs   # batches decided ahead by the gang
+    finally:
+        md.close()
+
+
 @pytest.mark.gpu_big          # opt-in (--gpu-big): 8 GiB of HBM, 215 k frames synthesised on the host, minutes of wall time
 @pytest.mark.limit(1500)
 def test_a_stream_just_below_the_sample_counter_limit(capi, torch_cuda):
