@@ -26,7 +26,8 @@ constexpr int kClistCap = 256;  // CRC-valid candidates staged per tile for the 
                                 // offsets full of 112-bit frames packed back to back decodes at ~130-190 offsets: BASELINE configs[2])
 constexpr int ADSB_DECOFFSET_K = 1200; // longest span an accepted frame jumps (adsbdec.h:3)
 constexpr int kCandWords = 6;   // {g_rel, pw, frame[0..13] | len<<16 in the last word}
-constexpr int kSyndWords = 14 * 256 + 28 * 8; // the CRC-24 syndrome table, and behind it the slicer's column masks (slicer_bits.h: kColMaskWords)
+constexpr int kColMaskLds = 28 * 8;  // the slicer's column masks, copied into LDS by every tile (slicer_bits.h: kColMaskWords)
+constexpr int kSyndWords = 14 * 256 + kColMaskLds; // the CRC-24 syndrome table, and behind it the slicer's column masks (slicer_bits.h: kColMaskWords)
 constexpr int kFixSlots = 512;
 constexpr int kCounterWords = 8; // the launch counters as the host sees them (ScanArgs::report)
 // On the device every counter has a 128-byte line of its own (ScanArgs::counters[i * kCounterPad]; the two
@@ -37,7 +38,7 @@ constexpr int owned_runs(int passes) { return kPassRuns * passes - kReachRuns; }
 constexpr int tile_offsets(int passes) { return kRun * owned_runs(passes); }
 constexpr size_t lds_bytes(int passes)
 {
-    return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6);
+    return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6 + kColMaskLds);
 }
 // Tile geometry of a launch.  Every tile takes K = `passes` passes, except that the first
 // `stagger` tiles (a multiple of 4, K >= 5; 0 = off, the default) cycle through K-3, K-2,

@@ -71,6 +71,9 @@
 
 namespace adsb {
 
+static_assert(kColMaskLds == kColMaskWords, "scan_kernel.h sizes the LDS copy of slicer_bits.h's table");
+static_assert(5 * lds_bytes(7) <= 160 * 1024, "five workgroups of a K = 7 tile share a CU's LDS");
+
 namespace {
 
 // air.c:36-45. Each tap is (float)<double literal>, as in the reference's
@@ -476,12 +479,11 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
 template <bool kStats>
 __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t tile, const int K, const int64_t t0, const int tid,
                                         const uint32_t *pl_d, const uint32_t *pl_e1, const uint32_t *pl_e2, uint32_t *queue,
-                                        uint32_t *qcount, uint32_t *cl_rec, const int clist_cap, uint64_t &stamp_last)
+                                        uint32_t *qcount, uint32_t *cl_rec, const int clist_cap, const uint32_t *colmask, uint64_t &stamp_last)
 {
     constexpr int NT = kThreads;
     constexpr int kFallbackChunks = 256 / NT; // a fallback round takes one bit position of 256 runs: <= 256 entries
     const uint32_t *__restrict__ xin = args.x;
-    const uint32_t *__restrict__ colmask = args.synd + 14 * 256; // (the slicer's column masks lie behind the syndrome table: kSyndWords)
     const int64_t pbuf0 = args.pbuf0, p_lo = args.p_lo, p_hi = args.p_hi;
     const int own = kPassRuns * K - kReachRuns;
     uint32_t *tile_n = qcount + 4;    // records this tile keeps (ranked into its hand-off range)
@@ -538,9 +540,11 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     // tile); a single chunk that does not fit goes bit position by bit position (offset within the run): <= 256
     // entries per round, which cannot overflow (queue_cap >= 256).  The CRC-valid candidates of every round are
     // staged in the same list, which the filter behind the loop sees whole.
-    constexpr int kGateBatch = 4; // chunks whose gate words are computed together
+    constexpr int kGateHalf = 4, kGateBatch = 2 * kGateHalf; // chunks whose gate words are computed together (a whole K = 7 tile: 7)
     int ch_lo = 0, ch_hi = nchunks, grp = -1, width = nchunks;
     uint32_t try_fill = 0; // (kStats) try words in the tile's region so far: workgroup-uniform
+    int64_t pf_g = -1;     // the last candidate this thread staged: its samples are asked for ahead of pw_at (below)
+    uint32_t pf_land = 0;
     const bool stage_cands = !args.all_candidates;
     for (;;) {
         if (tid == 0) {
@@ -554,10 +558,15 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             // Two steps per batch of chunks.  First every gate word: plane reads and word-wide logic with no
             // dependence between chunks, so the LDS reads of a whole batch are in flight together (one chunk at
             // a time this loop took 3.2 us of a 46 us tile, most of it LDS latency) ...
+            // (Round 6: the batch is a whole tile's seven chunks instead of four, in two halves that each know whether they
+            // are `full`, and a thread reserves queue slots for ALL its survivors of the batch with one LDS atomic instead of
+            // one per chunk: the gate + queue phase of a sparse tile took 3.6 us, two LDS round trips per chunk.)
             uint32_t gt[kGateBatch], gb1[kGateBatch], gb4[kGateBatch];
-            // workgroup-uniform: every run of the batch exists and is complete (all but a tile's last batch, and
+            // workgroup-uniform, per half: every run of the half exists and is complete (all but a tile's last chunks, and
             // the last tiles of a launch): no per-lane range logic at all
-            const bool full = grp < 0 && base + kGateBatch <= ch_hi && kRun * NT * (base + kGateBatch) <= off_end;
+            auto half_full = [&](int h) {
+                return grp < 0 && base + kGateHalf * (h + 1) <= ch_hi && kRun * NT * (base + kGateHalf * (h + 1)) <= off_end;
+            };
             auto gate_word = [&](int u, auto is_full) {
                 const int vq = (base + u) * NT + tid;
                 const int nvalid = off_end - kRun * vq; // <= 0: the run does not exist (vq >= own included: off_end <= 28 own)
@@ -585,33 +594,43 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                 }
                 gt[u] = gate, gb1[u] = b1, gb4[u] = b4; // of a passing offset: b1 set <=> DF11; else b4 set <=> DF17
             };
-            if (full) {
 #pragma unroll
-                for (int u = 0; u < kGateBatch; u++)
-                    gate_word(u, std::true_type{});
-            } else {
+            for (int h = 0; h < 2; h++) {
+                if (base + kGateHalf * h >= ch_hi) { // (workgroup-uniform) nothing of this half is in the range
 #pragma unroll
-                for (int u = 0; u < kGateBatch; u++)
-                    gate_word(u, std::false_type{});
+                    for (int u = 0; u < kGateHalf; u++)
+                        gt[kGateHalf * h + u] = 0, gb1[kGateHalf * h + u] = 0, gb4[kGateHalf * h + u] = 0;
+                } else if (half_full(h)) {
+#pragma unroll
+                    for (int u = 0; u < kGateHalf; u++)
+                        gate_word(kGateHalf * h + u, std::true_type{});
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kGateHalf; u++)
+                        gate_word(kGateHalf * h + u, std::false_type{});
+                }
             }
             // ... then the survivors (13 % of the lanes have one) go to the queue
+            int n = 0;
 #pragma unroll
-            for (int u = 0; u < kGateBatch; u++) {
-                uint32_t gate = gt[u];
-                const int n = __popc(gate);
-                if (n) {
-                    const int v = (base + u) * NT + tid;
-                    uint32_t slot = atomicAdd(qcount, (uint32_t)n);
-                    if (slot + n <= qcap) {
+            for (int u = 0; u < kGateBatch; u++)
+                n += __popc(gt[u]);
+            if (n) {
+                uint32_t slot = atomicAdd(qcount, (uint32_t)n);
+                if (slot + n <= qcap) {
+#pragma unroll
+                    for (int u = 0; u < kGateBatch; u++) {
+                        uint32_t gate = gt[u];
+                        const int v = (base + u) * NT + tid;
                         while (gate) {
                             const int j = __ffs(gate) - 1;
                             gate &= gate - 1;
                             const uint32_t code = ((gb1[u] >> j) & 1u) ? 0u : ((gb4[u] >> j) & 1u) ? 1u : 2u;
                             queue[slot++] = ((uint32_t)v << 7) | ((uint32_t)j << 2) | code;
                         }
-                    } else {
-                        *qover = 1;
                     }
+                } else {
+                    *qover = 1;
                 }
             }
         }
@@ -689,6 +708,7 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                     rec[3] = cw[1];
                     rec[4] = cw[2];
                     rec[5] = cw[3];
+                    pf_g = t0 + (int64_t)kRun * sv + sj;
                     continue;
                 }
                 *cl_over = 1; // list full: this one is finished and emitted right here
@@ -746,6 +766,21 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     }
     if (kStats && args.try_counts && tid == 0)
         args.try_counts[tile] = try_fill;
+    // Every staged candidate's pw (demod.c:127,133) is recomputed from 52 input pairs that this tile's Stage A read ~20 us
+    // ago and the L2 has since given up (a pass of the resident waves is 3.7 MB per XCD against 4 MB of L2): the thread that
+    // staged a candidate touches their lines now, behind its last slicer round, so that pw_at -- after the filter and the
+    // ranking, by whichever thread then holds the entry -- finds them in the L2.  They land in a register nobody reads; the
+    // one wait for them stands in front of pw_at, microseconds later.
+    if (stage_cands && pf_g - 6 >= p_lo && pf_g + 45 < p_hi) { // (pf_g == -1: p_lo >= 0 is never below -7 ... the test fails)
+        const uint32_t *pfb = xin + (pf_g - pbuf0);
+        asm volatile("global_load_dword %0, %1, off offset:-24\n\t"
+                     "global_load_dword %0, %1, off offset:40\n\t"
+                     "global_load_dword %0, %1, off offset:104\n\t"
+                     "global_load_dword %0, %1, off offset:180"
+                     : "=&v"(pf_land)
+                     : "v"(pfb)
+                     : "memory");
+    }
 
     if (stage_cands) {
         // Drop candidates the greedy scan (demod.c:89,128,134,141) can never visit.
@@ -820,49 +855,73 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                 }
             }
         } else {
-            // More than a wave of entries (a tile of 48 k offsets full of 112-bit frames back to back stages ~150: BASELINE
-            // configs[2]): the same all-pairs rule, the keys and frame ends laid out as two arrays in the survivor queue's LDS
-            // (free behind the rounds) and read four to a broadcast load -- 2 x ncl / 4 LDS reads per entry and pass.  (Until
-            // round 5 this path read the staged records themselves, 2 dependent words per pair: 4 x ncl reads per entry and
-            // three passes -- ~15 us of such a tile's life.)
-            uint32_t *fk = queue, *fe = queue + kClistCap, *kkv = queue + 2 * kClistCap;
+            // More than a wave of entries (a tile of 48 k offsets full of 112-bit frames back to back stages ~130: BASELINE
+            // configs[2]): the same all-pairs rule over two arrays of keys and frame ends in LDS, read four to a broadcast load.  Round 6: up to 128 entries are served by TWO threads each
+            // (half of the pairs per thread, the two maxima merged by an LDS atomic: all four waves work instead of two), and
+            // "the largest key below mine" is one subtraction and one unsigned maximum per pair -- k - mine wraps to a huge
+            // number exactly for the keys below mine, and among those the largest k gives the largest difference -- where a
+            // compare, a select and a signed maximum stood; the ranking pass is split the same way.  (Round 5: 32 rounds of 22
+            // instructions per entry and pass on two waves, 6.7 us of such a tile's life.)
+            uint32_t *fk = queue, *fe = queue + kClistCap, *kkv = queue + 2 * kClistCap; // (the survivor queue's words: free behind the rounds)
+            uint32_t *rk = const_cast<uint32_t *>(pl_e1), *re = rk + kClistCap; // ... and the E1 plane's (>= 512 words: K >= 2)
             const bool has = tid < ncl;
             const int gi = has ? (int)(ri[0] - tile_rel) : 0x3fffffff; // tile-local offset
             const bool lng = has && (ri[1] & 0xFFu) != 0;
             const int key = 2 * gi + (lng ? 1 : 0), g2 = 2 * gi;
             fk[tid] = (uint32_t)key;                                          // (NT == kClistCap: one slot per thread)
             fe[tid] = (uint32_t)(has ? gi + (lng ? 1200 : 640) : 0x7fffffff); // where the candidate's frame ends
+            rk[tid] = 0;
+            re[tid] = 0;
             __syncthreads();
             const int n4 = (ncl + 3) & ~3;
-            int pk = -1, emax = -1;
-            if (has) {
-                for (int j = 0; j < n4; j += 4) {
+            // entry `en` of this thread's part of the pairs: [j0, j1)
+            const int parts = ncl <= NT / 2 ? 2 : 1, slots = NT / parts;
+            const int en = tid & (slots - 1), part = tid / slots;
+            const int per = ((n4 / 4 + parts - 1) / parts) * 4, j0 = part * per, j1 = min(n4, j0 + per);
+            const uint32_t en_key = fk[en], en_g2 = en_key & ~1u, en_g1 = (en_key >> 1) + 1u; // (garbage for en >= ncl: never used)
+            if (en < ncl) {
+                uint32_t bk = 0, be = 0; // max over the pairs of (k - 2 g) and (end - (g + 1)), unsigned: >= 2^31 <=> some k < 2 g / some end <= g
+                for (int j = j0; j < j1; j += 4) {
                     const u32x4 k4 = *reinterpret_cast<const u32x4 *>(fk + j), e4 = *reinterpret_cast<const u32x4 *>(fe + j);
-                    int kj[4] = {(int)k4.x, (int)k4.y, (int)k4.z, (int)k4.w}, ej[4] = {(int)e4.x, (int)e4.y, (int)e4.z, (int)e4.w};
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        kj[u] = kj[u] < g2 ? kj[u] : -1;
-                        ej[u] = ej[u] <= gi ? ej[u] : -1;
-                    }
-                    pk = max(max(pk, kj[0]), max(max(kj[1], kj[2]), kj[3]));
-                    emax = max(max(emax, ej[0]), max(max(ej[1], ej[2]), ej[3]));
+                    bk = max(max(bk, k4.x - en_g2), max(k4.y - en_g2, max(k4.z - en_g2, k4.w - en_g2)));
+                    be = max(max(be, e4.x - en_g1), max(e4.y - en_g1, max(e4.z - en_g1, e4.w - en_g1)));
+                }
+                if (parts > 1) {
+                    atomicMax(&rk[en], bk);
+                    atomicMax(&re[en], be);
+                } else {
+                    rk[en] = bk;
+                    re[en] = be;
                 }
             }
+            __syncthreads();
+            const uint32_t bk = rk[tid], be = re[tid];
+            const int pk = bk >= 0x80000000u ? (int)(bk + (uint32_t)g2) : -1;       // the largest key below this one's
+            const int emax = be >= 0x80000000u ? (int)(be + (uint32_t)gi + 1u) : -1; // the latest frame end that is not beyond this candidate
             const int pg = pk >> 1, pspan = (pk & 1) ? 1200 : 640; // pk == -1: pg == -1, nothing precedes
             const bool drop = complete && pg >= ADSB_DECOFFSET_K - 1 && gi < pg + pspan && !(emax > pg);
             keep = has && !drop;
             kkv[tid] = keep ? (uint32_t)key : 0x7fffffffu; // the entries that stay, as keys; the others never count
+            rk[tid] = 0;                                    // (read above by this thread alone: now the rank's accumulator)
             const unsigned long long kept = __ballot(keep);
             if ((tid & 63) == 0 && kept)
                 atomicAdd(tile_n, (uint32_t)__popcll(kept));
             if (tid == 0)
                 *any_nb = 1; // (more than a wave of entries: frames back to back, copies everywhere)
             __syncthreads();
-            if (keep)
-                for (int j = 0; j < n4; j += 4) {
+            if (en < ncl && kkv[en] != 0x7fffffffu) { // rank = kept entries with a smaller key: this thread's part of them
+                uint32_t cnt = 0;
+                for (int j = j0; j < j1; j += 4) {
                     const u32x4 k4 = *reinterpret_cast<const u32x4 *>(kkv + j);
-                    rank += (uint32_t)((int)k4.x < g2) + (uint32_t)((int)k4.y < g2) + (uint32_t)((int)k4.z < g2) + (uint32_t)((int)k4.w < g2);
+                    cnt += (uint32_t)(k4.x < en_g2) + (uint32_t)(k4.y < en_g2) + (uint32_t)(k4.z < en_g2) + (uint32_t)(k4.w < en_g2);
                 }
+                if (parts > 1)
+                    atomicAdd(&rk[en], cnt);
+                else
+                    rk[en] = cnt;
+            }
+            __syncthreads();
+            rank = rk[tid];
         }
         // ---- from the staged entries that stay to the tile's records in the stream.
         // One record per RUN OF COPIES.  A frame decodes at two or three neighbouring offsets (the half-sample shifts); an
@@ -948,6 +1007,9 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             res_need = stream_granules(nrec);
             res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
         }
+        // (the landing register of the lines touched ahead is reserved until here, and they HAVE landed: pw_at is a call, and a
+        // callee may use any caller-saved register from its first instruction on)
+        asm volatile("s_waitcnt vmcnt(0)" : : "v"(pf_land) : "memory");
         // finish the entry: bytes in order, pw (demod.c:127,133) -- every offset has a pw of its own
         uint32_t fin[6] = {0, 0, 0, 0, 0, 0};
         if (act) {
@@ -1056,6 +1118,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArg
     uint32_t *queue = smem + 3 * nplane;
     uint32_t *qcount = queue + kQueueCap;
     uint32_t *cl_rec = qcount + 16; // kClistCap records of kCandWords
+    uint32_t *colmask = cl_rec + kClistCap * kCandWords; // the slicer's column masks (16-byte aligned: two ds_read_b128 per entry)
 
     const int tid = threadIdx.x;
     // The kMinWaves workgroups that start together on a CU at the head of a large launch (blocks b, b + 256, b + 512,
@@ -1076,6 +1139,11 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArg
     const int64_t t0 = // first owned offset
         (int64_t)args.g_begin + (int64_t)kRun * (int64_t)tile_first_run(blockIdx.x, args.stagger, args.passes);
 
+    // the slicer's 28 x 8 column masks come from behind the syndrome table (kSyndWords) into LDS: a candidate's masks
+    // are then an LDS round trip away instead of a global one in front of its 41 plane reads (the load is in flight
+    // under Stage A; the barrier behind Stage A publishes it)
+    if (tid < kColMaskLds)
+        colmask[tid] = args.synd[14 * 256 + tid];
     // plane words past the last computed run are read (never used) by Stage B
     if (tid < kPlanePad) {
         pl_d[kPassRuns * K + tid] = 0;
@@ -1090,7 +1158,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArg
     __syncthreads();
     ADSB_STAMP(1); // Stage A
     ADSB_COUNT(0, 1);
-    stage_b<kStats>(args, blockIdx.x, K, t0, tid, pl_d, pl_e1, pl_e2, queue, qcount, cl_rec, args.clist_cap, stamp_last);
+    stage_b<kStats>(args, blockIdx.x, K, t0, tid, pl_d, pl_e1, pl_e2, queue, qcount, cl_rec, args.clist_cap, colmask, stamp_last);
     ADSB_STAMP_END(13); // the marker
 
     if (args.profile) { // the launch's duration is (latest tile end) - (earliest tile start)

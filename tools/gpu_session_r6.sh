@@ -7,6 +7,7 @@
 #   prof         rocprofv3 evidence sets (tools/profile_session.sh): r6 (sparse headline), r6_stats, r6_dense10, r6_dense10_stats,
 #                r6_storm, r6_storm_stats
 #   profdense    only the dense10 / storm sets
+#   abparity     the parity tests that exercise the kernel's every path, once per library build under adsbdec_amd/lib_ab/
 #   ab           same-box A/B of the library builds under adsbdec_amd/lib_ab/ against the tree's: sparse headline + dense captures
 #   shard        bench.py --mode shard runs -> r6_bench_shard_*
 #   cli          the C host program's per-stage timing on a 510 MiB tmpfs capture
@@ -37,10 +38,16 @@ while [ $# -gt 0 ]; do
             if [ $v = tree ]; then unset ADSB_LIB_PATH; else export ADSB_LIB_PATH=$PWD/adsbdec_amd/lib_ab/$v/libadsbdec_amd.so; fi
             echo "== $v (rep $rep): bench.py --steps 1000 --no-extras --no-cpu-baseline"; bench_line
             echo "== $v (rep $rep): --dense10"; bench_line --dense10
+            if [ -z "$AB_SHORT" ]; then
             echo "== $v (rep $rep): --dense10 --stats"; bench_line --dense10 --stats
             echo "== $v (rep $rep): --gate-storm"; bench_line --gate-storm --steps 300
             echo "== $v (rep $rep): --gate-storm --stats"; bench_line --gate-storm --stats --steps 300
+            fi
           done; done; unset ADSB_LIB_PATH; } > $O/r6_ab.txt 2>&1; grep -v "amdgpu.ids" $O/r6_ab.txt | tail -60;;
+    abparity) { for v in $(ls adsbdec_amd/lib_ab 2>/dev/null | grep -v "^r5$"); do
+            echo "== $v"; ADSB_LIB_PATH=$PWD/adsbdec_amd/lib_ab/$v/libadsbdec_amd.so timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_configs.py -m gpu -x -q \
+              -k "golden_device or seeded_vs or full_range or statistics_read or try_counting or back_to_back or queue_overflow or overflow_rounds or staged_list or one_bit or exhaustive or at_ten_percent" 2>&1 | tail -3
+          done; } > $O/r6_abparity.txt 2>&1; cat $O/r6_abparity.txt;;
     shard)
       run r6_bench_shard_N1_2Gi --mode shard --steps 20 --warmup 3
       run r6_bench_shard_N1_2Gi_stats --mode shard --steps 10 --warmup 2 --stats
