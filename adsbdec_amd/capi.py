@@ -59,7 +59,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("abi", C.c_uint32), ("df18", C.c_int32), ("device", C.c_int32),
                 ("collect_stats", C.c_int32), ("profile", C.c_int32), ("stage_samples", C.c_uint64), ("stream", C.c_void_p),
                 ("all_candidates", C.c_int32), ("fix_1bit", C.c_int32), ("push_overlap", C.c_int32), ("host_threads", C.c_int32),
-                ("wait_timeout_s", C.c_int32), ("reserved", C.c_int32), ("debug", C.c_void_p)]
+                ("wait_timeout_s", C.c_int32), ("warm_start", C.c_int32), ("debug", C.c_void_p)]
 
 
 class DebugConfig(C.Structure):
@@ -256,7 +256,7 @@ DEBUG_KNOBS = ("queue_cap", "cand_cap", "try_cap", "clist_cap", "no_streaming", 
 def make_config(df18: bool = False, device: int = -1, collect_stats: bool = False,
                 profile: bool = False, stage_samples: int = 0, stream: int | None = None,
                 all_candidates: bool = False, fix_1bit: bool = False, push_overlap: bool = False,
-                host_threads: int = 0, wait_timeout_s: int = 0, **debug):
+                host_threads: int = 0, wait_timeout_s: int = 0, warm_start: bool = False, **debug):
     """adsb_config from keywords (adsb_config_default + the members named).  Keywords debug_<knob> (DEBUG_KNOBS) fill an
     adsb_debug_config that the returned struct points at (and keeps alive: cfg._debug)."""
     L = load()
@@ -275,6 +275,7 @@ def make_config(df18: bool = False, device: int = -1, collect_stats: bool = Fals
         cfg = Config()
         L.adsb_config_init(C.byref(cfg), C.sizeof(cfg))
         cfg.wait_timeout_s = wait_timeout_s
+        cfg.warm_start = int(warm_start)
         if any(debug.values()):
             dbg = DebugConfig()
             dbg.struct_size = C.sizeof(dbg)

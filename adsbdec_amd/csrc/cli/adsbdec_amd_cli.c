@@ -520,6 +520,7 @@ int main(int argc, char **argv)
     cfg.fix_1bit = fix1;
     cfg.collect_stats = 1; /* the reference always prints Try/Ok */
     cfg.device = device;   /* (-1: the current one; after the narrowing above, 0) */
+    cfg.warm_start = 1;    /* a one-shot process: the runtime's first-use costs are paid inside adsb_create, beside its other work */
     adsb_decoder *dec = adsb_create(&cfg);
     if (!dec) {
         fprintf(stderr, "adsb_create() failed: %s\n", adsb_last_error(NULL));

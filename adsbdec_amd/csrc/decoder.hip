@@ -1391,8 +1391,8 @@ int process_stage(adsb_decoder *d, bool final, bool in_flight = false)
             // that has already completed costs nothing).
             if (aside && d->piece > 1)
                 HIP_TRY(d, hipStreamWaitEvent(ts, d->ev_copy[(d->piece - 1) % adsb_decoder::kCopyStreams], 0));
-            HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur ^ 1], d->stage[d->cur] + skip, left * sizeof(uint16_t),
-                                      hipMemcpyDeviceToDevice, ts));
+            HIP_TRY(d, adsb::launch_copy_samples(d->stage[d->cur ^ 1], d->stage[d->cur] + skip, left, ts)); // (the library's own kernel:
+            //                                the runtime's first device-to-device copy of a process costs 7 ms, scan_kernel.hip)
             // Behind EVERY tail copy, the one of a synchronous push on the scan stream included: a following
             // adsb_push_async copies right behind this tail on a copy stream that nothing else orders against it.
             if (d->dbg_async != 4) {
@@ -1511,8 +1511,19 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
     if (d->stage_cap < (1u << 16))
         d->stage_cap = 1u << 16;
 
+    std::thread warm; // cfg.warm_start: the process's first large host-to-device copy, made beside the rest of this function
+    struct JoinWarm {
+        std::thread &t;
+        ~JoinWarm()
+        {
+            if (t.joinable())
+                t.join();
+        }
+    } join_warm{warm}; // (every way out of this function waits for it)
     auto bail = [&](const char *what, hipError_t err) -> adsb_decoder * {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        if (warm.joinable())
+            warm.join();
         adsb_destroy(d);
         return nullptr;
     };
@@ -1525,6 +1536,27 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipStreamCreate", e);
         d->own_stream = true;
     }
+    // The staging buffers first, so that a one-shot process (cfg.warm_start: the C host program) can pay the runtime's
+    // first-use cost of a large page-locked host-to-device copy -- 7-9 ms inside the first such hipMemcpyAsync of a process,
+    // profiles/r5_cli_timing.txt -- on a thread of its own while this one creates the other four streams (5-6 ms each).
+    for (int i = 0; i < 2; i++)
+        if ((e = hipMalloc(&d->stage[i], d->stage_cap * sizeof(uint16_t))) != hipSuccess)
+            return bail("hipMalloc(stage)", e);
+    if (cfg.warm_start) {
+        const size_t bytes = std::min<size_t>(32u << 20, d->stage_cap * sizeof(uint16_t));
+        try {
+            warm = std::thread([d, bytes] {
+                void *tmp = nullptr;
+                if (hipSetDevice(d->device) != hipSuccess || hipHostMalloc(&tmp, bytes, hipHostMallocDefault) != hipSuccess)
+                    return; // (best effort: the first push then pays what it always paid)
+                std::memset(tmp, 0, 4096);
+                if (hipMemcpyAsync(d->stage[0], tmp, bytes, hipMemcpyHostToDevice, d->stream) == hipSuccess)
+                    (void)hipStreamSynchronize(d->stream);
+                (void)hipHostFree(tmp);
+            });
+        } catch (...) { // no thread to be had: nothing is warmed
+        }
+    }
     if (d->own_stream && !(tuning_env("ADSB_ALT_STREAMS") && atoi(tuning_env("ADSB_ALT_STREAMS")) == 0) &&
         (e = hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate(second scan stream)", e);
@@ -1534,9 +1566,6 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipStreamCreate(copy)", e);
     if ((e = hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming)) != hipSuccess)
         return bail("hipEventCreate(tail)", e);
-    for (int i = 0; i < 2; i++)
-        if ((e = hipMalloc(&d->stage[i], d->stage_cap * sizeof(uint16_t))) != hipSuccess)
-            return bail("hipMalloc(stage)", e);
     for (ScanSlot &sl : d->slots) {
         if ((e = hipMalloc(&sl.d_counters, adsb::kDevCounterWords * sizeof(uint32_t))) != hipSuccess)
             return bail("hipMalloc(counters)", e);
@@ -1605,6 +1634,8 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         d->shard_head = (uint64_t)dbg.shard_head;
     d->dbg_async = tuning_env("ADSB_DEBUG_ASYNC") ? atoi(tuning_env("ADSB_DEBUG_ASYNC")) : 0;
     d->res.reset();
+    if (warm.joinable())
+        warm.join();
     return d;
 }
 
@@ -1975,8 +2006,7 @@ int push_device_impl(adsb_decoder *d, const void *device_samples, size_t n, bool
     if (left > d->stage_cap - kStageSlack)
         return d->fail("in-place tail (%llu samples) exceeds the staging buffer", (unsigned long long)left);
     d->cur ^= 1; // the seam scan above may still be reading the other buffer
-    HIP_TRY(d, hipMemcpyAsync(d->stage[d->cur], p + (keep_first - first), left * sizeof(uint16_t),
-                              hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(d, adsb::launch_copy_samples(d->stage[d->cur], p + (keep_first - first), left, d->stream));
     d->stage_first = keep_first;
     d->stage_fill = left;
     if (g_end > d->g_scanned) {

@@ -26,8 +26,7 @@ constexpr int kClistCap = 256;  // CRC-valid candidates staged per tile for the 
                                 // offsets full of 112-bit frames packed back to back decodes at ~130-190 offsets: BASELINE configs[2])
 constexpr int ADSB_DECOFFSET_K = 1200; // longest span an accepted frame jumps (adsbdec.h:3)
 constexpr int kCandWords = 6;   // {g_rel, pw, frame[0..13] | len<<16 in the last word}
-constexpr int kColMaskLds = 28 * 8;  // the slicer's column masks, copied into LDS by every tile (slicer_bits.h: kColMaskWords)
-constexpr int kSyndWords = 14 * 256 + kColMaskLds; // the CRC-24 syndrome table, and behind it the slicer's column masks (slicer_bits.h: kColMaskWords)
+constexpr int kSyndWords = 14 * 256;
 constexpr int kFixSlots = 512;
 constexpr int kCounterWords = 8; // the launch counters as the host sees them (ScanArgs::report)
 // On the device every counter has a 128-byte line of its own (ScanArgs::counters[i * kCounterPad]; the two
@@ -38,7 +37,7 @@ constexpr int owned_runs(int passes) { return kPassRuns * passes - kReachRuns; }
 constexpr int tile_offsets(int passes) { return kRun * owned_runs(passes); }
 constexpr size_t lds_bytes(int passes)
 {
-    return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6 + kColMaskLds);
+    return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6);
 }
 // Tile geometry of a launch.  Every tile takes K = `passes` passes, except that the first
 // `stagger` tiles (a multiple of 4, K >= 5; 0 = off, the default) cycle through K-3, K-2,
@@ -102,7 +101,7 @@ struct ScanArgs {
     uint32_t gen;
     const uint32_t *fix_tab; // EXTENSION (not in the reference): 512-entry perfect hash syndrome -> bit, or null
     uint32_t fix_mul;
-    const uint32_t *synd; // [14][256] CRC-24 syndrome table + [28][8] column masks behind it (make_syndrome_table: kSyndWords)
+    const uint32_t *synd; // [14][256] CRC-24 syndrome table (make_syndrome_table)
     // Device counters, zero at launch: [0] loose candidates, [1] tries (may exceed the
     // capacities), [2] hand-off granules, [3] unused; with `profile` [4..5] max over tiles of
     // ~(start) and [6..7] max of end on the device's 100 MHz clock (64-bit).  launch_scan
@@ -159,7 +158,7 @@ struct TryCountArgs {
 };
 hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream);
 
-// Host: fill the 14 x 256 syndrome table (crc.h generator 0xFFF409) and the slicer's 28 x 8 column masks behind it.
+// Host: fill the 14 x 256 syndrome table (crc.h generator 0xFFF409).
 void make_syndrome_table(uint32_t *out /* kSyndWords */);
 // Host: perfect hash of the single-bit syndromes of bits 5..111 of a long frame:
 // tab[(syn * mul) >> 23] = (syn << 8) | bit. Returns the multiplier.
@@ -170,5 +169,7 @@ int choose_passes(uint64_t n_offsets, int cus);
 // Host: a forced stagger (adsb_config.debug_stagger), made valid for the launch (multiple of 4, K >= 5, enough tiles), else 0.
 uint32_t checked_stagger(uint64_t n_offsets, int passes, int forced);
 hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream);
+// Device-to-device copy of n uint16 samples by the library's own kernel (the staging tail: see scan_kernel.hip).
+hipError_t launch_copy_samples(uint16_t *dst, const uint16_t *src, size_t n, hipStream_t stream);
 
 } // namespace adsb

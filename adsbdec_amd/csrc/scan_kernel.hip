@@ -71,7 +71,6 @@
 
 namespace adsb {
 
-static_assert(kColMaskLds == kColMaskWords, "scan_kernel.h sizes the LDS copy of slicer_bits.h's table");
 static_assert(5 * lds_bytes(7) <= 160 * 1024, "five workgroups of a K = 7 tile share a CU's LDS");
 
 namespace {
@@ -479,7 +478,7 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
 template <bool kStats>
 __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t tile, const int K, const int64_t t0, const int tid,
                                         const uint32_t *pl_d, const uint32_t *pl_e1, const uint32_t *pl_e2, uint32_t *queue,
-                                        uint32_t *qcount, uint32_t *cl_rec, const int clist_cap, const uint32_t *colmask, uint64_t &stamp_last)
+                                        uint32_t *qcount, uint32_t *cl_rec, const int clist_cap, uint64_t &stamp_last)
 {
     constexpr int NT = kThreads;
     constexpr int kFallbackChunks = 256 / NT; // a fallback round takes one bit position of 256 runs: <= 256 entries
@@ -543,8 +542,6 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     constexpr int kGateHalf = 4, kGateBatch = 2 * kGateHalf; // chunks whose gate words are computed together (a whole K = 7 tile: 7)
     int ch_lo = 0, ch_hi = nchunks, grp = -1, width = nchunks;
     uint32_t try_fill = 0; // (kStats) try words in the tile's region so far: workgroup-uniform
-    int64_t pf_g = -1;     // the last candidate this thread staged: its samples are asked for ahead of pw_at (below)
-    uint32_t pf_land = 0;
     const bool stage_cands = !args.all_candidates;
     for (;;) {
         if (tid == 0) {
@@ -664,11 +661,11 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             const uint32_t code = ent & 3u;
             const uint32_t g_rel = (uint32_t)(t0 - (int64_t)args.g_begin) + (uint32_t)(kRun * sv + sj);
             // Frame bit k = 14 b + c lies 80 + 10 k samples after g: the 14 column bytes come out of the D plane as word-wide
-            // logic (slicer_bits.h: masks, nibble merges, one funnel shift -- ~150 instructions and 41 LDS reads per entry
+            // logic (slicer_bits.h: computed masks, nibble merges, one funnel shift -- ~165 instructions and 41 LDS reads per entry
             // where picking the 112 bits one by one took ~310 and 112; the same function runs on the CPU in
             // tests/cpp/slicer_bits.cpp against the definition).
             uint32_t cw[4];
-            gather_columns(pl_d + sv, sj, colmask, cw);
+            gather_columns(pl_d + sv, sj, cw);
             // short frames are bits 0..55 = rows b < 4; their syndromes are the long frame's 56 bits (4 rows) further
             // on: the low nibble of every column byte, in the high nibble's place
             uint32_t syn = 0;
@@ -708,7 +705,6 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                     rec[3] = cw[1];
                     rec[4] = cw[2];
                     rec[5] = cw[3];
-                    pf_g = t0 + (int64_t)kRun * sv + sj;
                     continue;
                 }
                 *cl_over = 1; // list full: this one is finished and emitted right here
@@ -766,22 +762,6 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     }
     if (kStats && args.try_counts && tid == 0)
         args.try_counts[tile] = try_fill;
-    // Every staged candidate's pw (demod.c:127,133) is recomputed from 52 input pairs that this tile's Stage A read ~20 us
-    // ago and the L2 has since given up (a pass of the resident waves is 3.7 MB per XCD against 4 MB of L2): the thread that
-    // staged a candidate touches their lines now, behind its last slicer round, so that pw_at -- after the filter and the
-    // ranking, by whichever thread then holds the entry -- finds them in the L2.  They land in a register nobody reads; the
-    // one wait for them stands in front of pw_at, microseconds later.
-    if (stage_cands && pf_g - 6 >= p_lo && pf_g + 45 < p_hi) { // (pf_g == -1: p_lo >= 0 is never below -7 ... the test fails)
-        const uint32_t *pfb = xin + (pf_g - pbuf0);
-        asm volatile("global_load_dword %0, %1, off offset:-24\n\t"
-                     "global_load_dword %0, %1, off offset:40\n\t"
-                     "global_load_dword %0, %1, off offset:104\n\t"
-                     "global_load_dword %0, %1, off offset:180"
-                     : "=&v"(pf_land)
-                     : "v"(pfb)
-                     : "memory");
-    }
-
     if (stage_cands) {
         // Drop candidates the greedy scan (demod.c:89,128,134,141) can never visit.
         // Let c' be the closest candidate before c, with c inside c' (c.g < c'.g +
@@ -1007,9 +987,6 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             res_need = stream_granules(nrec);
             res_base = atomicAdd(&args.counters[2 * kCounterPad], res_need);
         }
-        // (the landing register of the lines touched ahead is reserved until here, and they HAVE landed: pw_at is a call, and a
-        // callee may use any caller-saved register from its first instruction on)
-        asm volatile("s_waitcnt vmcnt(0)" : : "v"(pf_land) : "memory");
         // finish the entry: bytes in order, pw (demod.c:127,133) -- every offset has a pw of its own
         uint32_t fin[6] = {0, 0, 0, 0, 0, 0};
         if (act) {
@@ -1118,7 +1095,6 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArg
     uint32_t *queue = smem + 3 * nplane;
     uint32_t *qcount = queue + kQueueCap;
     uint32_t *cl_rec = qcount + 16; // kClistCap records of kCandWords
-    uint32_t *colmask = cl_rec + kClistCap * kCandWords; // the slicer's column masks (16-byte aligned: two ds_read_b128 per entry)
 
     const int tid = threadIdx.x;
     // The kMinWaves workgroups that start together on a CU at the head of a large launch (blocks b, b + 256, b + 512,
@@ -1139,11 +1115,6 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArg
     const int64_t t0 = // first owned offset
         (int64_t)args.g_begin + (int64_t)kRun * (int64_t)tile_first_run(blockIdx.x, args.stagger, args.passes);
 
-    // the slicer's 28 x 8 column masks come from behind the syndrome table (kSyndWords) into LDS: a candidate's masks
-    // are then an LDS round trip away instead of a global one in front of its 41 plane reads (the load is in flight
-    // under Stage A; the barrier behind Stage A publishes it)
-    if (tid < kColMaskLds)
-        colmask[tid] = args.synd[14 * 256 + tid];
     // plane words past the last computed run are read (never used) by Stage B
     if (tid < kPlanePad) {
         pl_d[kPassRuns * K + tid] = 0;
@@ -1158,7 +1129,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArg
     __syncthreads();
     ADSB_STAMP(1); // Stage A
     ADSB_COUNT(0, 1);
-    stage_b<kStats>(args, blockIdx.x, K, t0, tid, pl_d, pl_e1, pl_e2, queue, qcount, cl_rec, args.clist_cap, colmask, stamp_last);
+    stage_b<kStats>(args, blockIdx.x, K, t0, tid, pl_d, pl_e1, pl_e2, queue, qcount, cl_rec, args.clist_cap, stamp_last);
     ADSB_STAMP_END(13); // the marker
 
     if (args.profile) { // the launch's duration is (latest tile end) - (earliest tile start)
@@ -1368,7 +1339,6 @@ hipError_t launch_count_tries(const TryCountArgs &args, hipStream_t stream)
 
 void make_syndrome_table(uint32_t *out)
 {
-    make_colmask_table(out + 14 * 256); // (the slicer's second table rides behind the first: one buffer, one kernel argument)
     // S[k] = x^(111-k) mod G, G = x^24 + 0xFFF409 (crc.h): the residual of
     // valid.c:49-51,71-73 is the XOR of S[k] over the set frame bits k.
     uint32_t s[112];
@@ -1456,6 +1426,32 @@ uint32_t checked_stagger(uint64_t n_offsets, int passes, int forced)
     const uint32_t st = (uint32_t)forced & ~3u;
     const uint64_t tiles = (n_offsets + tile_offsets(passes) - 1) / tile_offsets(passes);
     return tiles >= 2ull * st ? st : 0u;
+}
+
+// The staging buffer's unscanned tail (a few KB) moved to the other buffer, by a kernel of the library's own: the
+// runtime's device-to-device copy loads its blit kernels on first use -- 7 ms inside the first such hipMemcpyAsync of a
+// process, a quarter of what the C host program needs to decode a 510 MiB capture (profiles/r5_cli_timing.txt).  src and dst are
+// 16-byte aligned (the tail starts on a 128-byte line of one buffer and goes to the first sample of the other).
+__global__ __launch_bounds__(256) void copy_samples_kernel(uint16_t *__restrict__ dst, const uint16_t *__restrict__ src, size_t n)
+{
+    const size_t n8 = n / 8, stride = (size_t)gridDim.x * blockDim.x;
+    const u32x4 *s4 = reinterpret_cast<const u32x4 *>(src);
+    u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride)
+        d4[i] = s4[i];
+    if (blockIdx.x == 0 && threadIdx.x < n - 8 * n8)
+        dst[8 * n8 + threadIdx.x] = src[8 * n8 + threadIdx.x];
+}
+
+hipError_t launch_copy_samples(uint16_t *dst, const uint16_t *src, size_t n, hipStream_t stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) // (not the tail's case: let the runtime do it)
+        return hipMemcpyAsync(dst, src, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, stream);
+    const unsigned blocks = (unsigned)std::min<size_t>(1024, (n / 8 + 255) / 256 + 1);
+    hipLaunchKernelGGL(copy_samples_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream)

@@ -10,7 +10,7 @@
 //
 // Until round 5 the slicer picked the 112 bits one by one (a dependent LDS read, a shift and a funnel shift per bit: ~310
 // VALU instructions and 112 LDS reads per candidate).  Here: the 41 words w[0..40] that hold them (row b = words 5b ..
-// 5b+5) are ANDed with the row's column mask (the bits r + 10 c, r = (sj + 80) mod 28: a table of 28 x 6 words), four
+// 5b+5) are ANDed with the row's column mask (the bits r + 10 c, r = (sj + 80) mod 28: column_masks()), four
 // rows are merged into one word per word column with shifts of 0..3 (a nibble per column: the masks are 10 bits apart),
 // the two groups of rows are laid into one linear bit string at the compile-time offsets 28 q and 28 q + 4, one funnel
 // shift by r makes every column byte start at the FIXED bit 10 c, and 14 field extracts finish.  ~150 VALU, 41 LDS reads.
@@ -44,18 +44,38 @@ ADSB_HD inline uint32_t funnel_right(uint32_t hi, uint32_t lo, uint32_t s)
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
 }
 
-// dcol: the D plane from the candidate's own run on (dcol[0] holds offset g - sj); sj = 0..27; colmask: make_colmask_table.
+// The six mask words of row r WITHOUT a table: the pattern of bits 10 c (c = 0..13: a 131-bit constant in five dwords)
+// shifted left by r, cut into words of 28 bits.  17 instructions on the device -- against a dependent load in front of
+// the 41 plane reads (from global memory: an L2 round trip; from LDS: 900 bytes per workgroup, which cost the kernel its
+// fifth workgroup per CU: +3 %, profiles/r6_ab_runs.txt).
+ADSB_HD inline void column_masks(uint32_t r, uint32_t (&m)[6])
+{
+    constexpr uint32_t B[5] = {0x40100401u, 0x10040100u, 0x04010040u, 0x01004010u, 0x00000004u}; // bits 0, 10, .., 130
+    uint32_t S[6]; // the pattern << r (r <= 27: bit 157 at most)
+    S[0] = B[0] << r;
+#pragma unroll
+    for (int d = 1; d < 6; d++) {
+        const uint64_t pair = ((uint64_t)(d < 5 ? B[d] : 0u) << 32) | B[d - 1];
+        S[d] = (uint32_t)((pair << r) >> 32);
+    }
+    m[0] = S[0] & 0x0FFFFFFFu;
+#pragma unroll
+    for (int q = 1; q < 6; q++) { // bits [28 q, 28 q + 28): they start at bit 32 - 4 q of dword q - 1
+        const int sh = 32 - 4 * q;
+        m[q] = funnel_right(S[q], S[q - 1], (uint32_t)sh) & 0x0FFFFFFFu;
+    }
+}
+
+// dcol: the D plane from the candidate's own run on (dcol[0] holds offset g - sj); sj = 0..27.
 // cw[j] = columns 4j .. 4j+3, one byte each (column c in byte c & 3 of cw[c >> 2]); cw[3] bits 16..31 are zero.
-template <class Plane, class Mask>
-ADSB_HD inline void gather_columns(Plane dcol, int sj, Mask colmask, uint32_t (&cw)[4])
+template <class Plane>
+ADSB_HD inline void gather_columns(Plane dcol, int sj, uint32_t (&cw)[4])
 {
     const int P = sj + 80;                 // 80 .. 107
     const int w0 = P >= 84 ? 3 : 2;        // P / 28
     const uint32_t r = (uint32_t)(P - 28 * w0);
     uint32_t m[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++)
-        m[q] = colmask[r * kColMaskRow + q];
+    column_masks(r, m);
     // rows 0..3 -> za, rows 4..7 -> zb: bit (b & 3) of the nibble that starts at the column's bit position
     uint32_t za[6], zb[6];
 #pragma unroll

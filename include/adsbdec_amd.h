@@ -90,7 +90,8 @@ typedef struct adsb_config {
                                exists; same frames, same order, same counters whatever the value.                 */
     int32_t wait_timeout_s; /* no wait for the device lasts longer (0 = default, 120 s): a launch or copy that never
                                completes ends the call with -1 and adsb_last_error() names what was waited for     */
-    int32_t reserved;
+    int32_t warm_start;     /* 1: adsb_create also makes the process's first large host-to-device copy (the runtime's
+                               first-use cost, 7-9 ms once per process) beside its other work: for a one-shot process   */
     const void *debug;      /* NULL, or an adsb_debug_config (adsbdec_amd_diag.h: test knobs); copied by adsb_create */
 } adsb_config;
 

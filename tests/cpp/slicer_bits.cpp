@@ -28,6 +28,16 @@ int main()
             return 1;
         }
     }
+    // ... and the masks computed without it (what the kernel does) are its rows
+    for (uint32_t r = 0; r < 28; r++) {
+        uint32_t m[6];
+        adsb::column_masks(r, m);
+        for (int q = 0; q < 6; q++)
+            if (m[q] != tab[r * adsb::kColMaskRow + q]) {
+                printf("column_masks(%u)[%d] = %08x, table %08x\n", r, q, m[q], tab[r * adsb::kColMaskRow + q]);
+                return 1;
+            }
+    }
     const int kWords = 64;
     long checked = 0;
     for (int it = 0; it < 20000; it++) {
@@ -49,7 +59,7 @@ int main()
         for (int v0 = 0; v0 < 12; v0 += 5)                                   // the candidate's run
             for (int sj = 0; sj < 28; sj++) {
                 uint32_t cw[4];
-                adsb::gather_columns(pl.data() + v0, sj, tab.data(), cw);
+                adsb::gather_columns(pl.data() + v0, sj, cw);
                 for (int c = 0; c < 14; c++) {
                     uint32_t want = 0;
                     for (int b = 0; b < 8; b++)

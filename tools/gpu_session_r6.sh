@@ -34,7 +34,7 @@ while [ $# -gt 0 ]; do
     profdense)
           bash tools/profile_session.sh r6_dense10 --dense10; bash tools/profile_session.sh r6_dense10_stats --dense10 --stats
           bash tools/profile_session.sh r6_storm --gate-storm; bash tools/profile_session.sh r6_storm_stats --gate-storm --stats;;
-    ab) { for rep in 1 2; do for v in $(ls adsbdec_amd/lib_ab 2>/dev/null) tree; do
+    ab) { for rep in $(seq 1 ${AB_REPS:-2}); do for v in $(ls adsbdec_amd/lib_ab 2>/dev/null | grep -v -x "${AB_SKIP:-none}") tree; do
             if [ $v = tree ]; then unset ADSB_LIB_PATH; else export ADSB_LIB_PATH=$PWD/adsbdec_amd/lib_ab/$v/libadsbdec_amd.so; fi
             echo "== $v (rep $rep): bench.py --steps 1000 --no-extras --no-cpu-baseline"; bench_line
             echo "== $v (rep $rep): --dense10"; bench_line --dense10
@@ -48,6 +48,7 @@ while [ $# -gt 0 ]; do
             echo "== $v"; ADSB_LIB_PATH=$PWD/adsbdec_amd/lib_ab/$v/libadsbdec_amd.so timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_configs.py -m gpu -x -q \
               -k "golden_device or seeded_vs or full_range or statistics_read or try_counting or back_to_back or queue_overflow or overflow_rounds or staged_list or one_bit or exhaustive or at_ten_percent" 2>&1 | tail -3
           done; } > $O/r6_abparity.txt 2>&1; cat $O/r6_abparity.txt;;
+    why) shift; v=$1; ADSB_LIB_PATH=$PWD/adsbdec_amd/lib_ab/$v/libadsbdec_amd.so timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "golden_device" 2>&1 | grep -v amdgpu.ids | tail -40 > $O/r6_why_$v.txt; cat $O/r6_why_$v.txt;;
     shard)
       run r6_bench_shard_N1_2Gi --mode shard --steps 20 --warmup 3
       run r6_bench_shard_N1_2Gi_stats --mode shard --steps 10 --warmup 2 --stats
