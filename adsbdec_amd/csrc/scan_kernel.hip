@@ -539,7 +539,9 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
     // tile); a single chunk that does not fit goes bit position by bit position (offset within the run): <= 256
     // entries per round, which cannot overflow (queue_cap >= 256).  The CRC-valid candidates of every round are
     // staged in the same list, which the filter behind the loop sees whole.
-    constexpr int kGateHalf = 4, kGateBatch = 2 * kGateHalf; // chunks whose gate words are computed together (a whole K = 7 tile: 7)
+    // chunks whose gate words are computed together.  (Round 6 tried a whole tile's seven chunks in one batch with ONE queue
+    // reservation per thread: equal on the sparse capture, 1.4 % slower on BASELINE configs[2] -- profiles/r6_ab_runs.txt.)
+    constexpr int kGateBatch = 4;
     int ch_lo = 0, ch_hi = nchunks, grp = -1, width = nchunks;
     uint32_t try_fill = 0; // (kStats) try words in the tile's region so far: workgroup-uniform
     const bool stage_cands = !args.all_candidates;
@@ -555,15 +557,10 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             // Two steps per batch of chunks.  First every gate word: plane reads and word-wide logic with no
             // dependence between chunks, so the LDS reads of a whole batch are in flight together (one chunk at
             // a time this loop took 3.2 us of a 46 us tile, most of it LDS latency) ...
-            // (Round 6: the batch is a whole tile's seven chunks instead of four, in two halves that each know whether they
-            // are `full`, and a thread reserves queue slots for ALL its survivors of the batch with one LDS atomic instead of
-            // one per chunk: the gate + queue phase of a sparse tile took 3.6 us, two LDS round trips per chunk.)
             uint32_t gt[kGateBatch], gb1[kGateBatch], gb4[kGateBatch];
-            // workgroup-uniform, per half: every run of the half exists and is complete (all but a tile's last chunks, and
+            // workgroup-uniform: every run of the batch exists and is complete (all but a tile's last batch, and
             // the last tiles of a launch): no per-lane range logic at all
-            auto half_full = [&](int h) {
-                return grp < 0 && base + kGateHalf * (h + 1) <= ch_hi && kRun * NT * (base + kGateHalf * (h + 1)) <= off_end;
-            };
+            const bool full = grp < 0 && base + kGateBatch <= ch_hi && kRun * NT * (base + kGateBatch) <= off_end;
             auto gate_word = [&](int u, auto is_full) {
                 const int vq = (base + u) * NT + tid;
                 const int nvalid = off_end - kRun * vq; // <= 0: the run does not exist (vq >= own included: off_end <= 28 own)
@@ -591,43 +588,33 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
                 }
                 gt[u] = gate, gb1[u] = b1, gb4[u] = b4; // of a passing offset: b1 set <=> DF11; else b4 set <=> DF17
             };
+            if (full) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if (base + kGateHalf * h >= ch_hi) { // (workgroup-uniform) nothing of this half is in the range
+                for (int u = 0; u < kGateBatch; u++)
+                    gate_word(u, std::true_type{});
+            } else {
 #pragma unroll
-                    for (int u = 0; u < kGateHalf; u++)
-                        gt[kGateHalf * h + u] = 0, gb1[kGateHalf * h + u] = 0, gb4[kGateHalf * h + u] = 0;
-                } else if (half_full(h)) {
-#pragma unroll
-                    for (int u = 0; u < kGateHalf; u++)
-                        gate_word(kGateHalf * h + u, std::true_type{});
-                } else {
-#pragma unroll
-                    for (int u = 0; u < kGateHalf; u++)
-                        gate_word(kGateHalf * h + u, std::false_type{});
-                }
+                for (int u = 0; u < kGateBatch; u++)
+                    gate_word(u, std::false_type{});
             }
             // ... then the survivors (13 % of the lanes have one) go to the queue
-            int n = 0;
 #pragma unroll
-            for (int u = 0; u < kGateBatch; u++)
-                n += __popc(gt[u]);
-            if (n) {
-                uint32_t slot = atomicAdd(qcount, (uint32_t)n);
-                if (slot + n <= qcap) {
-#pragma unroll
-                    for (int u = 0; u < kGateBatch; u++) {
-                        uint32_t gate = gt[u];
-                        const int v = (base + u) * NT + tid;
+            for (int u = 0; u < kGateBatch; u++) {
+                uint32_t gate = gt[u];
+                const int n = __popc(gate);
+                if (n) {
+                    const int v = (base + u) * NT + tid;
+                    uint32_t slot = atomicAdd(qcount, (uint32_t)n);
+                    if (slot + n <= qcap) {
                         while (gate) {
                             const int j = __ffs(gate) - 1;
                             gate &= gate - 1;
                             const uint32_t code = ((gb1[u] >> j) & 1u) ? 0u : ((gb4[u] >> j) & 1u) ? 1u : 2u;
                             queue[slot++] = ((uint32_t)v << 7) | ((uint32_t)j << 2) | code;
                         }
+                    } else {
+                        *qover = 1;
                     }
-                } else {
-                    *qover = 1;
                 }
             }
         }
