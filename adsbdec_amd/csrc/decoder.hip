@@ -181,7 +181,7 @@ struct adsb_decoder {
     uint32_t reader_min_tiles = 1024; // launches below this many tiles are collected by the calling thread alone
     uint64_t last_launch_records = 0; // records the previous launch handed over (auto: the thread pays from kAutoReaderRecords on)
     bool no_streaming = false; // dbg.no_streaming: always collect after completion
-    uint64_t shard_head = 16384; // offsets of a resolved shard whose candidates are ALL kept for the stitcher (dbg.shard_head)
+    uint64_t shard_head = ADSB_SHARD_HEAD; // offsets of a resolved shard whose candidates are ALL kept for the stitcher (dbg.shard_head)
     int dbg_async = 0;         // tuning builds only (ADSB_DEBUG_ASYNC, tools/async_race.py): 1 = wait for every async copy,
                                // 2 = copies on the scan stream, 4 = tail copies not ordered before the next copy (the old race)
     // device-side visited-try count (scan_kernel.h TryCountArgs)
@@ -1550,8 +1550,12 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
                 if (hipSetDevice(d->device) != hipSuccess || hipHostMalloc(&tmp, bytes, hipHostMallocDefault) != hipSuccess)
                     return; // (best effort: the first push then pays what it always paid)
                 std::memset(tmp, 0, 4096);
-                if (hipMemcpyAsync(d->stage[0], tmp, bytes, hipMemcpyHostToDevice, d->stream) == hipSuccess)
-                    (void)hipStreamSynchronize(d->stream);
+                // into BOTH staging buffers: the first copy into the second one -- at the stream's first compaction, seven
+                // pushes into a 510 MiB file -- cost the C host program another 7 ms (profiles/r6_cli_timing.txt)
+                for (int i = 0; i < 2; i++)
+                    if (hipMemcpyAsync(d->stage[i], tmp, bytes, hipMemcpyHostToDevice, d->stream) != hipSuccess)
+                        break;
+                (void)hipStreamSynchronize(d->stream);
                 (void)hipHostFree(tmp);
             });
         } catch (...) { // no thread to be had: nothing is warmed

@@ -428,7 +428,7 @@ void run_shard(Worker &w, const Job &j, uint64_t piece)
     // (the two windows are scanned outside the shard's stream: before it starts, and after it has ended -- a stateless
     // scan does not touch the resolver, so the frames adsb_shard_end handed out stay where they are)
     if (j.stats) {
-        const uint64_t head_span = w.dbg.shard_head > 0 ? (uint64_t)w.dbg.shard_head : 16384;
+        const uint64_t head_span = w.dbg.shard_head > 0 ? (uint64_t)w.dbg.shard_head : ADSB_SHARD_HEAD;
         w.head_tries_end = std::min(j.g_end, j.g_begin + head_span + kHeadTryReach);
         if (window_tries(w, j, j.g_begin, w.head_tries_end, w.head_tries))
             return;

@@ -1036,11 +1036,13 @@ def run_shard(args, torch, capi, rank, world, fence):
         step()
     torch.cuda.synchronize()
     prof0 = [md.worker_profile(i) for i in range(len(plan))]
-    serial, stitch, workers = [], [], []
+    serial, stitch, workers, each = [], [], [], []
     t0 = time.perf_counter()
     raw = None
     for _ in range(args.steps):
+        ts0 = time.perf_counter()
         raw = step()
+        each.append(round((time.perf_counter() - ts0) * 1e3, 4))
         inf = md.info()
         serial.append(inf["serial_us"])
         stitch.append(inf["stitch_us"])
@@ -1102,6 +1104,7 @@ def run_shard(args, torch, capi, rank, world, fence):
                                   "the frames into one array (ts offsets applied on the way)",
                    "stitch_us": round(float(np.median(stitch)), 1),
                    "slowest_worker_ms": round(float(np.median(workers)), 4),
+                   "ms_each_step": each,
                    "deqframe_calls_walked": int(info["calls_walked"]), "deqframe_calls_jumped": int(info["calls_jumped"]),
                    "create_ms": round(info["create_ms"], 1),
                    "helper_threads": int(info.get("helper_threads", 0)),

@@ -25,7 +25,7 @@ typedef struct adsb_debug_config {
     int32_t no_streaming;     /* 1: every launch is collected after completion (no hand-off stream)                   */
     int32_t frames_cap;       /* collect_stats: accepted frames the upload buffers start with (regrow path)           */
     int32_t reader_min_tiles; /* host_threads >= 2: launches of at least this many tiles go through the reader thread */
-    int32_t shard_head;       /* resolved shards: offsets whose candidates are all kept for the stitcher (16384)      */
+    int32_t shard_head;       /* resolved shards: offsets whose candidates are all kept for the stitcher (ADSB_SHARD_HEAD) */
     int32_t passes;           /* passes per tile of every launch (2..32) instead of the cost model's choice           */
     int32_t stagger;          /* leading tiles of staggered size (scan_kernel.h tile_passes)                          */
     int32_t gang_min;         /* host_threads >= 3: batches of at least this many records go through the gang
@@ -116,6 +116,13 @@ int adsb_scan_shard_host(adsb_decoder *d, const uint16_t *host_samples, uint64_t
  * started at the shard's first offset, as if no frame of the previous shard reached into it -- and one rank only
  * repairs the seams, hands out per-shard ts offsets (demod.c:86,99) and applies the end-of-file horizon
  * (air.c:94-99).  No reference counterpart: the reference is one thread on one stream. */
+/* The head window of a shard: every CRC-valid candidate of its first ADSB_SHARD_HEAD offsets is kept for the stitcher, which
+ * re-runs the greedy chain from the true entry position over them until it accepts a candidate the shard's speculative chain
+ * accepted too.  16 384 until round 6; on a channel whose frames stand back to back (BASELINE configs[2]) two chains that
+ * entered a run of frames at different half-sample copies stay apart until a copy is missing or the run ends -- hundreds of
+ * frames -- and every seam of such a capture was undecidable (-3: the driver then decodes on ONE device).  262 144 offsets are
+ * 218 frame lengths; the cost is a few hundred candidates and one small stateless scan per shard. */
+#define ADSB_SHARD_HEAD 262144
 typedef struct adsb_shard_head {
     uint64_t g_begin, g_end; /* the offsets this shard owns                                                      */
     uint64_t n_frames;       /* speculative frames; their ts is LOCAL: g + 1 - (offsets jumped inside the shard) */

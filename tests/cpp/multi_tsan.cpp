@@ -218,7 +218,7 @@ static void fill_head(adsb_decoder *d, adsb_shard_head *head, size_t nf)
     head->g_end = d->g_end;
     head->n_frames = nf;
     head->n_head = d->hv.size();
-    head->head_end = std::min<uint64_t>(d->g_end, d->g_begin + 16384);
+    head->head_end = std::min<uint64_t>(d->g_end, d->g_begin + ADSB_SHARD_HEAD);
     head->skipped = d->res.skipped();
     if (d->bases_cap) {
         head->n_bases = d->res.walk_bases() <= d->bases_cap ? d->res.walk_bases() : 0;
@@ -239,7 +239,7 @@ static int resolve_shard(adsb_decoder *d, const uint16_t *x, uint64_t first, uin
     if (fake_scan(d, x, first, n, d->g_begin, d->g_end, d->cands, d->cfg.collect_stats ? &d->tries : nullptr))
         return -1;
     d->hv.clear();
-    d->res.start_chain(d->g_begin, std::min<uint64_t>(d->g_end, d->g_begin + 16384), &d->hv);
+    d->res.start_chain(d->g_begin, std::min<uint64_t>(d->g_end, d->g_begin + ADSB_SHARD_HEAD), &d->hv);
     d->bases_cap = (bases && bases_cap) ? bases_cap : 0;
     if (d->bases_cap)
         d->res.start_walk(d->g_begin, d->g_end, d->total, bases, bases_cap);

@@ -57,6 +57,10 @@ while [ $# -gt 0 ]; do
       run r6_bench_shard_file_fed_N1_512Mi --mode shard --shard-source file --steps 5 --warmup 1 --stats
       run r6_bench_shard_host_fed_4handles_512Mi --mode shard --gpus 4 --one-device-test --shard-source host --steps 5 --warmup 1 --stats
       run r6_bench_shard_file_fed_4handles_512Mi --mode shard --gpus 4 --one-device-test --shard-source file --steps 5 --warmup 1 --stats
+      run r6_bench_shard_dense10_1handle_512Mi --mode shard --dense10 --samples 536870912 --steps 10 --warmup 2 --stats
+      run r6_bench_shard_dense10_4handles_512Mi --mode shard --dense10 --samples 536870912 --gpus 4 --one-device-test --steps 10 --warmup 2 --stats
+      run r6_bench_shard_dense10_8handles_512Mi --mode shard --dense10 --samples 536870912 --gpus 8 --one-device-test --steps 10 --warmup 2 --stats
+      run r6_bench_shard_dense10_8handles_2Gi --mode shard --dense10 --gpus 8 --one-device-test --steps 5 --warmup 1 --stats --no-cpu-baseline
       run r6_bench_stream_N8_one_device_plumbing --gpus 8 --one-device-test --samples 67108864 --steps 10 --warmup 2 --no-extras
       ;;
     cli) { python - <<'PY'
