@@ -69,6 +69,7 @@ struct Fault { // test hooks: which device cannot be created, how many pushes a 
     std::atomic<int> hang_ms{0}; // a handle's SECOND push sleeps this long: a device that stops answering
 };
 Fault g_fault;
+std::atomic<int> g_gang_streams{0}, g_gang_shards{0}; // decodes whose frames went through a handle's gang (streams: decided ahead too)
 thread_local std::string g_err;
 thread_local std::mt19937 g_rng{std::random_device{}()};
 
@@ -95,7 +96,35 @@ struct adsb_decoder {
     std::vector<uint64_t> tries;
     int pushes_left = -1;
     int pushes = 0;
+    // cfg.host_threads >= 3: a gang of frame-writing threads of the handle's own (gang.hpp), like the real decoder's; the
+    // records then reach the resolver as tiles of a hand-off stream image (Resolver::advance_tiles: the product's dense path)
+    adsb::FormatGang *gang = nullptr;
+    std::vector<uint32_t> stream, t_start, t_count;
 };
+
+// The candidates of [g0, g1) as the image of a hand-off stream (scan_kernel_format.h): tiles of `per` offsets, a marker granule
+// and two granules per record.  g_rel is relative to g0.
+static uint32_t fake_tiles(adsb_decoder *d, uint64_t g0, uint64_t g1, uint32_t per)
+{
+    const uint32_t ntiles = (uint32_t)((g1 - g0 + per - 1) / per);
+    d->stream.clear();
+    d->t_start.assign(ntiles, 0);
+    d->t_count.assign(ntiles, 0);
+    size_t i = 0;
+    for (uint32_t t = 0; t < ntiles; t++) {
+        d->stream.insert(d->stream.end(), 4, 0xDEADBEEFu); // the marker granule
+        d->t_start[t] = (uint32_t)(d->stream.size() / 4);
+        for (; i < d->cands.size() && d->cands[i].g < g0 + (uint64_t)(t + 1) * per; i++) {
+            const adsb_candidate &c = d->cands[i];
+            uint32_t w[8] = {(uint32_t)(c.g - g0), c.pw, 0, 0, 0, 0, 0, 0};
+            std::memcpy(&w[2], c.frame, 14);
+            w[5] = (w[5] & 0xFFFFu) | ((uint32_t)c.len << 16) | ((uint32_t)(c.reserved & 1u) << 24);
+            d->stream.insert(d->stream.end(), w, w + 8);
+            d->t_count[t]++;
+        }
+    }
+    return ntiles;
+}
 
 static int dfail(adsb_decoder *d, const char *what)
 {
@@ -137,9 +166,24 @@ adsb_decoder *adsb_create(const adsb_config *cfg)
     d->device = cfg->device;
     d->pushes_left = fake::g_fault.push_budget.load();
     d->res.reset();
+    if (cfg->host_threads >= 3) {
+        d->gang = new adsb::FormatGang;
+        if (!d->gang->start(cfg->host_threads - 2)) {
+            delete d->gang;
+            d->gang = nullptr;
+        }
+    }
     return d;
 }
-void adsb_destroy(adsb_decoder *d) { delete d; }
+void adsb_destroy(adsb_decoder *d)
+{
+    if (d && d->gang) {
+        d->res.set_gang(nullptr);
+        d->gang->stop();
+        delete d->gang;
+    }
+    delete d;
+}
 const char *adsb_last_error(const adsb_decoder *d) { return d ? d->err.c_str() : fake::g_err.c_str(); }
 void *adsb_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 void adsb_host_free(void *p)
@@ -198,8 +242,28 @@ int adsb_finish(adsb_decoder *d)
     d->tries.clear();
     if (fake_scan(d, d->x.data(), 0, n, 0, n_off, d->cands, d->cfg.collect_stats ? &d->tries : nullptr))
         return -1;
-    d->res.feed(d->cands.data(), d->cands.size(), d->tries.data(), d->tries.size());
-    d->res.advance(2 * ((n + 3) / 4), n_off);
+    if (d->gang && !d->cfg.collect_stats && n_off) {
+        // the dense path of the real decoder: tiles of a stream image, every batch decided AHEAD by the gang and taken over by
+        // this thread, the frames written by the gang (decoder.hip slot_collect_streaming)
+        const uint32_t per = 12880, ntiles = fake_tiles(d, 0, n_off, per);
+        d->res.set_gang(d->gang, 1);
+        d->res.set_ahead_min_records(1);
+        d->gang->begin();
+        for (uint32_t t = 0; t < ntiles;) {
+            const uint32_t t1 = std::min<uint32_t>(ntiles, t + 1 + fake::g_rng() % 9);
+            d->res.speculate_tiles(d->stream.data(), d->t_start.data(), d->t_count.data(), t, t1, 0);
+            fake::jitter();
+            d->res.advance_tiles(d->stream.data(), d->t_start.data(), d->t_count.data(), t, t1, 0, 2 * ((n + 3) / 4),
+                                 std::min<uint64_t>(n_off, (uint64_t)t1 * per));
+            t = t1;
+        }
+        d->res.sync();
+        d->gang->end();
+        fake::g_gang_streams++;
+    } else {
+        d->res.feed(d->cands.data(), d->cands.size(), d->tries.data(), d->tries.size());
+        d->res.advance(2 * ((n + 3) / 4), n_off);
+    }
     d->finished = true;
     return 0;
 }
@@ -243,6 +307,29 @@ static int resolve_shard(adsb_decoder *d, const uint16_t *x, uint64_t first, uin
     d->bases_cap = (bases && bases_cap) ? bases_cap : 0;
     if (d->bases_cap)
         d->res.start_walk(d->g_begin, d->g_end, d->total, bases, bases_cap);
+    if (d->gang && !d->cfg.collect_stats && d->g_end > d->g_begin) {
+        // chain mode over tiles: this thread decides, the gang writes the frames (what a worker of the real driver does on
+        // a full channel)
+        const uint32_t per = 12880, ntiles = fake_tiles(d, d->g_begin, d->g_end, per);
+        d->res.set_gang(d->gang, 1);
+        d->gang->begin();
+        for (uint32_t t = 0; t < ntiles;) {
+            const uint32_t t1 = std::min<uint32_t>(ntiles, t + 1 + fake::g_rng() % 9);
+            d->res.capture_head_tiles(d->stream.data(), d->t_start.data(), d->t_count.data(), t, t1, d->g_begin);
+            d->res.advance_tiles(d->stream.data(), d->t_start.data(), d->t_count.data(), t, t1, d->g_begin, 0,
+                                 std::min<uint64_t>(d->g_end, d->g_begin + (uint64_t)t1 * per));
+            fake::jitter();
+            t = t1;
+        }
+        d->res.advance(0, d->g_end);
+        d->res.sync();
+        d->gang->end();
+        fake::g_gang_shards++;
+        const size_t nf = d->res.take(frames);
+        *head_cands = d->hv.empty() ? nullptr : d->hv.data();
+        fill_head(d, head, nf);
+        return 0;
+    }
     // records arrive in batches, as from a kernel that is still running
     size_t ci = 0, ti = 0;
     for (uint64_t g = d->g_begin; g < d->g_end;) {
@@ -427,6 +514,7 @@ int main(int argc, char **argv)
         adsb_config cfg;
         adsb_config_default(&cfg);
         cfg.collect_stats = stats;
+        cfg.host_threads = round % 4 == 1 ? 5 : 0; // a gang of three frame-writing threads per worker's handle now and then (never with the table: the fake counts tries in the resolver)
         cfg.stage_samples = round % 3 == 0 ? 1u << 17 : 0; // small pieces now and then
         std::vector<int> devs(workers);
         for (int i = 0; i < workers; i++)
@@ -589,7 +677,8 @@ int main(int argc, char **argv)
         std::this_thread::sleep_for(std::chrono::milliseconds(4500)); // the orphaned workers come back, free their handles and end
     }
     unlink(path);
-    printf("ok: %d sharded decodes (%d shards, %d fell back to one stream), streams and error paths; %d slices asked where they live\n", decodes,
-           shards, fallbacks, placements);
+    printf("ok: %d sharded decodes (%d shards, %d fell back to one stream), streams and error paths; %d slices asked where they live; "
+           "%d shards and %d streams through a handle's gang\n", decodes, shards, fallbacks, placements, fake::g_gang_shards.load(),
+           fake::g_gang_streams.load());
     return 0;
 }

@@ -50,3 +50,9 @@ def test_multi_gpu_driver_under_sanitizers(tmp_path, san):
     # adsb_multi_host_alloc + adsb_multi_worker_placement against a made-up two-node map (numa.cpp): where the kernel answers
     # the placement query at all, every slice was asked about and the answers were what a one-node machine must give
     assert "slices asked where they live" in out
+    # round 6: every fourth round gives the workers' handles a gang of frame-writing threads (cfg.host_threads = 5): shards in
+    # chain mode over tiles with the frames written by the gang, independent streams decided ahead by it -- several handles'
+    # gangs at work at once inside one driver
+    import re
+    m = re.search(r"(\d+) shards and (\d+) streams through a handle's gang", out)
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, out
