@@ -1511,19 +1511,21 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
     if (d->stage_cap < (1u << 16))
         d->stage_cap = 1u << 16;
 
-    std::thread warm; // cfg.warm_start: the process's first large host-to-device copy, made beside the rest of this function
+    std::thread warm, warm2; // cfg.warm_start: the process's first-use costs, paid beside the rest of this function
     struct JoinWarm {
-        std::thread &t;
-        ~JoinWarm()
+        std::thread &a, &b;
+        void join()
         {
-            if (t.joinable())
-                t.join();
+            if (a.joinable())
+                a.join();
+            if (b.joinable())
+                b.join();
         }
-    } join_warm{warm}; // (every way out of this function waits for it)
+        ~JoinWarm() { join(); }
+    } join_warm{warm, warm2}; // (every way out of this function waits for them)
     auto bail = [&](const char *what, hipError_t err) -> adsb_decoder * {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
-        if (warm.joinable())
-            warm.join();
+        join_warm.join();
         adsb_destroy(d);
         return nullptr;
     };
@@ -1570,6 +1572,22 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
             return bail("hipStreamCreate(copy)", e);
     if ((e = hipEventCreateWithFlags(&d->ev_tail, hipEventDisableTiming)) != hipSuccess)
         return bail("hipEventCreate(tail)", e);
+    if (cfg.warm_start) {
+        // ... and the first KERNEL on each copy stream: the staging buffer's first compaction puts the tail's copy kernel on
+        // one of them, and the first dispatch on a stream that has only ever carried copies took 7 ms in the middle of the C
+        // host program's pushes (profiles/r6_cli_timing.txt: push 7)
+        try {
+            warm2 = std::thread([d] {
+                if (hipSetDevice(d->device) != hipSuccess)
+                    return;
+                for (hipStream_t cs : d->copy_stream)
+                    (void)adsb::launch_copy_samples(d->stage[1] + 64, d->stage[1], 8, cs);
+                for (hipStream_t cs : d->copy_stream)
+                    (void)hipStreamSynchronize(cs);
+            });
+        } catch (...) {
+        }
+    }
     for (ScanSlot &sl : d->slots) {
         if ((e = hipMalloc(&sl.d_counters, adsb::kDevCounterWords * sizeof(uint32_t))) != hipSuccess)
             return bail("hipMalloc(counters)", e);
@@ -1638,8 +1656,7 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
         d->shard_head = (uint64_t)dbg.shard_head;
     d->dbg_async = tuning_env("ADSB_DEBUG_ASYNC") ? atoi(tuning_env("ADSB_DEBUG_ASYNC")) : 0;
     d->res.reset();
-    if (warm.joinable())
-        warm.join();
+    join_warm.join();
     return d;
 }
 

@@ -209,6 +209,7 @@ def test_shard_stream_primitives_equal_the_one_call_scan(capi, captures, torch_c
     total = x.size
     d1 = capi.Decoder(df18=True, collect_stats=True)
     d2 = capi.Decoder(df18=True, collect_stats=True, stage_samples=1 << 18)
+    every = None
     try:
         for p in capi.plan_shards(total, 5):
             cap = (p["g_end"] - p["g_begin"]) // 39780 + 8
@@ -231,13 +232,31 @@ def test_shard_stream_primitives_equal_the_one_call_scan(capi, captures, torch_c
             fp, cp = C.POINTER(capi.Frame)(), C.POINTER(capi.Candidate)()
             assert L.adsb_shard_end(d2._h, C.byref(h2), C.byref(fp), C.byref(cp)) == 0, L.adsb_last_error(d2._h)
             for k, _ in capi.ShardHead._fields_:
+                if k == "n_head":   # (see below: the two lists may differ in candidates no chain can reach)
+                    continue
                 v1, v2 = getattr(h1, k), getattr(h2, k)
                 assert (list(v1) == list(v2)) if k in ("tries", "ok") else (v1 == v2), (k, v1, v2)
             assert h1.n_frames > 50 and h1.has_tries == 1 and sum(h1.tries) > 0
             key = lambda f: (int(f.g), int(f.ts), int(f.pw), int(f.len), bytes(f.frame), int(f.reserved))
             assert [key(f1[i]) for i in range(h1.n_frames)] == [key(fp[i]) for i in range(h2.n_frames)]
+            # The head candidates are what the device's never-visited filter let through of the first ADSB_SHARD_HEAD (262 144)
+            # offsets, and that filter is conservative at tile starts: small pieces make other tiles than one launch does, so
+            # the two lists may differ -- in candidates that no chain can reach.  Both are ascending, lie inside the window, are
+            # CRC-valid candidates of the capture (the exhaustive list of a handle with all_candidates = 1), and hold every
+            # candidate either speculative chain accepted there.
             ckey = lambda c: (int(c.g), int(c.pw), int(c.len), bytes(c.frame))
-            assert [ckey(c1[i]) for i in range(h1.n_head)] == [ckey(cp[i]) for i in range(h2.n_head)]
+            hc1, hc2 = [ckey(c1[i]) for i in range(h1.n_head)], [ckey(cp[i]) for i in range(h2.n_head)]
+            if every is None:
+                d3 = capi.Decoder(df18=True, all_candidates=True)
+                cs, nc, _ = d3.scan_shard(t.data_ptr(), 0, total, 0, max(0, total // 2 - 1195), cand_cap=1 << 18)
+                every = {ckey(cs[i]) for i in range(nc)}
+                d3.close()
+            for hc in (hc1, hc2):
+                assert hc == sorted(hc) and all(p["g_begin"] <= c[0] < h1.head_end for c in hc) and set(hc) <= every
+                accepted = {(int(f1[i].g), int(f1[i].pw), int(f1[i].len), bytes(f1[i].frame)[: f1[i].len].ljust(14, b"\0")) for i in range(h1.n_frames)
+                            if f1[i].g < h1.head_end}
+                assert {(c[0], c[1], c[2], c[3][: c[2]].ljust(14, b"\0")) for c in hc} >= accepted
+            assert abs(h1.n_head - h2.n_head) <= max(8, h1.n_head // 8)
             assert list(b1[: h1.n_bases]) == list(b2[: h2.n_bases])
             # a shard stream refuses what belongs to an ordinary stream, and the other way round
             assert L.adsb_push(d2._h, x.ctypes.data, 8) != 0
