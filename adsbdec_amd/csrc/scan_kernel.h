@@ -78,9 +78,6 @@ struct ScanArgs {
     uint64_t g_end;      // one past the last offset
     int df18;            // demod.c:26
     int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
-    int reserved0;       // three members of round 3's experiments, kept as padding: with the kernel-argument layout
-    uint32_t reserved1;  // unchanged, the gfx950 code of scan_kernel<> is instruction for instruction what round 3
-    uint32_t *reserved2; // measured (profiles/r4_isa_identity.txt); removing them re-allocates every scalar register
     uint32_t stagger;    // the first `stagger` tiles take K-3..K passes in turn (tile_passes)
     int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
     int all_candidates;  // 1: emit every CRC-valid offset (no never-visited filter)
@@ -90,7 +87,9 @@ struct ScanArgs {
     // stream_granules(n) consecutive granules (whole 64-byte lines) with one atomicAdd on
     // counters[2] (so ranges appear in tile COMPLETION order) and writes
     //     marker  {tile, n | flags, check_lo, check_hi}
-    //     n x     {g_rel, pw, w0, w1} {w2, w3, 0, 0}            (ascending g_rel)
+    //     n x     {g_rel, pw, w0, w1} {w2, w3 | len << 16 | flags << 24, pw', pw''}   (ascending g_rel; pw', pw'': the copies'
+    //                                                                                pw of a record that stands for a run of copies:
+    //                                                                                scan_kernel_format.h)
     // Nothing orders these stores on their way to host memory, so the marker carries
     // marker_check() of the records: the host consumes a tile only when the marker and
     // the XOR of the 2n granules behind it agree (gen changes with every launch, so

@@ -103,7 +103,7 @@ def run(seconds: float, seed: int = 1, log=print):
 
     t0, it, frames_total, ref_checked, tight_runs = time.time(), 0, 0, 0, 0
     modes = [0] * 10
-    multis, multi_fallbacks = {}, [0]
+    multis, multi_fallbacks, multi_storms = {}, [0], [0]
     stitch_fallbacks = [0]
     reader_runs = 0
     storms = 0
@@ -128,6 +128,7 @@ def run(seconds: float, seed: int = 1, log=print):
         mode = int(rng.integers(0, 10))
         d = dec(df18, stats, fix, caps, overlap=(mode == 8))
         modes[mode] += 1
+        multi_storms[0] += int(stormy and mode == 9)
         reader_runs += int(getattr(d, "fuzz_reader", False))
         rng.integers(0, 3)     # (round 3 drew the scan kernel here; the draw stays so that a seed still means the same capture and mode)
         d.reset()
@@ -253,7 +254,7 @@ def run(seconds: float, seed: int = 1, log=print):
                                          device_split_unaligned=modes[3], shards=modes[4], host_push_async=modes[5],
                                          mixed_async_sync_device=modes[6], resolved_shards=modes[7], push_overlap=modes[8],
                                          multi_gpu_driver=modes[9]),
-                   multi_driver_fallbacks=multi_fallbacks[0],
+                   multi_driver_fallbacks=multi_fallbacks[0], multi_driver_captures_with_storms=multi_storms[0],
                    with_the_reader_thread=reader_runs, stitcher_fallbacks=stitch_fallbacks[0],
                    also_checked_against_real_reference_chain=ref_checked,
                    with_shrunken_record_buffers=tight_runs, with_frame_start_storms=storms,
