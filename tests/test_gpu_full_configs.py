@@ -266,7 +266,9 @@ def test_config2_dense_traffic_through_the_multi_gpu_driver(capi, oracle, torch_
     m = (64 << 20) - (64 << 20) % 28
     xs = [_host(make_dense10(torch_cuda, m, 140 + s)) for s in range(4)]
     wants = [oracle.decode(v, df18=True) for v in xs]
-    md = sharding.MultiDecoder(2, [0, 0], df18=True, collect_stats=True, host_threads=6)
+    # (a stream fed in 32 MiB pieces has launches of 8 Mi offsets: 64 tiles of them hold fewer than the 2 048 records from
+    # which a batch is decided ahead by default -- the knob makes every batch go that way, as on a resident 256 Mi-sample capture)
+    md = sharding.MultiDecoder(2, [0, 0], df18=True, collect_stats=True, host_threads=6, debug_gang_min=1)
     try:
         with capi.PinnedBuffers(4, m) as bufs:
             for s in range(4):

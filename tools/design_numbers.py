@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Regenerates the two measured tables of DESIGN.md (section 7 results, section 6 shard runs) from the files under profiles/,
-between the <!-- r5-...:begin/end --> markers: every number in them is read from a committed file, none is typed.
+between the <!-- r6-...:begin/end --> markers: every number in them is read from a committed file, none is typed.
 
     python tools/design_numbers.py          # rewrites DESIGN.md in place
 """
@@ -27,51 +27,57 @@ def frac(us):
 
 def results():
     import ast
-    fz = ast.literal_eval([ln for ln in open(P('r5_fuzz.txt')) if ln.startswith('fuzz ok: ')][-1][len('fuzz ok: '):].strip())
-    d, u, pmc = J("r5_bench.json"), J("r5_bench_under_rocprofv3.json"), J("r5_pmc.json")
-    dur, sdur = durations("r5_dispatches.csv"), durations("r5_stats_dispatches.csv")
+    fz = ast.literal_eval([ln for ln in open(P('r6_fuzz.txt')) if ln.startswith('fuzz ok: ')][-1][len('fuzz ok: '):].strip())
+    d, u, pmc = J("r6_bench.json"), J("r6_bench_under_rocprofv3.json"), J("r6_pmc.json")
+    dur, sdur = durations("r6_dispatches.csv"), durations("r6_stats_dispatches.csv")
     c = pmc["counters"]
     wc = c["SQ_WAVE_CYCLES"]["mean"]
-    cnt = [r for r in csv.reader(open(P("r5_stats_kernel_stats.csv"))) if "count_tries_kernel" in r[0]][0]
+    cnt = [r for r in csv.reader(open(P("r6_stats_kernel_stats.csv"))) if "count_tries_kernel" in r[0]][0]
     e, k = d["e2e_host_fed"], d["value_1000_steps"]
     sh, cli, dn = d["e2e_host_fed_sharded"], d["cli_whole_process"], d["dense"]
     x = cli.get("crossover") or {}
     files = " / ".join(f"{n}: {r['wall_ms']:.0f} ms against {r.get('reference_wall_ms', float('nan')):.0f} ms" for n, r in cli["files"].items())
     return f"""| what | value | file |
 |---|---|---|
-| `bench.py`, default line (one box) | **{d['value'] / 1e6:.3f} Tsamples/s**, {d['ms_per_step']:.4f} ms per 256 Mi-sample step; scan kernel {d['roofline']['launch_ms'] * 1e3:.1f} µs on its own clock = {d['roofline']['achieved']:.0f} GB/s = **{d['roofline']['frac']:.3f} of 8 TB/s** | `r5_bench.json` |
-| ... the same region with 1000 steps instead of the driver's 20 (`value_1000_steps`) | {k['value'] / 1e6:.3f} Tsamples/s, {k['ms_per_step']:.4f} ms per step, kernel {k['launch_ms'] * 1e3:.1f} µs = {k['roofline_frac']:.3f} | `r5_bench.json` |
-| the same command under `rocprofv3 --kernel-trace --stats`, 1000 timed steps (the same box, the same gpurun call) | `scan_kernel<false>`: {len(dur)} dispatches, average **{statistics.mean(dur):.1f} µs** (pre-roll and warm-up included) = {frac(statistics.mean(dur)):.3f}; last 1000: {statistics.mean(dur[-1000:]):.1f} µs = **{frac(statistics.mean(dur[-1000:])):.3f}**; minimum {min(dur):.1f} µs; the bench line of that very run read {u['roofline']['launch_ms'] * 1e3:.1f} µs in-kernel (1 % below the trace, as in every round) | `r5_kernel_stats.csv`, `r5_dispatches.csv`, `r5_bench_under_rocprofv3.json` |
-| spread of the kernel | box to box 0.132–0.148 ms (0.453–0.508) for the same command (rounds 3 to 5's boxes; the round-5 kernel is 0.85 % slower than round 4's on one box: `r5_ab_runs.txt` §6); on one box the 200 default steps read ≈ 3 % longer than 1000 steps right behind them (the clock governor is still ramping: rows 1 and 2) | `r3_ab_runs.txt`, `r4_ab_runs.txt`, `r5_ab_runs.txt` |
-| HBM traffic per launch | {pmc['hbm_bytes_per_launch'] / 1e6:.1f} MB = {pmc['hbm_bytes_per_launch'] / B:.3f} × the 536.9 MB of algorithmic input (FETCH_SIZE × 2 + WRITE_SIZE, separate passes) | `r5_pmc.json` |
-| VALU wave-instructions per launch | {c['SQ_INSTS_VALU']['mean'] / 1e6:.2f} M; Stage A's pass 661 instructions = 2 558 issue cycles (3.87 per instruction) | `r5_pmc.json`, `r5_isa_mix.json` |
-| wave time | issuing {c['SQ_ACTIVE_INST_ANY']['mean'] / wc * 100:.0f} %, stalled wanting to issue {c['SQ_WAIT_INST_ANY']['mean'] / wc * 100:.0f} %, parked on `s_waitcnt` / `s_barrier` {c['SQ_WAIT_ANY']['mean'] / wc * 100:.0f} % | `r5_pmc.json` |
-| with the Try/Ok table (`collect_stats=1`: what the drop-in runs) | {d['with_stats']['ms_per_step']:.4f} ms per step = **{d['with_stats']['value'] / 1e6:.3f} Tsamples/s** (`value_dropin`); under rocprofv3 `scan_kernel<true>` {statistics.mean(sdur[-1000:]):.1f} µs (last 1000 of {len(sdur)}), `count_tries_kernel` {float(cnt[3]) / 1e3:.1f} µs on its own stream | `r5_bench.json`, `r5_stats_kernel_stats.csv`, `r5_stats_dispatches.csv` |
-| dense, σ = 300 noise + one 112-bit frame per ms, `-a` (rounds 1–3's `configs[2]`) | {dn['noise']['plain']['ms_per_step']:.4f} ms per step, kernel {dn['noise']['plain']['launch_ms'] * 1e3:.1f} µs = {dn['noise']['plain']['roofline_frac']:.3f}; {dn['noise']['preamble_pass_fraction'] * 100:.2f} % of the offsets pass the preamble test, {dn['noise']['df_gate_pass_fraction_of_visited'] * 100:.3f} % the DF gate; with the table {dn['noise']['with_stats']['ms_per_step']:.4f} ms | `r5_bench.json` `dense.noise` |
-| dense, **`configs[2]` at its stated density** (112-bit frames packed back to back in σ = 300 noise, 3 % of the ms slots full of frame starts) | **{dn['target_10_percent']['preamble_pass_fraction'] * 100:.2f} %** of the offsets pass the preamble test; {dn['target_10_percent']['plain']['frames']} frames per step; {dn['target_10_percent']['plain']['ms_per_step']:.3f} ms per step = {dn['target_10_percent']['plain']['value'] / 1e3:.1f} Gsamples/s (kernel {dn['target_10_percent']['plain']['launch_ms']:.3f} ms: {dn['target_10_percent']['plain']['ms_per_step'] / dn['target_10_percent']['plain']['launch_ms']:.2f} × — the handle's reader thread and gang of four at work, see below); with the table {dn['target_10_percent']['with_stats']['ms_per_step']:.3f} ms; frames and table equal to the oracle's | `r5_bench.json` `dense.target_10_percent` |
-| adversarial: nothing but frame starts (`gate_storm`) | {dn['gate_storm']['preamble_pass_fraction'] * 100:.1f} % pass the preamble test, {dn['gate_storm']['df_gate_pass_fraction_of_visited'] * 100:.2f} % of ALL offsets the DF gate: every tile overflows its survivor queue; kernel {dn['gate_storm']['plain']['launch_ms']:.3f} ms = **{dn['gate_storm']['plain']['launch_ms'] / d['roofline']['launch_ms']:.1f} × the sparse launch**, step {dn['gate_storm']['plain']['ms_per_step']:.3f} ms; with the table step {dn['gate_storm']['with_stats']['ms_per_step']:.3f} ms (kernel {dn['gate_storm']['with_stats']['launch_ms']:.2f} ms, {dn['gate_storm']['with_stats']['relaunches']} relaunches); table equal to the oracle's | `r5_bench.json` `dense.gate_storm` |
-| cold (first steps after 0.5 s of idle) | {d['value_cold']['ms_each_step']} ms: only the FIRST step is slow; `value_cold` = {d['value_cold']['value'] / 1e6:.2f} Tsamples/s | `r5_bench.json` `value_cold` |
-| host-fed, PCIe-inclusive (never `value`) | 1 Mi-sample calls: `adsb_push` {e['push_1Mi_sync'] / 1e3:.1f}, with `push_overlap` {e['push_1Mi_overlap'] / 1e3:.1f}, `adsb_push_async` {e['push_1Mi_async'] / 1e3:.1f} GS/s; 16 Mi: {e['push_16Mi_sync'] / 1e3:.1f} / {e['push_16Mi_overlap'] / 1e3:.1f} / {e['push_16Mi_async'] / 1e3:.1f}; 1 / 2 / 4 streams on one GPU: {d['multi_stream_host_fed']['streams_1']['aggregate'] / 1e3:.1f} / {d['multi_stream_host_fed']['streams_2']['aggregate'] / 1e3:.1f} / {d['multi_stream_host_fed']['streams_4']['aggregate'] / 1e3:.1f} GS/s | `r5_bench.json` `e2e_host_fed`, `multi_stream_host_fed` |
-| the multi-GPU driver on ONE page-locked capture, Try/Ok table included, 1 / 2 / 4 handles on this one device (`e2e_host_fed_sharded`) | {sh['handles_1']['value'] / 1e3:.1f} / {sh['handles_2']['value'] / 1e3:.1f} / {sh['handles_4']['value'] / 1e3:.1f} GS/s (one link: plumbing, not scaling); calling thread's share {sh['handles_1']['serial_us']:.0f} / {sh['handles_2']['serial_us']:.0f} / {sh['handles_4']['serial_us']:.0f} µs per call | `r5_bench.json` |
-| the C host program, whole process, exec to exit, against the reference's wall time on the same file | {files}; below **{x.get('samples', 0) / 1e6:.0f} M samples ({x.get('file_MB', 0)} MB, {x.get('seconds_of_signal', 0)} s of signal) the reference's one CPU thread finishes first** (start-up {x.get('startup_ms', 0):.0f} ms, then {x.get('gpu_ms_per_Mi_samples', 0):.2f} against {x.get('reference_ms_per_Mi_samples', 0):.2f} ms per Mi samples); every device visible to the runtime: {cli['largest_file_all_devices_visible']['runtime_init_ms']:.0f} ms of runtime start against {cli['runtime_init_ms']:.0f} (a one-GPU box: no difference to see); `-G 0,0`: {cli['largest_file_G_0_0']['wall_ms']:.0f} ms | `r5_bench.json` `cli_whole_process` |
-| CPU beside it (the REAL reference chain, 1 core, EPYC 9575F) | {d['cpu_baseline']['value']:.0f} Msamples/s (the oracle's restatement: {d['cpu_baseline']['port_value']:.0f}) | `r5_bench.json` `cpu_baseline` |
-| fuzz | {fz['seconds']:.0f} s, {fz['captures']} random captures ({fz.get('with_frame_start_storms', 0)} with stretches of nothing but frame starts, {fz['with_shrunken_record_buffers']} on handles with shrunken record buffers, {fz['also_checked_against_real_reference_chain']} also against the real reference chain) over ten feeding modes (the multi-GPU driver and resolved shards with statistics among them), {fz['frames']} frames: {fz['mismatches']} mismatches | `r5_fuzz.txt` |"""
+| `bench.py`, default line (one box) | **{d['value'] / 1e6:.3f} Tsamples/s**, {d['ms_per_step']:.4f} ms per 256 Mi-sample step; scan kernel {d['roofline']['launch_ms'] * 1e3:.1f} µs on its own clock = {d['roofline']['achieved']:.0f} GB/s = **{d['roofline']['frac']:.3f} of 8 TB/s** | `r6_bench.json` |
+| ... the same region with 1000 steps instead of the driver's 20 (`value_1000_steps`) | {k['value'] / 1e6:.3f} Tsamples/s, {k['ms_per_step']:.4f} ms per step, kernel {k['launch_ms'] * 1e3:.1f} µs = {k['roofline_frac']:.3f} | `r6_bench.json` |
+| the same command under `rocprofv3 --kernel-trace --stats`, 1000 timed steps (the same box, the same gpurun call) | `scan_kernel<false>`: {len(dur)} dispatches, average **{statistics.mean(dur):.1f} µs** (pre-roll and warm-up included) = {frac(statistics.mean(dur)):.3f}; last 1000: {statistics.mean(dur[-1000:]):.1f} µs = **{frac(statistics.mean(dur[-1000:])):.3f}**; minimum {min(dur):.1f} µs; the bench line of that very run read {u['roofline']['launch_ms'] * 1e3:.1f} µs in-kernel (1 % below the trace, as in every round) | `r6_kernel_stats.csv`, `r6_dispatches.csv`, `r6_bench_under_rocprofv3.json` |
+| spread of the kernel | box to box 0.132–0.148 ms (0.453–0.508) for the same command over rounds 3 to 6's boxes; same-box against round 5's library: **−1.8 %** (three boxes, `r6_ab_runs.txt`); on one box the 200 default steps read ≈ 3 % longer than 1000 steps right behind them (the clock governor is still ramping: rows 1 and 2) | `r3_ab_runs.txt` … `r6_ab_runs.txt` |
+| HBM traffic per launch | {pmc['hbm_bytes_per_launch'] / 1e6:.1f} MB = {pmc['hbm_bytes_per_launch'] / B:.3f} × the 536.9 MB of algorithmic input (FETCH_SIZE × 2 + WRITE_SIZE, separate passes) | `r6_pmc.json` |
+| VALU wave-instructions per launch | {c['SQ_INSTS_VALU']['mean'] / 1e6:.2f} M; Stage A's pass 661 instructions = 2 558 issue cycles (3.87 per instruction) | `r6_pmc.json`, `r6_isa_mix.json` |
+| wave time | issuing {c['SQ_ACTIVE_INST_ANY']['mean'] / wc * 100:.0f} %, stalled wanting to issue {c['SQ_WAIT_INST_ANY']['mean'] / wc * 100:.0f} %, parked on `s_waitcnt` / `s_barrier` {c['SQ_WAIT_ANY']['mean'] / wc * 100:.0f} % | `r6_pmc.json` |
+| with the Try/Ok table (`collect_stats=1`: what the drop-in runs) | {d['with_stats']['ms_per_step']:.4f} ms per step = **{d['with_stats']['value'] / 1e6:.3f} Tsamples/s** (`value_dropin`); under rocprofv3 `scan_kernel<true>` {statistics.mean(sdur[-1000:]):.1f} µs (last 1000 of {len(sdur)}), `count_tries_kernel` {float(cnt[3]) / 1e3:.1f} µs on its own stream | `r6_bench.json`, `r6_stats_kernel_stats.csv`, `r6_stats_dispatches.csv` |
+| dense, σ = 300 noise + one 112-bit frame per ms, `-a` (rounds 1–3's `configs[2]`) | {dn['noise']['plain']['ms_per_step']:.4f} ms per step, kernel {dn['noise']['plain']['launch_ms'] * 1e3:.1f} µs = {dn['noise']['plain']['roofline_frac']:.3f}; {dn['noise']['preamble_pass_fraction'] * 100:.2f} % of the offsets pass the preamble test, {dn['noise']['df_gate_pass_fraction_of_visited'] * 100:.3f} % the DF gate; with the table {dn['noise']['with_stats']['ms_per_step']:.4f} ms | `r6_bench.json` `dense.noise` |
+| dense, **`configs[2]` at its stated density** (112-bit frames packed back to back in σ = 300 noise, 3 % of the ms slots full of frame starts) | **{dn['target_10_percent']['preamble_pass_fraction'] * 100:.2f} %** of the offsets pass the preamble test; {dn['target_10_percent']['plain']['frames']} frames per step; {dn['target_10_percent']['plain']['ms_per_step']:.3f} ms per step = {dn['target_10_percent']['plain']['value'] / 1e3:.1f} Gsamples/s (kernel {dn['target_10_percent']['plain']['launch_ms']:.3f} ms: {dn['target_10_percent']['plain']['ms_per_step'] / dn['target_10_percent']['plain']['launch_ms']:.2f} × — the handle's reader thread and gang of four at work, see below); with the table {dn['target_10_percent']['with_stats']['ms_per_step']:.3f} ms; frames and table equal to the oracle's | `r6_bench.json` `dense.target_10_percent` |
+| ... the same capture as the MAIN workload under `rocprofv3` (`bench.py --dense10`, 1000 steps) | `scan_kernel<false>` average **{statistics.mean(durations("r6_dense10_dispatches.csv")):.1f} µs** = {frac(statistics.mean(durations("r6_dense10_dispatches.csv"))):.3f}; VALU wave-instructions {J("r6_dense10_pmc.json")["counters"]["SQ_INSTS_VALU"]["mean"] / 1e6:.1f} M per launch (sparse: {c['SQ_INSTS_VALU']['mean'] / 1e6:.1f} M), HBM traffic {J("r6_dense10_pmc.json")["hbm_bytes_per_launch"] / B:.3f} × algorithmic; with the table `scan_kernel<true>` {statistics.mean(durations("r6_dense10_stats_dispatches.csv")):.1f} µs, `count_tries_kernel` {float([r for r in csv.reader(open(P("r6_dense10_stats_kernel_stats.csv"))) if "count_tries_kernel" in r[0]][0][3]) / 1e3:.1f} µs | `r6_dense10_*`, `r6_dense10_stats_*` |
+| adversarial: nothing but frame starts (`gate_storm`) | {dn['gate_storm']['preamble_pass_fraction'] * 100:.1f} % pass the preamble test, {dn['gate_storm']['df_gate_pass_fraction_of_visited'] * 100:.2f} % of ALL offsets the DF gate: every tile overflows its survivor queue; kernel {dn['gate_storm']['plain']['launch_ms']:.3f} ms = **{dn['gate_storm']['plain']['launch_ms'] / d['roofline']['launch_ms']:.1f} × the sparse launch**, step {dn['gate_storm']['plain']['ms_per_step']:.3f} ms; with the table step {dn['gate_storm']['with_stats']['ms_per_step']:.3f} ms (kernel {dn['gate_storm']['with_stats']['launch_ms']:.2f} ms, {dn['gate_storm']['with_stats']['relaunches']} relaunches); table equal to the oracle's | `r6_bench.json` `dense.gate_storm` |
+| ... under `rocprofv3` (`bench.py --gate-storm`) | `scan_kernel<false>` average {statistics.mean(durations("r6_storm_dispatches.csv")):.1f} µs, VALU {J("r6_storm_pmc.json")["counters"]["SQ_INSTS_VALU"]["mean"] / 1e6:.1f} M; with the table `scan_kernel<true>` {statistics.mean(durations("r6_storm_stats_dispatches.csv")):.1f} µs and `count_tries_kernel` **{float([r for r in csv.reader(open(P("r6_storm_stats_kernel_stats.csv"))) if "count_tries_kernel" in r[0]][0][3]) / 1e3:.1f} µs** (round 5's build: 479 µs, `r5build_storm_stats_kernel_stats.csv`) | `r6_storm_*`, `r6_storm_stats_*` |
+| cold (first steps after 0.5 s of idle) | {d['value_cold']['ms_each_step']} ms: only the FIRST step is slow; `value_cold` = {d['value_cold']['value'] / 1e6:.2f} Tsamples/s | `r6_bench.json` `value_cold` |
+| host-fed, PCIe-inclusive (never `value`) | 1 Mi-sample calls: `adsb_push` {e['push_1Mi_sync'] / 1e3:.1f}, with `push_overlap` {e['push_1Mi_overlap'] / 1e3:.1f}, `adsb_push_async` {e['push_1Mi_async'] / 1e3:.1f} GS/s; 16 Mi: {e['push_16Mi_sync'] / 1e3:.1f} / {e['push_16Mi_overlap'] / 1e3:.1f} / {e['push_16Mi_async'] / 1e3:.1f}; 1 / 2 / 4 streams on one GPU: {d['multi_stream_host_fed']['streams_1']['aggregate'] / 1e3:.1f} / {d['multi_stream_host_fed']['streams_2']['aggregate'] / 1e3:.1f} / {d['multi_stream_host_fed']['streams_4']['aggregate'] / 1e3:.1f} GS/s | `r6_bench.json` `e2e_host_fed`, `multi_stream_host_fed` |
+| the multi-GPU driver on ONE page-locked capture, Try/Ok table included, 1 / 2 / 4 handles on this one device (`e2e_host_fed_sharded`) | {sh['handles_1']['value'] / 1e3:.1f} / {sh['handles_2']['value'] / 1e3:.1f} / {sh['handles_4']['value'] / 1e3:.1f} GS/s (one link: plumbing, not scaling); calling thread's share {sh['handles_1']['serial_us']:.0f} / {sh['handles_2']['serial_us']:.0f} / {sh['handles_4']['serial_us']:.0f} µs per call | `r6_bench.json` |
+| the C host program, whole process, exec to exit, against the reference's wall time on the same file | {files}; below **{x.get('samples', 0) / 1e6:.0f} M samples ({x.get('file_MB', 0)} MB, {x.get('seconds_of_signal', 0)} s of signal) the reference's one CPU thread finishes first** (start-up {x.get('startup_ms', 0):.0f} ms, then {x.get('gpu_ms_per_Mi_samples', 0):.2f} against {x.get('reference_ms_per_Mi_samples', 0):.2f} ms per Mi samples); every device visible to the runtime: {cli['largest_file_all_devices_visible']['runtime_init_ms']:.0f} ms of runtime start against {cli['runtime_init_ms']:.0f} (a one-GPU box: no difference to see); `-G 0,0`: {cli['largest_file_G_0_0']['wall_ms']:.0f} ms | `r6_bench.json` `cli_whole_process` |
+| CPU beside it (the REAL reference chain, 1 core, EPYC 9575F) | {d['cpu_baseline']['value']:.0f} Msamples/s (the oracle's restatement: {d['cpu_baseline']['port_value']:.0f}) | `r6_bench.json` `cpu_baseline` |
+| fuzz | {fz['seconds']:.0f} s, {fz['captures']} random captures ({fz.get('with_frame_start_storms', 0)} with stretches of nothing but frame starts, {fz['with_shrunken_record_buffers']} on handles with shrunken record buffers, {fz['also_checked_against_real_reference_chain']} also against the real reference chain) over ten feeding modes (the multi-GPU driver and resolved shards with statistics among them), {fz['frames']} frames: {fz['mismatches']} mismatches | `r6_fuzz.txt` |"""
 
 
 def shards():
     rows = []
-    for name, label in (("r5_bench_shard_N1_2Gi", "1 handle, 2 Gi samples resident in HBM"),
-                        ("r5_bench_shard_N1_2Gi_stats", "... with the Try/Ok table"),
-                        ("r5_bench_shard_8handles_one_device_2Gi", "8 handles on ONE device, 2 Gi samples resident, Try/Ok table"),
-                        ("r5_bench_shard_host_fed_N1_512Mi", "1 handle, 512 Mi samples in page-locked host memory placed by `adsb_multi_host_alloc`, Try/Ok table"),
-                        ("r5_bench_shard_file_fed_N1_512Mi", "1 handle, the capture as a tmpfs file (eight helper threads read ahead into a page-locked ring)"),
-                        ("r5_bench_shard_host_fed_4handles_512Mi", "4 handles on ONE device (one link), the capture in host memory"),
-                        ("r5_bench_shard_file_fed_4handles_512Mi", "4 handles, the capture as a tmpfs file")):
+    for name, label in (("r6_bench_shard_N1_2Gi", "1 handle, 2 Gi samples resident in HBM"),
+                        ("r6_bench_shard_N1_2Gi_stats", "... with the Try/Ok table"),
+                        ("r6_bench_shard_8handles_one_device_2Gi", "8 handles on ONE device, 2 Gi samples resident, Try/Ok table"),
+                        ("r6_bench_shard_host_fed_N1_512Mi", "1 handle, 512 Mi samples in page-locked host memory placed by `adsb_multi_host_alloc`, Try/Ok table"),
+                        ("r6_bench_shard_file_fed_N1_512Mi", "1 handle, the capture as a tmpfs file (eight helper threads read ahead into a page-locked ring)"),
+                        ("r6_bench_shard_host_fed_4handles_512Mi", "4 handles on ONE device (one link), the capture in host memory"),
+                        ("r6_bench_shard_file_fed_4handles_512Mi", "4 handles, the capture as a tmpfs file"),
+                        ("r6_bench_shard_dense10_1handle_512Mi", "**configs[4] × configs[2]**: 1 handle, 512 Mi samples of a full channel (112-bit frames back to back) resident in HBM, Try/Ok table"),
+                        ("r6_bench_shard_dense10_4handles_512Mi", "... 4 handles on ONE device"),
+                        ("r6_bench_shard_dense10_8handles_512Mi", "... 8 handles on ONE device"),
+                        ("r6_bench_shard_dense10_8handles_2Gi", "... 8 handles on ONE device, 2 Gi samples (850 k frames)")):
         j = J(name + ".json")
         c = j["config"]
         rows.append(f"| {label} | {j['ms_per_step']:.3f} | {j['value'] / 1e3:.1f} | {c['slowest_worker_ms']:.3f} ms | {c['serial_us']:.0f} µs (stitch {c['stitch_us']:.0f}) | "
                     f"{c['deqframe_calls_walked']} / {c['deqframe_calls_jumped']} | {c['frames_decoded']} frames; {c['parity']} |")
-    st8 = J("r5_bench_stream_N8_one_device_plumbing.json")
+    st8 = J("r6_bench_stream_N8_one_device_plumbing.json")
     rows.append(f"| `configs[3]` in the driver's command shape: 8 PROCESSES on one device, 64 Mi samples each (`bench.py --gpus 8 --one-device-test`) | {st8['ms_per_step']:.3f} | "
                 f"{st8['value'] / 1e3:.1f} | — | — | — | every one of the {st8['config']['ranks_gated']} ranks gated against the oracle |")
     return ("| run (`bench.py --mode shard`, one process) | ms per call | Gsamples/s | slowest worker | calling thread behind it | deqframe calls walked / jumped | parity |\n"
@@ -79,18 +85,18 @@ def shards():
 
 
 def file_source():
-    h1, f1 = J("r5_bench_shard_host_fed_N1_512Mi.json"), J("r5_bench_shard_file_fed_N1_512Mi.json")
-    h4, f4 = J("r5_bench_shard_host_fed_4handles_512Mi.json"), J("r5_bench_shard_file_fed_4handles_512Mi.json")
+    h1, f1 = J("r6_bench_shard_host_fed_N1_512Mi.json"), J("r6_bench_shard_file_fed_N1_512Mi.json")
+    h4, f4 = J("r6_bench_shard_host_fed_4handles_512Mi.json"), J("r6_bench_shard_file_fed_4handles_512Mi.json")
     return (f"**{f1['value'] / 1e3:.1f} of the host source's {h1['value'] / 1e3:.1f} Gsamples/s with one handle ({f1['value'] / h1['value']:.2f}), "
             f"{f4['value'] / 1e3:.1f} of {h4['value'] / 1e3:.1f} with four on the one link ({f4['value'] / h4['value']:.2f})** "
-            "(`profiles/r5_bench_shard_file_fed_*`, `…host_fed_*`: one box, one call; run to run the file source spreads by 10 %, `r5_file_readers.txt`)")
+            "(`profiles/r6_bench_shard_file_fed_*`, `…host_fed_*`: one box, one call; run to run the file source spreads by 10 %, `r5_file_readers.txt`)")
 
 
 def main():
     path = os.path.join(ROOT, "DESIGN.md")
     t = open(path).read()
     for tag, text in (("results", results()), ("shards", shards()), ("file", file_source())):
-        a, b = f"<!-- r5-{tag}:begin -->", f"<!-- r5-{tag}:end -->"
+        a, b = f"<!-- r6-{tag}:begin -->", f"<!-- r6-{tag}:end -->"
         assert a in t and b in t, tag
         t = t[: t.index(a) + len(a)] + "\n" + text + "\n" + t[t.index(b):]
     open(path, "w").write(t)
