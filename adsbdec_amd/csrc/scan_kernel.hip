@@ -1176,6 +1176,9 @@ constexpr int kCountThreads = 256;
 // blocks 0.149 ms and the statistics step 2 % less; with 16 the pass itself (0.33 ms) became the step, and with 64 a stream of
 // eight launches (2 Gi samples) ended 0.3 ms later, its passes queued up behind the scans (profiles/r4_ab_runs.txt section 8).
 constexpr int kCountRegionGrid = 256;
+// (32 VGPRs: what five resident scan waves of 96 leave free on a SIMD of 512.  Round 6's first version of the four-words-per-lane
+// loop took 40 and no longer fitted beside the scan it runs next to: the pass took 72 us instead of 53 on the sparse capture and
+// the scan beside it 3 % longer -- profiles/r6_ab_runs.txt section 5.)
 __global__ __launch_bounds__(kCountThreads) void count_tries_kernel(const TryCountArgs a)
 {
     uint32_t cnt[3] = {0, 0, 0};
@@ -1220,27 +1223,31 @@ __global__ __launch_bounds__(kCountThreads) void count_tries_kernel(const TryCou
             const uint32_t w = (uint32_t)__popcll(__ballot(have));
             const bool fits = w < 64u || lo + 64u >= a.n_frames || a.frames[lo + 64u].g >= t1; // wave-uniform
             const uint32_t *reg = a.regions + (size_t)tile * kTryRegion;
-            // Four tries per lane and round: the four loads are in flight together (a region of the adversarial capture holds
-            // 3 600 words: one load per round and lane was 57 dependent round trips per tile), and a broadcast of the window
-            // serves four comparisons.
-            for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
-                uint32_t word[4];
-                bool live[4];
+            const uint32_t base_minus_key = (uint32_t)(a.g_base - key); // (mod 2^32: key may lie up to 1199 offsets below the launch's base)
+            const uint32_t hi_rel = a.hi <= a.g_base ? 0u : (uint32_t)std::min<uint64_t>(a.hi - a.g_base, 0xFFFFFFFFull); // tries at or beyond are carried
+            // kW tries per lane and round: the loads are in flight together (a region of the adversarial capture holds 3 600
+            // words: one load per round and lane was 57 dependent round trips per tile), and a broadcast of the window serves kW
+            // comparisons.  kW = 2, not 4: the pass has to fit the 32 registers that five resident scan waves leave free on a SIMD
+            // (with 4 it took 40, ran 72 us instead of 53 on the sparse capture and cost the scan beside it 3 %).
+            constexpr int kW = 2;
+            for (uint32_t i0 = 0; i0 < n; i0 += 64u * kW) {
+                uint32_t word[kW];
+                bool live[kW];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < kW; u++) {
                     const uint32_t i = i0 + 64u * (uint32_t)u + lane;
                     live[u] = i < n;
                     word[u] = live[u] ? reg[i] : 0u;
                 }
-                uint64_t g[4];
-                uint32_t rt[4];
-                bool shadowed[4] = {false, false, false, false};
+                // (32-bit arithmetic relative to the launch's base and to the window's key: the pass has 32 registers)
+                uint32_t rt[kW];
+                bool shadowed[kW] = {};
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    g[u] = a.g_base + (word[u] >> 2);
-                    rt[u] = (uint32_t)(g[u] - key); // (only looked at for tries below a.hi: those lie inside the tile)
-                    if (live[u] && g[u] >= a.hi) {
-                        carry(g[u], word[u] & 3u);
+                for (int u = 0; u < kW; u++) {
+                    const uint32_t gr = word[u] >> 2;
+                    rt[u] = gr + base_minus_key; // (only looked at for tries below a.hi: those lie inside the tile)
+                    if (live[u] && gr >= hi_rel) {
+                        carry(a.g_base + gr, word[u] & 3u);
                         live[u] = false;
                     }
                 }
@@ -1248,16 +1255,16 @@ __global__ __launch_bounds__(kCountThreads) void count_tries_kernel(const TryCou
                     for (uint32_t j = 0; j < w; j++) { // (w is wave-uniform)
                         const uint32_t fj = __builtin_amdgcn_readlane(fr, j), ej = __builtin_amdgcn_readlane(fe, j);
 #pragma unroll
-                        for (int u = 0; u < 4; u++)
+                        for (int u = 0; u < kW; u++)
                             shadowed[u] |= fj < rt[u] && rt[u] < ej;
                     }
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        shadowed[u] = live[u] && try_shadowed(a, g[u]);
+                    for (int u = 0; u < kW; u++)
+                        shadowed[u] = live[u] && try_shadowed(a, a.g_base + (word[u] >> 2));
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < kW; u++)
                     if (live[u] && !shadowed[u]) {
                         const uint32_t code = word[u] & 3u;
                         cnt[code < 3 ? code : 2]++;

@@ -47,6 +47,10 @@ def test_no_scratch_and_gfx950_only(isa):
         assert int(size) == 0, f"{name} spills to scratch"
     for name, vgprs in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", isa):
         assert int(vgprs) <= 96, (name, vgprs)
+        # the try-count pass runs BESIDE the next scan: five scan waves of 96 VGPRs leave 32 of a SIMD's 512 free (round 6's
+        # first four-words-per-lane version took 40 and did not fit: +36 % pass time, +3 % on the scan beside it)
+        if "count_tries_kernel" in name:
+            assert int(vgprs) <= 32, (name, vgprs)
 
 
 def test_shipped_library_reads_no_environment():

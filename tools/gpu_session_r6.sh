@@ -74,6 +74,38 @@ PY
            echo "-G 1"; for i in 1 2 3; do ADSB_CLI_TIMING=1 adsbdec_amd/lib/adsbdec_amd_cli -G 1 -f /dev/shm/r6_cap.u16 2>&1 >/dev/null | grep timing; done
            echo "-G 0,0"; for i in 1 2 3; do ADSB_CLI_TIMING=1 adsbdec_amd/lib/adsbdec_amd_cli -G 0,0 -f /dev/shm/r6_cap.u16 2>&1 >/dev/null | grep timing; done
            rm -f /dev/shm/r6_cap.u16; } > $O/r6_cli.txt 2>&1; grep timing $O/r6_cli.txt;;
+    clitrace) { python - <<'PY'
+import numpy as np
+rng = np.random.default_rng(5)
+x = (2048 + rng.normal(0, 20, 255 << 20)).clip(0, 4095).astype(np.uint16)
+x.tofile("/dev/shm/r6_cap.u16")
+PY
+           cd /tmp; rm -rf /tmp/clitrace; timeout 300 rocprofv3 --hip-runtime-trace --kernel-trace --memory-copy-trace --output-format csv -d /tmp/clitrace -o run -- $OLDPWD/adsbdec_amd/lib/adsbdec_amd_cli -f /dev/shm/r6_cap.u16 > /dev/null 2> /tmp/clitrace.err; cd $OLDPWD
+           python - <<'PY'
+import csv, glob
+rows = []
+for f in glob.glob("/tmp/clitrace/**/*hip_api_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Function"]))
+rows.sort()
+t0 = rows[0][0] if rows else 0
+print("HIP calls longer than 0.4 ms (start ms, duration ms, call), and every call between 300 ms and the end that follows a hipMemcpyAsync:")
+for a, b, f in rows:
+    if b - a > 400000:
+        print(f"  {(a - t0) / 1e6:9.2f} ms  {(b - a) / 1e6:8.2f} ms  {f}")
+kr = []
+for f in glob.glob("/tmp/clitrace/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        kr.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:40]))
+for f in glob.glob("/tmp/clitrace/**/*memory_copy_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        kr.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r.get("Direction", "")))
+kr.sort()
+print("device timeline (start ms, duration ms):")
+for a, b, n in kr[:120]:
+    print(f"  {(a - t0) / 1e6:9.2f} ms  {(b - a) / 1e6:8.3f} ms  {n}")
+PY
+           rm -f /dev/shm/r6_cap.u16; } > $O/r6_cli_trace.txt 2>&1; head -60 $O/r6_cli_trace.txt;;
     fuzz) shift; FZ=${1:-300}; timeout $((FZ + 300)) python tools/fuzz_parity.py --seconds $FZ --seed 960000 > $O/r6_fuzz.txt 2>&1; echo "fuzz exit $?"; tail -2 $O/r6_fuzz.txt | cut -c1-900;;
   esac
   shift
