@@ -38,7 +38,7 @@ while [ $# -gt 0 ]; do
             if [ $v = tree ]; then unset ADSB_LIB_PATH; else export ADSB_LIB_PATH=$PWD/adsbdec_amd/lib_ab/$v/libadsbdec_amd.so; fi
             echo "== $v (rep $rep): bench.py --steps 1000 --no-extras --no-cpu-baseline"; bench_line
             echo "== $v (rep $rep): --dense10"; bench_line --dense10
-            if [ "$AB_SHORT" = 2 ]; then echo "== $v (rep $rep): --stats"; bench_line --stats; fi
+            if [ "$AB_SHORT" = 2 ] || [ -z "$AB_SHORT" ]; then echo "== $v (rep $rep): --stats"; bench_line --stats; fi
             if [ -z "$AB_SHORT" ]; then
             echo "== $v (rep $rep): --dense10 --stats"; bench_line --dense10 --stats
             echo "== $v (rep $rep): --gate-storm"; bench_line --gate-storm --steps 300
