@@ -218,6 +218,11 @@ public:
         }
         advance(power_samples, g_complete);
         if (a.posted) {
+            // (a chain whose position already lies beyond this batch never enters the call that would have waited for it:
+            // the arena must not be unpinned under a thread that is still writing the batch's decisions)
+            for (uint32_t spins = 1; a.n.load(std::memory_order_acquire) < 0; spins++)
+                if (!gang_ || !gang_->help())
+                    FormatGang::relax(spins);
             ahead_now_ = nullptr;
             a.posted = false;
             arena_pins_--;
@@ -669,7 +674,7 @@ private:
     void run_calls_tiles(uint64_t power_samples, uint64_t g_complete, uint64_t single_limit)
     {
         if (ahead_now_) {
-            run_calls_tiles_ahead(power_samples, g_complete);
+            run_calls_tiles_ahead(power_samples, g_complete, single_limit);
             return;
         }
         Batch &b = batch_;
@@ -813,11 +818,14 @@ private:
 public:
     static constexpr size_t kAheadMinRecords = 2048;
     // Tiles [t0, t1) will be handed to advance_tiles() later, behind the batches posted before (at most kAheadSlots wait): have
-    // them decided ahead.  Returns false if that is not to be had (no gang, a chain, a small batch): advance_tiles() then decides itself.
+    // them decided ahead.  Returns false if that is not to be had (no gang, a small batch): advance_tiles() then decides itself.
     bool speculate_tiles(const uint32_t *stream, const uint32_t *starts, const uint32_t *counts, uint32_t t0, uint32_t t1, uint64_t g_base)
     {
         Ahead &a = ahead_[ahead_tail_ % kAheadSlots];
-        if (!gang_ || chain_ || w_on_ || head_ || ahead_tail_ - ahead_head_ == kAheadSlots)
+        // (round 6: a chain -- a shard of the multi-GPU driver -- is decided ahead too: it is the simpler case, one call without
+        // a pattern of calls; its walk of the deqframe calls and its head candidates ride on emit() and on capture_head_tiles(),
+        // not on the deciding loop)
+        if (!gang_ || ahead_tail_ - ahead_head_ == kAheadSlots)
             return false;
         size_t records = 0;
         for (uint32_t u = t0; u < t1; u++)
@@ -889,7 +897,9 @@ private:
         j = i;
     }
 
-    void run_calls_tiles_ahead(uint64_t power_samples, uint64_t g_complete)
+    // (single_limit != 0: chain mode -- ONE call with that limit, as in run_calls_tiles; adopt_calls then finds no further call
+    // to open: power_samples is 0 there)
+    void run_calls_tiles_ahead(uint64_t power_samples, uint64_t g_complete, uint64_t single_limit)
     {
         Batch &b = batch_;
         Ahead &a = *ahead_now_;
@@ -899,7 +909,7 @@ private:
         const size_t n = (size_t)a.n.load(std::memory_order_relaxed);
         Walk w;
         w.recs = b.recs, w.starts = b.starts, w.counts = b.counts;
-        w.g_base = b.g_base, w.power_samples = power_samples, w.g_complete = g_complete, w.single_limit = 0;
+        w.g_base = b.g_base, w.power_samples = power_samples, w.g_complete = g_complete, w.single_limit = single_limit;
         w.base = base_, w.tsb = b.g_base + 1 - skipped_;
         w.in_call = false;
         uint32_t u = b.u;

@@ -308,13 +308,15 @@ static int resolve_shard(adsb_decoder *d, const uint16_t *x, uint64_t first, uin
     if (d->bases_cap)
         d->res.start_walk(d->g_begin, d->g_end, d->total, bases, bases_cap);
     if (d->gang && !d->cfg.collect_stats && d->g_end > d->g_begin) {
-        // chain mode over tiles: this thread decides, the gang writes the frames (what a worker of the real driver does on
-        // a full channel)
+        // chain mode over tiles: every batch decided ahead by the gang and taken over by this thread, the frames written by the
+        // gang (what a worker of the real driver does on a full channel)
         const uint32_t per = 12880, ntiles = fake_tiles(d, d->g_begin, d->g_end, per);
         d->res.set_gang(d->gang, 1);
+        d->res.set_ahead_min_records(1);
         d->gang->begin();
         for (uint32_t t = 0; t < ntiles;) {
             const uint32_t t1 = std::min<uint32_t>(ntiles, t + 1 + fake::g_rng() % 9);
+            d->res.speculate_tiles(d->stream.data(), d->t_start.data(), d->t_count.data(), t, t1, d->g_begin); // (round 6: a chain's batches too)
             d->res.capture_head_tiles(d->stream.data(), d->t_start.data(), d->t_count.data(), t, t1, d->g_begin);
             d->res.advance_tiles(d->stream.data(), d->t_start.data(), d->t_count.data(), t, t1, d->g_begin, 0,
                                  std::min<uint64_t>(d->g_end, d->g_begin + (uint64_t)t1 * per));

@@ -65,7 +65,8 @@ int main(int argc, char **argv)
             return 1;
         }
     }
-    uint64_t taken = 0, frames_e = 0;
+    uint64_t taken = 0, frames_e = 0, taken_chain = 0, frames_g = 0;
+    int chain_rounds = 0;
     for (int round = 0; round < rounds; round++) {
         if (round && round % 37 == 0) { // ... and between rounds of real work (nothing is in flight here)
             gang.stop();
@@ -232,6 +233,125 @@ int main(int argc, char **argv)
             }
             re.sync();
             taken += re.ahead_taken(), frames_e += fe.size();
+            // (f), (g) CHAIN mode (a shard of the multi-GPU driver: the greedy rule from g_begin on, one call per advance, head
+            // candidates and the walk of the deqframe calls beside it): the queue path against tiles whose batches are decided
+            // AHEAD by the gang and taken over -- round 6; until then a chain refused to be decided ahead.
+            {
+                const uint64_t g_begin = 28 * (rng() % 2000), head_end = std::min<uint64_t>(total, g_begin + 3000 + rng() % 60000);
+                const uint64_t total_samples = 2 * power_samples;
+                std::vector<adsb_candidate> hf, hg;
+                std::vector<uint64_t> bf(4096), bg(4096);
+                adsb::Resolver rf, rg;
+                rf.start_chain(g_begin, head_end, &hf);
+                rf.start_walk(g_begin, total, total_samples, bf.data(), bf.size());
+                rg.start_chain(g_begin, head_end, &hg);
+                rg.start_walk(g_begin, total, total_samples, bg.data(), bg.size());
+                rg.set_gang(&gang, round % 2 ? 8 : 1);
+                rg.set_ahead_min_records(round % 5 == 0 ? 40 : 1);
+                if (round % 2)
+                    rg.set_arena_chunk(48);
+                std::vector<adsb_frame> ff, fg;
+                {   // (f) the queue
+                    size_t i = 0;
+                    while (i < recs.size() && recs[i].g < g_begin)
+                        i++;
+                    uint64_t gc = g_begin;
+                    while (gc < total) {
+                        gc = std::min<uint64_t>(total, gc + 1 + rng() % 300000);
+                        std::vector<adsb_candidate> batch;
+                        for (; i < recs.size() && recs[i].g < gc; i++) {
+                            adsb_candidate c;
+                            std::memset(&c, 0, sizeof c);
+                            c.g = recs[i].g, c.pw = recs[i].pw;
+                            std::memcpy(c.frame, recs[i].w, 14);
+                            c.len = (uint8_t)((recs[i].w[3] >> 16) & 0xFF);
+                            c.reserved = (uint8_t)((recs[i].w[3] >> 24) & 1u);
+                            batch.push_back(c);
+                        }
+                        rf.feed(batch.data(), batch.size(), nullptr, 0);
+                        rf.advance(0, gc);
+                        auto f = drain_all(rf);
+                        ff.insert(ff.end(), f.begin(), f.end());
+                    }
+                }
+                {   // (g) tiles of a stream whose records start at g_begin (a shard only holds its own offsets), decided ahead
+                    const uint32_t t_first = (uint32_t)(g_begin / per);
+                    std::vector<uint32_t> cstream, cstarts(ntiles, 0), ccounts(ntiles, 0);
+                    for (uint32_t t = 0; t < ntiles; t++) {
+                        cstream.insert(cstream.end(), 4, 0xDEADBEEFu);
+                        cstarts[t] = (uint32_t)(cstream.size() / 4);
+                        for (size_t i : by_tile[t]) {
+                            const Rec &r = collapsed[i];
+                            if (r.g < g_begin) // (a record that straddles g_begin with its copies is cut: the copies below are not the shard's)
+                                continue;
+                            const uint32_t w[8] = {(uint32_t)r.g, r.pw, r.w[0], r.w[1], r.w[2], r.w[3] | (r.copies - 1) << adsb::kRecCopiesShift, r.pw2, r.pw3};
+                            cstream.insert(cstream.end(), w, w + 8);
+                            ccounts[t]++;
+                        }
+                    }
+                    std::vector<std::pair<uint32_t, uint32_t>> cb;
+                    for (uint32_t t = t_first; t < ntiles;) {
+                        const uint32_t t1 = std::min<uint32_t>(ntiles, t + 1 + (uint32_t)(rng() % 40));
+                        cb.emplace_back(t, t1);
+                        t = t1;
+                    }
+                    const size_t cdepth = 1 + round % 3;
+                    for (size_t k = 0; k < cdepth && k < cb.size(); k++)
+                        rg.speculate_tiles(cstream.data(), cstarts.data(), ccounts.data(), cb[k].first, cb[k].second, 0);
+                    for (size_t k = 0; k < cb.size(); k++) {
+                        if (k + cdepth < cb.size())
+                            rg.speculate_tiles(cstream.data(), cstarts.data(), ccounts.data(), cb[k + cdepth].first, cb[k + cdepth].second, 0);
+                        rg.capture_head_tiles(cstream.data(), cstarts.data(), ccounts.data(), cb[k].first, cb[k].second, 0);
+                        rg.advance_tiles(cstream.data(), cstarts.data(), ccounts.data(), cb[k].first, cb[k].second, 0, 0,
+                                         std::min<uint64_t>(total, (uint64_t)cb[k].second * per));
+                        if (rng() % 4 == 0 || k + 1 == cb.size()) {
+                            auto f = drain_all(rg);
+                            fg.insert(fg.end(), f.begin(), f.end());
+                        }
+                    }
+                    rg.advance(0, total);
+                    auto f = drain_all(rg);
+                    fg.insert(fg.end(), f.begin(), f.end());
+                    rg.sync();
+                    taken_chain += rg.ahead_taken(), frames_g += fg.size();
+                }
+                // a record of copies that straddles g_begin exists in (f) as single candidates from g_begin on and in (g) not at
+                // all: such rounds are skipped (the device never makes one: a shard's first tile starts at g_begin)
+                bool straddle = false;
+                for (const Rec &r : collapsed)
+                    straddle |= r.g < g_begin && r.g + r.copies > g_begin;
+                auto same_c = [](const std::vector<adsb_candidate> &x, const std::vector<adsb_candidate> &y) {
+                    if (x.size() != y.size())
+                        return false;
+                    for (size_t i = 0; i < x.size(); i++)
+                        if (x[i].g != y[i].g || x[i].pw != y[i].pw || x[i].len != y[i].len || std::memcmp(x[i].frame, y[i].frame, 14))
+                            return false;
+                    return true;
+                };
+                int fin_f = 0, fin_g = 0;
+                if (!straddle) {
+                    const bool walk_ok = rf.walk_bases() == rg.walk_bases() && rf.walk_final() == rg.walk_final() &&
+                                         !std::memcmp(bf.data(), bg.data(), std::min(rf.walk_bases(), bf.size()) * sizeof(uint64_t));
+                    (void)fin_f, (void)fin_g;
+                    auto same_f = [](const std::vector<adsb_frame> &x, const std::vector<adsb_frame> &y) {
+                        if (x.size() != y.size())
+                            return false;
+                        for (size_t i = 0; i < x.size(); i++)
+                            if (x[i].g != y[i].g || x[i].ts != y[i].ts || x[i].pw != y[i].pw || x[i].len != y[i].len ||
+                                std::memcmp(x[i].frame, y[i].frame, x[i].len) || x[i].reserved != y[i].reserved)
+                                return false;
+                        return true;
+                    };
+                    if (!same_f(ff, fg) || rf.skipped() != rg.skipped() || !same_c(hf, hg) || !walk_ok || rf.base() != rg.base() ||
+                        std::memcmp(&rf.stats(), &rg.stats(), sizeof(adsb_stats))) {
+                        printf("round %d: CHAIN MISMATCH (%zu / %zu frames, skipped %llu / %llu, head %zu / %zu, walk %zu / %zu, base %llu / %llu)\n", round,
+                               ff.size(), fg.size(), (unsigned long long)rf.skipped(), (unsigned long long)rg.skipped(), hf.size(), hg.size(),
+                               rf.walk_bases(), rg.walk_bases(), (unsigned long long)rf.base(), (unsigned long long)rg.base());
+                        return 1;
+                    }
+                    chain_rounds++;
+                }
+            }
         }
         auto same = [](const std::vector<adsb_frame> &x, const std::vector<adsb_frame> &y) {
             if (x.size() != y.size())
@@ -257,7 +377,12 @@ int main(int argc, char **argv)
         printf("only %llu of %llu frames were taken over from batches decided ahead\n", (unsigned long long)taken, (unsigned long long)frames_e);
         return 1;
     }
-    printf("ok: %d rounds (%llu of %llu frames of path (e) taken over from batches decided ahead)\n", rounds, (unsigned long long)taken,
-           (unsigned long long)frames_e);
+    if (chain_rounds * 2 < rounds || taken_chain * 2 < frames_g) { // (g) must really take a chain's batches over
+        printf("chain mode: %d of %d rounds compared, %llu of %llu frames taken over\n", chain_rounds, rounds, (unsigned long long)taken_chain,
+               (unsigned long long)frames_g);
+        return 1;
+    }
+    printf("ok: %d rounds (%llu of %llu frames of path (e) taken over from batches decided ahead; chain mode: %d rounds, %llu of %llu)\n", rounds,
+           (unsigned long long)taken, (unsigned long long)frames_e, chain_rounds, (unsigned long long)taken_chain, (unsigned long long)frames_g);
     return 0;
 }
