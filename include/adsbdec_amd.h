@@ -28,11 +28,10 @@
 extern "C" {
 #endif
 
-/* Bumped when an entry point or struct member changes meaning or place.  adsb_config grows at its END only within one
- * ABI version (adsb_create reads no further than cfg->struct_size); adsb_profile likewise (adsb_get_profile passes its size).
- * 5 (round 6): adsb_config carries `abi` (adsb_config_init sets it; adsb_create / adsb_multi_create refuse any other value
- *    with a message: a binary built against ABI <= 4 must be rebuilt) and the twelve debug_* test knobs left it for
- *    adsb_debug_config behind the `debug` pointer (adsbdec_amd_diag.h); adsb_profile grew (host threads, gang batches). */
+/* Bumped when an entry point or struct member changes meaning or place; within one version adsb_config and adsb_profile grow
+ * at their END only (adsb_create reads cfg->struct_size bytes, adsb_get_profile passes the caller's size).
+ * 5 (round 6): adsb_config carries `abi` (adsb_create / adsb_multi_create refuse any other value by name: a binary built against
+ *    ABI <= 4 must be rebuilt); the debug_* test knobs left it for adsb_debug_config (adsbdec_amd_diag.h); adsb_profile grew. */
 #define ADSB_ABI_VERSION 5
 
 /* Constants of the path (adsbdec.h:1-3, air.c:32,47). */
@@ -77,21 +76,19 @@ typedef struct adsb_config {
     int32_t push_overlap;   /* 1: adsb_push() returns once `samples` is COPIED to the device and leaves the scan in
                                flight; the frames of a call become drainable during the NEXT push / finish / sync
                                (same frames, same order).  0 (default): drainable when the call returns.          */
-    int32_t host_threads;   /* Host threads that consume the device's hand-off stream (decodeiq, air.c:54, never
-                               started one: 1 is that contract).
+    int32_t host_threads;   /* Threads that consume the device's hand-off stream (decodeiq, air.c:54, never started one).
                                1: the calling thread alone, ALWAYS -- the library never starts a thread.
-                               2: + one thread of the handle's own that reads and checks the stream of large launches.
-                               N >= 3 (<= 17): + N - 2 more that decide batches of tiles ahead and write the frames.
-                               0 (default): 1, until a launch hands over 65 536 records or more (a channel near its
-                               capacity: ~20 k frames per second of signal); every launch that follows such a one
-                               runs with 6 (5 threads that poll during a launch and ~0.4 ms beyond, then sleep) -- 2
-                               where the process may use fewer than 12 CPUs.  BASELINE configs[2]: the step takes
-                               1.2 x its kernel instead of 3.3 x.  adsb_profile.host_threads_running says what
-                               exists; same frames, same order, same counters whatever the value.                 */
+                               2: + a thread of the handle's own that reads the stream of large launches; N >= 3
+                               (<= 17): + N - 2 more that decide batches of tiles ahead and write the frames.
+                               0 (default): 1, until a launch hands over >= 65 536 records (a channel near its capacity);
+                               launches that follow such a one run with 6 (5 threads that poll during a launch and
+                               0.4 ms beyond, then sleep; 2 where the process has < 12 CPUs): the step takes 1.2 x its
+                               kernel instead of 3.3 x.  adsb_profile.host_threads_running says what exists; same
+                               frames, order and counters whatever the value.                     */
     int32_t wait_timeout_s; /* no wait for the device lasts longer (0 = default, 120 s): a launch or copy that never
                                completes ends the call with -1 and adsb_last_error() names what was waited for     */
-    int32_t warm_start;     /* 1: adsb_create also makes the process's first large host-to-device copy (the runtime's
-                               first-use cost, 7-9 ms once per process) beside its other work: for a one-shot process   */
+    int32_t warm_start;     /* 1: adsb_create also pays the runtime's first-use cost of a large copy (7-9 ms once per
+                               process) beside its other work: for a one-shot process                              */
     const void *debug;      /* NULL, or an adsb_debug_config (adsbdec_amd_diag.h: test knobs); copied by adsb_create */
 } adsb_config;
 
@@ -117,8 +114,7 @@ typedef struct adsb_profile {
     uint64_t gang_batches;         /* batches of tiles handed to the gang to be decided ahead of the caller        */
 } adsb_profile;
 
-/* Defaults.  The struct's size is the CALLER's, so it is passed along: adsb_config_default(&cfg) compiles to
- * adsb_config_init(&cfg, sizeof cfg), which also sets cfg.abi. */
+/* Defaults; the struct's size is the CALLER's: adsb_config_default(&cfg) = adsb_config_init(&cfg, sizeof cfg), which sets cfg.abi. */
 void adsb_config_init(adsb_config *cfg, size_t struct_size);
 #define adsb_config_default(cfg) adsb_config_init((cfg), sizeof(adsb_config))
 
@@ -127,7 +123,6 @@ void adsb_config_init(adsb_config *cfg, size_t struct_size);
 adsb_decoder *adsb_create(const adsb_config *cfg);
 void adsb_destroy(adsb_decoder *d);
 int adsb_reset(adsb_decoder *d);
-
 /* Sample ingress; replaces `decodeiq(const unsigned short *r, const int len)` (air.c:54), called from fileInput
  * (air.c:239) / rx_callback (air.c:175).  `samples` is borrowed for the call.  Any n is accepted; the stream is the
  * concatenation of all pushes (the reference requires n % 4 == 0). */
@@ -146,7 +141,6 @@ int adsb_push_device_final(adsb_decoder *d, const void *device_samples, size_t n
 long adsb_decode_device(adsb_decoder *d, const void *device_samples, size_t n, const adsb_frame **frames);
 /* End of input (fileInput's EOF, air.c:241-244): the remaining offsets, and the end-of-file horizon. */
 int adsb_finish(adsb_decoder *d);
-
 /* Page-locked host buffers: the counterpart of `iqbuff = malloc(...)` (air.c:230), so that a push is one DMA.
  * adsb_host_alloc_on binds the memory to the NUMA node of `device` (two-socket hosts; best effort).  adsb_host_register
  * page-locks memory the caller already owns.  0 / -1. */
@@ -155,14 +149,12 @@ void *adsb_host_alloc_on(size_t bytes, int device);
 void adsb_host_free(void *p);
 int adsb_host_register(void *p, size_t bytes);
 int adsb_host_unregister(void *p);
-
 /* Frame egress: the records the reference hands to netout() (output.c:159), in the same order.  adsb_drain copies
  * (returns the number, <= cap, or -1); adsb_take hands every pending frame out in place -- valid until the next call
  * that pushes into, finishes, resets or destroys the handle. */
 long adsb_drain(adsb_decoder *d, adsb_frame *out, size_t cap);
 long adsb_take(adsb_decoder *d, const adsb_frame **frames);
 size_t adsb_pending(const adsb_decoder *d);
-
 /* print_stats() counters (valid.c:84-100); try_ needs collect_stats=1 (counted on the device, fetched by this call). */
 int adsb_get_stats(const adsb_decoder *d, adsb_stats *out);
 /* Fills the first `size` bytes of *out (the macro passes the caller's sizeof: adsb_profile grows at its end). */
@@ -170,29 +162,24 @@ int adsb_get_profile_sized(const adsb_decoder *d, adsb_profile *out, size_t size
 #define adsb_get_profile(d, out) adsb_get_profile_sized((d), (out), sizeof(adsb_profile))
 /* Last error text of a handle, or of the last failed adsb_create() when d == NULL. */
 const char *adsb_last_error(const adsb_decoder *d);
-
 /* formatpkt() (output.c:204-262, WITH_AIR).  outformat 0 = AVR "*hex;\n", 1 = AVR-MLAT "@ts48hex;\n", 2 = Beast.
  * pkt must hold 256 bytes.  Returns the packet length. */
 int adsb_format_frame(const adsb_frame *f, int outformat, char *pkt);
-
 /* The CPUs local to HIP device `device` (/sys/bus/pci/devices/<bdf>/local_cpulist, e.g. "0-63,128-191") and its NUMA
  * node: the thread that feeds a handle polls memory the device writes; on the far socket it was measured 2.5-3 x slower.
  * Length of the string, 0 when the platform does not say, -1 on error / node or -1. */
 int adsb_device_cpulist(int device, char *out, size_t cap);
 int adsb_device_numa_node(int device);
-
 /* Shard planning: splits the offsets [0, power_samples - ADSB_WINDOW] of one stream over n_shards owners.
  * Shard i owns offsets [g_begin[i], g_end[i]) (g_begin a multiple of 28) and must be given the input samples
  * [first_sample[i], first_sample[i] + n_samples[i]) -- 2 408 samples of halo.  Returns the shards used (<= n_shards). */
 int adsb_plan_shards(uint64_t total_samples, int n_shards, uint64_t *g_begin, uint64_t *g_end,
                      uint64_t *first_sample, uint64_t *n_samples);
-
 /* ---- ONE process, several GPUs (csrc/multi.cpp): the host of BASELINE configs[3] / configs[4] ---------------------
  * A worker thread and a decoder handle per device; no collective on the data path.  Stands where
  * fileInput's loop (air.c:217-246) hands its buffers to decodeiq and the frames come back in ascending order for
  * netout (output.c:159-182). */
 typedef struct adsb_multi adsb_multi;
-
 typedef struct adsb_multi_info { /* of the last adsb_multi_decode_* call */
     int32_t shards;         /* shards the capture was cut into (streams decoded side by side, for the stream calls)  */
     int32_t fallback;       /* 1: a seam could not be decided from the head candidates; the capture then went through
