@@ -932,23 +932,47 @@ __device__ __forceinline__ void stage_b(const ScanArgs &args, const uint32_t til
             __syncthreads();
             act = (uint32_t)tid < nk;
             lead = false;
+            // Is this entry the previous entry's frame, one offset on?  One comparison per entry; the chains of links are then bit
+            // logic on the four waves' ballots.  (Until round 6 every thread walked its chain backwards through the list -- up to
+            // five evaluations of 12 dependent LDS reads each: 2.3 us of a full-channel tile's life.)
+            bool lk = false;
             if (act) {
-                auto linked = [&](uint32_t a) { // is entry a the previous entry's frame, one offset on?
-                    if (a == 0 || a >= nk)
-                        return false;
-                    const uint32_t *p = cl_rec + (a - 1) * kCandWords, *q = p + kCandWords;
-                    return q[0] == p[0] + 1u && q[1] == p[1] && q[2] == p[2] && q[3] == p[3] && q[4] == p[4] && q[5] == p[5];
-                };
-                uint32_t back = 0; // links behind this entry
-                while (linked((uint32_t)tid - back))
-                    back++;
-                lead = back % 3u == 0;
-                c1 = lead && linked((uint32_t)tid + 1);
-                c2 = c1 && linked((uint32_t)tid + 2);
                 const uint32_t *my = cl_rec + tid * kCandWords;
 #pragma unroll
                 for (int k = 0; k < kCandWords; k++)
                     e[k] = my[k];
+                if (tid > 0) {
+                    const uint32_t *p = my - kCandWords;
+                    lk = e[0] == p[0] + 1u && e[1] == p[1] && e[2] == p[2] && e[3] == p[3] && e[4] == p[4] && e[5] == p[5];
+                }
+            }
+            uint32_t *lmw = queue + kQueueCap - 16; // (eight free words of the survivor queue's LDS: the link masks, a wave each)
+            const unsigned long long lm = __ballot(lk);
+            if ((tid & 63) == 0) {
+                lmw[2 * (tid >> 6)] = (uint32_t)lm;
+                lmw[2 * (tid >> 6) + 1] = (uint32_t)(lm >> 32);
+            }
+            __syncthreads();
+            if (act) {
+                auto mask_of = [&](int w) { return (unsigned long long)lmw[2 * w] | (unsigned long long)lmw[2 * w + 1] << 32; };
+                auto linked = [&](uint32_t a) { return a < (uint32_t)NT && ((mask_of((int)(a >> 6)) >> (a & 63u)) & 1ull) != 0; }; // (bits of entries >= nk are 0)
+                // links behind this entry = the run of set bits that ends at its own bit: leading zeros of the inverted mask,
+                // shifted so that its bit is the top one (the zeros shifted in below bit 0 invert to ones: the count stops there)
+                int w = tid >> 6;
+                const uint32_t b = (uint32_t)tid & 63u;
+                const unsigned long long inv0 = ~(mask_of(w) << (63u - b));
+                uint32_t back = inv0 ? (uint32_t)__clzll((long long)inv0) : 64u;
+                if (back == b + 1u) // the run reaches the wave's first entry: on into the waves before
+                    while (w-- > 0) {
+                        const unsigned long long inv = ~mask_of(w);
+                        const uint32_t more = inv ? (uint32_t)__clzll((long long)inv) : 64u;
+                        back += more;
+                        if (more < 64u)
+                            break;
+                    }
+                lead = back % 3u == 0;
+                c1 = lead && linked((uint32_t)tid + 1);
+                c2 = c1 && linked((uint32_t)tid + 2);
             }
             const unsigned long long leaders = __ballot(lead);
             if ((tid & 63) == 0)
