@@ -106,3 +106,20 @@ def test_bind_near_gpu_never_fails_a_run(monkeypatch, tmp_path):
                 return Props()
     assert bench.bind_near_gpu(Absent, 0).startswith("none (")
     assert os.sched_getaffinity(0) == before
+
+
+def test_main_workloads_name_their_evidence_sets():
+    """--dense10 / --gate-storm / --dense are main workloads since round 6 (what tools/profile_session.sh puts under
+    rocprofv3); each looks its committed PMC evidence up under its own tag, newest round first, and the sets exist."""
+    import types
+    tag = lambda **kw: bench.profile_tag(types.SimpleNamespace(**{"dense": False, "dense10": False, "gate_storm": False, **kw}))
+    assert (tag(), tag(dense=True), tag(dense10=True), tag(gate_storm=True)) == ("", "_dense", "_dense10", "_storm")
+    assert bench.PROFILE_ROUNDS[0] == "r6"
+    for t in ("", "_stats", "_dense10", "_dense10_stats", "_storm", "_storm_stats"):
+        for kind in ("_pmc.json", "_kernel_stats.csv", "_dispatches.csv", "_bench_under_rocprofv3.json"):
+            assert os.path.exists(os.path.join(ROOT, "profiles", "r6" + t + kind)), t + kind
+    p0 = dict(kernel_ms=0.0, big_offsets=134216525, big_launches=0, big_ms=0.0, offsets=0)
+    p1 = dict(kernel_ms=17.5, big_offsets=134216525, big_launches=100, big_ms=17.5, offsets=100 * 134216525)
+    roof, valu = bench.roofline_objects(p0, p1, 100, "_dense10", clock=(2.3, 9), step_ms=0.21)
+    assert "profiles/r6_dense10_pmc.json" in roof["traffic_source"] and abs(roof["frac"] - 4 * 134216525 / 0.175e-3 / 1e9 / 8000) < 1e-3
+    assert valu["valu_wave_instructions"] > 70e6     # a full channel's tiles issue more than the sparse capture's 65 M
