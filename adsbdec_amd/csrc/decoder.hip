@@ -180,6 +180,7 @@ struct adsb_decoder {
     int gang_l3 = -1;
     uint32_t reader_min_tiles = 1024; // launches below this many tiles are collected by the calling thread alone
     uint64_t last_launch_records = 0; // records the previous launch handed over (auto: the thread pays from kAutoReaderRecords on)
+    uint64_t last_launch_offsets = 0; // ... out of this many offsets
     bool no_streaming = false; // dbg.no_streaming: always collect after completion
     uint64_t shard_head = ADSB_SHARD_HEAD; // offsets of a resolved shard whose candidates are ALL kept for the stitcher (dbg.shard_head)
     int dbg_async = 0;         // tuning builds only (ADSB_DEBUG_ASYNC, tools/async_race.py): 1 = wait for every async copy,
@@ -695,7 +696,7 @@ size_t deliver_tiles(adsb_decoder *d, ScanSlot &s, uint32_t from, uint32_t upto)
 // handle; 0 (auto) the first time a launch follows one that handed over kAutoReaderRecords or more -- at the channel's
 // capacity one thread needs four times the kernel's time for a launch's records, and reading + checking on one thread while
 // the caller resolves takes a quarter off that; under ordinary traffic the thread never exists.
-constexpr uint64_t kAutoReaderRecords = 65536;
+constexpr uint64_t kAutoReaderRecords = 65536, kAutoReaderMinRecords = 16384;
 void start_reader(adsb_decoder *d)
 {
     if (d->reader || d->reader_failed)
@@ -811,7 +812,12 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     };
     const adsb::HandJob job = hand_job(s);
     adsb::CollectEnd end;
-    const bool after_dense = d->cfg.host_threads == 0 && d->last_launch_records >= kAutoReaderRecords;
+    // "a channel near its capacity" is a DENSITY: 65 536 records out of a full launch's 128 Mi offsets = one per 2 048 (a full
+    // channel has one per 1 090).  Round 6: a shorter launch -- a 128 Mi-sample shard of the multi-GPU driver is 64 Mi offsets,
+    // 61 k records on a full channel -- counts by the same density, from 16 384 records on (below that a launch is resolved
+    // faster than five threads are woken).
+    const uint64_t dense_from = std::max<uint64_t>(kAutoReaderMinRecords, std::min<uint64_t>(kAutoReaderRecords, d->last_launch_offsets / 2048));
+    const bool after_dense = d->cfg.host_threads == 0 && d->last_launch_records >= dense_from;
     if (after_dense) {
         start_reader(d);
         cpu_set_t allowed; // (six threads that poll need cores of their own: on a small or confined host, round 4's pair)
@@ -897,6 +903,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     *tiles_in = end.frontier;
     *tries_listed = end.tries_listed;
     d->last_launch_records = recs_handed; // (a launch that is finished after completion adds its part there)
+    d->last_launch_offsets = s.args.g_end - s.args.g_begin;
     return overflowed ? 1 : 0;
 }
 

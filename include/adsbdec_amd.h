@@ -80,7 +80,7 @@ typedef struct adsb_config {
                                1: the calling thread alone, ALWAYS -- the library never starts a thread.
                                2: + a thread of the handle's own that reads the stream of large launches; N >= 3
                                (<= 17): + N - 2 more that decide batches of tiles ahead and write the frames.
-                               0 (default): 1, until a launch hands over >= 65 536 records (a channel near its capacity);
+                               0 (default): 1, until a launch hands over a record per 2 048 offsets (a channel near its capacity);
                                launches that follow such a one run with 6 (5 threads that poll during a launch and
                                0.4 ms beyond, then sleep; 2 where the process has < 12 CPUs): the step takes 1.2 x its
                                kernel instead of 3.3 x.  adsb_profile.host_threads_running says what exists; same

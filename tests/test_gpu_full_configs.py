@@ -238,7 +238,9 @@ def test_config2_dense_traffic_through_the_multi_gpu_driver(capi, oracle, torch_
     # handles, cfg.host_threads, helper threads per worker once the traffic has been seen: auto (0) starts reader + 4 behind a
     # launch of >= 65 536 records -- a 512 Mi-sample shard has two such launches, a 128 Mi-sample one stays below -- explicit 6
     # starts them at adsb_create, 1 never starts any
-    for handles, host_threads, per_worker in ((1, 0, 5 if roomy else 1), (4, 6, 5), (8, 6, 5), (4, 1, 0)):
+    # (round 6: "near its capacity" is a density -- a record per 2 048 offsets -- so the 128 Mi-sample shards of four workers,
+    # 61 k records per launch, start their helpers by themselves too)
+    for handles, host_threads, per_worker in ((1, 0, 5 if roomy else 1), (4, 0, 5 if roomy else 1), (4, 6, 5), (8, 6, 5), (4, 1, 0)):
         md = sharding.MultiDecoder(handles, [0] * handles, df18=True, collect_stats=True, host_threads=host_threads, profile=True)
         try:
             plan = md.plan(n)
