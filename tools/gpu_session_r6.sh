@@ -88,6 +88,12 @@ for f in glob.glob("/tmp/clitrace/**/*hip_api_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Function"]))
 rows.sort()
+if not rows:
+    import subprocess
+    print("no hip_api_trace rows; files under /tmp/clitrace:")
+    print(subprocess.run("find /tmp/clitrace -type f | head -20; echo; tail -20 /tmp/clitrace.err", shell=True, capture_output=True, text=True).stdout)
+    for f in glob.glob("/tmp/clitrace/**/*.csv", recursive=True)[:3]:
+        print(f, open(f).readline().strip())
 t0 = rows[0][0] if rows else 0
 print("HIP calls longer than 0.4 ms (start ms, duration ms, call), and every call between 300 ms and the end that follows a hipMemcpyAsync:")
 for a, b, f in rows:
