@@ -1153,3 +1153,36 @@ def test_take_is_drain_without_the_copy(oracle, dec_factory):
     p, n = d.take_raw()
     got += capi_frames(p, n)
     assert records(got) == records(want)
+
+
+def test_config_of_another_abi_is_refused_by_name_and_the_threads_are_visible(capi, oracle, torch_cuda):
+    """ABI 5 (round 6) on the device: a struct that carries another `abi` -- what a binary built against rounds 4-5's header
+    hands over, its df18 lying where `abi` is -- is refused with a message that says so (not misread); the legacy symbol
+    adsb_config_default leaves such a struct behind; adsb_profile reports the handle's own threads (none by default under
+    sparse traffic, reader + gang with host_threads = 5, never any with host_threads = 1), and the caller's struct may be
+    shorter than the library's (adsb_get_profile_sized fills what fits)."""
+    import ctypes as C
+    L = capi.load()
+    cfg = capi.make_config(df18=True)
+    cfg.abi = 1                                            # (an ABI-4 binary's df18 = 1)
+    assert not L.adsb_create(C.byref(cfg))
+    msg = L.adsb_last_error(None)
+    assert b"adsb_config.abi" in msg and b"rebuilt" in msg
+    legacy = (C.c_uint8 * 128)()
+    L.adsb_config_default(legacy)
+    assert not L.adsb_create(legacy) and b"adsb_config.abi" in L.adsb_last_error(None)
+    x, _ = __import__("tools.gen_signal", fromlist=["dense_capture"]).dense_capture(1 << 20, seed=77, sigma=40.0, n_frames=150, amp=(300, 1800))
+    want, _ = oracle.decode(x, df18=True)
+    for ht, threads in ((0, 0), (1, 0), (2, 1), (5, 4)):
+        d = capi.Decoder(df18=True, host_threads=ht, profile=True)
+        try:
+            assert records(d.decode(x)) == records(want), ht
+            p = d.profile()
+            assert p["host_threads_running"] == threads, (ht, p)
+            assert p["launches"] >= 1 and (p["gang_launches"] > 0) == (ht >= 3), (ht, p)
+            short = capi.Profile()
+            C.memset(C.byref(short), 0xEE, C.sizeof(short))
+            assert L.adsb_get_profile_sized(d._h, C.byref(short), capi.Profile.host_threads_running.offset) == 0   # an ABI-4-sized struct
+            assert short.launches == p["launches"] and short.host_threads_running == 0xEEEEEEEE                  # ... nothing written behind it
+        finally:
+            d.close()
