@@ -9,7 +9,7 @@
 namespace adsb {
 
 // Launch shape (what every measurement of DESIGN.md was taken with; the experiments that set other values are history)
-constexpr int kFirGroup = 4;       // FIR outputs advanced together (independent accumulation chains interleaved)
+
 constexpr int kSleepStagger = 90;  // s_sleep units (64 cycles) between the starts of a CU's first four workgroups
 constexpr int kMinWaves = 5;       // __launch_bounds__ second argument: waves per SIMD (96 VGPRs; 5 workgroups' LDS fit a CU)
 

@@ -86,74 +86,152 @@ __device__ __forceinline__ constexpr float tap()
     return (float)lit[K];
 }
 
-// One product-accumulate step of output J (J = index inside the 28-run).
+// The FIR of one run: 28 outputs, each the sum of seven (I, Q) products in the reference's order.
 //
-// Output m uses pairs m-6..m; the pair of AGE a (a = 0 newest) meets taps
-// T[12-2a] (I) and T[13-2a] (Q) (air.c:69-75 with o = 14 - fidx%14).  The
-// reference adds in physical ring order k = 0,2,..,12: the pair whose index is a
-// multiple of 7 first, then forward in time to the newest, then the wrapped older
-// ones: ages p, p-1, .., 0, 6, 5, .., p+1 with p = m mod 7.
-// vv holds the run's pairs as (I, Q) with the fs/4 sign already applied: slot s = rel+6.
+// Output m uses pairs m-6..m; the pair of AGE a (a = 0 newest) meets taps T[12-2a] (I) and T[13-2a] (Q) (air.c:69-75 with
+// o = 14 - fidx%14).  The reference adds in physical ring order k = 0,2,..,12: the pair whose index is a multiple of 7
+// first, then forward in time to the newest, then the wrapped older ones: ages p, p-1, .., 0, 6, 5, .., p+1 with
+// p = m mod 7.  Seven static orders, straight-line code.
 //
-// The I and Q sums are the two halves of ONE packed-f32 register pair: on gfx950
-// a wave64 VALU instruction occupies the SIMD for 4 cycles whether it is scalar or
-// packed (measured: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles), so
-// v_pk_mul_f32 / v_pk_add_f32 double the arithmetic rate.  Each half is still an
-// IEEE binary32 multiply followed by a binary32 add.
+// The I and Q sums are the two halves of ONE packed-f32 register pair (v_pk_*_f32: two results per lane for the issue slot
+// of one; tools/valu_bench.hip).  Every product is rounded, then every sum: binary32 multiply and binary32 add, as in the
+// reference -- written with two fused forms that round the SAME real numbers (round 6; parity bit for bit on every test
+// and fuzz run, profiles/r6_ab_runs.txt section 8):
+//
+//  (1) vv[slot] is the converted sample x itself (what the typed load delivers), not x - 2048 (air.c:64-67).  For a tap t,
+//      t (x - 2048) = t x - 2048 t as real numbers and 2048 t is a binary32 number (a power of two times t), so
+//      fma(t, x, -2048 t) rounds exactly the real number the reference's multiplication rounds: the 34 subtractions of a
+//      run are gone.  The fs/4 sign (pairs with odd index are negated, air.c:79-82; a compile-time property of the slot)
+//      is the sign of both constants: operand modifiers.  An instruction reads ONE scalar operand, so 2048 t sits in
+//      vector registers: four pairs -- ages 4..6 use the pairs of ages 2..0 with the halves exchanged (the filter is
+//      symmetric: op_sel), and they are written by volatile moves at the head of each pass so that they do not live
+//      across the plane arithmetic, where all 96 registers are taken.
+//
+//  (2) (float)0.025254 is exactly 2 x (float)0.012627 (a power-of-two multiple of a decimal literal rounds to the same
+//      multiple), so fl(2 h0 x) = 2 fl(h0 x) and  s + fl(2 h0 x)  rounds like  fma(fl(h0 x), 2, s).  The pair that is the
+//      NEWEST of output J (age 0: taps 2 h0, h0) is the OLDEST of output J + 6 (age 6: taps h0, 2 h0), and both add it in
+//      the same step (J mod 7 = p: step p; (J + 6) mod 7 = p - 1: age 6 comes at step p): ONE product M = h0 (I, Q) serves
+//      both, each through one fused multiply-add by (2, 1) or (1, 2).  The first step of an output has no addition
+//      (p = 0 / p = 6): nothing to share there.  Outputs J and J + 6 have to be advanced together for this: the plan below.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int J, int STEP>
-__device__ __forceinline__ void fir_step(const f32x2 (&vv)[34], f32x2 &s)
+// kc[0..3] = 2048 (T[12-2b], T[13-2b]) in vector registers, kc[4..7] = (T[12-2b], T[13-2b]) in scalar ones, b = 0..3
+struct FirConsts {
+    f32x2 c2048[4];
+    f32x2 taps[4];
+};
+
+// t (x - 2048) or -t (x - 2048) for the pair in `slot` and the taps of age `age`, from the converted sample x
+template <int SLOT, int AGE>
+__device__ __forceinline__ f32x2 fir_product(const f32x2 (&vv)[34], const FirConsts &k)
 {
+    constexpr int b = AGE <= 3 ? AGE : 6 - AGE;
+    const f32x2 c = AGE <= 3 ? k.c2048[b] : __builtin_shufflevector(k.c2048[b], k.c2048[b], 1, 0);
+    const f32x2 t = AGE <= 3 ? k.taps[b] : __builtin_shufflevector(k.taps[b], k.taps[b], 1, 0);
+    if constexpr (SLOT & 1)
+        return __builtin_elementwise_fma(-t, vv[SLOT], c);
+    else
+        return __builtin_elementwise_fma(t, vv[SLOT], -c);
+}
+
+// The order the 28 outputs are computed in, and the groups advanced together (independent accumulation chains interleaved in
+// program order, so that a dependent add rarely issues right behind the product it consumes).  The first eight outputs go
+// in index order: every input pair is still live there (68 registers), and an output that is finished frees the pair only
+// it still needed.  From output 8 on the registers that have come free pay for chain order (J, J + 6, J + 12, ..): 12 of
+// the 18 shareable products are shared.  (Chain order from output 4 or 6 shares 13-15 and spills; measured plans in
+// profiles/r6_ab_runs.txt section 8.)
+struct FirPlan {
+    int out[28];   // position -> output
+    int group[28]; // position -> first position of its group
+    int size[28];  // first position of a group -> outputs in the group
+};
+__host__ __device__ inline constexpr FirPlan fir_plan()
+{
+    FirPlan pl{};
+    constexpr int groups[6][6] = {{0, 1, 2, 3, -1, -1},     {4, 5, 6, 7, -1, -1},     {8, 14, 20, 26, -1, -1},
+                                  {9, 15, 21, 27, -1, -1},  {10, 16, 22, 11, 17, 23}, {12, 18, 24, 13, 19, 25}};
+    int pos = 0;
+    for (int g = 0; g < 6; g++) {
+        const int first = pos;
+        for (int k = 0; k < 6 && groups[g][k] >= 0; k++) {
+            pl.out[pos] = groups[g][k];
+            pl.group[pos] = first;
+            pos++;
+        }
+        pl.size[first] = pos - first;
+    }
+    return pl;
+}
+
+// One step of the output at position POS of the plan
+template <int POS, int STEP>
+__device__ __forceinline__ void fir_step(const f32x2 (&vv)[34], f32x2 &s, f32x2 &shared, const FirConsts &k)
+{
+    constexpr FirPlan plan = fir_plan();
+    constexpr int J = plan.out[POS];
     constexpr int p = J % 7;
     constexpr int age = (STEP <= p) ? (p - STEP) : (6 - (STEP - p - 1));
-    constexpr int slot = J - age + 6;
-    constexpr f32x2 t = {tap<12 - 2 * age>(), tap<13 - 2 * age>()};
-    if constexpr (STEP == 0)
-        s = t * vv[slot]; // 0.0f + x == x up to the sign of zero, which the square erases
-    else
-        s = s + t * vv[slot];
+    constexpr int slot = J - age + 6; // slot s <-> pair s - 6 of the run
+    // the partner is the neighbour in the plan, and only a neighbour inside the same group is advanced in the same step
+    constexpr int next = POS + 1 < 28 ? POS + 1 : POS, prev = POS > 0 ? POS - 1 : POS;
+    constexpr bool next_is_partner = next != POS && plan.out[next] == J + 6 && plan.group[next] == plan.group[POS];
+    constexpr bool prev_is_partner = prev != POS && plan.out[prev] == J - 6 && plan.group[prev] == plan.group[POS];
+    static_assert(tap<12>() == 2.0f * tap<13>() && tap<1>() == 2.0f * tap<0>() && tap<0>() == tap<13>(), "the exact doubling of (2)");
+    if constexpr (age == 0 && STEP > 0 && next_is_partner) {
+        // M = +-h0 (x - 2048) for both halves: the pair (h0, h0) is the high half of the age-0 constants, twice
+        const f32x2 c = __builtin_shufflevector(k.c2048[0], k.c2048[0], 1, 1), h = __builtin_shufflevector(k.taps[0], k.taps[0], 1, 1);
+        if constexpr (slot & 1)
+            shared = __builtin_elementwise_fma(-h, vv[slot], c);
+        else
+            shared = __builtin_elementwise_fma(h, vv[slot], -c);
+        constexpr f32x2 two_one = {2.0f, 1.0f};
+        s = __builtin_elementwise_fma(shared, two_one, s);
+    } else if constexpr (age == 6 && STEP > 0 && prev_is_partner) {
+        constexpr f32x2 one_two = {1.0f, 2.0f};
+        s = __builtin_elementwise_fma(shared, one_two, s); // made by output J - 6 in this step
+    } else if constexpr (STEP == 0) {
+        s = fir_product<slot, age>(vv, k); // 0.0f + x == x up to the sign of zero, which the square erases
+    } else {
+        s = s + fir_product<slot, age>(vv, k);
+    }
 }
 
-// G consecutive outputs advanced together, one FIR step at a time: G independent
-// accumulation chains are interleaved in program order, so a dependent add never
-// issues right behind the multiply it consumes (the compiler otherwise emits each
-// output's seven steps back to back and pads every mul->add pair with s_nop).
-template <int J0, int G, int STEP>
-__device__ __forceinline__ void fir_group_step(const f32x2 (&vv)[34], f32x2 (&s)[G])
+template <int POS0, int N, int STEP>
+__device__ __forceinline__ void fir_group_step(const f32x2 (&vv)[34], f32x2 (&s)[N], const FirConsts &k)
 {
     if constexpr (STEP < 7) {
-        fir_step<J0 + 0, STEP>(vv, s[0]);
-        if constexpr (G > 1) fir_step<J0 + 1, STEP>(vv, s[1]);
-        if constexpr (G > 2) fir_step<J0 + 2, STEP>(vv, s[2]);
-        if constexpr (G > 3) fir_step<J0 + 3, STEP>(vv, s[3]);
-        if constexpr (G > 4) fir_step<J0 + 4, STEP>(vv, s[4]);
-        if constexpr (G > 5) fir_step<J0 + 5, STEP>(vv, s[5]);
-        if constexpr (G > 6) fir_step<J0 + 6, STEP>(vv, s[6]);
-        fir_group_step<J0, G, STEP + 1>(vv, s);
+        f32x2 shared = {0.0f, 0.0f};
+        fir_step<POS0, STEP>(vv, s[0], shared, k);
+        if constexpr (N > 1) fir_step<POS0 + 1, STEP>(vv, s[1], shared, k);
+        if constexpr (N > 2) fir_step<POS0 + 2, STEP>(vv, s[2], shared, k);
+        if constexpr (N > 3) fir_step<POS0 + 3, STEP>(vv, s[3], shared, k);
+        if constexpr (N > 4) fir_step<POS0 + 4, STEP>(vv, s[4], shared, k);
+        if constexpr (N > 5) fir_step<POS0 + 5, STEP>(vv, s[5], shared, k);
+        fir_group_step<POS0, N, STEP + 1>(vv, s, k);
     }
 }
 
-template <int J0, int N, int G>
-__device__ __forceinline__ void power_block(const f32x2 (&vv)[34], float *a)
+// a[0..27] = the run's power samples (air.c:76,91)
+template <int POS0>
+__device__ __forceinline__ void power_run(const f32x2 (&vv)[34], float *a, const FirConsts &k)
 {
-    if constexpr (N > 0) {
-        constexpr int g = (N < G) ? N : G;
-        f32x2 s[g];
-        fir_group_step<J0, g, 0>(vv, s);
+    if constexpr (POS0 < 28) {
+        constexpr FirPlan plan = fir_plan();
+        constexpr int n = plan.size[POS0];
+        f32x2 s[n];
+        fir_group_step<POS0, n, 0>(vv, s, k);
 #pragma unroll
-        for (int k = 0; k < g; k++) {
-            const f32x2 sq = s[k] * s[k];
-            // air.c:76,91.  A plain `sq.x + sq.y` gets SLP-packed across two outputs at
-            // the price of three transposing moves per pair; keep it one scalar add.
+        for (int i = 0; i < n; i++) {
+            const f32x2 sq = s[i] * s[i];
+            // A plain `sq.x + sq.y` gets SLP-packed across two outputs at the price of three transposing moves per pair;
+            // keep it one scalar add.
             float r;
             asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(sq.x), "v"(sq.y));
-            a[J0 + k] = r;
+            a[plan.out[POS0 + i]] = r;
         }
-        power_block<J0 + g, N - g, G>(vv, a);
+        power_run<POS0 + n>(vv, a, k);
     }
 }
-
 
 // Same arithmetic for power samples at RUN-TIME indices (rare path: pw of a
 // CRC-valid candidate needs a[g], a[g+10], a[g+35], a[g+45]).  Rounds exactly like
@@ -343,6 +421,22 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
     auto pass_first_pair = [&](int ps) { return t0 + (int64_t)kRun * first_run(ps) - 8; }; // lane 0's
 #pragma unroll 1
     for (int pass = 0; pass < K; pass++) {
+        // the FIR's constants (fir_product): the vector ones written here, by instructions the compiler cannot hoist -- eight
+        // registers that live from here to the end of the FIR, not across the plane arithmetic behind it; the scalar ones
+        // made opaque INSIDE the loop, so that their exchanged and negated forms are operand modifiers, not hoisted copies
+        FirConsts kc = {{{0, 0}, {0, 0}, {0, 0}, {0, 0}}, {{tap<12>(), tap<13>()}, {tap<10>(), tap<11>()}, {tap<8>(), tap<9>()}, {tap<6>(), tap<7>()}}};
+#define ADSB_KC(b, T0, T1)                                                                                                          \
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"                                                                            \
+                 : "=v"(kc.c2048[b].x), "=v"(kc.c2048[b].y)                                                                         \
+                 : "i"(__builtin_bit_cast(uint32_t, 2048.0f * tap<T0>())), "i"(__builtin_bit_cast(uint32_t, 2048.0f * tap<T1>())))
+        ADSB_KC(0, 12, 13);
+        ADSB_KC(1, 10, 11);
+        ADSB_KC(2, 8, 9);
+        ADSB_KC(3, 6, 7);
+#undef ADSB_KC
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            asm volatile("" : "+s"(kc.taps[b]));
         const int v0 = first_run(pass); // first run of this wave in this pass
         const int v = v0 + lane;
         const int64_t wlo = pass_first_pair(pass);
@@ -393,21 +487,18 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
                 tl[k] = f32x4{(float)(d0 & 0xFFFFu), (float)(d0 >> 16), (float)(d1 & 0xFFFFu), (float)(d1 >> 16)};
             }
         }
-        // air.c:64-67,79-82: v = (float)x - 2048; pairs with odd index are negated
-        // (samples n mod 4 in {2,3}).  The run starts at an even pair index, so the
-        // sign is a compile-time property of the slot.  -(x-2048) == 2048-x exactly.
+        // the run's pairs as (I, Q), slot s <-> pair s - 6 of the run: the converted samples as they are -- the - 2048 of
+        // air.c:64-67 and the fs/4 sign of air.c:79-82 are inside the FIR's products (fir_product)
         f32x2 vv[34];
 #pragma unroll
         for (int s = 0; s < 34; s++) {
             const f32x4 q = tl[s >> 1];
-            const f32x2 f = (s & 1) ? f32x2{q.z, q.w} : f32x2{q.x, q.y};
-            const f32x2 mid = {2048.0f, 2048.0f};
-            vv[s] = ((s & 1) == 0) ? (f - mid) : (mid - f); // slot s <-> rel pair s-6: same parity
+            vv[s] = (s & 1) ? f32x2{q.z, q.w} : f32x2{q.x, q.y};
         }
 
         // a[0..27]: this run; a[28..43]: the first 16 samples of the next run (next lane)
         float a[44];
-        power_block<0, 28, kFirGroup>(vv, a);
+        power_run<0>(vv, a, kc);
 #pragma unroll
         for (int k = 0; k < 16; k++)
             a[28 + k] = from_next_lane(a[k]);

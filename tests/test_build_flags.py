@@ -1,6 +1,6 @@
-"""The kernel's arithmetic must be binary32 multiply-THEN-add: check the
-gfx950 ISA that hipcc emits for the scan kernel contains no fused multiply-add of
-any flavour, no scratch (spills), and that it is built for gfx950 only."""
+"""The kernel's arithmetic must round like binary32 multiply-THEN-add: check that the gfx950 ISA hipcc emits
+for the scan kernel contains exactly the fused operations the source writes (each exact by construction), no scratch
+(spills), and that it is built for gfx950 only."""
 import os
 import re
 import subprocess
@@ -18,23 +18,34 @@ def isa():
     return subprocess.run(cmd, capture_output=True, text=True, check=True).stdout
 
 
-def test_no_fused_multiply_add_in_scan_kernel(isa):
-    """The signal arithmetic (FIR, power, pair sums) must be mul-THEN-add.  The only
-    fused operations allowed are the 56 results per kernel instantiation that decide the SIGN
-    of 2*c' - c on already-truncated integers (exact by construction, see
-    scan_kernel.hip); anything else fused is a contraction bug."""
+def test_fused_operations_of_the_scan_kernel_are_the_exact_ones(isa):
+    """The signal arithmetic is binary32 multiply, THEN binary32 add.  The compiler contracts nothing
+    (-ffp-contract=off); the fused multiply-adds in the ISA are the ones scan_kernel.hip writes itself, each of which rounds
+    the same real number the reference's separate operation rounds:
+      * 56 sign tests per instantiation (2 c' - c on truncated integers: 22 packed + 12 scalar, the factor is the literal 2.0);
+      * the FIR's products  t (x - 2048) = fma(t, x, -2048 t)  (2048 t is exact): 196 per run of 28 outputs, 12 of them
+        shared by two outputs -> 184 packed instructions with a scalar tap pair and a vector constant pair;
+      * the 24 accumulations of a shared product  s + 2 M = fma(M, (2, 1) | (1, 2), s)  (doubling is exact).
+    Anything else fused, or another count, is a contraction bug or a change of the FIR that has to come here too."""
     fused = re.findall(r"^\s*(v_(?:pk_)?(?:fma|mac|mad|fmac|dot)\w*f(?:32|16)\w*)", isa, flags=re.M)
     kernels = len(re.findall(r"^\s*\.amdhsa_kernel\s.*scan_kernel", isa, flags=re.M))
     assert kernels == 2  # scan_kernel<true|false> (count_tries_kernel has no float math)
     assert set(fused) <= {"v_fma_f32", "v_pk_fma_f32"}, f"contracted arithmetic in the ISA: {sorted(set(fused))}"
-    # 28 E1 + 28 E2 sign tests per instantiation; a packed one decides two of them
-    lanes = sum(2 if f.startswith("v_pk_") else 1 for f in fused)
-    assert lanes == 56 * kernels, f"{lanes} fused results, expected {56 * kernels} (E1/E2 sign tests only)"
-    # each of them multiplies by the literal 2.0 (the SN factor of demod.c:83)
-    for line in re.findall(r"^\s*v_(?:pk_)?fma_f32.*$", isa, flags=re.M):
-        assert re.search(r"\b2\.0\b", line), line
+    packed = sum(1 for f in fused if f.startswith("v_pk_"))
+    scalar = len(fused) - packed
+    assert scalar == 12 * kernels, f"{scalar} scalar fused operations, expected {12 * kernels} (sign tests of the odd columns)"
+    assert packed == (22 + 184 + 24) * kernels, f"{packed} packed fused operations, expected {(22 + 184 + 24) * kernels}"
+    lines = re.findall(r"^\s*v_pk_fma_f32.*$", isa, flags=re.M)
+    by_two = [ln for ln in lines if re.search(r"\b2\.0\b", ln)]          # the sign tests multiply by the literal 2.0 ...
+    products = [ln for ln in lines if re.search(r",\s*s\[\d+:\d+\],\s*v\[\d+:\d+\]", ln) and ln not in by_two]
+    assert len(by_two) == 22 * kernels, len(by_two)                       # (demod.c:83's SN)
+    assert len(products) >= 184 * kernels, len(products)                  # ... a product reads scalar taps and a vector constant
+    for ln in re.findall(r"^\s*v_fma_f32.*$", isa, flags=re.M):
+        assert re.search(r"\b2\.0\b", ln), ln
     assert "-ffp-contract=off" in __import__("adsbdec_amd._build", fromlist=["HIP_FLAGS"]).HIP_FLAGS
-    assert re.search(r"v_pk_mul_f32", isa) and re.search(r"v_pk_add_f32", isa)
+    # the sums and the squares stay separate operations: 168 FIR additions + the pair sums, 28 squares per run
+    assert len(re.findall(r"^\s*v_pk_add_f32", isa, flags=re.M)) >= 168 * kernels
+    assert len(re.findall(r"^\s*v_pk_mul_f32", isa, flags=re.M)) >= 28 * kernels
 
 
 def test_no_scratch_and_gfx950_only(isa):

@@ -38,9 +38,11 @@ def main():
                              ("noise 7 %", lambda: make_dense(torch, n, 100), True),
                              ("dense10 (configs[2])", lambda: make_dense10(torch, n, 101), True),
                              ("gate_storm", lambda: make_gate_storm(torch, n, 102), True)):
+        if os.environ.get("PHASE_ONLY") and os.environ["PHASE_ONLY"] not in name:
+            continue
         x = make()
         torch.cuda.synchronize()
-        for stats in (False, True):
+        for stats in ((False,) if os.environ.get("PHASE_ONLY") else (False, True)):
             d = capi.Decoder(df18=df18, profile=True, collect_stats=stats)
             for _ in range(5):
                 d.decode_device_raw(x.data_ptr(), x.numel())

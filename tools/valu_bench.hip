@@ -21,6 +21,8 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
     }
     const float c = seed * 0.5f + 1.0f;
     const f32x2 c2 = {c, c + 1.0f};
+    f32x2 c3 = {c + 2.0f, c + 3.0f};
+    asm volatile("" : "+v"(c3));
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -58,6 +60,22 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
                 if (OP == 28) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[i]) : "v"(u[i]));
                 if (OP == 29) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 15]));
                 if (OP == 30) asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %1" : : "v"(a[i]), "v"(a[(i + 1) & 15]) : "s20", "s21");
+                if (OP == 40) { f32x2 t; asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(p[(i + 1) & 15]), "s"(c2)); asm volatile("" : : "v"(t)); }
+                if (OP == 41) { // round 5's FIR step: product with a scalar tap pair, then the accumulation
+                    f32x2 t;
+                    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(p[(i + 1) & 15]), "s"(c2));
+                    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(t));
+                }
+                if (OP == 42) { // round 6's: the product is a fused multiply-add with a vector constant, modifiers on
+                    f32x2 t;
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(t) : "v"(p[(i + 1) & 15]), "s"(c2), "v"(c3));
+                    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(t));
+                }
+                if (OP == 43) { f32x2 t; asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(t) : "v"(p[(i + 1) & 15]), "s"(c2), "v"(c3)); asm volatile("" : : "v"(t)); }
+                if (OP == 44) { f32x2 t; asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(p[(i + 1) & 15]), "s"(c2), "v"(c3)); asm volatile("" : : "v"(t)); }
+                if (OP == 45) { f32x2 t; asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(p[(i + 1) & 15]), "v"(c2), "v"(c3)); asm volatile("" : : "v"(t)); }
+                if (OP == 46) { f32x2 t; asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(p[(i + 1) & 15]), "v"(c2)); asm volatile("" : : "v"(t)); }
+                if (OP == 47) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 5) & 15]));
                 if (OP == 9) { // the FIR's dependent pair: pk_mul into a temp, pk_add accumulate (2 instr)
                     f32x2 t;
                     asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(p[(i + 1) & 15]), "v"(c2));
@@ -78,7 +96,7 @@ int run(const char *name, float *out, int per_iter)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 20000;
-    for (int wps = 1; wps <= 4; wps *= 4) { // waves per SIMD: blocks of 256 threads = 1 wave on each of 4 SIMDs
+    for (int wps : {1, 4, 5}) { // waves per SIMD: blocks of 256 threads = 1 wave on each of 4 SIMDs
         const int blocks = 256 * wps;
         k<OP><<<blocks, 256>>>(out, 100, 1.0f);
         CK(hipDeviceSynchronize());
@@ -95,6 +113,17 @@ int run(const char *name, float *out, int per_iter)
 int main()
 {
     float *out; CK(hipMalloc(&out, 4));
+    if (getenv("VB_FIR")) {
+        run<46>("pk_mul v,v,v", out, 64);
+        run<40>("pk_mul v,v,s", out, 64);
+        run<47>("pk_add v,v,v", out, 64);
+        run<44>("pk_fma v,v,s,v", out, 64);
+        run<45>("pk_fma v,v,v,v", out, 64);
+        run<43>("pk_fma v,v,s,v mods", out, 64);
+        run<41>("pk_mul(s)+pk_add", out, 128);
+        run<42>("pk_fma(s,v,mods)+pk_add", out, 128);
+        return 0;
+    }
     run<0>("v_add_f32", out, 64);
     run<6>("v_mul_f32", out, 64);
     run<4>("v_fma_f32", out, 64);
