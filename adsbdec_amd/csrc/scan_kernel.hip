@@ -54,9 +54,10 @@
 //  (the 1196-sample reach of a long frame) costs 44 runs of planes per tile (2 % at
 //  K = 8) instead of 1204 float samples of LDS.
 //
-// Arithmetic is strict binary32: multiply, then add (built with -ffp-contract=off;
-// tests/test_build_flags.py checks the ISA: the only fused operations are the 56 exact
-// sign tests of the preamble comparison).
+// Arithmetic rounds like strict binary32 multiply, then add (built with -ffp-contract=off: the compiler contracts
+// nothing).  The fused operations in the ISA are written here, each rounding the real number the reference's separate
+// operation rounds: the 56 sign tests of the preamble comparison, the FIR's products on the converted sample and the
+// accumulations of its twelve shared products ("The FIR of one run" below); tests/test_build_flags.py counts them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -508,8 +509,7 @@ __device__ __forceinline__ void stage_a(const uint32_t *__restrict__ xin, const 
         // magnitudes in the input domain); the integer comparisons `c > 2 c'` are
         // decided by the SIGN of 2 c' - c, which one fused multiply-add gives exactly
         // (a single rounding cannot change the sign of a non-zero difference and an
-        // exact zero stays zero).  These are the only FMAs in the kernel; the signal
-        // arithmetic above is mul-then-add.
+        // exact zero stays zero).
         //
         // Packing: every operation here combines index k with k + 5 or k + 10, so the
         // usual (k, k+1) register pairs cannot feed v_pk_* on both sides (5 is odd).

@@ -74,7 +74,7 @@ PY
            echo "-G 1"; for i in 1 2 3; do ADSB_CLI_TIMING=1 adsbdec_amd/lib/adsbdec_amd_cli -G 1 -f /dev/shm/r6_cap.u16 2>&1 >/dev/null | grep timing; done
            echo "-G 0,0"; for i in 1 2 3; do ADSB_CLI_TIMING=1 adsbdec_amd/lib/adsbdec_amd_cli -G 0,0 -f /dev/shm/r6_cap.u16 2>&1 >/dev/null | grep timing; done
            rm -f /dev/shm/r6_cap.u16; } > $O/r6_cli.txt 2>&1; grep timing $O/r6_cli.txt;;
-    clitrace) { python - <<'PY'
+    clitrace) { export ADSB_CLI_CLEAN_EXIT=1 ADSB_CLI_TIMING=2; python - <<'PY'
 import numpy as np
 rng = np.random.default_rng(5)
 x = (2048 + rng.normal(0, 20, 255 << 20)).clip(0, 4095).astype(np.uint16)
@@ -111,6 +111,7 @@ print("device timeline (start ms, duration ms):")
 for a, b, n in kr[:120]:
     print(f"  {(a - t0) / 1e6:9.2f} ms  {(b - a) / 1e6:8.3f} ms  {n}")
 PY
+           echo "the program's own timing lines of the traced run:"; grep "push\|timing" /tmp/clitrace.err | head -40
            rm -f /dev/shm/r6_cap.u16; } > $O/r6_cli_trace.txt 2>&1; head -60 $O/r6_cli_trace.txt;;
     fuzz) shift; FZ=${1:-300}; timeout $((FZ + 300)) python tools/fuzz_parity.py --seconds $FZ --seed 960000 > $O/r6_fuzz.txt 2>&1; echo "fuzz exit $?"; tail -2 $O/r6_fuzz.txt | cut -c1-900;;
   esac
