@@ -697,6 +697,15 @@ size_t deliver_tiles(adsb_decoder *d, ScanSlot &s, uint32_t from, uint32_t upto)
 // capacity one thread needs four times the kernel's time for a launch's records, and reading + checking on one thread while
 // the caller resolves takes a quarter off that; under ordinary traffic the thread never exists.
 constexpr uint64_t kAutoReaderRecords = 65536, kAutoReaderMinRecords = 16384;
+
+// Did the previous launch of this handle hand over a record per 2 048 offsets or more (and 16 384 at least)?  The traffic of a
+// channel does not change from one launch to the next: the host side starts its helper threads on this (slot_collect), and the
+// next launch takes tiles of six passes instead of seven (adsb::choose_passes).
+inline bool last_launch_was_dense(const adsb_decoder *d)
+{
+    const uint64_t dense_from = std::max<uint64_t>(kAutoReaderMinRecords, std::min<uint64_t>(kAutoReaderRecords, d->last_launch_offsets / 2048));
+    return d->last_launch_records >= dense_from;
+}
 void start_reader(adsb_decoder *d)
 {
     if (d->reader || d->reader_failed)
@@ -816,8 +825,7 @@ int slot_collect_streaming(adsb_decoder *d, ScanSlot &s, uint32_t *resume_tile, 
     // channel has one per 1 090).  Round 6: a shorter launch -- a 128 Mi-sample shard of the multi-GPU driver is 64 Mi offsets,
     // 61 k records on a full channel -- counts by the same density, from 16 384 records on (below that a launch is resolved
     // faster than five threads are woken).
-    const uint64_t dense_from = std::max<uint64_t>(kAutoReaderMinRecords, std::min<uint64_t>(kAutoReaderRecords, d->last_launch_offsets / 2048));
-    const bool after_dense = d->cfg.host_threads == 0 && d->last_launch_records >= dense_from;
+    const bool after_dense = d->cfg.host_threads == 0 && last_launch_was_dense(d);
     if (after_dense) {
         start_reader(d);
         cpu_set_t allowed; // (six threads that poll need cores of their own: on a small or confined host, round 4's pair)
@@ -1307,7 +1315,7 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
         a.g_end = g_stop;
         a.df18 = d->cfg.df18 ? 1 : 0;
         a.passes = (d->dbg.passes >= 2 && d->dbg.passes <= adsb::kMaxPasses) ? d->dbg.passes
-                                                                                         : adsb::choose_passes(n_off, d->n_cus);
+                                                                                         : adsb::choose_passes(n_off, d->n_cus, last_launch_was_dense(d));
         a.stagger = adsb::checked_stagger(n_off, a.passes, d->dbg.stagger);
         a.synd = d->d_synd;
         a.queue_cap = (d->dbg.queue_cap >= 256 && d->dbg.queue_cap <= adsb::kQueueCap)
@@ -1589,8 +1597,24 @@ adsb_decoder *adsb_create(const adsb_config *cfg_in)
                     return;
                 for (hipStream_t cs : d->copy_stream)
                     (void)adsb::launch_copy_samples(d->stage[1] + 64, d->stage[1], 8, cs);
+                // ... and the SECOND copy engine.  The runtime asks which engines are idle and takes another one when the
+                // usual one is busy (hsa_amd_memory_copy_engine_status, hsa_amd_memory_async_copy_on_engine); an engine's
+                // queue is created at its first use, 7.5 ms inside that call -- for the C host program in the copy behind
+                // its first compaction, the first one issued while the previous piece's copy was still running
+                // (profiles/r6_cli_trace.txt).  Two copies in flight at once, here, beside the rest of adsb_create.
+                void *tmp = nullptr;
+                const size_t bytes = std::min<size_t>(16u << 20, d->stage_cap * sizeof(uint16_t) / 4);
+                if (hipHostMalloc(&tmp, bytes, hipHostMallocDefault) == hipSuccess) {
+                    std::memset(tmp, 0, 4096);
+                    for (int rep = 0; rep < 2; rep++)
+                        for (int i = 0; i < adsb_decoder::kCopyStreams; i++)
+                            (void)hipMemcpyAsync(reinterpret_cast<char *>(d->stage[1]) + (size_t)i * bytes, tmp, bytes, hipMemcpyHostToDevice,
+                                                 d->copy_stream[i]);
+                }
                 for (hipStream_t cs : d->copy_stream)
                     (void)hipStreamSynchronize(cs);
+                if (tmp)
+                    (void)hipHostFree(tmp);
             });
         } catch (...) {
         }

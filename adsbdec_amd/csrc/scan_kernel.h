@@ -10,7 +10,10 @@ namespace adsb {
 
 // Launch shape (what every measurement of DESIGN.md was taken with; the experiments that set other values are history)
 
-constexpr int kSleepStagger = 90;  // s_sleep units (64 cycles) between the starts of a CU's first four workgroups
+#ifndef ADSB_SLEEP_STAGGER
+#define ADSB_SLEEP_STAGGER 90
+#endif
+constexpr int kSleepStagger = ADSB_SLEEP_STAGGER;  // s_sleep units (64 cycles) between the starts of a CU's first four workgroups
 constexpr int kMinWaves = 5;       // __launch_bounds__ second argument: waves per SIMD (96 VGPRs; 5 workgroups' LDS fit a CU)
 
 constexpr int kRun = 28;        // power samples per thread run (4 x 7: see scan_kernel.hip)
@@ -164,7 +167,7 @@ void make_syndrome_table(uint32_t *out /* kSyndWords */);
 uint32_t make_fix_table(uint32_t *tab /* kFixSlots */);
 // Host: choose the passes-per-tile for a launch of n_offsets on a device with `cus` compute units
 // (balances halo overhead against tail quantisation).
-int choose_passes(uint64_t n_offsets, int cus);
+int choose_passes(uint64_t n_offsets, int cus, bool dense = false);
 // Host: a forced stagger (adsb_config.debug_stagger), made valid for the launch (multiple of 4, K >= 5, enough tiles), else 0.
 uint32_t checked_stagger(uint64_t n_offsets, int passes, int forced);
 hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream);

@@ -1492,7 +1492,7 @@ uint32_t make_fix_table(uint32_t *tab)
     }
 }
 
-int choose_passes(uint64_t n_offsets, int cus)
+int choose_passes(uint64_t n_offsets, int cus, bool dense)
 {
     // Estimated time = rounds x passes, rounds = ceil(tiles / resident workgroups);
     // long tiles amortise the 44-run halo, short ones fill the last round better.
@@ -1502,8 +1502,13 @@ int choose_passes(uint64_t n_offsets, int cus)
     // workgroups, so there are no "rounds" to quantise), and a longer tile only amortises its
     // 44-run halo better.  Measured in bench.py at 128 Mi offsets: K = 5 / 6 / 7 / 8 / 10 ->
     // 0.214 / 0.212 / 0.208 / 0.211 / 0.211 ms per step.
+    // Round 6, launches interleaved in one process (tools/ab_interleaved.py, profiles/r6_ab_runs.txt section 9), K = 4 / 5 / 6 / 7 / 8:
+    // sparse 1.045 / 1.036 / 1.007 / 1 / 1.067 (from K = 8 on a CU's LDS holds four workgroups, not five), noise the same;
+    // BASELINE configs[2] at its stated density 0.970 / 0.981 / 0.972 / 1 / 1.093, with the Try/Ok table 0.961 / 0.939 /
+    // 0.938 / 1: a tile of frames back to back stages fewer candidates for its all-pairs filter, overflows its survivor
+    // queue less often.  `dense` = the handle's previous launch handed over a record per 2 048 offsets or more.
     if (n_offsets >= (96ull << 20))
-        return 7;
+        return dense ? 6 : 7;
     int best = 2;
     double best_cost = 1e300;
     for (int k = 2; k <= 6; k++) { // measured: 4..6 passes are best at every launch size

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from adsbdec_amd import capi  # noqa: E402
-from bench import make_dense10, make_gate_storm, make_workload  # noqa: E402
+from bench import make_dense, make_dense10, make_gate_storm, make_workload  # noqa: E402
 
 
 def bind(path):
@@ -35,20 +35,34 @@ def main():
     args = sys.argv[1:]
     dense10 = "--dense10" in args
     storm = "--gate-storm" in args
+    noise = "--dense" in args
     stats = "--stats" in args
     rounds = int(args[args.index("--rounds") + 1]) if "--rounds" in args else 40
     steps = int(args[args.index("--steps") + 1]) if "--steps" in args else 10
-    builds = [a.split("=", 1) for a in args if "=" in a]
+    builds = []  # name=path[@passes=N[,stagger=M]]: the same library under several adsb_debug_config settings
+    for a in args:
+        if "=" in a and not a.startswith("--"):
+            name, rest = a.split("=", 1)
+            path, _, knobs = rest.partition("@")
+            builds.append((name, path, dict(kv.split("=") for kv in knobs.split(",") if kv)))
     n = 256 << 20
     n -= n % 28
-    x = make_dense10(torch, n, 101) if dense10 else make_gate_storm(torch, n, 102) if storm else make_workload(torch, n, seed=1)[0]
+    x = make_dense10(torch, n, 101) if dense10 else make_gate_storm(torch, n, 102) if storm else make_dense(torch, n, 100) if noise else make_workload(torch, n, seed=1)[0]
     torch.cuda.synchronize()
     hs = []
-    for name, path in builds:
+    keep = []
+    for name, path, knobs in builds:
         L = bind(os.path.abspath(path))
         cfg = capi.Config()
         L.adsb_config_init(C.byref(cfg), C.sizeof(cfg))
-        cfg.df18 = 1 if (dense10 or storm) else 0
+        if knobs:
+            dbg = capi.DebugConfig()
+            dbg.struct_size = C.sizeof(dbg)
+            for k, v in knobs.items():
+                setattr(dbg, k, int(v))
+            keep.append(dbg)
+            cfg.debug = C.cast(C.pointer(dbg), C.c_void_p)
+        cfg.df18 = 1 if (dense10 or storm or noise) else 0
         cfg.collect_stats = 1 if stats else 0
         cfg.profile = 1
         h = L.adsb_create(C.byref(cfg))
@@ -78,7 +92,7 @@ def main():
             m1, l1 = kernel_ms(L, h)
             per[name].append((m1 - m0) / max(1, l1 - l0))
     base = per[hs[0][0]]
-    print(f"workload {'dense10' if dense10 else 'gate_storm' if storm else 'sparse'}{' +stats' if stats else ''}, {frames[hs[0][0]]} frames, "
+    print(f"workload {'dense10' if dense10 else 'gate_storm' if storm else 'noise 7 %' if noise else 'sparse'}{' +stats' if stats else ''}, {frames[hs[0][0]]} frames, "
           f"{rounds} rounds x {steps} launches per build, kernel clock, ms per launch")
     for name, _, _ in hs:
         v = sorted(per[name])

@@ -80,7 +80,7 @@ rng = np.random.default_rng(5)
 x = (2048 + rng.normal(0, 20, 255 << 20)).clip(0, 4095).astype(np.uint16)
 x.tofile("/dev/shm/r6_cap.u16")
 PY
-           cd /tmp; rm -rf /tmp/clitrace; timeout 300 rocprofv3 --hip-runtime-trace --kernel-trace --memory-copy-trace --output-format csv -d /tmp/clitrace -o run -- $OLDPWD/adsbdec_amd/lib/adsbdec_amd_cli -f /dev/shm/r6_cap.u16 > /dev/null 2> /tmp/clitrace.err; cd $OLDPWD
+           cd /tmp; rm -rf /tmp/clitrace; timeout 300 rocprofv3 --hip-runtime-trace --hsa-trace --kernel-trace --memory-copy-trace --output-format csv -d /tmp/clitrace -o run -- $OLDPWD/adsbdec_amd/lib/adsbdec_amd_cli -f /dev/shm/r6_cap.u16 > /dev/null 2> /tmp/clitrace.err; cd $OLDPWD
            python - <<'PY'
 import csv, glob
 rows = []
@@ -88,6 +88,35 @@ for f in glob.glob("/tmp/clitrace/**/*hip_api_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Function"]))
 rows.sort()
+tid = {}
+for f in glob.glob("/tmp/clitrace/**/*hip_api_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        tid[(int(r["Start_Timestamp"]), r["Function"])] = r.get("Thread_Id", "?")
+if rows:
+    # the longest hipMemcpyAsync behind the first scan kernel = the push that stalls: every call of every thread around it
+    t_first = rows[0][0]
+    t_ready = max([b for a, b, f in rows if f.startswith("hipStreamCreate")] or [t_first])  # adsb_create is over
+    late = [(b - a, a, b) for a, b, f in rows if f == "hipMemcpyAsync" and a > t_ready + 2e6]
+    if late:
+        d, a0, b0 = max(late)
+        print(f"every HIP call from 3 ms before the slow hipMemcpyAsync ({d / 1e6:.2f} ms) to 1 ms behind it (start ms, duration ms, thread, call):")
+        for a, b, f in rows:
+            if a0 - 3e6 <= a <= b0 + 1e6:
+                print(f"  {(a - t_first) / 1e6:9.3f} ms  {(b - a) / 1e6:8.3f} ms  {tid.get((a, f), '?'):>8}  {f}")
+        hs = []
+        for f in glob.glob("/tmp/clitrace/**/*hsa_api_trace.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                hs.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Function"], r.get("Thread_Id", "?")))
+        hs.sort()
+        print(f"HSA calls inside that hipMemcpyAsync (all threads), 20 us and longer, and a count of the shorter ones:")
+        short = {}
+        for a, b, f, t in hs:
+            if a0 <= a <= b0:
+                if b - a >= 20000:
+                    print(f"  {(a - t_first) / 1e6:9.3f} ms  {(b - a) / 1e6:8.3f} ms  {t:>8}  {f}")
+                else:
+                    short[f] = short.get(f, 0) + 1
+        print("  shorter:", short)
 if not rows:
     import subprocess
     print("no hip_api_trace rows; files under /tmp/clitrace:")
