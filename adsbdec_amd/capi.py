@@ -66,7 +66,7 @@ class DebugConfig(C.Structure):
     """adsb_debug_config (include/adsbdec_amd_diag.h): the test knobs behind adsb_config.debug."""
     _fields_ = [("struct_size", C.c_uint32), ("queue_cap", C.c_int32), ("cand_cap", C.c_int32), ("try_cap", C.c_int32),
                 ("clist_cap", C.c_int32), ("no_streaming", C.c_int32), ("frames_cap", C.c_int32), ("reader_min_tiles", C.c_int32),
-                ("shard_head", C.c_int32), ("passes", C.c_int32), ("stagger", C.c_int32), ("gang_min", C.c_int32)]
+                ("shard_head", C.c_int32), ("passes", C.c_int32), ("big_tiles", C.c_int32), ("gang_min", C.c_int32)]
 
 
 class ConfigV4(C.Structure):
@@ -250,7 +250,7 @@ def format_frame(fr: dict, outformat: int) -> bytes:
 
 
 DEBUG_KNOBS = ("queue_cap", "cand_cap", "try_cap", "clist_cap", "no_streaming", "frames_cap", "reader_min_tiles", "shard_head",
-               "passes", "stagger", "gang_min")
+               "passes", "big_tiles", "gang_min")
 
 
 def make_config(df18: bool = False, device: int = -1, collect_stats: bool = False,
@@ -267,7 +267,7 @@ def make_config(df18: bool = False, device: int = -1, collect_stats: bool = Fals
         cfg = ConfigV4()
         L.adsb_config_init(C.byref(cfg), C.sizeof(cfg))
         for k, v in debug.items():
-            if cfg.struct_size >= getattr(ConfigV4, k).offset + 4:
+            if hasattr(ConfigV4, k) and cfg.struct_size >= getattr(ConfigV4, k).offset + 4:
                 setattr(cfg, k, int(v))
         if cfg.struct_size >= ConfigV4.wait_timeout_s.offset + 4:
             cfg.wait_timeout_s = wait_timeout_s

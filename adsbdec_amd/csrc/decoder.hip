@@ -489,7 +489,7 @@ int slot_launch(adsb_decoder *d, ScanSlot &s)
     if (slot_settle_profile(d, s, s.ev_cur)) // two launches old: normally read long ago
         return -1;
     s.ev_offsets[s.ev_cur] = s.args.g_end - s.args.g_begin;
-    s.ntiles = adsb::tile_count(s.args.g_end - s.args.g_begin, s.args.stagger, s.args.passes);
+    s.ntiles = adsb::tile_count(s.args.g_end - s.args.g_begin, s.args.big_tiles, s.args.passes);
     // A stream's statistics run keeps the try words on the device (counted there after
     // resolution); a per-shard scan hands the list back, sorted, so it needs the list
     // complete on the host: collect after completion.
@@ -660,7 +660,7 @@ size_t deliver_tiles(adsb_decoder *d, ScanSlot &s, uint32_t from, uint32_t upto)
 {
     const uint32_t *t_start = d->tile_start.data(), *t_count = d->tile_count.data();
     const uint64_t g_complete = std::min<uint64_t>(
-        s.args.g_end, s.args.g_begin + adsb::kRun * adsb::tile_first_run(upto, s.args.stagger, s.args.passes));
+        s.args.g_end, s.args.g_begin + adsb::kRun * adsb::tile_first_run(upto, s.args.big_tiles, s.args.passes));
     size_t nc = 0;
     if (d->sink.cands) { // per-shard scan: the caller's vectors
         std::vector<uint32_t> &order = d->order; // the records in ascending g (granule indices)
@@ -674,7 +674,7 @@ size_t deliver_tiles(adsb_decoder *d, ScanSlot &s, uint32_t from, uint32_t upto)
         for (uint32_t u = from; u < upto; u++)
             nc += t_count[u];
         d->prof.candidates += nc;
-        if (d->res.head_wanted(s.args.g_begin + adsb::kRun * adsb::tile_first_run(from, s.args.stagger, s.args.passes)))
+        if (d->res.head_wanted(s.args.g_begin + adsb::kRun * adsb::tile_first_run(from, s.args.big_tiles, s.args.passes)))
             d->res.capture_head_tiles(s.hand, t_start, t_count, from, upto, s.args.g_begin);
         d->res.advance_tiles(s.hand, t_start, t_count, from, upto, s.args.g_begin, power_samples_produced(d->n_samples), g_complete);
     }
@@ -1024,7 +1024,7 @@ int count_tries_pass(adsb_decoder *d, ScanSlot *slot, uint32_t n_tries, uint64_t
     a.region_counts = regions ? slot->d_try_counts : nullptr;
     a.n_tiles = regions ? slot->ntiles : 0;
     a.passes = slot ? slot->args.passes : 0;
-    a.stagger = slot ? slot->args.stagger : 0;
+    a.big_tiles = slot ? slot->args.big_tiles : 0;
     a.g_base = g_base;
     a.carry_in = d->d_carry[d->carry_cur];
     a.n_carry = d->d_carry_n + c_in;
@@ -1191,7 +1191,7 @@ int slot_collect(adsb_decoder *d)
         }
         // The loose list may also hold records of tiles the streamed part has already delivered: after a relaunch (record
         // buffers regrown) every tile runs again, and whether a tile's range fits the stream depends on completion order.
-        const uint64_t resume_rel = (uint64_t)adsb::kRun * adsb::tile_first_run(resume_tile, s.args.stagger, s.args.passes);
+        const uint64_t resume_rel = (uint64_t)adsb::kRun * adsb::tile_first_run(resume_tile, s.args.big_tiles, s.args.passes);
         d->gather.clear();
         for (size_t i = 0; i < nc; i++) {
             const uint32_t *w = s.cands + i * adsb::kCandWords;
@@ -1206,7 +1206,7 @@ int slot_collect(adsb_decoder *d)
         size_t li = 0;
         uint32_t run_from = resume_tile;
         for (uint32_t u = resume_tile; u < s.ntiles; u++) {
-            const uint64_t hi_rel = (uint64_t)adsb::kRun * adsb::tile_first_run(u + 1, s.args.stagger, s.args.passes);
+            const uint64_t hi_rel = (uint64_t)adsb::kRun * adsb::tile_first_run(u + 1, s.args.big_tiles, s.args.passes);
             size_t lj = li;
             while (lj < n_loose && d->gather[(size_t)loose_order[lj] * adsb::kCandWords] < hi_rel)
                 lj++;
@@ -1316,7 +1316,7 @@ int scan_submit(adsb_decoder *d, const uint16_t *buf, uint64_t buf_first, uint64
         a.df18 = d->cfg.df18 ? 1 : 0;
         a.passes = (d->dbg.passes >= 2 && d->dbg.passes <= adsb::kMaxPasses) ? d->dbg.passes
                                                                                          : adsb::choose_passes(n_off, d->n_cus, last_launch_was_dense(d));
-        a.stagger = adsb::checked_stagger(n_off, a.passes, d->dbg.stagger);
+        a.big_tiles = adsb::choose_big_tiles(n_off, a.passes, d->n_cus, d->dbg.big_tiles);
         a.synd = d->d_synd;
         a.queue_cap = (d->dbg.queue_cap >= 256 && d->dbg.queue_cap <= adsb::kQueueCap)
                           ? d->dbg.queue_cap

@@ -42,33 +42,52 @@ constexpr size_t lds_bytes(int passes)
 {
     return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6);
 }
-// Tile geometry of a launch.  Every tile takes K = `passes` passes, except that the first
-// `stagger` tiles (a multiple of 4, K >= 5; 0 = off, the default) cycle through K-3, K-2,
-// K-1, K -- an experiment in spreading tile completions that did not pay; kept as a test knob
-// (adsb_config.debug_stagger) because it exercises the tile geometry functions.
-__host__ __device__ inline int tile_passes(uint32_t tile, uint32_t stagger, int k)
+// Tile geometry of a launch.  A tile takes K = `passes` passes -- except that a large launch ENDS in tiles of
+// kTaperPasses: the tiles from index `big_tiles` on (0: none; the host's choice, choose_big_tiles()).  Why: a launch costs
+// ~11 us beyond what its tiles cost at the steady rate (time = 10.7 us + 46 ns x tiles, profiles/r6_ab_runs.txt section 10),
+// half of it the drain -- the last tiles run on CUs that are emptying, a wave to a SIMD, at a fraction of the issue rate --
+// and a tile of four passes drains in about half the time of one of seven.  Every user of the geometry -- the kernel, the
+// count pass, the host's walk of the hand-off stream -- goes through these three functions (tests/cpp/tile_geometry.hip).
+constexpr int kTaperPasses = 4;
+__host__ __device__ inline int tile_passes(uint32_t tile, uint32_t big_tiles, int k)
 {
-    return tile < stagger ? k - 3 + (int)(tile & 3u) : k;
+    return (big_tiles == 0 || tile < big_tiles || k <= kTaperPasses) ? k : kTaperPasses;
 }
-__host__ __device__ inline uint64_t tile_first_run(uint32_t tile, uint32_t stagger, int k)
+__host__ __device__ inline uint64_t tile_first_run(uint32_t tile, uint32_t big_tiles, int k)
 {
-    const uint64_t quad = 4ull * (uint64_t)owned_runs(k) - 6ull * kPassRuns; // K-3, K-2, K-1, K passes
-    if (tile < stagger) {
-        const uint32_t q = tile >> 2, r = tile & 3u;
-        return q * quad + (uint64_t)r * (uint64_t)owned_runs(k - 3) + (uint64_t)kPassRuns * (r * (r - 1u) / 2u);
-    }
-    return (uint64_t)(stagger >> 2) * quad + (uint64_t)(tile - stagger) * (uint64_t)owned_runs(k);
+    if (big_tiles == 0 || tile <= big_tiles || k <= kTaperPasses)
+        return (uint64_t)tile * (uint64_t)owned_runs(k);
+    return (uint64_t)big_tiles * (uint64_t)owned_runs(k) + (uint64_t)(tile - big_tiles) * (uint64_t)owned_runs(kTaperPasses);
 }
-inline uint32_t tile_count(uint64_t n_offsets, uint32_t stagger, int k)
+inline uint32_t tile_count(uint64_t n_offsets, uint32_t big_tiles, int k)
 {
     const uint64_t runs = (n_offsets + kRun - 1) / kRun;
-    const uint64_t head = tile_first_run(stagger, stagger, k);
-    if (runs >= head)
-        return stagger + (uint32_t)((runs - head + owned_runs(k) - 1) / owned_runs(k));
-    uint32_t t = (uint32_t)(runs / (tile_first_run(4, 4, k))) * 4u; // whole quads, then at most four more
-    while (tile_first_run(t, stagger, k) < runs)
-        t++;
-    return t;
+    const uint64_t head = (uint64_t)big_tiles * (uint64_t)owned_runs(k);
+    if (big_tiles == 0 || k <= kTaperPasses || runs <= head)
+        return (uint32_t)((runs + owned_runs(k) - 1) / owned_runs(k));
+    return big_tiles + (uint32_t)((runs - head + owned_runs(kTaperPasses) - 1) / owned_runs(kTaperPasses));
+}
+
+// Host: how many of a launch's tiles take all K passes (0: all of them) -- launches of 96 Mi offsets and more end in
+// cus x kMinWaves / 2 tiles of kTaperPasses; `forced` > 0 (adsb_debug_config.big_tiles) is taken as it is.
+inline uint32_t choose_big_tiles(uint64_t n_offsets, int passes, int cus, int forced)
+{
+    if (passes <= kTaperPasses)
+        return 0;
+    if (forced > 0)
+        return (uint32_t)forced;
+    if (n_offsets < (72ull << 20))
+        return 0; // (measured from 64 Mi offsets on: K = 6 with the tail -3.5 % there, but K = 4 -- no tail to shorten -- better still)
+    if (cus <= 0)
+        cus = 256;
+    // Measured on 128 Mi offsets, launches interleaved in one process (profiles/r6_ab_runs.txt section 10), small tiles of 4
+    // passes: 405 / 512 / 634 of them -1.8 / -1.0..-2.0 / -1.4..-2.4 % (sparse), 709 / 785 -1.8 % (configs[2], K = 6); of 2
+    // or 3 passes -1.6..-1.9 % at best, of 5 nothing.  Half of what a device holds at once:
+    const uint64_t small = (uint64_t)cus * kMinWaves / 2;
+    const uint64_t runs = (n_offsets + kRun - 1) / kRun, tail_runs = small * (uint64_t)owned_runs(kTaperPasses);
+    if (runs <= 2 * tail_runs)
+        return 0;
+    return (uint32_t)((runs - tail_runs) / (uint64_t)owned_runs(passes));
 }
 
 constexpr uint64_t kMaxLaunchOffsets = (1ull << 30) - tile_offsets(kMaxPasses); // g_rel must fit 30 bits
@@ -81,7 +100,7 @@ struct ScanArgs {
     uint64_t g_end;      // one past the last offset
     int df18;            // demod.c:26
     int passes;          // K: runs per thread; a tile owns owned_runs(K) runs
-    uint32_t stagger;    // the first `stagger` tiles take K-3..K passes in turn (tile_passes)
+    uint32_t big_tiles;  // tiles from this index on take kTaperPasses passes (0: every tile takes K; tile_passes)
     int queue_cap;       // survivors compacted per round: 256..kQueueCap (kQueueCap unless testing)
     int all_candidates;  // 1: emit every CRC-valid offset (no never-visited filter)
     int clist_cap;       // CRC-valid candidates staged per tile: 1..kClistCap (kClistCap unless testing)
@@ -143,7 +162,7 @@ struct TryCountArgs {
     const uint32_t *region_counts;
     uint32_t n_tiles;
     int passes;                // the launch's tile geometry (tile_first_run)
-    uint32_t stagger;
+    uint32_t big_tiles;
     uint64_t g_base;
     const uint64_t *carry_in;  // undecided tries of earlier passes: (g << 2) | code
     const uint32_t *n_carry;   // device: how many (left there by the previous pass)
@@ -168,8 +187,7 @@ uint32_t make_fix_table(uint32_t *tab /* kFixSlots */);
 // Host: choose the passes-per-tile for a launch of n_offsets on a device with `cus` compute units
 // (balances halo overhead against tail quantisation).
 int choose_passes(uint64_t n_offsets, int cus, bool dense = false);
-// Host: a forced stagger (adsb_config.debug_stagger), made valid for the launch (multiple of 4, K >= 5, enough tiles), else 0.
-uint32_t checked_stagger(uint64_t n_offsets, int passes, int forced);
+
 hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream);
 // Device-to-device copy of n uint16 samples by the library's own kernel (the staging tail: see scan_kernel.hip).
 hipError_t launch_copy_samples(uint16_t *dst, const uint16_t *src, size_t n, hipStream_t stream);

@@ -1189,7 +1189,7 @@ template <bool kStats>
 __global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int K = tile_passes(blockIdx.x, args.stagger, args.passes);
+    const int K = tile_passes(blockIdx.x, args.big_tiles, args.passes);
     const int nplane = kPassRuns * K + kPlanePad;
     uint32_t *pl_d = smem;
     uint32_t *pl_e1 = smem + nplane;
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void scan_kernel(const ScanArg
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int64_t t0 = // first owned offset
-        (int64_t)args.g_begin + (int64_t)kRun * (int64_t)tile_first_run(blockIdx.x, args.stagger, args.passes);
+        (int64_t)args.g_begin + (int64_t)kRun * (int64_t)tile_first_run(blockIdx.x, args.big_tiles, args.passes);
 
     // plane words past the last computed run are read (never used) by Stage B
     if (tid < kPlanePad) {
@@ -1313,8 +1313,8 @@ __global__ __launch_bounds__(kCountThreads) void count_tries_kernel(const TryCou
         const uint32_t tile = rb * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
         const uint32_t n = tile < a.n_tiles ? min(a.region_counts[tile], (uint32_t)kTryRegion) : 0u;
         if (n) { // wave-uniform
-            const uint64_t t0 = a.g_base + (uint64_t)kRun * tile_first_run(tile, a.stagger, a.passes);
-            const uint64_t t1 = t0 + (uint64_t)kRun * (uint64_t)owned_runs(tile_passes(tile, a.stagger, a.passes));
+            const uint64_t t0 = a.g_base + (uint64_t)kRun * tile_first_run(tile, a.big_tiles, a.passes);
+            const uint64_t t1 = t0 + (uint64_t)kRun * (uint64_t)owned_runs(tile_passes(tile, a.big_tiles, a.passes));
             const uint64_t key = t0 >= (uint64_t)(ADSB_DECOFFSET_K - 1) ? t0 - (ADSB_DECOFFSET_K - 1) : 0; // frames below cannot reach t0
             // first frame with g >= key: the answer lies in [lo, hi]
             uint32_t lo = 0, hi = a.n_frames;
@@ -1494,52 +1494,30 @@ uint32_t make_fix_table(uint32_t *tab)
 
 int choose_passes(uint64_t n_offsets, int cus, bool dense)
 {
-    // Estimated time = rounds x passes, rounds = ceil(tiles / resident workgroups);
-    // long tiles amortise the 44-run halo, short ones fill the last round better.
     if (cus <= 0)
         cus = 256;
-    // Large launches: tiles retire at a steady rate in index order (each CU favours its older
-    // workgroups, so there are no "rounds" to quantise), and a longer tile only amortises its
-    // 44-run halo better.  Measured in bench.py at 128 Mi offsets: K = 5 / 6 / 7 / 8 / 10 ->
-    // 0.214 / 0.212 / 0.208 / 0.211 / 0.211 ms per step.
-    // Round 6, launches interleaved in one process (tools/ab_interleaved.py, profiles/r6_ab_runs.txt section 9), K = 4 / 5 / 6 / 7 / 8:
-    // sparse 1.045 / 1.036 / 1.007 / 1 / 1.067 (from K = 8 on a CU's LDS holds four workgroups, not five), noise the same;
-    // BASELINE configs[2] at its stated density 0.970 / 0.981 / 0.972 / 1 / 1.093, with the Try/Ok table 0.961 / 0.939 /
-    // 0.938 / 1: a tile of frames back to back stages fewer candidates for its all-pairs filter, overflows its survivor
-    // queue less often.  `dense` = the handle's previous launch handed over a record per 2 048 offsets or more.
-    if (n_offsets >= (96ull << 20))
-        return dense ? 6 : 7;
-    int best = 2;
-    double best_cost = 1e300;
-    for (int k = 2; k <= 6; k++) { // measured: 4..6 passes are best at every launch size
-        const uint64_t per = (uint64_t)tile_offsets(k);
-        const uint64_t tiles = (n_offsets + per - 1) / per;
-        int per_cu = (int)(160 * 1024 / lds_bytes(k));
-        if (per_cu > kMinWaves)
-            per_cu = kMinWaves; // register-limited: __launch_bounds__(256, kMinWaves)
-        if (per_cu < 1)
-            continue;
-        const uint64_t slots = (uint64_t)cus * per_cu;
-        const uint64_t rounds = (tiles + slots - 1) / slots;
-        // a partially filled last round runs faster per workgroup; weight it by its fill
-        const double last = (double)(tiles - (rounds - 1) * slots) / (double)slots;
-        const double eff_rounds = (double)(rounds - 1) + (0.35 + 0.65 * last);
-        const double cost = eff_rounds * (k + 0.25) / per_cu;
-        if (cost < best_cost) {
-            best_cost = cost;
-            best = k;
-        }
-    }
-    return best;
-}
-
-uint32_t checked_stagger(uint64_t n_offsets, int passes, int forced)
-{
-    if (passes < 5 || forced <= 0)
-        return 0;
-    const uint32_t st = (uint32_t)forced & ~3u;
-    const uint64_t tiles = (n_offsets + tile_offsets(passes) - 1) / tile_offsets(passes);
-    return tiles >= 2ull * st ? st : 0u;
+    // Measured, not modelled (round 6: launches of every size interleaved in one process, K = 2..7 side by side on the
+    // kernel's own clock: tools/ab_interleaved.py, profiles/r6_ab_passes_sizes.txt; rounds 1-5 chose by a cost model of
+    // "rounds of resident workgroups" that the same measurement refutes -- a large launch's time is 10.7 us + 46 ns per tile,
+    // no steps -- and that was up to 14 % off the best K at 16 Mi offsets).  Below ~64 Mi offsets the best K is not monotonic:
+    // the launch is one or two device-fulls of tiles and the fill of the last one decides.
+    //   offsets (Mi)      1     2     4     8     16    24    32    48    64    80    88   128
+    //   best K            2     2     3     3     5     5     3     3     4     6     6     7
+    //   next best, +%   3:17  3:13  2:7   2:4   2:10  4:5   7:2   5:2   5:1   7:2   5:2   6:1
+    // From K = 8 on a CU's LDS holds four workgroups, not five (+7 % and more).  At 128 Mi offsets, K = 4 / 5 / 6 / 7 / 8:
+    // sparse 1.045 / 1.036 / 1.007 / 1 / 1.067, noise the same; BASELINE configs[2] at its stated density 0.970 / 0.981 /
+    // 0.972 / 1 / 1.093, with the Try/Ok table 0.961 / 0.939 / 0.938 / 1: a tile of frames back to back stages fewer
+    // candidates for its all-pairs filter and overflows its survivor queue less often.  `dense` = the handle's previous
+    // launch handed over a record per 2 048 offsets or more.
+    const uint64_t n = n_offsets * 256u / (uint64_t)cus; // (the table is a 256-CU device's)
+    constexpr struct {
+        uint32_t below_mi;
+        int k;
+    } table[] = {{3, 2}, {12, 3}, {28, 5}, {56, 3}, {72, 4}, {96, 6}};
+    for (const auto &row : table)
+        if (n < ((uint64_t)row.below_mi << 20))
+            return row.k;
+    return dense ? 6 : 7;
 }
 
 // The staging buffer's unscanned tail (a few KB) moved to the other buffer, by a kernel of the library's own: the
@@ -1572,7 +1550,7 @@ hipError_t launch_scan(const ScanArgs &args, bool stats, hipStream_t stream)
 {
     if (args.g_end <= args.g_begin)
         return hipSuccess;
-    const unsigned blocks = tile_count(args.g_end - args.g_begin, args.stagger, args.passes);
+    const unsigned blocks = tile_count(args.g_end - args.g_begin, args.big_tiles, args.passes);
     const size_t lds = lds_bytes(args.passes);
     if (stats)
         hipLaunchKernelGGL(scan_kernel<true>, dim3(blocks), dim3(kThreads), lds, stream, args);

@@ -27,7 +27,7 @@ typedef struct adsb_debug_config {
     int32_t reader_min_tiles; /* host_threads >= 2: launches of at least this many tiles go through the reader thread */
     int32_t shard_head;       /* resolved shards: offsets whose candidates are all kept for the stitcher (ADSB_SHARD_HEAD) */
     int32_t passes;           /* passes per tile of every launch (2..32) instead of the cost model's choice           */
-    int32_t stagger;          /* leading tiles of staggered size (scan_kernel.h tile_passes)                          */
+    int32_t big_tiles;        /* tiles of a launch that take all its passes; the rest four (scan_kernel.h tile_passes) */
     int32_t gang_min;         /* host_threads >= 3: batches of at least this many records go through the gang
                                  (default: 2048 records decided ahead, 1024 frames written)                           */
 } adsb_debug_config;

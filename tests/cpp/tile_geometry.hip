@@ -1,5 +1,6 @@
 // tile_geometry.hip -- host-side check of the tile geometry the kernel and the host must
-// agree on (scan_kernel.h: tile_passes / tile_first_run / tile_count), staggered or not.
+// agree on (scan_kernel.h: tile_passes / tile_first_run / tile_count), with and without a tail of small tiles,
+// and of the host's choice of that tail (choose_big_tiles).
 // Built with hipcc and run on the CPU by tests/test_host_logic.py.
 #include <cstdio>
 #include <random>
@@ -10,8 +11,8 @@ int main()
 {
     std::mt19937_64 rng(7);
     for (int it = 0; it < 20000; it++) {
-        const int k = 2 + (int)(rng() % 5);
-        const uint32_t stagger = (k >= 5 && (rng() & 1)) ? 4u * (uint32_t)(rng() % 300) : 0u;
+        const int k = 2 + (int)(rng() % 6);
+        const uint32_t stagger = (rng() & 1) ? (uint32_t)(rng() % 3000) : 0u; // (big_tiles: tiles from this index on are small)
         const uint64_t n = 1 + rng() % (it % 3 ? 3000000ull : 400000000ull);
         const uint32_t tiles = adsb::tile_count(n, stagger, k);
         const uint64_t runs = (n + adsb::kRun - 1) / adsb::kRun;
@@ -26,10 +27,24 @@ int main()
             const uint32_t t = (uint32_t)(rng() % (tiles + 8));
             const uint64_t d = adsb::tile_first_run(t + 1, stagger, k) - adsb::tile_first_run(t, stagger, k);
             const int kt = adsb::tile_passes(t, stagger, k);
-            if (d != (uint64_t)adsb::owned_runs(kt) || kt < 2 || kt > k) {
+            const int want = (stagger == 0 || t < stagger || k <= adsb::kTaperPasses) ? k : adsb::kTaperPasses;
+            if (d != (uint64_t)adsb::owned_runs(kt) || kt != want) {
                 printf("tile %u (stagger %u, k %d): width %llu, passes %d\n", t, stagger, k, (unsigned long long)d, kt);
                 return 1;
             }
+        }
+    }
+    // the host's choice: none for small launches and short tiles; for a full launch half a device's worth of small tiles
+    if (adsb::choose_big_tiles(1 << 20, 7, 256, 0) != 0 || adsb::choose_big_tiles(134216525, 4, 256, 0) != 0 ||
+        adsb::choose_big_tiles(134216525, 7, 256, 17) != 17) {
+        printf("choose_big_tiles: small launch / short tiles / forced\n");
+        return 1;
+    }
+    for (int k : {6, 7}) {
+        const uint32_t big = adsb::choose_big_tiles(134216525, k, 256, 0), all = adsb::tile_count(134216525, big, k);
+        if (big == 0 || all - big < 600 || all - big > 680) {
+            printf("choose_big_tiles(128 Mi offsets, %d) = %u of %u tiles\n", k, big, all);
+            return 1;
         }
     }
     // LDS of the largest tile fits four workgroups per CU

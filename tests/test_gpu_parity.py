@@ -597,7 +597,7 @@ def test_overflow_rounds_ranges_and_bit_positions(oracle, dec_factory, torch_cud
                     assert d.stats() == wstats, (qcap, kw)
     # tiles of 2 .. 7 passes (2 .. 7 chunks of 256 runs): every shape of the range loop
     for passes in (2, 3, 5, 7):
-        d = dec_factory(df18=True, collect_stats=True, debug_queue_cap=256, debug_passes=passes, debug_stagger=0)
+        d = dec_factory(df18=True, collect_stats=True, debug_queue_cap=256, debug_passes=passes)
         d.reset()
         d.push_device_final(t.data_ptr(), t.numel())
         assert records(d.drain()) == records(want), passes
@@ -1070,17 +1070,18 @@ def test_cli_tcp_sinks_carry_the_same_packets(capi, tmp_path):
     assert subprocess.run([capi.CLI_PATH, "-G", "0,0", "-s", "127.0.0.1:9", "-f", str(path), "-f", str(path)], capture_output=True).returncode == 1
 
 
-def test_staggered_tile_sizes(oracle, dec_factory, torch_cuda):
-    """Staggered tile sizes (the first tiles of a launch take K-3..K passes in turn, scan_kernel.h tile_passes)
-    were an experiment that did not pay and are off; the tile geometry functions stay covered by forcing it on a
-    small capture (cfg.debug_passes / cfg.debug_stagger) and comparing with the oracle, statistics included."""
+def test_a_launch_that_ends_in_small_tiles(oracle, dec_factory, torch_cuda):
+    """A large launch ends in tiles of four passes (scan_kernel.h tile_passes, choose_big_tiles): the kernel, the count pass
+    and the host's walk of the hand-off stream share one geometry.  Forced on a small capture (adsb_debug_config.passes /
+    .big_tiles: the first N tiles are whole, the rest small; N beyond the launch's tiles = none small) and compared with the
+    oracle, statistics included; test_config1_256Mi_sparse and the other full-size tests run the host's own choice."""
     from tools import gen_signal as G
     x, _ = G.dense_capture(1 << 22, seed=77, sigma=25.0, n_frames=1200, amp=(150, 1800))
     want, wstats = oracle.decode(x, df18=True)
     t = _dev(torch_cuda, x)
-    for passes, stagger in ((5, 8), (6, 16), (5, 60)):
+    for passes, big in ((5, 8), (6, 1), (7, 3), (5, 60), (4, 2)):
         for stats in (False, True):
-            d = dec_factory(df18=True, collect_stats=stats, debug_passes=passes, debug_stagger=stagger)
+            d = dec_factory(df18=True, collect_stats=stats, debug_passes=passes, debug_big_tiles=big)
             d.reset()
             d.push_device_final(t.data_ptr(), t.numel())
             assert records(d.drain()) == records(want)

@@ -39,13 +39,13 @@ def main():
     stats = "--stats" in args
     rounds = int(args[args.index("--rounds") + 1]) if "--rounds" in args else 40
     steps = int(args[args.index("--steps") + 1]) if "--steps" in args else 10
-    builds = []  # name=path[@passes=N[,stagger=M]]: the same library under several adsb_debug_config settings
+    builds = []  # name=path[@passes=N[,big_tiles=M]]: the same library under several adsb_debug_config settings
     for a in args:
         if "=" in a and not a.startswith("--"):
             name, rest = a.split("=", 1)
             path, _, knobs = rest.partition("@")
             builds.append((name, path, dict(kv.split("=") for kv in knobs.split(",") if kv)))
-    n = 256 << 20
+    n = int(args[args.index("--samples") + 1]) if "--samples" in args else 256 << 20
     n -= n % 28
     x = make_dense10(torch, n, 101) if dense10 else make_gate_storm(torch, n, 102) if storm else make_dense(torch, n, 100) if noise else make_workload(torch, n, seed=1)[0]
     torch.cuda.synchronize()
@@ -92,7 +92,7 @@ def main():
             m1, l1 = kernel_ms(L, h)
             per[name].append((m1 - m0) / max(1, l1 - l0))
     base = per[hs[0][0]]
-    print(f"workload {'dense10' if dense10 else 'gate_storm' if storm else 'noise 7 %' if noise else 'sparse'}{' +stats' if stats else ''}, {frames[hs[0][0]]} frames, "
+    print(f"{n} samples; workload {'dense10' if dense10 else 'gate_storm' if storm else 'noise 7 %' if noise else 'sparse'}{' +stats' if stats else ''}, {frames[hs[0][0]]} frames, "
           f"{rounds} rounds x {steps} launches per build, kernel clock, ms per launch")
     for name, _, _ in hs:
         v = sorted(per[name])

@@ -58,7 +58,7 @@ int main(int argc, char **argv)
         a.hand = hand; a.hand_cap = (uint32_t)gran; a.gen = 12345;
     }
     a.passes = argc > 3 && atoi(argv[3]) > 0 ? atoi(argv[3]) : adsb::choose_passes(a.g_end - a.g_begin, 256);
-    a.stagger = 0;
+    a.big_tiles = 0;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++) { CK(hipMemset(counters, 0, adsb::kDevCounterWords * 4)); CK(adsb::launch_scan(a, false, 0)); }
     CK(hipDeviceSynchronize());
