@@ -87,8 +87,8 @@ typedef struct adsb_config {
                                frames, order and counters whatever the value.                     */
     int32_t wait_timeout_s; /* no wait for the device lasts longer (0 = default, 120 s): a launch or copy that never
                                completes ends the call with -1 and adsb_last_error() names what was waited for     */
-    int32_t warm_start;     /* 1: adsb_create also pays the runtime's first-use cost of a large copy (7-9 ms once per
-                               process) beside its other work: for a one-shot process                              */
+    int32_t warm_start;     /* 1: adsb_create also pays the runtime's first-use costs of copying (first large copy,
+                               second copy engine: 7-9 ms each) beside its other work: for a one-shot process      */
     const void *debug;      /* NULL, or an adsb_debug_config (adsbdec_amd_diag.h: test knobs); copied by adsb_create */
 } adsb_config;
 
