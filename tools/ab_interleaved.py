@@ -26,7 +26,12 @@ def bind(path):
     L = C.CDLL(path)
     for name in ("adsb_config_init", "adsb_create", "adsb_destroy", "adsb_decode_device", "adsb_get_profile_sized", "adsb_last_error"):
         res, args = capi.SYMBOLS[name]
-        fn = getattr(L, name)
+        try:
+            fn = getattr(L, name)
+        except AttributeError:  # a build of rounds 4-5: adsb_get_profile(handle, struct) -- it fills the members it knows
+            fn = L.adsb_get_profile
+            res, args = C.c_int, [C.c_void_p, C.POINTER(capi.Profile)]
+            L.adsb_get_profile_sized = lambda h, p, n, fn=fn: fn(h, p)
         fn.restype, fn.argtypes = res, args
     return L
 
@@ -53,9 +58,14 @@ def main():
     keep = []
     for name, path, knobs in builds:
         L = bind(os.path.abspath(path))
-        cfg = capi.Config()
+        L.adsb_abi_version.restype = C.c_int
+        old_abi = L.adsb_abi_version() < 5  # a build of rounds 4-5: its struct (no `abi` member, debug_* members inside)
+        cfg = capi.ConfigV4() if old_abi else capi.Config()
         L.adsb_config_init(C.byref(cfg), C.sizeof(cfg))
-        if knobs:
+        if knobs and old_abi:
+            for k, v in knobs.items():
+                setattr(cfg, "debug_" + k, int(v))
+        elif knobs:
             dbg = capi.DebugConfig()
             dbg.struct_size = C.sizeof(dbg)
             for k, v in knobs.items():

@@ -43,9 +43,9 @@ def results():
 | `bench.py`, default line (one box) | **{d['value'] / 1e6:.3f} Tsamples/s**, {d['ms_per_step']:.4f} ms per 256 Mi-sample step; scan kernel {d['roofline']['launch_ms'] * 1e3:.1f} µs on its own clock = {d['roofline']['achieved']:.0f} GB/s = **{d['roofline']['frac']:.3f} of 8 TB/s** | `r6_bench.json` |
 | ... the same region with 1000 steps instead of the driver's 20 (`value_1000_steps`) | {k['value'] / 1e6:.3f} Tsamples/s, {k['ms_per_step']:.4f} ms per step, kernel {k['launch_ms'] * 1e3:.1f} µs = {k['roofline_frac']:.3f} | `r6_bench.json` |
 | the same command under `rocprofv3 --kernel-trace --stats`, 1000 timed steps (the same box, the same gpurun call) | `scan_kernel<false>`: {len(dur)} dispatches, average **{statistics.mean(dur):.1f} µs** (pre-roll and warm-up included) = {frac(statistics.mean(dur)):.3f}; last 1000: {statistics.mean(dur[-1000:]):.1f} µs = **{frac(statistics.mean(dur[-1000:])):.3f}**; minimum {min(dur):.1f} µs; the bench line of that very run read {u['roofline']['launch_ms'] * 1e3:.1f} µs in-kernel (1 % below the trace, as in every round) | `r6_kernel_stats.csv`, `r6_dispatches.csv`, `r6_bench_under_rocprofv3.json` |
-| spread of the kernel | box to box 0.132–0.148 ms (0.453–0.508) for the same command over rounds 3 to 6's boxes; same-box against round 5's library: **−1.8 %** (three boxes, `r6_ab_runs.txt`); on one box the 200 default steps read ≈ 3 % longer than 1000 steps right behind them (the clock governor is still ramping: rows 1 and 2) | `r3_ab_runs.txt` … `r6_ab_runs.txt` |
+| spread of the kernel | box to box 0.132–0.148 ms (0.453–0.508) for the same command over rounds 3 to 6's boxes; against round 5's library, launches of both interleaved in one process: see the A/B row below (`r6_ab_runs.txt` §8–10, `r6_ab_vs_r5.txt`); on one box the 200 default steps read ≈ 3 % longer than 1000 steps right behind them (the clock governor is still ramping: rows 1 and 2) | `r3_ab_runs.txt` … `r6_ab_runs.txt` |
 | HBM traffic per launch | {pmc['hbm_bytes_per_launch'] / 1e6:.1f} MB = {pmc['hbm_bytes_per_launch'] / B:.3f} × the 536.9 MB of algorithmic input (FETCH_SIZE × 2 + WRITE_SIZE, separate passes) | `r6_pmc.json` |
-| VALU wave-instructions per launch | {c['SQ_INSTS_VALU']['mean'] / 1e6:.2f} M; Stage A's pass 661 instructions = 2 558 issue cycles (3.87 per instruction) | `r6_pmc.json`, `r6_isa_mix.json` |
+| VALU wave-instructions per launch | {c['SQ_INSTS_VALU']['mean'] / 1e6:.2f} M; Stage A's pass {J('r6_isa_mix.json')['valu_instructions_per_pass']} instructions = {J('r6_isa_mix.json')['issue_cycles_per_pass']} issue cycles ({J('r6_isa_mix.json')['cycles_per_valu_instruction']:.2f} per instruction; rounds 1–5: 659–661 = 2 558) | `r6_pmc.json`, `r6_isa_mix.json` |
 | wave time | issuing {c['SQ_ACTIVE_INST_ANY']['mean'] / wc * 100:.0f} %, stalled wanting to issue {c['SQ_WAIT_INST_ANY']['mean'] / wc * 100:.0f} %, parked on `s_waitcnt` / `s_barrier` {c['SQ_WAIT_ANY']['mean'] / wc * 100:.0f} % | `r6_pmc.json` |
 | with the Try/Ok table (`collect_stats=1`: what the drop-in runs) | {d['with_stats']['ms_per_step']:.4f} ms per step = **{d['with_stats']['value'] / 1e6:.3f} Tsamples/s** (`value_dropin`); under rocprofv3 `scan_kernel<true>` {statistics.mean(sdur[-1000:]):.1f} µs (last 1000 of {len(sdur)}), `count_tries_kernel` {float(cnt[3]) / 1e3:.1f} µs on its own stream | `r6_bench.json`, `r6_stats_kernel_stats.csv`, `r6_stats_dispatches.csv` |
 | dense, σ = 300 noise + one 112-bit frame per ms, `-a` (rounds 1–3's `configs[2]`) | {dn['noise']['plain']['ms_per_step']:.4f} ms per step, kernel {dn['noise']['plain']['launch_ms'] * 1e3:.1f} µs = {dn['noise']['plain']['roofline_frac']:.3f}; {dn['noise']['preamble_pass_fraction'] * 100:.2f} % of the offsets pass the preamble test, {dn['noise']['df_gate_pass_fraction_of_visited'] * 100:.3f} % the DF gate; with the table {dn['noise']['with_stats']['ms_per_step']:.4f} ms | `r6_bench.json` `dense.noise` |
