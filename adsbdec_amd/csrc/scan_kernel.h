@@ -10,10 +10,7 @@ namespace adsb {
 
 // Launch shape (what every measurement of DESIGN.md was taken with; the experiments that set other values are history)
 
-#ifndef ADSB_SLEEP_STAGGER
-#define ADSB_SLEEP_STAGGER 90
-#endif
-constexpr int kSleepStagger = ADSB_SLEEP_STAGGER;  // s_sleep units (64 cycles) between the starts of a CU's first four workgroups
+constexpr int kSleepStagger = 90;  // s_sleep units (64 cycles) between the starts of a CU's first five workgroups (0 / 45 / 70 / 110: +6.2 / +1.4 / +1.1 / +1.5 %, r6_ab_runs.txt 9a)
 constexpr int kMinWaves = 5;       // __launch_bounds__ second argument: waves per SIMD (96 VGPRs; 5 workgroups' LDS fit a CU)
 
 constexpr int kRun = 28;        // power samples per thread run (4 x 7: see scan_kernel.hip)
@@ -42,12 +39,12 @@ constexpr size_t lds_bytes(int passes)
 {
     return sizeof(uint32_t) * (size_t)(3 * (kPassRuns * passes + kPlanePad) + kQueueCap + 16 + kClistCap * 6);
 }
-// Tile geometry of a launch.  A tile takes K = `passes` passes -- except that a large launch ENDS in tiles of
-// kTaperPasses: the tiles from index `big_tiles` on (0: none; the host's choice, choose_big_tiles()).  Why: a launch costs
-// ~11 us beyond what its tiles cost at the steady rate (time = 10.7 us + 46 ns x tiles, profiles/r6_ab_runs.txt section 10),
-// half of it the drain -- the last tiles run on CUs that are emptying, a wave to a SIMD, at a fraction of the issue rate --
-// and a tile of four passes drains in about half the time of one of seven.  Every user of the geometry -- the kernel, the
-// count pass, the host's walk of the hand-off stream -- goes through these three functions (tests/cpp/tile_geometry.hip).
+// Tile geometry of a launch.  A tile takes K = `passes` passes -- except that a launch MAY end in tiles of kTaperPasses: the
+// tiles from index `big_tiles` on (0: none).  Why one would: a launch costs ~11 us beyond what its tiles cost at the steady
+// rate (time = 10.7 us + 46 ns x tiles, profiles/r6_ab_runs.txt section 10), half of it the drain -- the last tiles run on
+// CUs that are emptying, a wave to a SIMD, at a fraction of the issue rate -- and a tile of four passes drains in about half
+// the time of one of seven.  Why it is not the default: choose_big_tiles() below.  Every user of the geometry -- the kernel,
+// the count pass, the host's walk of the hand-off stream -- goes through these three functions (tests/cpp/tile_geometry.hip).
 constexpr int kTaperPasses = 4;
 __host__ __device__ inline int tile_passes(uint32_t tile, uint32_t big_tiles, int k)
 {
@@ -68,26 +65,16 @@ inline uint32_t tile_count(uint64_t n_offsets, uint32_t big_tiles, int k)
     return big_tiles + (uint32_t)((runs - head + owned_runs(kTaperPasses) - 1) / owned_runs(kTaperPasses));
 }
 
-// Host: how many of a launch's tiles take all K passes (0: all of them) -- launches of 96 Mi offsets and more end in
-// cus x kMinWaves / 2 tiles of kTaperPasses; `forced` > 0 (adsb_debug_config.big_tiles) is taken as it is.
+// Host: how many of a launch's tiles take all K passes -- 0, all of them, unless `forced` > 0 (adsb_debug_config.big_tiles; the
+// tests and tools/ab_interleaved.py).  The tail of small tiles is NOT shipped: 640 of them (cus x kMinWaves / 2) make the
+// kernel 1.5-2 % faster -- 405 / 512 / 634 tiles of four passes -1.8 / -1.0..-2.0 / -1.4..-2.4 %, of two or three passes
+// -1.6..-1.9 % at best, of five nothing -- and the CALL 3 % slower (adsb_decode_device 0.1512 -> 0.1563 ms; 256 small tiles
+// +2.3 %, 128 +1.6 %; configs[2] +10 %): the host walks the hand-off stream tile by tile and was already the later of the
+// two to finish; small tiles arrive 1.75 x as fast exactly where it has to catch up (profiles/r6_ab_runs.txt section 10).
 inline uint32_t choose_big_tiles(uint64_t n_offsets, int passes, int cus, int forced)
 {
-    if (passes <= kTaperPasses)
-        return 0;
-    if (forced > 0)
-        return (uint32_t)forced;
-    if (n_offsets < (72ull << 20))
-        return 0; // (measured from 64 Mi offsets on: K = 6 with the tail -3.5 % there, but K = 4 -- no tail to shorten -- better still)
-    if (cus <= 0)
-        cus = 256;
-    // Measured on 128 Mi offsets, launches interleaved in one process (profiles/r6_ab_runs.txt section 10), small tiles of 4
-    // passes: 405 / 512 / 634 of them -1.8 / -1.0..-2.0 / -1.4..-2.4 % (sparse), 709 / 785 -1.8 % (configs[2], K = 6); of 2
-    // or 3 passes -1.6..-1.9 % at best, of 5 nothing.  Half of what a device holds at once:
-    const uint64_t small = (uint64_t)cus * kMinWaves / 2;
-    const uint64_t runs = (n_offsets + kRun - 1) / kRun, tail_runs = small * (uint64_t)owned_runs(kTaperPasses);
-    if (runs <= 2 * tail_runs)
-        return 0;
-    return (uint32_t)((runs - tail_runs) / (uint64_t)owned_runs(passes));
+    (void)n_offsets, (void)cus;
+    return (passes > kTaperPasses && forced > 0) ? (uint32_t)forced : 0u;
 }
 
 constexpr uint64_t kMaxLaunchOffsets = (1ull << 30) - tile_offsets(kMaxPasses); // g_rel must fit 30 bits

@@ -34,18 +34,11 @@ int main()
             }
         }
     }
-    // the host's choice: none for small launches and short tiles; for a full launch half a device's worth of small tiles
-    if (adsb::choose_big_tiles(1 << 20, 7, 256, 0) != 0 || adsb::choose_big_tiles(134216525, 4, 256, 0) != 0 ||
-        adsb::choose_big_tiles(134216525, 7, 256, 17) != 17) {
-        printf("choose_big_tiles: small launch / short tiles / forced\n");
+    // the host's choice: no tail of small tiles unless one is forced, and never for tiles that are short already
+    if (adsb::choose_big_tiles(1 << 20, 7, 256, 0) != 0 || adsb::choose_big_tiles(134216525, 7, 256, 0) != 0 ||
+        adsb::choose_big_tiles(134216525, 4, 256, 17) != 0 || adsb::choose_big_tiles(134216525, 7, 256, 17) != 17) {
+        printf("choose_big_tiles: default / short tiles / forced\n");
         return 1;
-    }
-    for (int k : {6, 7}) {
-        const uint32_t big = adsb::choose_big_tiles(134216525, k, 256, 0), all = adsb::tile_count(134216525, big, k);
-        if (big == 0 || all - big < 600 || all - big > 680) {
-            printf("choose_big_tiles(128 Mi offsets, %d) = %u of %u tiles\n", k, big, all);
-            return 1;
-        }
     }
     // LDS of the largest tile fits four workgroups per CU
     if (adsb::lds_bytes(6) * 4 > 160 * 1024) {

@@ -13,6 +13,7 @@ import ctypes as C
 import os
 import statistics
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -62,6 +63,8 @@ def main():
         old_abi = L.adsb_abi_version() < 5  # a build of rounds 4-5: its struct (no `abi` member, debug_* members inside)
         cfg = capi.ConfigV4() if old_abi else capi.Config()
         L.adsb_config_init(C.byref(cfg), C.sizeof(cfg))
+        for k in [k for k in knobs if k.startswith("cfg.")]:  # cfg.host_threads=2: a member of adsb_config itself
+            setattr(cfg, k[4:], int(knobs.pop(k)))
         if knobs and old_abi:
             for k, v in knobs.items():
                 setattr(cfg, "debug_" + k, int(v))
@@ -93,12 +96,15 @@ def main():
     if len(set(frames.values())) != 1:
         raise SystemExit(f"the builds disagree: {frames}")
     per = {name: [] for name, _, _ in hs}
+    wall = {name: [] for name, _, _ in hs}  # the call as the caller sees it: adsb_decode_device back to back
     for r in range(rounds):
         order = hs[r % len(hs):] + hs[:r % len(hs)]
         for name, L, h in order:
             m0, l0 = kernel_ms(L, h)
+            t0 = time.perf_counter()
             for _ in range(steps):
                 L.adsb_decode_device(h, x.data_ptr(), x.numel(), C.byref(out))
+            wall[name].append((time.perf_counter() - t0) * 1e3 / steps)
             m1, l1 = kernel_ms(L, h)
             per[name].append((m1 - m0) / max(1, l1 - l0))
     base = per[hs[0][0]]
@@ -108,7 +114,9 @@ def main():
         v = sorted(per[name])
         q = statistics.quantiles(v, n=4)
         ratio = statistics.median(a / b for a, b in zip(per[name], base))
-        print(f"  {name:10s} median {statistics.median(v):.5f}  quartiles {q[0]:.5f} .. {q[2]:.5f}  min {v[0]:.5f}  ratio to {hs[0][0]} (median of rounds) {ratio:.4f}")
+        wr = statistics.median(a / b for a, b in zip(wall[name], wall[hs[0][0]]))
+        print(f"  {name:10s} median {statistics.median(v):.5f}  quartiles {q[0]:.5f} .. {q[2]:.5f}  min {v[0]:.5f}  ratio to {hs[0][0]} (median of rounds) {ratio:.4f}"
+              f"  | call {statistics.median(wall[name]):.5f} ms, ratio {wr:.4f}")
     for name, L, h in hs:
         L.adsb_destroy(h)
 
