@@ -25,6 +25,22 @@ def frac(us):
     return B / us / 1e3 / 8000  # bytes per microsecond = 1e-3 GB/s
 
 
+def ab_vs_r5():
+    """'sparse -4.6 % / -3.6 %; ...' from profiles/r6_ab_vs_r5.txt (the tree's line of every workload)."""
+    out, wl = [], None
+    for ln in open(P("r6_ab_vs_r5.txt")):
+        m = re.search(r"workload ([^,]+),", ln)
+        if m:
+            wl = m.group(1).replace("dense10", "`configs[2]`").replace("gate_storm", "storm").replace("+stats", "+ table")
+        m = re.match(r"\s+tree\s.*ratio to r5 \(median of rounds\) ([0-9.]+)\s+\| call [0-9.]+ ms, ratio ([0-9.]+)", ln)
+        if m and wl:
+            k, c = float(m.group(1)), float(m.group(2))
+            # (with the table the other handle's count pass runs beside this one's scan: the call figures of those rows say
+            # nothing about a process that owns the device alone, so only the kernel is quoted)
+            out.append(f"{wl} {100 * (k - 1):+.1f} %" + ("" if "table" in wl else f" / {100 * (c - 1):+.1f} %"))
+    return "; ".join(out)
+
+
 def results():
     import ast
     fz = ast.literal_eval([ln for ln in open(P('r6_fuzz_600s.txt')) if ln.startswith('fuzz ok: ')][-1][len('fuzz ok: '):].strip())
@@ -42,8 +58,9 @@ def results():
 |---|---|---|
 | `bench.py`, default line (one box) | **{d['value'] / 1e6:.3f} Tsamples/s**, {d['ms_per_step']:.4f} ms per 256 Mi-sample step; scan kernel {d['roofline']['launch_ms'] * 1e3:.1f} µs on its own clock = {d['roofline']['achieved']:.0f} GB/s = **{d['roofline']['frac']:.3f} of 8 TB/s** | `r6_bench.json` |
 | ... the same region with 1000 steps instead of the driver's 20 (`value_1000_steps`) | {k['value'] / 1e6:.3f} Tsamples/s, {k['ms_per_step']:.4f} ms per step, kernel {k['launch_ms'] * 1e3:.1f} µs = {k['roofline_frac']:.3f} | `r6_bench.json` |
-| the same command under `rocprofv3 --kernel-trace --stats`, 1000 timed steps (the same box, the same gpurun call) | `scan_kernel<false>`: {len(dur)} dispatches, average **{statistics.mean(dur):.1f} µs** (pre-roll and warm-up included) = {frac(statistics.mean(dur)):.3f}; last 1000: {statistics.mean(dur[-1000:]):.1f} µs = **{frac(statistics.mean(dur[-1000:])):.3f}**; minimum {min(dur):.1f} µs; the bench line of that very run read {u['roofline']['launch_ms'] * 1e3:.1f} µs in-kernel (1 % below the trace, as in every round) | `r6_kernel_stats.csv`, `r6_dispatches.csv`, `r6_bench_under_rocprofv3.json` |
-| spread of the kernel | box to box 0.132–0.148 ms (0.453–0.508) for the same command over rounds 3 to 6's boxes; against round 5's library, launches of both interleaved in one process: see the A/B row below (`r6_ab_runs.txt` §8–10, `r6_ab_vs_r5.txt`); on one box the 200 default steps read ≈ 3 % longer than 1000 steps right behind them (the clock governor is still ramping: rows 1 and 2) | `r3_ab_runs.txt` … `r6_ab_runs.txt` |
+| the same command under `rocprofv3 --kernel-trace --stats`, 1000 timed steps (another box of the pool, a faster one: the bench line printed under the profiler is in the row) | `scan_kernel<false>`: {len(dur)} dispatches, average **{statistics.mean(dur):.1f} µs** (pre-roll and warm-up included) = {frac(statistics.mean(dur)):.3f}; last 1000: {statistics.mean(dur[-1000:]):.1f} µs = **{frac(statistics.mean(dur[-1000:])):.3f}**; minimum {min(dur):.1f} µs; the bench line of that very run read {u['roofline']['launch_ms'] * 1e3:.1f} µs in-kernel (1 % below the trace, as in every round) | `r6_kernel_stats.csv`, `r6_dispatches.csv`, `r6_bench_under_rocprofv3.json` |
+| spread of the kernel | box to box 0.127–0.140 ms (0.48–0.53) for this build: the boxes' clocks differ (sysfs reads 2.23–2.39 GHz under the same load); rounds 3–5's builds 0.132–0.148 | `r6_bench.json` `roofline_valu.clock_ghz`, `r6_ab_*.txt` |
+| against round 5's library, launches of both interleaved in ONE process (`tools/ab_interleaved.py`: kernel on its own clock / `adsb_decode_device` as the caller sees it) | {ab_vs_r5()} | `r6_ab_vs_r5.txt` |
 | HBM traffic per launch | {pmc['hbm_bytes_per_launch'] / 1e6:.1f} MB = {pmc['hbm_bytes_per_launch'] / B:.3f} × the 536.9 MB of algorithmic input (FETCH_SIZE × 2 + WRITE_SIZE, separate passes) | `r6_pmc.json` |
 | VALU wave-instructions per launch | {c['SQ_INSTS_VALU']['mean'] / 1e6:.2f} M; Stage A's pass {J('r6_isa_mix.json')['valu_instructions_per_pass']} instructions = {J('r6_isa_mix.json')['issue_cycles_per_pass']} issue cycles ({J('r6_isa_mix.json')['cycles_per_valu_instruction']:.2f} per instruction; rounds 1–5: 659–661 = 2 558) | `r6_pmc.json`, `r6_isa_mix.json` |
 | wave time | issuing {c['SQ_ACTIVE_INST_ANY']['mean'] / wc * 100:.0f} %, stalled wanting to issue {c['SQ_WAIT_INST_ANY']['mean'] / wc * 100:.0f} %, parked on `s_waitcnt` / `s_barrier` {c['SQ_WAIT_ANY']['mean'] / wc * 100:.0f} % | `r6_pmc.json` |
