@@ -307,6 +307,9 @@ class Decoder:
         self._h = L.adsb_create(C.byref(cfg))
         if not self._h:
             raise AdsbError("adsb_create failed: " + (L.adsb_last_error(None) or b"").decode())
+        self._out = C.POINTER(Frame)()          # decode_device_raw's result pointer and its reference, made once
+        self._out_ref = C.byref(self._out)
+        self._decode_device = L.adsb_decode_device
 
     def _check(self, rc, what):
         if rc != 0:
@@ -350,12 +353,13 @@ class Decoder:
         self._check(self._L.adsb_push_device_final(self._h, ptr, n), "adsb_push_device_final")
 
     def decode_device_raw(self, ptr: int, n: int):
-        """adsb_decode_device: reset + push_device_final + take in one call -> (Frame pointer, count)."""
-        p = C.POINTER(Frame)()
-        k = self._L.adsb_decode_device(self._h, ptr, n, C.byref(p))
+        """adsb_decode_device: reset + push_device_final + take in one call -> (Frame pointer, count).  The pointer object is
+        the decoder's own, reused by every call (a timed loop pays for the call, not for Python objects): what it points at
+        is valid until the next call of this decoder, as adsb_take says."""
+        k = self._decode_device(self._h, ptr, n, self._out_ref)
         if k < 0:
             self._check(-1, "adsb_decode_device")
-        return p, int(k)
+        return self._out, k
 
     def finish(self):
         self._check(self._L.adsb_finish(self._h), "adsb_finish")
