@@ -141,7 +141,8 @@ def test_config2_256Mi_at_ten_percent_density_and_the_gate_storm(capi, oracle, t
             try:
                 # three times on one handle: cfg.host_threads = 0 (auto) hands the stream of a launch that FOLLOWS a dense one
                 # (65 536 records or more) to the handle's reader thread and its gang of four (batches decided ahead, frames
-                # written by the gang), which are started then; same records either way
+                # written by the gang), which are started then -- and gives that launch tiles of six passes instead of seven
+                # (scan_kernel.hip choose_passes: a dense channel); same records either way
                 for rep in range(3):
                     d.reset()
                     d.push_device_final(t.data_ptr(), t.numel())
