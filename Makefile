@@ -5,7 +5,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 CC       ?= gcc
 # -ffp-contract=off: the reference arithmetic is binary32 multiply THEN add
 # -amdgpu-atomic-optimizer-strategy=None: see adsbdec_amd/_build.py (the LDS survivor-queue atomics stay per lane)
-HIPFLAGS ?= --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function -mllvm -amdgpu-atomic-optimizer-strategy=None
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function -mllvm -amdgpu-atomic-optimizer-strategy=None -Xarch_host -mavx2
 CSRC     := adsbdec_amd/csrc
 LIBDIR   := adsbdec_amd/lib
 LIB      := $(LIBDIR)/libadsbdec_amd.so

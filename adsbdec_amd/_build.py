@@ -32,8 +32,12 @@ CXX_SOURCES = ["multi.cpp", "host_abi.cpp", "numa.cpp"]
 # -amdgpu-atomic-optimizer-strategy=None: the compiler otherwise turns the survivor queue's per-lane LDS
 # atomicAdd(qcount, n) into a scalar loop over the active lanes (readlane / writelane prefix sum, one iteration per
 # lane) -- a fine trade for contended global atomics, a bad one for an LDS counter: kernel -3.9 % without it.
+# -Xarch_host -mavx2: the HOST side of decoder.hip (the hand-off stream's check, the resolver's two loops, the frame writer) is
+# what a call of the benchmark capture ends on; with 256-bit moves it is 2 % shorter (adsb_decode_device 0.1544 -> 0.1510 ms,
+# profiles/r6_ab_runs.txt section 15; BMI / POPCNT alone: nothing).  Every x86-64 host an MI355X ships in has AVX2; one that has
+# not is refused by adsb_create with a message (host_abi.cpp adsb_host_cpu_refusal, built without the flag).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
-             "-Wno-unused-function", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+             "-Wno-unused-function", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-Xarch_host", "-mavx2"]
 
 
 def _newer(target: str, deps: list[str]) -> bool:

@@ -139,6 +139,7 @@ SYMBOLS = {
     "adsb_handoff_walk": (C.c_long, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "adsb_shard_layout_check": (C.c_int, [C.c_size_t, C.c_size_t]),
+    "adsb_host_cpu_refusal": (C.c_char_p, []),
     "adsb_device_numa_node": (C.c_int, [C.c_int]),
     "adsb_host_alloc_on": (C.c_void_p, [C.c_size_t, C.c_int]),
     "adsb_host_alloc_sharded": (C.c_void_p, [C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),

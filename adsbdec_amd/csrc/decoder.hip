@@ -55,6 +55,8 @@
 namespace {
 
 thread_local std::string g_create_error;
+const char *g_cpu_refusal = nullptr; // set by adsb_create on a host without AVX2 (a plain pointer store: nothing of this file's
+                                     // vector code has run by then); adsb_last_error(NULL) shows it
 
 // The shipped library reads NO environment variable: what a test must be able to force is a member of adsb_config
 // (debug_*).  Builds with -DADSB_TUNING (tools/build_variant.sh; never the one in adsbdec_amd/lib) keep a few knobs for
@@ -1483,6 +1485,8 @@ extern "C" {
 
 adsb_decoder *adsb_create(const adsb_config *cfg_in)
 {
+    if ((g_cpu_refusal = adsb_host_cpu_refusal()) != nullptr)
+        return nullptr;
     adsb_config cfg;
     adsb_debug_config dbg;
     if (const char *why = adsb::accept_config(cfg_in, cfg, dbg)) {
@@ -2172,7 +2176,7 @@ int adsb_get_profile_sized(const adsb_decoder *d, adsb_profile *out, size_t size
 
 const char *adsb_last_error(const adsb_decoder *d)
 {
-    return d ? d->err.c_str() : g_create_error.c_str();
+    return d ? d->err.c_str() : g_cpu_refusal ? g_cpu_refusal : g_create_error.c_str();
 }
 
 // ---- stateless per-shard scan (multi-GPU path) -----------------

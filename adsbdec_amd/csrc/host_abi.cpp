@@ -22,6 +22,15 @@ extern "C" {
 
 int adsb_abi_version(void) { return ADSB_ABI_VERSION; }
 
+// decoder.hip's host side is built with -mavx2 (adsbdec_amd/_build.py says why); this file is not.  adsb_create asks here,
+// before anything else, whether the host can run it: a C string to show, or NULL.
+const char *adsb_host_cpu_refusal(void)
+{
+    __builtin_cpu_init();
+    return __builtin_cpu_supports("avx2") ? nullptr
+                                          : "this build of libadsbdec_amd needs a host CPU with AVX2 (rebuild without -Xarch_host -mavx2 for an older one)";
+}
+
 void adsb_config_init(adsb_config *cfg, size_t struct_size)
 {
     if (!cfg || struct_size < offsetof(adsb_config, device) + sizeof(int32_t))

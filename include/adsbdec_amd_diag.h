@@ -186,6 +186,9 @@ int adsb_scan_shard_resolved_take(adsb_decoder *d, const void *device_samples, u
 /* 0 when the caller's adsb_shard_head / adsb_shard_part have the size this library writes and reads (see ADSB_ABI_VERSION 4);
  * -1 otherwise: the caller was built against another layout and must not call the shard API. */
 int adsb_shard_layout_check(size_t sizeof_shard_head, size_t sizeof_shard_part);
+/* NULL when this host can run the library (its host side is built for x86-64 with AVX2), else the message adsb_create fails
+ * with (adsb_last_error(NULL)).  The function itself is built for the base instruction set. */
+const char *adsb_host_cpu_refusal(void);
 size_t adsb_shard_walk(adsb_shard_head *head, const adsb_frame *frames, uint64_t total_samples, uint64_t *bases, size_t cap);
 /* The serial part, on one rank: parts in shard order.  0; -1 on bad arguments (or inconsistent statistics input); -2 when
  * new_cap is too small (*n_new_total = a lower bound of what is needed: grow new_frames and call again); -3 when a seam cannot

@@ -92,3 +92,16 @@ def test_atomic_optimizer_off_and_bitop3_gate(isa):
     assert "-amdgpu-atomic-optimizer-strategy=None" in _build.HIP_FLAGS
     assert len(re.findall(r"^\s*v_bitop3_b32", isa, flags=re.M)) >= 24   # 6 per chunk, 4 chunks per batch, two paths, two kernels
     assert re.search(r"^\s*ds_add_rtn_u32", isa, flags=re.M)
+
+
+def test_host_side_is_built_for_avx2_and_the_refusal_is_not():
+    """decoder.hip's host side (hand-off check, resolver, frame writer) is built with -mavx2 (adsbdec_amd/_build.py: 2 % of a
+    call); the function that tells adsb_create whether the host can run that, and the rest of host_abi.cpp, are not."""
+    from adsbdec_amd import _build, capi
+    lib = _build.build()
+    assert "-mavx2" in _build.HIP_FLAGS and _build.HIP_FLAGS[_build.HIP_FLAGS.index("-mavx2") - 1] == "-Xarch_host"
+    dis = subprocess.run(["objdump", "-d", "--no-show-raw-insn", lib], capture_output=True, text=True, check=True).stdout
+    assert "%ymm" in dis                                             # the flag reached the host compile
+    body = dis.split("<adsb_host_cpu_refusal>:")[1].split("\n\n")[0]
+    assert "ymm" not in body and "ret" in body                       # ... and not this function
+    assert capi.load().adsb_host_cpu_refusal() is None               # (every host these tests run on has AVX2)

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.." || exit 1
 name=$1; shift
 out=adsbdec_amd/lib_var/$name
 mkdir -p "$out"
-FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wno-unused-function -mllvm -amdgpu-atomic-optimizer-strategy=None $*"
+FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wno-unused-function -mllvm -amdgpu-atomic-optimizer-strategy=None -Xarch_host -mavx2 $*"
 for s in scan_kernel decoder; do
   /opt/rocm/bin/hipcc $FLAGS -c adsbdec_amd/csrc/$s.hip -o "$out/$s.o" || exit 1
 done
