@@ -46,6 +46,7 @@ def results():
     fz = ast.literal_eval([ln for ln in open(P('r6_fuzz_600s.txt')) if ln.startswith('fuzz ok: ')][-1][len('fuzz ok: '):].strip())
     fz2 = ast.literal_eval([ln for ln in open(P('r6_fuzz.txt')) if ln.startswith('fuzz ok: ')][-1][len('fuzz ok: '):].strip())
     fz3 = ast.literal_eval([ln for ln in open(P('r6_fuzz_900s.txt')) if ln.startswith('fuzz ok: ')][-1][len('fuzz ok: '):].strip())
+    fz4 = ast.literal_eval([ln for ln in open(P('r6_fuzz_1500s.txt')) if ln.startswith('fuzz ok: ')][-1][len('fuzz ok: '):].strip())
     d, u, pmc = J("r6_bench.json"), J("r6_bench_under_rocprofv3.json"), J("r6_pmc.json")
     dur, sdur = durations("r6_dispatches.csv"), durations("r6_stats_dispatches.csv")
     c = pmc["counters"]
@@ -76,7 +77,7 @@ def results():
 | the multi-GPU driver on ONE page-locked capture, Try/Ok table included, 1 / 2 / 4 handles on this one device (`e2e_host_fed_sharded`) | {sh['handles_1']['value'] / 1e3:.1f} / {sh['handles_2']['value'] / 1e3:.1f} / {sh['handles_4']['value'] / 1e3:.1f} GS/s (one link: plumbing, not scaling); calling thread's share {sh['handles_1']['serial_us']:.0f} / {sh['handles_2']['serial_us']:.0f} / {sh['handles_4']['serial_us']:.0f} µs per call | `r6_bench.json` |
 | the C host program, whole process, exec to exit, against the reference's wall time on the same file | {files}; below **{x.get('samples', 0) / 1e6:.0f} M samples ({x.get('file_MB', 0)} MB, {x.get('seconds_of_signal', 0)} s of signal) the reference's one CPU thread finishes first** (start-up {x.get('startup_ms', 0):.0f} ms, then {x.get('gpu_ms_per_Mi_samples', 0):.2f} against {x.get('reference_ms_per_Mi_samples', 0):.2f} ms per Mi samples); every device visible to the runtime: {cli['largest_file_all_devices_visible']['runtime_init_ms']:.0f} ms of runtime start against {cli['runtime_init_ms']:.0f} (a one-GPU box: no difference to see); `-G 0,0`: {cli['largest_file_G_0_0']['wall_ms']:.0f} ms | `r6_bench.json` `cli_whole_process` |
 | CPU beside it (the REAL reference chain, 1 core, EPYC 9575F) | {d['cpu_baseline']['value']:.0f} Msamples/s (the oracle's restatement: {d['cpu_baseline']['port_value']:.0f}) | `r6_bench.json` `cpu_baseline` |
-| fuzz | {fz['seconds']:.0f} s, {fz['captures']} random captures ({fz.get('with_frame_start_storms', 0)} with stretches of nothing but frame starts, {fz['with_shrunken_record_buffers']} on handles with shrunken record buffers, {fz['also_checked_against_real_reference_chain']} also against the real reference chain) over ten feeding modes (the multi-GPU driver and resolved shards with statistics among them), {fz['frames']} frames: {fz['mismatches']} mismatches ({fz.get('multi_driver_captures_with_storms', 0)} storm captures through the multi-GPU driver, {fz['multi_driver_fallbacks']} fallbacks); the final build (the FIR's fused forms, measured passes per tile) for {fz2['seconds']:.0f} s + {fz3['seconds']:.0f} s: {fz2['captures'] + fz3['captures']} captures, {fz2['frames'] + fz3['frames']} frames, {fz2['mismatches'] + fz3['mismatches']} mismatches | `r6_fuzz_600s.txt` (the build before the FIR work), `r6_fuzz.txt`, `r6_fuzz_900s.txt` |"""
+| fuzz | {fz['seconds']:.0f} s, {fz['captures']} random captures ({fz.get('with_frame_start_storms', 0)} with stretches of nothing but frame starts, {fz['with_shrunken_record_buffers']} on handles with shrunken record buffers, {fz['also_checked_against_real_reference_chain']} also against the real reference chain) over ten feeding modes (the multi-GPU driver and resolved shards with statistics among them), {fz['frames']} frames: {fz['mismatches']} mismatches ({fz.get('multi_driver_captures_with_storms', 0)} storm captures through the multi-GPU driver, {fz['multi_driver_fallbacks']} fallbacks); the final build (the FIR's fused forms, measured passes per tile) for {fz2['seconds']:.0f} s + {fz3['seconds']:.0f} s + {fz4['seconds']:.0f} s (the last on other seeds, with the AVX2 host side like the first): {fz2['captures'] + fz3['captures'] + fz4['captures']} captures, {fz2['frames'] + fz3['frames'] + fz4['frames']} frames, {fz2['mismatches'] + fz3['mismatches'] + fz4['mismatches']} mismatches | `r6_fuzz_600s.txt` (the build before the FIR work), `r6_fuzz.txt`, `r6_fuzz_900s.txt`, `r6_fuzz_1500s.txt` |"""
 
 
 def shards():
